@@ -1,0 +1,567 @@
+"""PyTorch-CPU fp32 restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+
+Every function cites the reference (JulianKnodt/nerf_atlas) file:line it follows.
+It is checked against fixtures produced by the real reference (tests/golden/, made by
+tools/gen_golden.py) in tests/test_oracle_golden.py -> the oracle is *pinned*.
+
+Nothing in nerf_atlas_amd/ imports this module.  It exists so that (a) the GPU parity
+tests have a same-box checker (the reference's Python cannot travel to the GPU box) and
+(b) bench.py can time a CPU baseline ("port") next to the HIP path.
+"""
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+__all__ = [
+    "pixel_grid", "nerf_camera_rays", "dtu_camera_rays", "compute_ts", "compute_pts",
+    "cumuprod_exclusive", "alpha_from_density", "volumetric_integrate", "sky_white",
+    "hash_resolutions", "hash_corner_indices", "hash_encode", "fourier_encode",
+    "positional_encode", "skip_mlp", "mlp_linear_shapes", "dir_to_elev_azim", "sigmoid",
+    "expected_sin", "integrated_pos_enc_diag", "radii_x", "cylinder_moments",
+    "cone_moments", "lift_gaussian_intended", "mip_latent_intended", "de_casteljau",
+    "cubic_bezier", "laplace_cdf", "tiny_nerf", "plain_nerf", "volsdf", "dynamic_nerf_spline",
+    "view_refl", "positional_refl", "pos_linear_view_refl", "mse2psnr", "render_tiled",
+    "HASH_PRIMES",
+]
+
+# ----------------------------------------------------------------------------- A1 pixels
+
+
+def pixel_grid(size: int, crop=None) -> torch.Tensor:
+    """runner.py:490-503: positions[r, c] = (u=c, v=r) as float, then crop rows t:t+h, cols l:l+w."""
+    ii, jj = torch.meshgrid(
+        torch.arange(size, dtype=torch.float), torch.arange(size, dtype=torch.float), indexing="ij")
+    positions = torch.stack([ii.transpose(-1, -2), jj.transpose(-1, -2)], dim=-1)
+    if crop is not None:
+        t, l, h, w = crop
+        positions = positions[t:t + h, l:l + w, :]
+    return positions
+
+
+# ----------------------------------------------------------------------------- A2 cameras
+
+
+def nerf_camera_rays(positions, c2w, focal: float, size: int, noise=None, with_noise: float = 0.0):
+    """src/cameras.py:45-66 NeRFCamera.sample_positions.
+
+    `noise` ([H,W,2] uniform [0,1) draws for (u, v)) replaces the reference's global-RNG
+    rand_like so that jittered rays are reproducible.
+    """
+    u, v = positions.split([1, 1], dim=-1)
+    if with_noise and noise is not None:
+        u = u + (noise[..., 0:1] - 0.5) * with_noise
+        v = v + (noise[..., 1:2] - 0.5) * with_noise
+    d = torch.stack([(u - size * 0.5) / focal, -(v - size * 0.5) / focal, -torch.ones_like(u)], dim=-1)
+    r_d = torch.sum(d[..., None, :] * c2w[..., :3, :3], dim=-1)
+    r_d = r_d.permute(2, 0, 1, 3)
+    r_o = c2w[..., :3, -1][:, None, None, :].expand_as(r_d)
+    return torch.cat([r_o, r_d], dim=-1)
+
+
+def _dtu_lift(x, y, z, intrinsics):
+    """src/cameras.py:159-174 lift."""
+    shape = x.shape
+    fx = intrinsics[..., 0, 0, None].expand(shape)
+    fy = intrinsics[..., 1, 1, None].expand(shape)
+    cx = intrinsics[..., 0, 2, None].expand(shape)
+    cy = intrinsics[..., 1, 2, None].expand(shape)
+    sk = intrinsics[..., 0, 1, None].expand(shape)
+    x_lift = (x - cx + cy * sk / fy - sk * y / fy) / fx * z
+    y_lift = (y - cy) / fy * z
+    return torch.stack([x_lift, y_lift, z, torch.ones_like(z)], dim=-1)
+
+
+def dtu_camera_rays(positions, pose, intrinsic, size: int):
+    """src/cameras.py:190-223 DTUCamera.sample_positions (pose-matrix branch)."""
+    r_o = pose[:, :3, 3]
+    W, H, _ = positions.shape
+    N = pose.shape[0]
+    normalize = torch.tensor([1600, 1200], dtype=torch.float) / size
+    u, v = (positions * normalize).reshape(-1, 2).split([1, 1], dim=-1)
+    u = u.reshape(1, -1).expand(N, -1)
+    v = v.reshape(1, -1).expand(N, -1)
+    points = _dtu_lift(u, v, torch.ones_like(u), intrinsic)
+    world = torch.bmm(pose, points.permute(0, 2, 1)).permute(0, 2, 1)[..., :3]
+    r_o = r_o[:, None, :].expand_as(world)
+    r_d = F.normalize(world - r_o, dim=-1)
+    return torch.cat([r_o, r_d], dim=-1).reshape(N, W, H, 6)
+
+
+# ----------------------------------------------------------------------------- A3 sampling
+
+
+def compute_ts(near: float, far: float, steps: int, lindisp: bool = False, perturb: float = 0.0,
+               rand: Optional[torch.Tensor] = None):
+    """src/nerf.py:29-47 compute_ts.  `rand` [T] replaces torch.rand_like (Q7/Q13)."""
+    if lindisp:
+        t_vals = torch.linspace(0, 1, steps, dtype=torch.float)
+        ts = 1 / (1 / max(near, 1e-10) * (1 - t_vals) + 1 / far * t_vals)
+    else:
+        ts = torch.linspace(near, far, steps=steps, dtype=torch.float)
+    mids = None
+    if perturb > 0:
+        mids = 0.5 * (ts[:-1] + ts[1:])
+        lower = torch.cat([mids, ts[-1:]])
+        upper = torch.cat([ts[:1], mids])
+        ts = lower + (upper - lower) * (rand * perturb)
+    return ts, mids
+
+
+def compute_pts(r_o, r_d, ts):
+    """src/nerf.py:50-55: pts[T,...,3] = r_o[None] + ts (x) r_d."""
+    return r_o.unsqueeze(0) + torch.tensordot(ts, r_d, dims=0)
+
+
+# ----------------------------------------------------------------------------- A8 compositing
+
+
+def cumuprod_exclusive(t):
+    """src/nerf.py:22-27."""
+    cp = torch.cumprod(t, dim=0)
+    cp = torch.roll(cp, 1, dims=0)
+    cp[0, ...] = 1.0
+    return cp
+
+
+def alpha_from_density(density, ts, r_d, softplus: bool = True):
+    """src/nerf.py:60-73 (Q1,Q3,Q5,Q6)."""
+    sigma_a = F.softplus(density - 1) if softplus else F.relu(density)
+    end_val = torch.full_like(ts[..., :1], 1e10)
+    dists = torch.cat([ts[..., 1:] - ts[..., :-1], end_val], dim=-1).clamp(min=1e-5)
+    while len(dists.shape) < 4:
+        dists = dists[..., None]
+    dists = dists * torch.linalg.norm(r_d, dim=-1)
+    alpha = 1 - torch.exp(-sigma_a * dists)
+    weights = alpha * cumuprod_exclusive(1.0 - alpha + 1e-10)
+    return alpha, weights
+
+
+def volumetric_integrate(weights, other):
+    """src/nerf.py:79-80."""
+    return torch.sum(weights[..., None] * other, dim=0)
+
+
+def sky_white(weights):
+    """src/nerf.py:98 (Q4)."""
+    return 1 - weights[:-1].sum(dim=0).unsqueeze(-1)
+
+
+# ----------------------------------------------------------------------------- A5 hash encoder
+
+HASH_PRIMES = (1, 2654435761, 805459861)
+
+
+def hash_resolutions(levels: int = 8, low: int = 16, high: int = 1 << 14):
+    """src/neural_blocks.py:126-128,146 (Q8): N_l = low * scale**i as a *Python double*,
+    scale = exp((ln high - ln low)/levels - 1)."""
+    scale = math.exp((math.log(high) - math.log(low)) / levels - 1)
+    return [low * (scale ** i) for i in range(levels)]
+
+
+def _hash_fn(v):
+    """src/neural_blocks.py:135-139 (int64 multiply, xor)."""
+    primes = torch.tensor(HASH_PRIMES, dtype=torch.long)
+    vs = (v * primes).split(1, dim=-1)
+    out = vs[0]
+    for w in vs[1:]:
+        out = out.bitwise_xor(w)
+    return out
+
+
+def _corners(l):
+    """src/neural_blocks.py:149-165 corner order."""
+    lx, ly, lz = l.split([1, 1, 1], dim=-1)
+    h = l + 1
+    hx, hy, hz = h.split([1, 1, 1], dim=-1)
+    cat = lambda a, b, c: torch.cat([a, b, c], dim=-1)
+    return [l, cat(lx, ly, hz), cat(lx, hy, lz), cat(lx, hy, hz),
+            cat(hx, ly, lz), cat(hx, ly, hz), cat(hx, hy, lz), h]
+
+
+def hash_corner_indices(x, levels: int = 8, emb_size: int = 1 << 16):
+    """Table indices [levels, 8, N] (int64), src/neural_blocks.py:143-166."""
+    out = []
+    for N_l in hash_resolutions(levels):
+        l = (x * N_l).floor().long()
+        out.append(torch.stack([(_hash_fn(v) % emb_size).squeeze(-1) for v in _corners(l)], dim=0))
+    return torch.stack(out, dim=0)
+
+
+def hash_encode(x, tables: Sequence[torch.Tensor], include_input: bool = True, emb_size: int = 1 << 16):
+    """src/neural_blocks.py:139-193 HashEncoder.forward.  x [N,3]; tables: 8 x [65536,4]."""
+    out = []
+    res = hash_resolutions(len(tables))
+    for i, emb in enumerate(tables):
+        v_l = x * res[i]
+        l = v_l.floor().long()
+        embs = torch.stack([emb[(_hash_fn(v) % emb_size).squeeze(-1)] for v in _corners(l)], dim=0)
+        ws = v_l - l
+        wx, wy, wz = ws.split([1, 1, 1], dim=-1)
+        iwx, iwy, iwz = (1 - ws).split([1, 1, 1], dim=-1)
+        weights = torch.stack([
+            iwx * iwy * iwz, iwx * iwy * wz, iwx * wy * iwz, iwx * wy * wz,
+            wx * iwy * iwz, wx * iwy * wz, wx * wy * iwz, wx * wy * wz], dim=0)
+        out.append((embs * weights).sum(dim=0))
+    out = torch.cat(out, dim=-1)
+    if include_input:
+        out = torch.cat([x, out], dim=-1)
+    return out
+
+
+# ----------------------------------------------------------------------------- A5' Fourier
+
+
+def fourier_encode(x, basis, extra_scale: float = 1.0):
+    """src/utils.py:14-17 fourier + src/neural_blocks.py:52; basis [D,F]."""
+    mapped = x @ (extra_scale * basis)
+    return torch.cat([mapped.sin(), mapped.cos()], dim=-1)
+
+
+def positional_encode(x, bands):
+    """src/neural_blocks.py:30-34 PositionalEncoder.forward."""
+    raw = torch.tensordot(x, bands, dims=0).reshape(x.shape[:-1] + (-1,))
+    return torch.cat([raw.sin(), raw.cos()], dim=-1)
+
+
+# ----------------------------------------------------------------------------- A4 SkipConnMLP
+
+
+def mlp_linear_shapes(dim_p: int, num_layers: int, hidden: int, out: int, skip: int = 3):
+    """src/neural_blocks.py:234-249: (in,out) of init, layers[i], out."""
+    shapes = [(dim_p, hidden)]
+    for i in range(num_layers):
+        shapes.append(((hidden + dim_p) if (i % skip) == 0 and i != num_layers - 1 else hidden, hidden))
+    shapes.append((hidden, out))
+    return shapes
+
+
+def _act(kind):
+    if kind == "leaky_relu":
+        return lambda t: F.leaky_relu(t, 0.01)
+    if kind == "sin":
+        return torch.sin
+    raise NotImplementedError(kind)
+
+
+def skip_mlp(params: dict, prefix: str, p, latent=None, act: str = "leaky_relu", skip: int = 3,
+             enc=None, collect=None):
+    """src/neural_blocks.py:279-296 SkipConnMLP.forward.
+
+    params: state-dict style {prefix+'init.weight', prefix+'layers.0.weight', ..., prefix+'out.bias'}.
+    enc: callable on [N,in] -> [N,E] or None.  collect: optional list receiving per-layer outputs.
+    """
+    a = _act(act)
+    batches = p.shape[:-1]
+    init = p.reshape(-1, p.shape[-1])
+    if enc is not None:
+        init = torch.cat([init, enc(init)], dim=-1)
+    if latent is not None and latent.shape[-1] != 0:
+        init = torch.cat([init, latent.reshape(-1, latent.shape[-1])], dim=-1)
+    n_layers = 0
+    while f"{prefix}layers.{n_layers}.weight" in params:
+        n_layers += 1
+    x = F.linear(init, params[prefix + "init.weight"], params[prefix + "init.bias"])
+    if collect is not None:
+        collect.append(x)
+    for i in range(n_layers):
+        if i != n_layers - 1 and (i % skip) == 0:
+            x = torch.cat([x, init], dim=-1)
+        x = F.linear(a(x), params[f"{prefix}layers.{i}.weight"], params[f"{prefix}layers.{i}.bias"])
+        if collect is not None:
+            collect.append(x)
+    y = F.linear(a(x), params[prefix + "out.weight"], params[prefix + "out.bias"])
+    return y.reshape(batches + (y.shape[-1],))
+
+
+# ----------------------------------------------------------------------------- A7 view / heads
+
+
+def dir_to_elev_azim(direc):
+    """src/utils.py:247-254."""
+    lim = 1 - 1e-6
+    x, y, z = F.normalize(direc, dim=-1).clamp(min=-lim, max=lim).split([1, 1, 1], dim=-1)
+    return torch.cat([z.acos(), torch.atan2(y, x)], dim=-1)
+
+
+def sigmoid(kind: str):
+    """src/utils.py:484-518 sigmoid_kinds (subset that is reachable from the 5 configs + cheap ones)."""
+    fat = lambda v, eps=1e-2: v.sigmoid() * (1 + 2 * eps) - eps
+    table = {
+        "normal": torch.sigmoid,
+        "thin": lambda v: fat(v, -1e-2) + 1e-2,
+        "fat": fat,
+        "tanh": torch.tanh,
+        "upshifted": lambda v: v.sigmoid() + 1e-2,
+        "relu": F.relu,
+        "sin": torch.sin,
+        "leaky_relu": F.leaky_relu,
+        "upshifted_softplus": lambda v: F.softplus(v) + 1e-2,
+        "upshifted_relu": lambda v: F.relu(v) + 1e-2,
+        "cyclic": lambda v: ((v / 5).sin() + 1) / 2 * (1 + 2 * -1e-2) - (-1e-2),
+    }
+    if kind not in table:
+        raise NotImplementedError(kind)
+    return table[kind]
+
+
+def _hash_enc_from(params, prefix):
+    tables = [params[f"{prefix}embs.{i}.weight"] for i in range(8)]
+    return lambda x: hash_encode(x, tables)
+
+
+def view_refl(params, prefix, x, view, latent, act="thin"):
+    """src/refl.py:190-207 View: act(mlp([x | elaz(view)], latent)), sin activations."""
+    v = dir_to_elev_azim(view)
+    return sigmoid(act)(skip_mlp(params, prefix + "mlp.", torch.cat([x, v], dim=-1), latent, act="sin"))
+
+
+def positional_refl(params, prefix, x, latent, act="thin"):
+    """src/refl.py:230-245 Positional: act(mlp(x, latent)), hash encoder, 5x256 LeakyReLU."""
+    enc = _hash_enc_from(params, prefix + "mlp.enc.")
+    return sigmoid(act)(skip_mlp(params, prefix + "mlp.", x, latent, enc=enc))
+
+
+def pos_linear_view_refl(params, prefix, x, view, latent, act="thin", out_features=3, im=64):
+    """src/refl.py:248-290 PosLinearView.forward (view='raw')."""
+    enc = _hash_enc_from(params, prefix + "pos.enc.")
+    pos_all = sigmoid(act)(skip_mlp(params, prefix + "pos.", x, latent, enc=enc))
+    pos, intermediate = pos_all.split([out_features, im], dim=-1)
+    view_latent = intermediate if latent is None else torch.cat([latent, intermediate], dim=-1)
+    vin = torch.cat([x, F.normalize(view, dim=-1)], dim=-1)
+    linear = skip_mlp(params, prefix + "view.", vin, view_latent, act="sin").sigmoid()
+    return (linear / 2 + 0.5) * pos
+
+
+# ----------------------------------------------------------------------------- A6 mip IPE primitives
+
+
+def expected_sin(x, x_var):
+    """src/utils.py:23-27."""
+    y = (-0.5 * x_var).exp() * x.sin()
+    y_var = (0.5 * (1 - (-2 * x_var).exp() * (2 * x).cos()) - y.square()).clamp(min=0)
+    return y, y_var
+
+
+def integrated_pos_enc_diag(x, x_cov, min_deg: int, max_deg: int):
+    """src/utils.py:39-48."""
+    scales = torch.exp2(torch.arange(min_deg, max_deg, dtype=x.dtype))
+    out_shape = x.shape[:-1] + (-1,)
+    y = (x[..., None, :] * scales[..., None]).reshape(out_shape)
+    y_var = (x_cov[..., None, :] * scales[..., None].square()).reshape(out_shape)
+    return expected_sin(torch.cat([y, y + 0.5 * math.pi], dim=-1), torch.cat([y_var, y_var], dim=-1))[0]
+
+
+def radii_x(r_d):
+    """src/utils.py:77-81 (r_d [B,H,W,3] -> [B,H,W,1])."""
+    dx = (r_d[..., :-1, :, :] - r_d[..., 1:, :, :]).square().sum(dim=-1).sqrt()
+    dx = torch.cat([dx, dx[:, -2:-1, :]], dim=-2)
+    return dx[..., None] * 2 / math.sqrt(12)
+
+
+def cylinder_moments(t0, t1, rad):
+    """src/utils.py:95-101 scalar moments (t_mean, t_var, r_var)."""
+    return (t1 + t0) / 2, (t1 - t0).square() / 12, rad * rad / 4
+
+
+def cone_moments(t0, t1, rad):
+    """src/utils.py:83-91 scalar moments (note t_var uses hw/3, as written in the reference)."""
+    mu = (t1 + t0) / 2
+    hw = (t1 - t0) / 2
+    mu2, hw2 = mu * mu, hw * hw
+    hw4 = hw2 * hw2
+    t_mean = mu + (2 * mu * hw2) / (3 * mu2 + hw2)
+    t_var = hw / 3 - (4 / 15) * ((hw4 * (12 * mu2 - hw2)) / (3 * mu2 + hw2).square())
+    r_var = rad * rad * (mu2 / 4 + (5 / 12) * hw2 - 4 / 15 * hw4 / (3 * mu2 + hw2))
+    return t_mean, t_var, r_var
+
+
+def lift_gaussian_intended(r_d, t_mean, t_var, r_var):
+    """Intended layout of src/utils.py:60-73 (the reference returns cov as [3,B,H,W,T];
+    here mean and cov are both [T,B,H,W,3]).  t_* are [T]; r_var is [B,H,W,1] (or [T,B,H,W,1])."""
+    T = t_mean.shape[0]
+    tm = t_mean.reshape(T, 1, 1, 1, 1)
+    tv = t_var.reshape(T, 1, 1, 1, 1)
+    rv = r_var if r_var.dim() == 5 else r_var[None]
+    mean = r_d[None] * tm
+    magn_sq = r_d.square().sum(dim=-1, keepdim=True).clamp(min=1e-10)
+    outer_diag = r_d.square()
+    null_outer_diag = 1 - outer_diag / magn_sq
+    cov = tv * outer_diag[None] + rv * null_outer_diag[None]
+    return mean, cov
+
+
+def mip_latent_intended(r_o, r_d, ts, kind: str = "cylinder", min_deg=0, max_deg=16, end: float = 1e10):
+    """Intended composed mip latent (src/nerf.py:256-261 + src/utils.py:103-140): [T,B,H,W,96].
+    Deliberate divergence from HEAD; for the cone the last interval is clamped by the
+    caller via `end`."""
+    t0 = ts
+    t1 = torch.cat([ts[1:], torch.tensor([end], dtype=ts.dtype)])
+    rad = radii_x(r_d)
+    if kind == "cylinder":
+        t_mean, t_var, r_var = cylinder_moments(t0, t1, rad)
+    else:
+        t_mean, t_var, r_var = cone_moments(t0.reshape(-1, 1, 1, 1, 1), t1.reshape(-1, 1, 1, 1, 1), rad[None])
+        t_mean, t_var = t_mean.reshape(-1), t_var.reshape(-1)
+    mean, cov = lift_gaussian_intended(r_d, t_mean, t_var, r_var)
+    mean = mean + r_o[None]
+    return integrated_pos_enc_diag(mean, cov, min_deg, max_deg)
+
+
+# ----------------------------------------------------------------------------- A11 Bezier
+
+
+def de_casteljau(coeffs, t, N: int):
+    """src/nerf.py:1173-1178."""
+    betas = coeffs
+    m1t = 1 - t
+    for _ in range(1, N):
+        betas = betas[:-1] * m1t + betas[1:] * t
+    return betas.squeeze(0)
+
+
+def cubic_bezier(coeffs, t, N: int = 4):
+    """src/nerf.py:1201-1206."""
+    m1t = 1 - t
+    m1t_sq, t_sq = m1t * m1t, t * t
+    k = torch.stack([m1t_sq * m1t, 3 * m1t_sq * t, 3 * t_sq * m1t, t_sq * t], dim=0)
+    return (k * coeffs).sum(dim=0)
+
+
+# ----------------------------------------------------------------------------- A12 VolSDF density
+
+
+def laplace_cdf(sdf_vals, scale):
+    """src/utils.py:50-58."""
+    scaled = sdf_vals / scale
+    return torch.where(scaled <= 0, scaled.clamp(max=0).exp() / 2, 1 - scaled.clamp(min=0).neg().exp() / 2)
+
+
+# ----------------------------------------------------------------------------- model forwards
+
+
+def _sky(bg, weights):
+    if bg == "black":
+        return 0
+    if bg == "white":
+        return sky_white(weights)
+    raise NotImplementedError(bg)
+
+
+def tiny_nerf(params, rays, near, far, steps, act="upshifted", bg="black", aux=None):
+    """Intended TinyNeRF (src/nerf.py:278-305 composed as SURVEY 8(c).5: density = estim[...,0])."""
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    ts, _ = compute_ts(near, far, steps)
+    pts = compute_pts(r_o, r_d, ts)
+    out = skip_mlp(params, "estim.", pts)
+    density, feats = out[..., 0], out[..., 1:]
+    alpha, weights = alpha_from_density(density, ts, r_d)
+    if aux is not None:
+        aux.update(ts=ts, alpha=alpha, weights=weights)
+    return volumetric_integrate(weights, sigmoid(act)(feats)) + _sky(bg, weights)
+
+
+def _refl_dispatch(params, refl_kind, x, view, latent, act):
+    if refl_kind == "view":
+        return view_refl(params, "refl.", x, view, latent, act)
+    if refl_kind == "pos":
+        return positional_refl(params, "refl.", x, latent, act)
+    if refl_kind == "pos-linear-view":
+        return pos_linear_view_refl(params, "refl.", x, view, latent, act)
+    raise NotImplementedError(refl_kind)
+
+
+def plain_nerf_from_pts(params, pts, ts, r_o, r_d, refl_kind="view", act="thin", bg="black",
+                        mip_latent=None, refl_latent=None, aux=None, prefix=""):
+    """src/nerf.py:337-361 PlainNeRF.from_pts (eval mode)."""
+    p = {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)} if prefix else params
+    latent = mip_latent
+    first_out = skip_mlp(p, "first.", pts, latent, enc=_hash_enc_from(p, "first.enc."))
+    density = first_out[..., 0]
+    intermediate = first_out[..., 1:]
+    view = r_d.unsqueeze(0).expand_as(pts)
+    rl = intermediate if refl_latent is None else torch.cat([intermediate, refl_latent], dim=-1)
+    if latent is not None:
+        rl = torch.cat([latent, rl], dim=-1)
+    rgb = _refl_dispatch(p, refl_kind, pts, view, rl, act)
+    alpha, weights = alpha_from_density(density, ts, r_d)
+    if aux is not None:
+        aux.update(ts=ts, alpha=alpha, weights=weights, density=density, rgb=rgb)
+    return volumetric_integrate(weights, rgb) + _sky(bg, weights)
+
+
+def plain_nerf(params, rays, near, far, steps, refl_kind="view", act="thin", bg="black",
+               mip: Optional[str] = None, aux=None):
+    """src/nerf.py:326-361 PlainNeRF.forward (eval mode: no perturb, no density noise)."""
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    ts, _ = compute_ts(near, far, steps)
+    pts = compute_pts(r_o, r_d, ts)
+    mip_latent = None if mip is None else mip_latent_intended(r_o, r_d, ts, mip, end=(2 * ts[-1] - ts[-2]).item())
+    return plain_nerf_from_pts(params, pts, ts, r_o, r_d, refl_kind, act, bg, mip_latent, aux=aux)
+
+
+def volsdf(params, rays, near, far, steps, sdf_kind="mlp", refl_kind="view", act="thin", aux=None):
+    """src/nerf.py:981-1013 VolSDF.forward/from_pts (no normals, no secondary), src/sdf.py:109-112,250-287."""
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    ts, _ = compute_ts(near, far, steps)
+    pts = compute_pts(r_o, r_d, ts)
+    if sdf_kind == "mlp":
+        basis = params["sdf.underlying.mlp.enc.basis"]
+        raw = skip_mlp(params, "sdf.underlying.mlp.", pts, enc=lambda x: fourier_encode(x, basis))
+    elif sdf_kind == "siren":
+        raw = skip_mlp(params, "sdf.underlying.siren.", pts, act="sin")
+    else:
+        raise NotImplementedError(sdf_kind)
+    sdf_vals, latent = raw[..., 0], raw[..., 1:]
+    scale = params["scale"]
+    density = 1 / scale * laplace_cdf(-sdf_vals, scale)
+    alpha, weights = alpha_from_density(density, ts, r_d, softplus=False)
+    view = r_d.unsqueeze(0).expand_as(pts)
+    rgb = _refl_dispatch({k[len("sdf."):]: v for k, v in params.items() if k.startswith("sdf.")},
+                         refl_kind, pts, view, latent, act)
+    if aux is not None:
+        aux.update(ts=ts, alpha=alpha, weights=weights, sdf=sdf_vals)
+    return volumetric_integrate(weights, rgb)
+
+
+def dynamic_nerf_spline(params, rays, times, near, far, steps, spline: int, refl_kind="view", act="thin",
+                        bg="black", aux=None):
+    """src/nerf.py:1241-1303 DynamicNeRF (spline>1, refl_latent=0) over a canonical PlainNeRF."""
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    ts, _ = compute_ts(near, far, steps)
+    pts = compute_pts(r_o, r_d, ts)
+    t = times[None, :, None, None, None].expand(*pts.shape[:-1], 1)
+    est = skip_mlp(params, "delta_estim.", pts, enc=_hash_enc_from(params, "delta_estim.enc."))
+    rigidity, ps = est[..., :1], est[..., 1:1 + 3 * spline]
+    rigidity = (rigidity / 2).sigmoid()
+    ps = torch.stack(ps.split([3] * spline, dim=-1), dim=0)
+    fn = cubic_bezier if spline == 4 else de_casteljau
+    dp = fn(ps, t, spline)
+    rigid_dp = dp * rigidity
+    if aux is not None:
+        aux.update(dp=dp, rigidity=rigidity, rigid_dp=rigid_dp, pts=pts)
+    return plain_nerf_from_pts(params, pts + rigid_dp, ts, r_o, r_d, refl_kind, act, bg, aux=aux,
+                               prefix="canonical.")
+
+
+# ----------------------------------------------------------------------------- test()-style frame
+
+
+def mse2psnr(mse):
+    """src/utils.py:184."""
+    return -10 * torch.log10(mse)
+
+
+def render_tiled(model_fn, c2w, focal, size: int, crop_size: int):
+    """runner.py:879-892: tile loop, x over rows then y over cols, ragged last tile via slicing."""
+    got = torch.zeros(size, size, 3)
+    n = math.ceil(size / crop_size)
+    for x in range(n):
+        c0 = x * crop_size
+        for y in range(n):
+            c1 = y * crop_size
+            pos = pixel_grid(size, (c0, c1, crop_size, crop_size))
+            rays = nerf_camera_rays(pos, c2w, focal, size)
+            got[c0:c0 + crop_size, c1:c1 + crop_size, :] = model_fn(rays).squeeze(0)
+    return got
