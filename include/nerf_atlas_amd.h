@@ -1,0 +1,194 @@
+/*
+ * nerf_atlas_amd.h -- C ABI of the MI355X (gfx950) NeRF volume-rendering hot path.
+ *
+ * The reference (JulianKnodt/nerf_atlas) has no FFI: its "operator API" is the Python
+ * protocol of src/cameras.py, src/nerf.py, src/neural_blocks.py.  Each
+ * entry point below replaces one reference operator (file:line cited per function) and is
+ * what a reference-side ctypes stub would bind.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer owned by the
+ *    caller (PyTorch allocates); the library never allocates or frees caller memory.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream).  No hidden synchronisation.
+ *  - Return 0 on success, a negative NA_E* code otherwise; na_last_error() gives a
+ *    thread-local message.
+ *  - Layouts follow the reference: sample tensors are T-major ([T, R, ...], R = B*H*W rays).
+ */
+#ifndef NERF_ATLAS_AMD_H
+#define NERF_ATLAS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NA_VERSION 100 /* 0.1.0 */
+
+enum {
+  NA_OK = 0,
+  NA_EINVAL = -1,      /* bad shape / argument */
+  NA_ENULL = -2,       /* required pointer is NULL */
+  NA_EUNSUPPORTED = -3,/* shape or kind has no kernel */
+  NA_EHIP = -4,        /* HIP runtime error (launch failed) */
+  NA_EWORKSPACE = -5   /* workspace too small */
+};
+
+/* activation applied to the INPUT of every hidden Linear and of `out` (src/neural_blocks.py:290-296) */
+enum { NA_ACT_NONE = 0, NA_ACT_LEAKY_RELU = 1, NA_ACT_SIN = 2 };
+/* encoder fused in front of a SkipConnMLP */
+enum { NA_ENC_NONE = 0, NA_ENC_HASH = 1, NA_ENC_FOURIER = 2 };
+/* MLP arithmetic */
+enum {
+  NA_PREC_BF16 = 0,   /* bf16 operands, fp32 accumulate (1 MFMA product)            */
+  NA_PREC_BF16X3 = 1  /* 2-way split bf16, 3 MFMA products, fp32-class accuracy     */
+};
+/* weight-stream layouts */
+enum { NA_LAYOUT_GENERIC = 0, NA_LAYOUT_PLAIN_FIRST = 1, NA_LAYOUT_PLAIN_VIEW = 2 };
+/* density -> sigma (src/nerf.py:64-65) */
+enum { NA_DENSITY_SOFTPLUS_M1 = 0, NA_DENSITY_RELU = 1 };
+/* background (src/nerf.py:96-109) */
+enum { NA_BG_BLACK = 0, NA_BG_WHITE = 1 };
+/* colour-head activations, src/utils.py:484-518 sigmoid_kinds */
+enum {
+  NA_SIG_NORMAL = 0, NA_SIG_THIN = 1, NA_SIG_FAT = 2, NA_SIG_TANH = 3, NA_SIG_UPSHIFTED = 4,
+  NA_SIG_RELU = 5, NA_SIG_SIN = 6, NA_SIG_LEAKY_RELU = 7, NA_SIG_UPSHIFTED_SOFTPLUS = 8,
+  NA_SIG_UPSHIFTED_RELU = 9, NA_SIG_CYCLIC = 10, NA_SIG_IDENTITY = 11
+};
+
+int na_version(void);
+const char* na_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1+A2  pixel grid + NeRFCamera.sample_positions   (runner.py:490-503, src/cameras.py:45-66)
+ * rays[b, r, c, :] for the crop rows crop_t..crop_t+crop_h, cols crop_l..crop_l+crop_w of a
+ * size x size image (the crop is clipped to the image like the reference's slicing, so the
+ * caller passes the clipped h,w).  noise: NULL, or [h,w,2] uniform[0,1) draws (u then v)
+ * used as (noise-0.5)*with_noise  (replaces the reference's global-RNG rand_like).
+ * rays: [B, h, w, 6] = origin | un-normalised direction.                                      */
+int na_raygen(const float* c2w /*[B,3,4]*/, int B, float focal, int size,
+              int crop_t, int crop_l, int crop_h, int crop_w,
+              const float* noise, float with_noise, float* rays, void* stream);
+
+/* A2' DTUCamera.sample_positions + lift  (src/cameras.py:159-223); rays [B, h, w, 6] with
+ * normalised directions; pose/intrinsic [B,4,4].                                              */
+int na_raygen_dtu(const float* pose, const float* intrinsic, int B, int size,
+                  int crop_t, int crop_l, int crop_h, int crop_w, float* rays, void* stream);
+
+/* A3 compute_ts (src/nerf.py:29-47).  rand: NULL or device [T] uniform draws (perturb>0).
+ * ts: [T]; mids: NULL or [T-1].                                                               */
+int na_compute_ts(float near, float far, int T, int lindisp, float perturb, const float* rand,
+                  float* ts, float* mids, void* stream);
+
+/* A3 compute_pts_ts (src/nerf.py:50-55): pts[t, r, :] = r_o[r] + ts[t] * r_d[r].
+ * rays [R,6]; pts [T,R,3].                                                                    */
+int na_compute_pts(const float* rays, const float* ts, int T, int64_t R, float* pts, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A5 HashEncoder.forward (src/neural_blocks.py:139-193).  x [N,3]; tables [8,65536,4] fp32;
+ * out [N, 32 + 3*include_input]; idx_out: NULL or int64 [8 levels, 8 corners, N] table rows
+ * (bit-exact int64 hashing).                                                                  */
+int na_hash_encode(const float* x, int64_t N, const float* tables, int include_input,
+                   float* out, int64_t* idx_out, void* stream);
+
+/* A5' FourierEncoder.forward / fourier (src/neural_blocks.py:52, src/utils.py:14-17).
+ * basis [D,F] (already multiplied by extra_scale by the caller or pass scale); out [N,2F].    */
+int na_fourier_encode(const float* x, int64_t N, int D, const float* basis, int F, float scale,
+                      float* out, void* stream);
+
+/* PositionalEncoder.forward (src/neural_blocks.py:30-34): out [N, 2*D*NB].                     */
+int na_positional_encode(const float* x, int64_t N, int D, const float* bands, int NB,
+                         float* out, void* stream);
+
+/* A7 dir_to_elev_azim (src/utils.py:247-254): dirs [N,3] -> out [N,2].                         */
+int na_view_elaz(const float* dirs, int64_t N, float* out, void* stream);
+
+/* sigmoid_kinds (src/utils.py:484-518) elementwise, in place allowed.                          */
+int na_sigmoid(const float* x, int64_t N, int kind, float* out, void* stream);
+
+/* A6 mip integrated positional encoding, intended layout: rays [B*H*W,6] of an
+ * H x W crop (radii_x differences rows), ts [T]; kind 0 = cylinder, 1 = cone; t_end = upper
+ * bound of the last interval; out [T, B*H*W, 6*(max_deg-min_deg)].                            */
+int na_mip_encode(const float* rays, int B, int H, int W, const float* ts, int T, int kind,
+                  float t_end, int min_deg, int max_deg, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A8 alpha_from_density + volumetric_integrate + sky (src/nerf.py:22-27,60-80,96-109).
+ * density [T,R]; feat [T,R,C]; ts [T]; rays [R,6] (direction norm scales the intervals, Q1);
+ * alpha/weights: NULL or [T,R]; out [R,C].                                                    */
+int na_composite(const float* density, const float* feat, const float* ts, const float* rays,
+                 int T, int64_t R, int C, int density_kind, int bg_kind,
+                 float* alpha, float* weights, float* out, void* stream);
+
+/* volumetric_integrate(weights, other) alone (src/nerf.py:79-80; depth/flow maps,
+ * runner.py:894-920): weights [T,R], other [T,R,C] -> out [R,C].                              */
+int na_integrate(const float* weights, const float* other, int T, int64_t R, int C, float* out,
+                 void* stream);
+
+/* A12 VolSDF density = 1/beta * laplace_cdf(-sdf, beta) (src/utils.py:50-58, src/nerf.py:1000-1003);
+ * beta is a device scalar (learned parameter).                                                */
+int na_laplace_density(const float* sdf, int64_t N, const float* beta, float* density, void* stream);
+
+/* A11 spline warp (src/nerf.py:1173-1178,1201-1206,1267-1278): est [N, 1+3n] = rigidity | n
+ * control points; t [N] (or per-view broadcast via t_stride 0... caller expands); pts [N,3].
+ * out_pts = pts + bezier(t) * sigmoid(rigidity/2); optional dp, rigidity_out [N,3],[N].       */
+int na_bezier_warp(const float* est, int est_stride, const float* pts, const float* t, int64_t N,
+                   int n_ctrl, float* out_pts, float* dp, float* rigidity_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4 SkipConnMLP (src/neural_blocks.py:204-296).
+ *
+ * Exact-fp32 Linear used for any layer shape: y[N,out] = W[out,in] . act(x[N,in]) + b
+ * (f32 MFMA, v_mfma_f32_32x32x2_f32 -- bitwise an fp32 fma chain).  x may be the concatenation
+ * of two buffers (skip connection): x = [x0 (in0 cols) | x1 (in1 cols)].                      */
+int na_linear_f32(const float* x0, int in0, const float* x1, int in1, int64_t N,
+                  const float* W, const float* b, int out, int pre_act, float* y, void* stream);
+
+typedef struct NaMlpDesc {
+  int32_t in_size;     /* raw input width (p)                                         */
+  int32_t enc_kind;    /* NA_ENC_*                                                    */
+  int32_t enc_dims;    /* encoder output width (35 hash, 2F fourier, 0 none)          */
+  int32_t latent_size; /* extra per-sample latent columns                             */
+  int32_t num_layers;  /* hidden Linear count L (src/neural_blocks.py:240-244)        */
+  int32_t hidden;      /* hidden width; the MFMA path requires 256                    */
+  int32_t out_size;
+  int32_t skip;        /* 3                                                           */
+  int32_t activation;  /* NA_ACT_LEAKY_RELU | NA_ACT_SIN                              */
+  int32_t layout;      /* NA_LAYOUT_*: GENERIC for na_mlp_forward; the PLAIN_* values
+                          re-order rows/columns for na_render_plain_view               */
+} NaMlpDesc;
+
+/* Fused MFMA SkipConnMLP: weights are re-laid out once into the MFMA A-fragment stream
+ * (bf16 hi [+ lo]) that the kernel DMA-streams through LDS.
+ *   na_mlp_packed_bytes : size of that stream for (desc, precision); 0 if unsupported.
+ *   na_mlp_pack         : device-side pack.  weights/biases: HOST arrays of L+2 DEVICE pointers
+ *                         in the order init, layers[0..L-1], out  (nn.Linear layout [out,in]).
+ *   na_mlp_forward      : p [N,in_size]; latent [N,latent_size] or NULL; enc_params: hash tables
+ *                         [8,65536,4] or Fourier basis [D,F] or NULL; y [N,out_size].          */
+size_t na_mlp_packed_bytes(const NaMlpDesc* desc, int precision);
+int na_mlp_pack(const NaMlpDesc* desc, int precision, const float* const* weights,
+                const float* const* biases, void* packed, void* stream);
+int na_mlp_forward(const NaMlpDesc* desc, int precision, const void* packed,
+                   const float* p, const float* latent, const float* enc_params, int64_t N,
+                   float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A10 PlainNeRF.forward with the View head (src/nerf.py:326-361, src/refl.py:190-207), fully
+ * fused: sample -> hash encode -> first MLP -> elaz -> View MLP -> sigmoid -> composite.
+ *   rays [R,6]; ts [T]; hash tables [8,65536,4]; packed_first / packed_view from na_mlp_pack
+ *   (descs: first = {3,HASH,35,0,4,256,1+64,3,LEAKY,PLAIN_FIRST}, view = {5,NONE,0,64,4,256,3,3,SIN,PLAIN_VIEW}).
+ *   workspace: na_render_workspace_bytes(T,R) bytes of device scratch (per-(ray,block) partials).
+ *   alpha/weights: NULL or [T,R].  out [R,3].                                                 */
+size_t na_render_workspace_bytes(int T, int64_t R);
+int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T,
+                         const float* hash_tables, const void* packed_first, const void* packed_view,
+                         int precision, int sigmoid_kind, int bg_kind,
+                         float* alpha, float* weights, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_ATLAS_AMD_H */

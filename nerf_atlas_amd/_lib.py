@@ -1,0 +1,97 @@
+"""ctypes loader for libnerf_atlas_amd.so (the C ABI of include/nerf_atlas_amd.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared object is missing
+(or a symbol of the header is missing from it) importing ops raises immediately.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnerf_atlas_amd.so")
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+c_i64 = C.c_int64
+
+
+class NaMlpDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "in_size", "enc_kind", "enc_dims", "latent_size", "num_layers", "hidden", "out_size", "skip",
+        "activation", "layout")]
+
+
+# name -> (restype, argtypes); mirrors include/nerf_atlas_amd.h one to one
+SIGNATURES = {
+    "na_version": (C.c_int, []),
+    "na_last_error": (C.c_char_p, []),
+    "na_raygen": (C.c_int, [c_f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+                            C.c_float, c_f32p, C.c_void_p]),
+    "na_raygen_dtu": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+                                C.c_void_p]),
+    "na_compute_ts": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,
+                                C.c_void_p]),
+    "na_compute_pts": (C.c_int, [c_f32p, c_f32p, C.c_int, c_i64, c_f32p, C.c_void_p]),
+    "na_hash_encode": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p]),
+    "na_fourier_encode": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    "na_positional_encode": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_view_elaz": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
+    "na_sigmoid": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_mip_encode": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                C.c_int, c_f32p, C.c_void_p]),
+    "na_composite": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, c_f32p,
+                               c_f32p, c_f32p, C.c_void_p]),
+    "na_integrate": (C.c_int, [c_f32p, c_f32p, C.c_int, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_laplace_density": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),
+    "na_bezier_warp": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_f32p,
+                                 C.c_void_p]),
+    "na_linear_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p,
+                                C.c_void_p]),
+    "na_mlp_packed_bytes": (C.c_size_t, [C.POINTER(NaMlpDesc), C.c_int]),
+    "na_mlp_pack": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                              C.c_void_p, C.c_void_p]),
+    "na_mlp_forward": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p,
+                                 C.c_void_p]),
+    "na_render_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),
+    "na_render_plain_view": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]),
+}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (after torch, so both share one libamdhip64)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is the only implementation of the hot path. "
+            "Build it with `python -m nerf_atlas_amd.build` (or __graft_entry__.build()).")
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryMissing(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class NaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nerf_atlas_amd error {code}: {msg}")
+        self.code = code
+
+
+def check(code):
+    if code != 0:
+        msg = load().na_last_error()
+        raise NaError(code, msg.decode() if msg else "")

@@ -1,0 +1,546 @@
+// Memory-bound operators of the hot path (ray generation, sampling, encoders, compositing).
+// Built with -ffp-contract=off: every rounding matches the reference's separate fp32 ops unless a
+// fused multiply-add is written explicitly (torch's CPU linspace uses one).
+#include "common.h"
+#include <math.h>
+#include <string.h>
+
+namespace na {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+HashRes hash_resolutions() {
+  HashRes r;
+  const double scale = exp((log(16384.0) - log(16.0)) / 8.0 - 1.0);
+  double p = 1.0;
+  for (int i = 0; i < 8; ++i) {
+    r.n[i] = (float)(16.0 * pow(scale, (double)i));
+    (void)p;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------ raygen
+// runner.py:490-503 (positions[r,c] = (u=c, v=r)) + src/cameras.py:45-66.
+__global__ void raygen_kernel(const float* __restrict__ c2w, int B, float focal, float half, int t0, int l0,
+                              int h, int w, const float* __restrict__ noise, float with_noise,
+                              float* __restrict__ rays) {
+  int64_t total = (int64_t)B * h * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % w);
+    int r = (int)((i / w) % h);
+    int b = (int)(i / ((int64_t)w * h));
+    float u = (float)(l0 + c), v = (float)(t0 + r);
+    if (noise != nullptr) {
+      const float* nz = noise + ((int64_t)r * w + c) * 2;
+      u = u + (nz[0] - 0.5f) * with_noise;
+      v = v + (nz[1] - 0.5f) * with_noise;
+    }
+    float d0 = (u - half) / focal;
+    float d1 = -(v - half) / focal;
+    float d2 = -1.0f;
+    const float* M = c2w + (int64_t)b * 12;
+    float* o = rays + i * 6;
+    o[0] = M[3];
+    o[1] = M[7];
+    o[2] = M[11];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float p0 = d0 * M[k * 4 + 0], p1 = d1 * M[k * 4 + 1], p2 = d2 * M[k * 4 + 2];
+      o[3 + k] = (p0 + p1) + p2;
+    }
+  }
+}
+
+// src/cameras.py:159-223 DTUCamera (pose-matrix branch).  Output layout [B, h, w, 6] with the crop's
+// first axis as "W" exactly like the reference's reshape(N, W, H, 6).
+__global__ void raygen_dtu_kernel(const float* __restrict__ pose, const float* __restrict__ intr, int B, int size,
+                                  int t0, int l0, int h, int w, float* __restrict__ rays) {
+  int64_t total = (int64_t)B * h * w;
+  const float nx = 1600.0f / (float)size, ny = 1200.0f / (float)size;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % w);
+    int r = (int)((i / w) % h);
+    int b = (int)(i / ((int64_t)w * h));
+    float u = (float)(l0 + c) * nx, v = (float)(t0 + r) * ny;
+    const float* K = intr + (int64_t)b * 16;
+    const float* P = pose + (int64_t)b * 16;
+    float fx = K[0], fy = K[5], cx = K[2], cy = K[6], sk = K[1];
+    float z = 1.0f;
+    float xl = (((u - cx) + cy * sk / fy) - sk * v / fy) / fx * z;
+    float yl = (v - cy) / fy * z;
+    float pt[4] = {xl, yl, z, 1.0f};
+    float wc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      // torch.bmm row . column, accumulated in index order
+      float acc = P[k * 4 + 0] * pt[0];
+      acc = acc + P[k * 4 + 1] * pt[1];
+      acc = acc + P[k * 4 + 2] * pt[2];
+      acc = acc + P[k * 4 + 3] * pt[3];
+      wc[k] = acc;
+    }
+    float ox = P[3], oy = P[7], oz = P[11];
+    float dx = wc[0] - ox, dy = wc[1] - oy, dz = wc[2] - oz;
+    float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+    float* o = rays + i * 6;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+    o[3] = dx / nrm; o[4] = dy / nrm; o[5] = dz / nrm;
+  }
+}
+
+// ------------------------------------------------------------------------------------ sampling
+// src/nerf.py:29-47.  torch's CPU linspace: step=(end-start)/(steps-1); first half start+step*i,
+// second half end-step*(steps-1-i), each with ONE rounding (fma) -- probed, see DESIGN.md.
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  float step = (end - start) / (float)(steps - 1);
+  if (i < steps / 2) return fmaf(step, (float)i, start);
+  return fmaf(-step, (float)(steps - 1 - i), end);
+}
+
+__device__ __forceinline__ float ts_base(float near, float far, float inv_near, float inv_far, int T, int lindisp, int i) {
+  if (lindisp) {
+    float tv = linspace_at(0.f, 1.f, T, i);
+    return 1.0f / (inv_near * (1.0f - tv) + inv_far * tv);
+  }
+  return linspace_at(near, far, T, i);
+}
+
+__global__ void compute_ts_kernel(float near, float far, float inv_near, float inv_far, int T, int lindisp,
+                                  float perturb, const float* __restrict__ rand, float* __restrict__ ts,
+                                  float* __restrict__ mids) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  float t = ts_base(near, far, inv_near, inv_far, T, lindisp, i);
+  if (perturb > 0.f) {
+    float tp = i > 0 ? ts_base(near, far, inv_near, inv_far, T, lindisp, i - 1) : t;
+    float tn = i < T - 1 ? ts_base(near, far, inv_near, inv_far, T, lindisp, i + 1) : t;
+    float mid_lo = 0.5f * (tp + t);  // mids[i-1]
+    float mid_hi = 0.5f * (t + tn);  // mids[i]
+    float lower = i < T - 1 ? mid_hi : t;  // cat([mids, ts[-1:]])
+    float upper = i > 0 ? mid_lo : t;      // cat([ts[:1], mids])
+    if (mids != nullptr && i < T - 1) mids[i] = mid_hi;
+    t = lower + (upper - lower) * (rand[i] * perturb);
+  }
+  ts[i] = t;
+}
+
+// src/nerf.py:53: pts = r_o + ts (x) r_d, T-major [T,R,3]
+__global__ void compute_pts_kernel(const float* __restrict__ rays, const float* __restrict__ ts, int T, int64_t R,
+                                   float* __restrict__ pts) {
+  int64_t total = (int64_t)T * R;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i % R;
+    int t = (int)(i / R);
+    const float* ry = rays + r * 6;
+    float tt = ts[t];
+    float* o = pts + i * 3;
+    o[0] = ry[0] + tt * ry[3];
+    o[1] = ry[1] + tt * ry[4];
+    o[2] = ry[2] + tt * ry[5];
+  }
+}
+
+// ------------------------------------------------------------------------------------ hash encoder
+// src/neural_blocks.py:139-193.  One thread per (sample, level): 8 float4 gathers from a 1 MiB table.
+__global__ void hash_encode_kernel(const float* __restrict__ x, int64_t N, const float4* __restrict__ tables,
+                                   HashRes res, int include_input, float* __restrict__ out,
+                                   int64_t* __restrict__ idx_out) {
+  const int odim = 32 + 3 * include_input;
+  int64_t total = N * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int lvl = (int)(i & 7);
+    int64_t n = i >> 3;
+    float px = x[n * 3 + 0], py = x[n * 3 + 1], pz = x[n * 3 + 2];
+    float Nl = res.n[lvl];
+    float vx = px * Nl, vy = py * Nl, vz = pz * Nl;
+    float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
+    int lx = (int)fx, ly = (int)fy, lz = (int)fz;
+    float wx = vx - fx, wy = vy - fy, wz = vz - fz;
+    float iwx = 1.f - wx, iwy = 1.f - wy, iwz = 1.f - wz;
+    const float4* tab = tables + (int64_t)lvl * 65536;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      // corner order of the reference: bit2 = x high, bit1 = y high, bit0 = z high
+      int cx = lx + ((c >> 2) & 1), cy = ly + ((c >> 1) & 1), cz = lz + (c & 1);
+      uint32_t id = hash_index(cx, cy, cz);
+      if (idx_out != nullptr) idx_out[((int64_t)lvl * 8 + c) * N + n] = (int64_t)id;
+      float w = (((c >> 2) & 1) ? wx : iwx) * (((c >> 1) & 1) ? wy : iwy) * ((c & 1) ? wz : iwz);
+      float4 e = tab[id];
+      if (c == 0) {
+        acc.x = e.x * w; acc.y = e.y * w; acc.z = e.z * w; acc.w = e.w * w;
+      } else {
+        acc.x = acc.x + e.x * w; acc.y = acc.y + e.y * w; acc.z = acc.z + e.z * w; acc.w = acc.w + e.w * w;
+      }
+    }
+    float* o = out + n * odim + 3 * include_input + lvl * 4;
+    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+    if (include_input && lvl == 0) {
+      out[n * odim + 0] = px; out[n * odim + 1] = py; out[n * odim + 2] = pz;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ fourier / positional
+// src/utils.py:14-17: [sin(x@B) | cos(x@B)], accurate sinf/cosf (arguments reach 1e3).
+__global__ void fourier_kernel(const float* __restrict__ x, int64_t N, int D, const float* __restrict__ basis, int F,
+                               float scale, float* __restrict__ out) {
+  int64_t total = N * F;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int j = (int)(i % F);
+    int64_t n = i / F;
+    float m = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float b = scale == 1.0f ? basis[d * F + j] : scale * basis[d * F + j];
+      m = d == 0 ? x[n * D + d] * b : fmaf(x[n * D + d], b, m);
+    }
+    out[n * 2 * F + j] = sinf(m);
+    out[n * 2 * F + F + j] = cosf(m);
+  }
+}
+
+// src/neural_blocks.py:30-34: raw[n, d*NB + k] = x[n,d]*bands[k]; out = [sin(raw) | cos(raw)]
+__global__ void positional_kernel(const float* __restrict__ x, int64_t N, int D, const float* __restrict__ bands, int NB,
+                                  float* __restrict__ out) {
+  int W = D * NB;
+  int64_t total = N * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int j = (int)(i % W);
+    int64_t n = i / W;
+    float raw = x[n * D + j / NB] * bands[j % NB];
+    out[n * 2 * W + j] = sinf(raw);
+    out[n * 2 * W + W + j] = cosf(raw);
+  }
+}
+
+__global__ void elaz_kernel(const float* __restrict__ d, int64_t N, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    float e, a;
+    elev_azim(d[i * 3], d[i * 3 + 1], d[i * 3 + 2], e, a);
+    out[i * 2] = e;
+    out[i * 2 + 1] = a;
+  }
+}
+
+__global__ void sigmoid_kernel(const float* __restrict__ x, int64_t N, int kind, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = apply_sigmoid_kind(x[i], kind);
+}
+
+// ------------------------------------------------------------------------------------ mip IPE (intended layout)
+// src/utils.py:23-27,39-48,60-101 with cov laid out like mean ([T,B,H,W,3]); radii_x differences rows of
+// the crop (src/utils.py:77-81; the appended last row repeats the second-to-last difference).
+__global__ void mip_kernel(const float* __restrict__ rays, int B, int H, int W, const float* __restrict__ ts, int T,
+                           int kind, float t_end, int min_deg, int max_deg, float* __restrict__ out) {
+  const int nd = max_deg - min_deg;
+  const int F = 6 * nd;
+  int64_t R = (int64_t)B * H * W;
+  int64_t total = (int64_t)T * R;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i % R;
+    int t = (int)(i / R);
+    int wq = (int)(r % W);
+    int hq = (int)((r / W) % H);
+    int b = (int)(r / ((int64_t)W * H));
+    // radii_x: rows hq and hq+1 (last row: rows H-2... the reference appends dx[:, -2:-1], i.e. the
+    // difference of rows H-3 and H-2 when H>=3)
+    int h0 = hq < H - 1 ? hq : H - 3;
+    if (h0 < 0) h0 = 0;
+    const float* ra = rays + (((int64_t)b * H + h0) * W + wq) * 6 + 3;
+    const float* rb = rays + (((int64_t)b * H + h0 + 1) * W + wq) * 6 + 3;
+    float e0 = ra[0] - rb[0], e1 = ra[1] - rb[1], e2 = ra[2] - rb[2];
+    float rad = sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * 2.0f / 3.4641016151377544f;
+    const float* ry = rays + r * 6;
+    float t0 = ts[t], t1 = t < T - 1 ? ts[t + 1] : t_end;
+    float t_mean, t_var, r_var;
+    if (kind == 0) {
+      t_mean = (t1 + t0) / 2.f;
+      r_var = rad * rad / 4.f;
+      float dt = t1 - t0;
+      t_var = dt * dt / 12.f;
+    } else {
+      float mu = (t1 + t0) / 2.f, hw = (t1 - t0) / 2.f;
+      float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+      float den = 3.f * mu2 + hw2;
+      t_mean = mu + (2.f * mu * hw2) / den;
+      t_var = hw / 3.f - (4.f / 15.f) * ((hw4 * (12.f * mu2 - hw2)) / (den * den));
+      r_var = rad * rad * (mu2 / 4.f + (5.f / 12.f) * hw2 - 4.f / 15.f * hw4 / den);
+    }
+    float dsq[3] = {ry[3] * ry[3], ry[4] * ry[4], ry[5] * ry[5]};
+    float magn = fmaxf((dsq[0] + dsq[1]) + dsq[2], 1e-10f);
+    float* o = out + i * F;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float mean = ry[3 + a] * t_mean + ry[a];
+      float cov = t_var * dsq[a] + r_var * (1.f - dsq[a] / magn);
+      for (int k = 0; k < nd; ++k) {
+        float sc = exp2f((float)(min_deg + k));
+        float y = mean * sc;
+        float yv = cov * (sc * sc);
+        float damp = expf(-0.5f * yv);
+        o[k * 3 + a] = damp * sinf(y);
+        o[3 * nd + k * 3 + a] = damp * sinf(y + 0.5f * 3.14159265358979323846f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ compositing
+// src/nerf.py:22-27,60-80,96-98.  One thread per ray walks T in order (T-major => every step is a
+// coalesced row read); the running product is the reference's cumprod association exactly.
+template <int C>
+__global__ void composite_kernel(const float* __restrict__ density, const float* __restrict__ feat,
+                                 const float* __restrict__ ts, const float* __restrict__ rays, int T, int64_t R,
+                                 int density_kind, int bg_kind, float* __restrict__ alpha_out,
+                                 float* __restrict__ weights_out, float* __restrict__ out, int Crt) {
+  const int CC = C > 0 ? C : Crt;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    const float* ry = rays + r * 6 + 3;
+    float nrm = sqrtf((ry[0] * ry[0] + ry[1] * ry[1]) + ry[2] * ry[2]);
+    float trans = 1.0f;
+    float acc[C > 0 ? C : 8];
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    float wsum_head = 0.f;  // sum of weights[:-1] for the white background (Q4)
+    for (int t = 0; t < T; ++t) {
+      float d = density[(int64_t)t * R + r];
+      float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
+      float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
+      dist = dist * nrm;
+      float a = 1.0f - expf(-sigma * dist);
+      float w = a * trans;
+      trans = trans * ((1.0f - a) + 1e-10f);
+      if (alpha_out != nullptr) alpha_out[(int64_t)t * R + r] = a;
+      if (weights_out != nullptr) weights_out[(int64_t)t * R + r] = w;
+      const float* f = feat + ((int64_t)t * R + r) * CC;
+      for (int c = 0; c < CC; ++c) acc[c] = acc[c] + w * f[c];
+      if (t < T - 1) wsum_head = wsum_head + w;
+    }
+    float sky = bg_kind == NA_BG_WHITE ? 1.0f - wsum_head : 0.f;
+    for (int c = 0; c < CC; ++c) out[r * CC + c] = acc[c] + sky;
+  }
+}
+
+__global__ void integrate_kernel(const float* __restrict__ weights, const float* __restrict__ other, int T, int64_t R,
+                                 int C, float* __restrict__ out) {
+  int64_t total = R * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / C;
+    int c = (int)(i % C);
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc = acc + weights[(int64_t)t * R + r] * other[((int64_t)t * R + r) * C + c];
+    out[i] = acc;
+  }
+}
+
+// src/utils.py:50-58 + src/nerf.py:1000-1003
+__global__ void laplace_density_kernel(const float* __restrict__ sdf, int64_t N, const float* __restrict__ beta,
+                                       float* __restrict__ density) {
+  float sc = beta[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    float scaled = (-sdf[i]) / sc;
+    float cdf = scaled <= 0.f ? expf(fminf(scaled, 0.f)) / 2.f : 1.f - expf(-fmaxf(scaled, 0.f)) / 2.f;
+    density[i] = (1.0f / sc) * cdf;
+  }
+}
+
+// src/nerf.py:1173-1178 (de Casteljau), 1201-1206 (cubic), 1267-1278 (warp)
+__global__ void bezier_warp_kernel(const float* __restrict__ est, int est_stride, const float* __restrict__ pts,
+                                   const float* __restrict__ tt, int64_t N, int n, float* __restrict__ out_pts,
+                                   float* __restrict__ dp_out, float* __restrict__ rig_out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* e = est + i * est_stride;
+    float rig = sigmoidf_(e[0] / 2.f);
+    float t = tt[i], m1t = 1.f - t;
+    float dp[3];
+    if (n == 4) {
+      float m2 = m1t * m1t, t2 = t * t;
+      float k0 = m2 * m1t, k1 = 3.f * m2 * t, k2 = 3.f * t2 * m1t, k3 = t2 * t;
+      for (int a = 0; a < 3; ++a)
+        dp[a] = ((k0 * e[1 + a] + k1 * e[4 + a]) + k2 * e[7 + a]) + k3 * e[10 + a];
+    } else {
+      float b[8][3];
+      for (int k = 0; k < n; ++k)
+        for (int a = 0; a < 3; ++a) b[k][a] = e[1 + 3 * k + a];
+      for (int it = 1; it < n; ++it)
+        for (int k = 0; k < n - it; ++k)
+          for (int a = 0; a < 3; ++a) b[k][a] = b[k][a] * m1t + b[k + 1][a] * t;
+      for (int a = 0; a < 3; ++a) dp[a] = b[0][a];
+    }
+    for (int a = 0; a < 3; ++a) {
+      out_pts[i * 3 + a] = pts[i * 3 + a] + dp[a] * rig;
+      if (dp_out != nullptr) dp_out[i * 3 + a] = dp[a];
+    }
+    if (rig_out != nullptr) rig_out[i] = rig;
+  }
+}
+
+}  // namespace na
+
+// ================================================================================================ C ABI
+using namespace na;
+
+extern "C" {
+
+int na_version(void) { return NA_VERSION; }
+const char* na_last_error(void) { return na::g_err; }
+
+int na_raygen(const float* c2w, int B, float focal, int size, int crop_t, int crop_l, int crop_h, int crop_w,
+              const float* noise, float with_noise, float* rays, void* stream) {
+  NA_REQUIRE(c2w && rays, NA_ENULL, "na_raygen: null pointer");
+  NA_REQUIRE(B > 0 && size > 0 && crop_h >= 0 && crop_w >= 0 && crop_t >= 0 && crop_l >= 0, NA_EINVAL,
+             "na_raygen: bad shape B=%d size=%d crop=(%d,%d,%d,%d)", B, size, crop_t, crop_l, crop_h, crop_w);
+  NA_REQUIRE(crop_t + crop_h <= size && crop_l + crop_w <= size, NA_EINVAL,
+             "na_raygen: crop (%d,%d,%d,%d) exceeds image %d (clip it like the reference's slicing)", crop_t, crop_l,
+             crop_h, crop_w, size);
+  int64_t total = (int64_t)B * crop_h * crop_w;
+  if (total == 0) return NA_OK;
+  const float* nz = (noise != nullptr && with_noise != 0.f) ? noise : nullptr;
+  hipLaunchKernelGGL(raygen_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, c2w, B, focal,
+                     (float)(size * 0.5), crop_t, crop_l, crop_h, crop_w, nz, with_noise, rays);
+  return check_launch("na_raygen");
+}
+
+int na_raygen_dtu(const float* pose, const float* intrinsic, int B, int size, int crop_t, int crop_l, int crop_h,
+                  int crop_w, float* rays, void* stream) {
+  NA_REQUIRE(pose && intrinsic && rays, NA_ENULL, "na_raygen_dtu: null pointer");
+  NA_REQUIRE(B > 0 && size > 0 && crop_h >= 0 && crop_w >= 0, NA_EINVAL, "na_raygen_dtu: bad shape");
+  int64_t total = (int64_t)B * crop_h * crop_w;
+  if (total == 0) return NA_OK;
+  hipLaunchKernelGGL(raygen_dtu_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, pose,
+                     intrinsic, B, size, crop_t, crop_l, crop_h, crop_w, rays);
+  return check_launch("na_raygen_dtu");
+}
+
+int na_compute_ts(float near, float far, int T, int lindisp, float perturb, const float* rand, float* ts, float* mids,
+                  void* stream) {
+  NA_REQUIRE(ts, NA_ENULL, "na_compute_ts: null ts");
+  NA_REQUIRE(T >= 1, NA_EINVAL, "na_compute_ts: T=%d", T);
+  NA_REQUIRE(!(perturb > 0.f) || rand != nullptr, NA_ENULL, "na_compute_ts: perturb>0 needs rand[T]");
+  float inv_near = (float)(1.0 / fmax((double)near, 1e-10));
+  float inv_far = (float)(1.0 / (double)far);
+  hipLaunchKernelGGL(compute_ts_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, near, far, inv_near,
+                     inv_far, T, lindisp, perturb, rand, ts, mids);
+  return check_launch("na_compute_ts");
+}
+
+int na_compute_pts(const float* rays, const float* ts, int T, int64_t R, float* pts, void* stream) {
+  NA_REQUIRE(rays && ts && pts, NA_ENULL, "na_compute_pts: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_compute_pts: bad shape");
+  if (R == 0) return NA_OK;
+  hipLaunchKernelGGL(compute_pts_kernel, dim3(grid_for((int64_t)T * R, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     rays, ts, T, R, pts);
+  return check_launch("na_compute_pts");
+}
+
+int na_hash_encode(const float* x, int64_t N, const float* tables, int include_input, float* out, int64_t* idx_out,
+                   void* stream) {
+  NA_REQUIRE(x && tables && out, NA_ENULL, "na_hash_encode: null pointer");
+  NA_REQUIRE(N >= 0, NA_EINVAL, "na_hash_encode: N=%lld", (long long)N);
+  if (N == 0) return NA_OK;
+  hipLaunchKernelGGL(hash_encode_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
+                     (const float4*)tables, hash_resolutions(), include_input ? 1 : 0, out, idx_out);
+  return check_launch("na_hash_encode");
+}
+
+int na_fourier_encode(const float* x, int64_t N, int D, const float* basis, int F, float scale, float* out,
+                      void* stream) {
+  NA_REQUIRE(x && basis && out, NA_ENULL, "na_fourier_encode: null pointer");
+  NA_REQUIRE(N >= 0 && D >= 1 && F >= 1, NA_EINVAL, "na_fourier_encode: bad shape");
+  if (N == 0) return NA_OK;
+  hipLaunchKernelGGL(fourier_kernel, dim3(grid_for(N * F, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D, basis,
+                     F, scale, out);
+  return check_launch("na_fourier_encode");
+}
+
+int na_positional_encode(const float* x, int64_t N, int D, const float* bands, int NB, float* out, void* stream) {
+  NA_REQUIRE(x && bands && out, NA_ENULL, "na_positional_encode: null pointer");
+  NA_REQUIRE(N >= 0 && D >= 1 && NB >= 1, NA_EINVAL, "na_positional_encode: bad shape");
+  if (N == 0) return NA_OK;
+  hipLaunchKernelGGL(positional_kernel, dim3(grid_for(N * D * NB, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
+                     D, bands, NB, out);
+  return check_launch("na_positional_encode");
+}
+
+int na_view_elaz(const float* dirs, int64_t N, float* out, void* stream) {
+  NA_REQUIRE(dirs && out, NA_ENULL, "na_view_elaz: null pointer");
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(elaz_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dirs, N, out);
+  return check_launch("na_view_elaz");
+}
+
+int na_sigmoid(const float* x, int64_t N, int kind, float* out, void* stream) {
+  NA_REQUIRE(x && out, NA_ENULL, "na_sigmoid: null pointer");
+  NA_REQUIRE(kind >= 0 && kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_sigmoid: unknown kind %d", kind);
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, N, kind, out);
+  return check_launch("na_sigmoid");
+}
+
+int na_mip_encode(const float* rays, int B, int H, int W, const float* ts, int T, int kind, float t_end, int min_deg,
+                  int max_deg, float* out, void* stream) {
+  NA_REQUIRE(rays && ts && out, NA_ENULL, "na_mip_encode: null pointer");
+  NA_REQUIRE(B >= 1 && H >= 2 && W >= 1 && T >= 1 && max_deg > min_deg, NA_EINVAL,
+             "na_mip_encode: bad shape (radii_x needs H>=2 rows)");
+  NA_REQUIRE(kind == 0 || kind == 1, NA_EUNSUPPORTED, "na_mip_encode: kind %d", kind);
+  int64_t total = (int64_t)T * B * H * W;
+  hipLaunchKernelGGL(mip_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, rays, B, H, W, ts,
+                     T, kind, t_end, min_deg, max_deg, out);
+  return check_launch("na_mip_encode");
+}
+
+int na_composite(const float* density, const float* feat, const float* ts, const float* rays, int T, int64_t R, int C,
+                 int density_kind, int bg_kind, float* alpha, float* weights, float* out, void* stream) {
+  NA_REQUIRE(density && feat && ts && rays && out, NA_ENULL, "na_composite: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0 && C >= 1 && C <= 8, NA_EINVAL, "na_composite: bad shape T=%d R=%lld C=%d (C<=8)", T,
+             (long long)R, C);
+  NA_REQUIRE(density_kind == 0 || density_kind == 1, NA_EUNSUPPORTED, "na_composite: density kind %d", density_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_composite: bg kind %d", bg_kind);
+  if (R == 0) return NA_OK;
+  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
+  if (C == 3)
+    hipLaunchKernelGGL(composite_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R, density_kind,
+                       bg_kind, alpha, weights, out, C);
+  else
+    hipLaunchKernelGGL(composite_kernel<0>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R, density_kind,
+                       bg_kind, alpha, weights, out, C);
+  return check_launch("na_composite");
+}
+
+int na_integrate(const float* weights, const float* other, int T, int64_t R, int C, float* out, void* stream) {
+  NA_REQUIRE(weights && other && out, NA_ENULL, "na_integrate: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0 && C >= 1, NA_EINVAL, "na_integrate: bad shape");
+  if (R == 0) return NA_OK;
+  hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(R * C, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, weights,
+                     other, T, R, C, out);
+  return check_launch("na_integrate");
+}
+
+int na_laplace_density(const float* sdf, int64_t N, const float* beta, float* density, void* stream) {
+  NA_REQUIRE(sdf && beta && density, NA_ENULL, "na_laplace_density: null pointer");
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(laplace_density_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, sdf, N,
+                     beta, density);
+  return check_launch("na_laplace_density");
+}
+
+int na_bezier_warp(const float* est, int est_stride, const float* pts, const float* t, int64_t N, int n_ctrl,
+                   float* out_pts, float* dp, float* rigidity_out, void* stream) {
+  NA_REQUIRE(est && pts && t && out_pts, NA_ENULL, "na_bezier_warp: null pointer");
+  NA_REQUIRE(n_ctrl >= 2 && n_ctrl <= 8 && est_stride >= 1 + 3 * n_ctrl, NA_EINVAL,
+             "na_bezier_warp: n_ctrl=%d (2..8) stride=%d", n_ctrl, est_stride);
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(bezier_warp_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
+                     est_stride, pts, t, N, n_ctrl, out_pts, dp, rigidity_out);
+  return check_launch("na_bezier_warp");
+}
+
+}  // extern "C"

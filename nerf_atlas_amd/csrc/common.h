@@ -1,0 +1,86 @@
+// Shared helpers for the gfx950 kernels of nerf_atlas_amd (C-ABI: include/nerf_atlas_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/nerf_atlas_amd.h"
+
+namespace na {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return NA_EHIP;
+  }
+  return NA_OK;
+}
+
+#define NA_REQUIRE(cond, code, ...)      \
+  do {                                   \
+    if (!(cond)) {                       \
+      na::set_error(__VA_ARGS__);        \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+// Python-double level resolutions of the reference hash encoder (src/neural_blocks.py:126-128,146):
+// N_l = 16 * exp((ln 16384 - ln 16)/8 - 1)^l, then cast to fp32 when multiplied with the fp32 input.
+struct HashRes { float n[8]; };
+HashRes hash_resolutions();
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float leaky_relu(float v) { return v > 0.f ? v : v * 0.01f; }
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float softplusf_(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+__device__ __forceinline__ float apply_sigmoid_kind(float v, int kind) {
+  switch (kind) {
+    case NA_SIG_NORMAL: return sigmoidf_(v);
+    case NA_SIG_THIN: return (sigmoidf_(v) * (1.f + 2.f * -1e-2f) - -1e-2f) + 1e-2f;
+    case NA_SIG_FAT: return sigmoidf_(v) * (1.f + 2.f * 1e-2f) - 1e-2f;
+    case NA_SIG_TANH: return tanhf(v);
+    case NA_SIG_UPSHIFTED: return sigmoidf_(v) + 1e-2f;
+    case NA_SIG_RELU: return fmaxf(v, 0.f);
+    case NA_SIG_SIN: return sinf(v);
+    case NA_SIG_LEAKY_RELU: return leaky_relu(v);
+    case NA_SIG_UPSHIFTED_SOFTPLUS: return softplusf_(v) + 1e-2f;
+    case NA_SIG_UPSHIFTED_RELU: return fmaxf(v, 0.f) + 1e-2f;
+    case NA_SIG_CYCLIC: return (sinf(v / 5.f) + 1.f) / 2.f * (1.f + 2.f * -1e-2f) - -1e-2f;
+    default: return v;
+  }
+}
+
+// Reference hash (src/neural_blocks.py:135-139,166): ((x*1) ^ (y*2654435761) ^ (z*805459861)) mod 2^16
+// in int64 with a non-negative remainder.  Only the low 16 bits survive the mod and the low bits of
+// a two's-complement product/xor depend only on the low bits of the operands, so uint32 arithmetic
+// reproduces the int64 result bit for bit.
+__device__ __forceinline__ uint32_t hash_index(int lx, int ly, int lz) {
+  return (((uint32_t)lx) ^ ((uint32_t)ly * 2654435761u) ^ ((uint32_t)lz * 805459861u)) & 0xFFFFu;
+}
+
+// dir_to_elev_azim (src/utils.py:247-254)
+__device__ __forceinline__ void elev_azim(float dx, float dy, float dz, float& elev, float& azim) {
+  const float lim = 1.f - 1e-6f;
+  float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+  nrm = fmaxf(nrm, 1e-12f);
+  float x = fminf(fmaxf(dx / nrm, -lim), lim);
+  float y = fminf(fmaxf(dy / nrm, -lim), lim);
+  float z = fminf(fmaxf(dz / nrm, -lim), lim);
+  elev = acosf(z);
+  azim = atan2f(y, x);
+}
+
+}  // namespace na

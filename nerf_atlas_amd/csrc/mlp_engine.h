@@ -1,0 +1,288 @@
+// Register-resident fused SkipConnMLP engine for gfx950 (CDNA4).
+//
+// Design (DESIGN.md "K5"):
+//  * one wave owns 32 samples for the whole network; the product is computed TRANSPOSED,
+//        C^T[feature, sample] = W[feature, k] . X^T[k, sample]
+//    with v_mfma_f32_32x32x16_bf16, weights as the A operand and activations as the B operand.
+//    The C layout of a 32x32 tile (lane = sample, regs = features) is, up to a fixed permutation of
+//    k inside each 16-chunk, exactly the B-operand layout of the next layer, so activations never
+//    leave the register file: no LDS round trip, no cross-lane shuffle.  The k permutation is folded
+//    into the weight packing (mlp_pack.hip).
+//  * weights are pre-packed into MFMA A-fragments (1 KiB = 64 lanes x 16 B each) and DMA-streamed
+//    global -> LDS with global_load_lds_dwordx4, one "tile" (32 output features x all K) at a time,
+//    double-buffered; every wave of the workgroup consumes the same tile for its own samples.
+//  * precision: bf16 (1 product) or 2-way split bf16 (hi+lo, 3 products: hi*hi + hi*lo + lo*hi) with
+//    fp32 accumulation -- the latter is fp32-class (SURVEY 7 "hard parts").
+#pragma once
+#include "common.h"
+
+namespace na {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kHidden = 256;
+constexpr int kHC = kHidden / 16;  // hidden K-chunks per layer
+constexpr int kMaxTiles = 112;
+
+// A packed MLP = [1-KiB header][weight stream].  Header (written by na_mlp_pack): uint32 ntiles, then per
+// tile {uint32 off_blocks, uint32 nblk}: tile t = `nblk` 1-KiB blocks at block offset `off` of the stream.
+constexpr int kHeaderBytes = 1024;
+constexpr int kMaxTilesPerMlp = 8 * 9 + 3;
+
+// Up to two packed MLPs consumed back to back (tiles [0, split) from the first, the rest from the second).
+struct TileTab {
+  const uint32_t* hdr0;
+  const uint32_t* hdr1;
+  int32_t ntiles;
+  int32_t split;
+};
+
+template <int PREC>
+struct Frag {
+  bf16x8 hi;
+  bf16x8 lo;  // dead (eliminated) when PREC == 0
+};
+
+// ------------------------------------------------------------------------------------------------ activations
+// sin with a 2-term Cody-Waite reduction by pi and a degree-9 odd polynomial (least-squares on
+// Chebyshev nodes of [-pi/2,pi/2]): max |err| 1.6e-7 for |x| <= 3e3 (checked against fp64).
+__device__ __forceinline__ float sin_cw(float x) {
+  float q = rintf(x * 0.318309886183790672f);
+  float r = fmaf(q, -3.140625f, x);
+  r = fmaf(q, -9.67502593994140625e-4f, r);
+  r = fmaf(q, -1.509957990978376432e-7f, r);
+  float r2 = r * r;
+  float p = fmaf(r2, 2.5962193818e-06f, -1.9804804431e-04f);
+  p = fmaf(p, r2, 8.3329907333e-03f);
+  p = fmaf(p, r2, -1.6666655917e-01f);
+  float s = fmaf(p * r2, r, r);
+  int qi = (int)q;
+  return (qi & 1) ? -s : s;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+  if constexpr (ACT == NA_ACT_LEAKY_RELU) return fmaxf(v, v * 0.01f);
+  else if constexpr (ACT == NA_ACT_SIN) return sin_cw(v);
+  else return v;
+}
+
+// ------------------------------------------------------------------------------------------------ fragments
+template <int PREC>
+__device__ __forceinline__ Frag<PREC> make_frag(const float (&v)[8]) {
+  Frag<PREC> f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 h = (__bf16)v[e];
+    f.hi[e] = h;
+    if constexpr (PREC == NA_PREC_BF16X3) f.lo[e] = (__bf16)(v[e] - (float)h);
+  }
+  return f;
+}
+
+template <int PREC>
+__device__ __forceinline__ float frag_value(const Frag<PREC>& f, int e) {
+  float v = (float)f.hi[e];
+  if constexpr (PREC == NA_PREC_BF16X3) v = v + (float)f.lo[e];
+  return v;
+}
+
+template <int PREC>
+__device__ __forceinline__ void pin_frag(Frag<PREC>& f) {
+  asm volatile("" : "+v"(f.hi));
+  if constexpr (PREC == NA_PREC_BF16X3) asm volatile("" : "+v"(f.lo));
+}
+
+// act() applied in place to an input fragment (the skip connection re-enters through the activation,
+// src/neural_blocks.py:291-293).
+template <int PREC, int ACT>
+__device__ __forceinline__ void frag_activate(Frag<PREC>& f) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = act_apply<ACT>(frag_value<PREC>(f, e));
+  f = make_frag<PREC>(v);
+  pin_frag<PREC>(f);
+}
+
+// ------------------------------------------------------------------------------------------------ weight stream
+__device__ __forceinline__ void glds16(const void* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int NWAVES>
+struct WeightStream {
+  const char* base0;
+  const char* base1;
+  char* lds;           // two buffers of buf_bytes each
+  uint32_t buf_bytes;
+  uint32_t parity;     // buffer holding the CURRENT tile
+  int wave, lane;
+
+  __device__ __forceinline__ void issue(const TileTab& tab, int t, uint32_t par) {
+    const bool first = t < tab.split;
+    const uint32_t* e = (first ? tab.hdr0 : tab.hdr1) + 1 + 2 * (first ? t : t - tab.split);
+    const uint32_t off = __builtin_amdgcn_readfirstlane(e[0]);
+    const int nblk = __builtin_amdgcn_readfirstlane(e[1]);
+    const char* src = (first ? base0 : base1) + (size_t)off * 1024 + lane * 16;
+    char* dst = lds + par * buf_bytes;
+    for (int b = wave; b < nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
+  }
+  // Make tile t resident (its loads were issued one tile earlier), then prefetch tile `tnext`
+  // (or nothing if tnext < 0) into the other buffer.  Returns the LDS address of tile t.
+  __device__ __forceinline__ const char* advance(const TileTab& tab, int tnext) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* cur = lds + parity * buf_bytes;
+    parity ^= 1u;
+    if (tnext >= 0) issue(tab, tnext, parity);
+    return cur;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ tile math
+// acc(32 features x 32 samples) += A[frag0 .. frag0+NCH) . B[0..NCH)
+// Software-pipelined in stages of kStage chunks: the A fragments of stage s+1 are read from LDS while the
+// MFMAs of stage s issue.  sched_barrier pins DS/MFMA order per stage (VALU/SALU may still move across)
+// so the compiler cannot hoist all 16..33 ds_read_b128 of a tile up front (that costs 64+ VGPRs and spills).
+constexpr int kStage = 4;
+#define NA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400)
+
+template <int PREC, int NCH>
+__device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int frag0, const Frag<PREC>* B, int lane) {
+  constexpr int FB = PREC == NA_PREC_BF16X3 ? 2048 : 1024;
+  constexpr int NS = (NCH + kStage - 1) / kStage;
+  bf16x8 ah[2][kStage], al[2][kStage];
+  const char* a0 = tile + frag0 * FB + lane * 16;
+#pragma unroll
+  for (int c = 0; c < kStage && c < NCH; ++c) {
+    ah[0][c] = *(const bf16x8*)(a0 + c * FB);
+    if constexpr (PREC == NA_PREC_BF16X3) al[0][c] = *(const bf16x8*)(a0 + c * FB + 1024);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int c = 0; c < kStage; ++c) {
+        const int cc = (s + 1) * kStage + c;
+        if (cc < NCH) {
+          ah[cur ^ 1][c] = *(const bf16x8*)(a0 + cc * FB);
+          if constexpr (PREC == NA_PREC_BF16X3) al[cur ^ 1][c] = *(const bf16x8*)(a0 + cc * FB + 1024);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kStage; ++c) {
+      const int cc = s * kStage + c;
+      if (cc < NCH) {
+        if constexpr (PREC == NA_PREC_BF16X3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][c], B[cc].hi, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].lo, acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].hi, acc, 0, 0, 0);
+      }
+    }
+    NA_SCHED_FENCE();
+  }
+}
+
+// bias block of a tile: floats [hi(2)][16] right after its `nfrag` fragments
+template <int PREC>
+__device__ __forceinline__ f32x16 load_bias(const char* tile, int nfrag, int lane) {
+  constexpr int FB = PREC == NA_PREC_BF16X3 ? 2048 : 1024;
+  const f32x4* b = (const f32x4*)(tile + nfrag * FB + (lane >> 5) * 64);
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = b[q];
+    acc[q * 4 + 0] = v[0]; acc[q * 4 + 1] = v[1]; acc[q * 4 + 2] = v[2]; acc[q * 4 + 3] = v[3];
+  }
+  return acc;
+}
+
+// accumulator tile -> activated input fragments of the next layer (chunks 2j and 2j+1)
+template <int PREC, int ACT>
+__device__ __forceinline__ void acc_to_frags(const f32x16& acc, Frag<PREC>& f0, Frag<PREC>& f1) {
+  float v0[8], v1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v0[e] = act_apply<ACT>(acc[e]);
+    v1[e] = act_apply<ACT>(acc[8 + e]);
+  }
+  f0 = make_frag<PREC>(v0);
+  f1 = make_frag<PREC>(v1);
+  // Pin the epilogue inside its tile.  The results are only consumed by the NEXT layer, so instruction
+  // selection would otherwise sink all eight epilogues of a layer behind its last tile (128 live fp32
+  // accumulators, no MFMA/VALU overlap between the waves of a SIMD).  An empty volatile asm that "modifies"
+  // the packed fragments is ordered with the barriers and forces them to exist here.
+  pin_frag<PREC>(f0);
+  pin_frag<PREC>(f1);
+}
+
+// One SkipConnMLP up to (not including) the `out` Linear.  On entry I[] holds the raw init input
+// fragments; on exit H[] holds act(last hidden) ready for the out layer, I[] holds act(init).
+// `t` is the running tile index (advanced), `tlast_next` is the tile to prefetch after the final
+// tile of this call's caller-visible sequence is handled by the caller.
+template <int PREC, int ACT, int NI, int NWAVES>
+__device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, const TileTab& tab, int& t, int num_layers,
+                                                  int skip, Frag<PREC> (&I)[NI], Frag<PREC> (&H)[kHC], int lane) {
+  Frag<PREC> Hn[kHC];
+  // ---- init Linear: dim_p -> 256
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const char* tile = ws.advance(tab, t + 1);
+    f32x16 acc = load_bias<PREC>(tile, NI, lane);
+    mma_chunks<PREC, NI>(acc, tile, 0, I, lane);
+    acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
+    ++t;
+  }
+#pragma unroll
+  for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
+#pragma unroll
+  for (int c = 0; c < NI; ++c) frag_activate<PREC, ACT>(I[c]);
+  // ---- hidden Linears
+  for (int i = 0; i < num_layers; ++i) {
+    const bool sk = (i % skip) == 0 && i != num_layers - 1;
+    if (sk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const char* tile = ws.advance(tab, t + 1);
+        f32x16 acc = load_bias<PREC>(tile, kHC + NI, lane);
+        mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
+        mma_chunks<PREC, NI>(acc, tile, kHC, I, lane);
+        acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
+        ++t;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const char* tile = ws.advance(tab, t + 1);
+        f32x16 acc = load_bias<PREC>(tile, kHC, lane);
+        mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
+        acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
+        ++t;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
+  }
+}
+
+// One 32-row tile of the `out` Linear (no activation on the result).
+template <int PREC, int NWAVES>
+__device__ __forceinline__ f32x16 mlp_out_tile(WeightStream<NWAVES>& ws, const TileTab& tab, int& t, int tnext,
+                                               const Frag<PREC> (&H)[kHC], int lane) {
+  const char* tile = ws.advance(tab, tnext);
+  f32x16 acc = load_bias<PREC>(tile, kHC, lane);
+  mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
+  ++t;
+  return acc;
+}
+
+// feature index (within a 32-row tile) held by accumulator register r of this lane
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+}  // namespace na

@@ -1,0 +1,117 @@
+// Generic fused SkipConnMLP forward kernel (instantiated per precision in mlp_fwd_inst.hip).
+#pragma once
+#include "mlp_layout.h"
+#include "encoders.h"
+
+namespace na {
+
+// ================================================================================================ forward
+struct MlpArgs {
+  NaMlpDesc d;
+  const char* packed;
+  const float* p;
+  const float* latent;
+  const float* enc;
+  float* y;
+  int64_t N;
+  int ngroups;  // ceil(N / (32*NWAVES))
+  int out_tiles;
+  uint32_t buf_bytes;
+  HashRes res;
+};
+
+template <int PREC, int ACT, int ENC, int NI, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, TileTab tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WeightStream<NWAVES> ws;
+  ws.base0 = a.packed + kHeaderBytes; ws.base1 = ws.base0; ws.lds = smem; ws.buf_bytes = a.buf_bytes; ws.parity = 0;
+  ws.wave = wave; ws.lane = lane;
+  ws.issue(tab, 0, 0);
+
+  for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    const int64_t n_raw = ((int64_t)g * NWAVES + wave) * 32 + (lane & 31);
+    const int64_t n = n_raw < a.N ? n_raw : a.N - 1;
+    const int hi = lane >> 5;
+    Frag<PREC> I[NI];
+    // ---------------- init input fragments
+    {
+      const NaMlpDesc& d = a.d;
+      int c0 = 0;  // first "rest" chunk
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if constexpr (ENC == NA_ENC_HASH) {
+        px = a.p[n * 3]; py = a.p[n * 3 + 1]; pz = a.p[n * 3 + 2];
+        float f[16];
+        hash_levels4(px, py, pz, (const float4*)a.enc, a.res, 4 * hi, f);
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; }
+        I[0] = make_frag<PREC>(v0);
+        if constexpr (NI > 1) I[1] = make_frag<PREC>(v1);
+        c0 = 2;
+      } else if constexpr (ENC == NA_ENC_FOURIER) {
+        const int F = d.enc_dims / 2, D = d.in_size;
+        float xv[8];
+        for (int q = 0; q < 8; ++q) xv[q] = q < D ? a.p[n * D + q] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NI; ++c) {
+          if ((c & 1) == 0 && c + 1 < F / 8) {
+            float sv[8], cv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              int freq = 16 * (c >> 1) + 8 * hi + e;
+              float m = 0.f;
+              for (int q = 0; q < D; ++q) m = q == 0 ? xv[0] * a.enc[freq] : fmaf(xv[q], a.enc[q * F + freq], m);
+              sv[e] = sinf(m);
+              cv[e] = cosf(m);
+            }
+            I[c] = make_frag<PREC>(sv);
+            if (c + 1 < NI) I[c + 1] = make_frag<PREC>(cv);
+          }
+        }
+        c0 = F / 8;
+      }
+#pragma unroll
+      for (int c = 0; c < NI; ++c) {
+        if (c >= c0) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            int f = init_slot_feature(d, c, 8 * hi + e);
+            float x = 0.f;
+            if (f >= 0) {
+              if (f < d.in_size) x = a.p[n * d.in_size + f];
+              else if (f < d.in_size + d.enc_dims) x = a.p[n * d.in_size + (f - d.in_size)];  // enc's include_input copy of p
+              else x = a.latent[n * d.latent_size + (f - d.in_size - d.enc_dims)];
+            }
+            v[e] = x;
+          }
+          I[c] = make_frag<PREC>(v);
+        }
+      }
+    }
+    // ---------------- network
+    int t = 0;
+    Frag<PREC> H[kHC];
+    mlp_hidden_layers<PREC, ACT, NI, NWAVES>(ws, tab, t, a.d.num_layers, a.d.skip, I, H, lane);
+    const bool more = g + (int)gridDim.x < a.ngroups;
+    for (int j = 0; j < a.out_tiles; ++j) {
+      const int tnext = j + 1 < a.out_tiles ? t + 1 : (more ? 0 : -1);
+      f32x16 acc = mlp_out_tile<PREC, NWAVES>(ws, tab, t, tnext, H, lane);
+      if (n_raw < a.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int f = 32 * j + acc_row(r, lane);
+          if (f < a.d.out_size) a.y[n_raw * a.d.out_size + f] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+
+int dispatch_forward_bf16(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s);
+int dispatch_forward_bf16x3(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s);
+
+}  // namespace na

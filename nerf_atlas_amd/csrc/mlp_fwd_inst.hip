@@ -1,0 +1,60 @@
+// Instantiations of the generic fused MLP forward kernel for ONE precision (NA_PREC_INST = 0 | 1); built as
+// two translation units so the heavy kernels compile in parallel.
+#include "mlp_forward_kernel.h"
+
+#ifndef NA_PREC_INST
+#error "compile with -DNA_PREC_INST=0 (bf16) or 1 (bf16x3)"
+#endif
+
+namespace na {
+
+template <int PREC, int ACT, int ENC, int NI, int NWAVES>
+static int launch_forward(const MlpArgs& a, const TileTab& tab, hipStream_t stream) {
+  auto kern = mlp_forward_kernel<PREC, ACT, ENC, NI, NWAVES>;
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
+    attr_done = true;
+  }
+  int grid = a.ngroups < 256 ? a.ngroups : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), 2 * a.buf_bytes, stream, a, tab);
+  return check_launch("na_mlp_forward");
+}
+
+template <int PREC>
+static int dispatch_forward(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s) {
+  const int act = a.d.activation;
+  // 8 waves (2 per SIMD, <=256 VGPR) when the fragments fit, else 4 waves with the whole register file
+  constexpr int NWS = PREC == NA_PREC_BF16X3 ? 4 : 8;
+#define NA_CASE(ACTV, ENCV, NIV, NW)                                                              \
+  if (act == ACTV && a.d.enc_kind == ENCV && NI == NIV) {                                         \
+    a.ngroups = (int)((a.N + 32 * NW - 1) / (32 * NW));                                           \
+    return launch_forward<PREC, ACTV, ENCV, NIV, NW>(a, tab, s);                                  \
+  }
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_NONE, 1, NWS)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_NONE, 3, NWS)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 3, NWS)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 7, NWS)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 9, 4)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_FOURIER, 17, 4)
+  NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 1, NWS)
+  NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 5, NWS)
+  NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 11, 4)
+#undef NA_CASE
+  set_error("na_mlp_forward: no kernel for activation %d, encoder %d, NI %d", act, a.d.enc_kind, NI);
+  return NA_EUNSUPPORTED;
+}
+
+
+#if NA_PREC_INST == 0
+int dispatch_forward_bf16(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s) {
+  return dispatch_forward<NA_PREC_BF16>(a, tab, NI, s);
+}
+#else
+int dispatch_forward_bf16x3(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s) {
+  return dispatch_forward<NA_PREC_BF16X3>(a, tab, NI, s);
+}
+#endif
+
+}  // namespace na

@@ -1,0 +1,252 @@
+// na_render_plain_view: PlainNeRF.forward with the View head (src/nerf.py:326-361, src/refl.py:190-207) as ONE
+// kernel: stratified samples -> hash encode -> `first` MLP -> elev/azim -> View MLP -> sigmoid -> per-ray
+// alpha compositing.  Nothing per-sample ever touches HBM: in = 24 B/ray, out = 12 B/ray (+ 32 B per
+// 32-sample block of compositing partials).
+//
+// Work item = (ray, block of 32 consecutive steps).  One wave owns one item: lane&31 = step inside the block,
+// so compositing is a 32-lane exclusive product scan in registers (wavefront shuffles).  Blocks of one ray are
+// combined by a tiny second kernel (na_render_finalize), which also adds the background term.
+//
+// Compiled once per precision (-DNA_PREC_INST=0|1).
+#include "mlp_layout.h"
+#include "encoders.h"
+
+#ifndef NA_PREC_INST
+#error "compile with -DNA_PREC_INST=0 (bf16) or 1 (bf16x3)"
+#endif
+
+namespace na {
+
+constexpr int kPartialFloats = 8;  // P, S_r, S_g, S_b, W_head, pad
+
+struct RenderArgs {
+  const float* rays;     // [R,6]
+  const float* ts;       // [T]
+  const float4* tables;  // [8,65536]
+  const char* packed_first;
+  const char* packed_view;
+  float* alpha;    // nullable [T,R]
+  float* weights;  // nullable [T,R] (block-local here; finalize applies the cross-block prefix)
+  float* partials; // [R*nb, 8]
+  int64_t R;
+  int64_t nitems;  // R * nb
+  int T, nb;
+  int ngroups;
+  int sigmoid_kind;
+  int first_layers, view_layers;
+  uint32_t buf_bytes;
+  HashRes res;
+};
+
+template <int PREC, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderArgs a, TileTab tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NI1 = 3, NI2 = 5;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, ln = lane & 31;
+  WeightStream<NWAVES> ws;
+  ws.base0 = a.packed_first + kHeaderBytes; ws.base1 = a.packed_view + kHeaderBytes;
+  ws.lds = smem; ws.buf_bytes = a.buf_bytes; ws.parity = 0; ws.wave = wave; ws.lane = lane;
+  ws.issue(tab, 0, 0);
+
+  for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    const int64_t item_raw = (int64_t)g * NWAVES + wave;
+    const bool item_ok = item_raw < a.nitems;
+    const int64_t item = item_ok ? item_raw : a.nitems - 1;
+    const int64_t ray = item / a.nb;
+    const int tb = (int)(item - ray * a.nb);
+    const int t = tb * 32 + ln;
+    const bool t_ok = t < a.T;
+    const int tc = t_ok ? t : a.T - 1;
+    // ---- sample position (src/nerf.py:53) and interval length (src/nerf.py:67-70)
+    const float* ry = a.rays + ray * 6;
+    const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
+    const float tt = a.ts[tc];
+    const float px = ox + tt * dx, py = oy + tt * dy, pz = oz + tt * dz;
+    float dist = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+    dist = dist * sqrtf((dx * dx + dy * dy) + dz * dz);
+
+    // ---- `first` MLP input: [hash levels 4hi..4hi+3 | p, x]
+    Frag<PREC> I1[NI1];
+    {
+      float f[16];
+      hash_levels4(px, py, pz, a.tables, a.res, 4 * hi, f);
+      float v0[8], v1[8], v2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; v2[e] = 0.f; }
+      if (hi == 0) { v2[0] = px; v2[1] = py; v2[2] = pz; v2[3] = px; v2[4] = py; v2[5] = pz; }
+      I1[0] = make_frag<PREC>(v0);
+      I1[1] = make_frag<PREC>(v1);
+      I1[2] = make_frag<PREC>(v2);
+    }
+    int tl = 0;
+    Frag<PREC> H[kHC];
+    mlp_hidden_layers<PREC, NA_ACT_LEAKY_RELU, NI1, NWAVES>(ws, tab, tl, a.first_layers, 3, I1, H, lane);
+
+    // ---- `first` out: rows 0..63 = intermediate (-> View latent), row 64 = density
+    Frag<PREC> I2[NI2];
+    float density;
+    {
+      f32x16 o0 = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, tl + 1, H, lane);
+      acc_to_frags<PREC, NA_ACT_NONE>(o0, I2[0], I2[1]);
+      f32x16 o1 = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, tl + 1, H, lane);
+      acc_to_frags<PREC, NA_ACT_NONE>(o1, I2[2], I2[3]);
+      f32x16 o2 = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, tl + 1, H, lane);
+      density = o2[0];  // row 64 lives in register 0 of the hi=0 lanes
+      float el, az;
+      elev_azim(dx, dy, dz, el, az);
+      float v4[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v4[e] = 0.f;
+      if (hi == 0) { v4[0] = px; v4[1] = py; v4[2] = pz; v4[3] = el; v4[4] = az; }
+      I2[4] = make_frag<PREC>(v4);
+    }
+    // ---- View MLP (sin activations)
+    mlp_hidden_layers<PREC, NA_ACT_SIN, NI2, NWAVES>(ws, tab, tl, a.view_layers, 3, I2, H, lane);
+    const bool more = g + (int)gridDim.x < a.ngroups;
+    f32x16 oc = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, more ? 0 : -1, H, lane);
+    const float cr = apply_sigmoid_kind(oc[0], a.sigmoid_kind);
+    const float cg = apply_sigmoid_kind(oc[1], a.sigmoid_kind);
+    const float cb = apply_sigmoid_kind(oc[2], a.sigmoid_kind);
+
+    // ---- compositing inside the block (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
+    const float sigma = softplusf_(density - 1.0f);
+    float alpha = t_ok ? 1.0f - expf(-sigma * dist) : 0.f;
+    float f = (1.0f - alpha) + 1e-10f;
+    float incl = f;  // inclusive product scan over the 32 lanes of this half
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      float up = __shfl_up(incl, d, 32);
+      if (ln >= d) incl = incl * up;
+    }
+    float excl = __shfl_up(incl, 1, 32);
+    if (ln == 0) excl = 1.0f;
+    const float w = alpha * excl;
+    float sr = w * cr, sg = w * cg, sb = w * cb;
+    float wh = (t < a.T - 1) ? w : 0.f;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+      sr += __shfl_xor(sr, d, 32);
+      sg += __shfl_xor(sg, d, 32);
+      sb += __shfl_xor(sb, d, 32);
+      wh += __shfl_xor(wh, d, 32);
+    }
+    const float P = __shfl(incl, 31, 32);
+    if (item_ok && hi == 0) {
+      if (ln == 0) {
+        float* o = a.partials + item * kPartialFloats;
+        o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
+      }
+      if (t_ok) {
+        if (a.alpha != nullptr) a.alpha[(int64_t)t * a.R + ray] = alpha;
+        if (a.weights != nullptr) a.weights[(int64_t)t * a.R + ray] = w;
+      }
+    }
+  }
+}
+
+#if NA_PREC_INST == 0
+// Combine the per-block partials of each ray in step order, add the background (src/nerf.py:96-98) and
+// turn block-local weights into global ones.
+__global__ void render_finalize_kernel(const float* __restrict__ partials, int64_t R, int nb, int T, int bg_kind,
+                                       float* __restrict__ weights, float* __restrict__ out) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    float prefix = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, wh = 0.f;
+    for (int b = 0; b < nb; ++b) {
+      const float* p = partials + (r * nb + b) * kPartialFloats;
+      c0 = c0 + prefix * p[1];
+      c1 = c1 + prefix * p[2];
+      c2 = c2 + prefix * p[3];
+      wh = wh + prefix * p[4];
+      if (weights != nullptr && b > 0) {
+        const int t1 = min(T, (b + 1) * 32);
+        for (int t = b * 32; t < t1; ++t) weights[(int64_t)t * R + r] *= prefix;
+      }
+      prefix = prefix * p[0];
+    }
+    const float sky = bg_kind == NA_BG_WHITE ? 1.0f - wh : 0.f;
+    out[r * 3 + 0] = c0 + sky;
+    out[r * 3 + 1] = c1 + sky;
+    out[r * 3 + 2] = c2 + sky;
+  }
+}
+
+#endif
+
+template <int PREC, int NWAVES>
+static int launch_render(RenderArgs& a, const TileTab& tab, hipStream_t stream) {
+  auto kern = render_plain_view_kernel<PREC, NWAVES>;
+  static thread_local bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
+    attr_done = true;
+  }
+  a.ngroups = (int)((a.nitems + NWAVES - 1) / NWAVES);
+  int grid = a.ngroups < 256 ? a.ngroups : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), 2 * a.buf_bytes, stream, a, tab);
+  return check_launch("na_render_plain_view");
+}
+
+#if NA_PREC_INST == 0
+int render_dispatch_bf16(RenderArgs& a, const TileTab& tab, hipStream_t s) { return launch_render<NA_PREC_BF16, 8>(a, tab, s); }
+#else
+int render_dispatch_bf16x3(RenderArgs& a, const TileTab& tab, hipStream_t s) { return launch_render<NA_PREC_BF16X3, 4>(a, tab, s); }
+#endif
+int render_dispatch_bf16(RenderArgs& a, const TileTab& tab, hipStream_t s);
+int render_dispatch_bf16x3(RenderArgs& a, const TileTab& tab, hipStream_t s);
+
+}  // namespace na
+
+#if NA_PREC_INST == 0
+// the C ABI entry points live in the bf16 translation unit
+using namespace na;
+
+extern "C" size_t na_render_workspace_bytes(int T, int64_t R) {
+  if (T < 1 || R < 0) return 0;
+  int64_t nb = (T + 31) / 32;
+  return (size_t)(R * nb * kPartialFloats * sizeof(float)) + 256;
+}
+
+extern "C" int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T, const float* hash_tables,
+                                    const void* packed_first, const void* packed_view, int precision, int sigmoid_kind,
+                                    int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(rays && ts && hash_tables && packed_first && packed_view && out && workspace, NA_ENULL,
+             "na_render_plain_view: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view: bad shape T=%d R=%lld", T, (long long)R);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED,
+             "na_render_plain_view: precision %d", precision);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_plain_view: sigmoid %d",
+             sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_plain_view: bg %d", bg_kind);
+  NA_REQUIRE(workspace_bytes >= na_render_workspace_bytes(T, R), NA_EWORKSPACE,
+             "na_render_plain_view: workspace %zu < %zu bytes", workspace_bytes, na_render_workspace_bytes(T, R));
+  if (R == 0) return NA_OK;
+  // the two MLP shapes this kernel is specialised for (src/nerf.py:320-324, src/refl.py:201-204)
+  NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+  NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  RenderArgs a;
+  a.rays = rays; a.ts = ts; a.tables = (const float4*)hash_tables;
+  a.packed_first = (const char*)packed_first; a.packed_view = (const char*)packed_view;
+  a.alpha = alpha; a.weights = weights;
+  a.partials = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.R = R; a.T = T; a.nb = (T + 31) / 32; a.nitems = R * a.nb;
+  a.sigmoid_kind = sigmoid_kind;
+  a.first_layers = d1.num_layers; a.view_layers = d2.num_layers;
+  a.buf_bytes = (uint32_t)((kHC + 5) * planes_of(precision) + 1) * 1024;
+  a.res = hash_resolutions();
+  TileTab tab;
+  tab.hdr0 = (const uint32_t*)packed_first;
+  tab.hdr1 = (const uint32_t*)packed_view;
+  tab.split = tile_count(d1);
+  tab.ntiles = tab.split + tile_count(d2);
+  int rc = precision == NA_PREC_BF16 ? render_dispatch_bf16(a, tab, (hipStream_t)stream)
+                                     : render_dispatch_bf16x3(a, tab, (hipStream_t)stream);
+  if (rc != NA_OK) return rc;
+  hipLaunchKernelGGL(render_finalize_kernel, dim3(grid_for(R, 128, 1 << 16)), dim3(128), 0, (hipStream_t)stream,
+                     a.partials, R, a.nb, T, bg_kind, weights, out);
+  return check_launch("na_render_finalize");
+}
+#endif

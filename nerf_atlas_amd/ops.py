@@ -1,0 +1,300 @@
+"""Torch-tensor wrappers over the C ABI (include/nerf_atlas_amd.h).
+
+PyTorch is only the memory/stream plumbing here: every function checks its tensors (cuda, fp32,
+contiguous), passes raw device pointers + the current HIP stream to the HIP library and returns the
+output tensor.  There is no eager/CPU fallback.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import NaMlpDesc, check
+
+ACT = {"none": 0, "leaky_relu": 1, "sin": 2}
+ENC = {"none": 0, "hash": 1, "fourier": 2}
+PREC = {"bf16": 0, "bf16x3": 1}
+LAYOUT = {"generic": 0, "plain_first": 1, "plain_view": 2}
+BG = {"black": 0, "white": 1}
+SIGMOID = {"normal": 0, "thin": 1, "fat": 2, "tanh": 3, "upshifted": 4, "relu": 5, "sin": 6, "leaky_relu": 7,
+           "upshifted_softplus": 8, "upshifted_relu": 9, "cyclic": 10, "identity": 11}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA(HIP) tensor: the hot path has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------- rays / samples
+def raygen(c2w: torch.Tensor, focal: float, size: int, crop, noise: Optional[torch.Tensor] = None,
+           with_noise: float = 0.0) -> torch.Tensor:
+    """rays[B,h,w,6] for crop (t,l,h,w) clipped to the image like the reference's slicing (runner.py:490-503,
+    src/cameras.py:45-66)."""
+    lib = _lib.load()
+    c2w = _f32(c2w, "c2w")
+    B = c2w.shape[0]
+    t, l, h, w = crop
+    h = max(0, min(h, size - t))
+    w = max(0, min(w, size - l))
+    rays = torch.empty(B, h, w, 6, device=c2w.device, dtype=torch.float32)
+    nz = None
+    if noise is not None and with_noise:
+        nz = _f32(noise, "noise")
+        assert nz.shape == (h, w, 2), nz.shape
+    check(lib.na_raygen(_ptr(c2w), B, float(focal), int(size), t, l, h, w, _ptr(nz), float(with_noise or 0.0),
+                        _ptr(rays), _stream()))
+    return rays
+
+
+def raygen_dtu(pose: torch.Tensor, intrinsic: torch.Tensor, size: int, crop) -> torch.Tensor:
+    lib = _lib.load()
+    pose, intrinsic = _f32(pose, "pose"), _f32(intrinsic, "intrinsic")
+    B = pose.shape[0]
+    t, l, h, w = crop
+    h = max(0, min(h, size - t))
+    w = max(0, min(w, size - l))
+    rays = torch.empty(B, h, w, 6, device=pose.device, dtype=torch.float32)
+    check(lib.na_raygen_dtu(_ptr(pose), _ptr(intrinsic), B, int(size), t, l, h, w, _ptr(rays), _stream()))
+    return rays
+
+
+def compute_ts(near: float, far: float, steps: int, device, lindisp: bool = False, perturb: float = 0.0,
+               rand: Optional[torch.Tensor] = None, want_mids: bool = False):
+    lib = _lib.load()
+    ts = torch.empty(steps, device=device, dtype=torch.float32)
+    mids = torch.empty(max(steps - 1, 0), device=device, dtype=torch.float32) if (want_mids or perturb > 0) else None
+    if perturb > 0:
+        rand = _f32(rand, "rand")
+        assert rand.shape == (steps,)
+    check(lib.na_compute_ts(float(near), float(far), int(steps), int(lindisp), float(perturb), _ptr(rand), _ptr(ts),
+                            _ptr(mids), _stream()))
+    return ts, (mids if perturb > 0 else None)
+
+
+def compute_pts(rays: torch.Tensor, ts: torch.Tensor) -> torch.Tensor:
+    """pts[T, *rays.shape[:-1], 3] (src/nerf.py:50-55)."""
+    lib = _lib.load()
+    rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    pts = torch.empty((T,) + tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    check(lib.na_compute_pts(_ptr(rays), _ptr(ts), T, R, _ptr(pts), _stream()))
+    return pts
+
+
+# ------------------------------------------------------------------------------------------------- encoders
+def hash_encode(x: torch.Tensor, tables: torch.Tensor, include_input: bool = True, want_indices: bool = False):
+    lib = _lib.load()
+    x, tables = _f32(x, "x"), _f32(tables, "tables")
+    assert x.shape[-1] == 3 and tables.shape == (8, 65536, 4), (x.shape, tables.shape)
+    N = x.numel() // 3
+    out = torch.empty(tuple(x.shape[:-1]) + (32 + 3 * int(include_input),), device=x.device, dtype=torch.float32)
+    idx = torch.empty(8, 8, N, device=x.device, dtype=torch.int64) if want_indices else None
+    check(lib.na_hash_encode(_ptr(x), N, _ptr(tables), int(include_input), _ptr(out), _ptr(idx), _stream()))
+    return (out, idx) if want_indices else out
+
+
+def fourier_encode(x: torch.Tensor, basis: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    lib = _lib.load()
+    x, basis = _f32(x, "x"), _f32(basis, "basis")
+    D, F = basis.shape
+    assert x.shape[-1] == D
+    N = x.numel() // D
+    out = torch.empty(tuple(x.shape[:-1]) + (2 * F,), device=x.device, dtype=torch.float32)
+    check(lib.na_fourier_encode(_ptr(x), N, D, _ptr(basis), F, float(scale), _ptr(out), _stream()))
+    return out
+
+
+def positional_encode(x: torch.Tensor, bands: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x, bands = _f32(x, "x"), _f32(bands, "bands")
+    D, NB = x.shape[-1], bands.shape[0]
+    N = x.numel() // D
+    out = torch.empty(tuple(x.shape[:-1]) + (2 * D * NB,), device=x.device, dtype=torch.float32)
+    check(lib.na_positional_encode(_ptr(x), N, D, _ptr(bands), NB, _ptr(out), _stream()))
+    return out
+
+
+def view_elaz(dirs: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    dirs = _f32(dirs, "dirs")
+    N = dirs.numel() // 3
+    out = torch.empty(tuple(dirs.shape[:-1]) + (2,), device=dirs.device, dtype=torch.float32)
+    check(lib.na_view_elaz(_ptr(dirs), N, _ptr(out), _stream()))
+    return out
+
+
+def sigmoid(x: torch.Tensor, kind: str) -> torch.Tensor:
+    lib = _lib.load()
+    if kind not in SIGMOID:
+        raise NotImplementedError(f"Unknown sigmoid kind({kind})")
+    x = _f32(x, "x")
+    out = torch.empty_like(x)
+    check(lib.na_sigmoid(_ptr(x), x.numel(), SIGMOID[kind], _ptr(out), _stream()))
+    return out
+
+
+def mip_encode(rays: torch.Tensor, ts: torch.Tensor, kind: str, t_end: float, min_deg: int = 0, max_deg: int = 16):
+    """rays [B,H,W,6] of ONE crop -> [T,B,H,W,6*(max_deg-min_deg)] (intended layout)."""
+    lib = _lib.load()
+    rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+    B, H, W, _ = rays.shape
+    T = ts.shape[0]
+    out = torch.empty(T, B, H, W, 6 * (max_deg - min_deg), device=rays.device, dtype=torch.float32)
+    check(lib.na_mip_encode(_ptr(rays), B, H, W, _ptr(ts), T, {"cylinder": 0, "cone": 1}[kind], float(t_end), min_deg,
+                            max_deg, _ptr(out), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- compositing
+def composite(density: torch.Tensor, feat: torch.Tensor, ts: torch.Tensor, rays: torch.Tensor, softplus: bool = True,
+              bg: str = "black", want_weights: bool = True):
+    """density [T,...], feat [T,...,C], rays [...,6] -> (out [...,C], alpha [T,...], weights [T,...])."""
+    lib = _lib.load()
+    density, feat, ts, rays = _f32(density, "density"), _f32(feat, "feat"), _f32(ts, "ts"), _f32(rays, "rays")
+    T = ts.shape[0]
+    Cn = feat.shape[-1]
+    R = rays.numel() // 6
+    assert density.numel() == T * R and feat.numel() == T * R * Cn, (density.shape, feat.shape, rays.shape)
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    out = torch.empty(tuple(rays.shape[:-1]) + (Cn,), device=rays.device, dtype=torch.float32)
+    alpha = torch.empty_like(density) if want_weights else None
+    weights = torch.empty_like(density) if want_weights else None
+    check(lib.na_composite(_ptr(density), _ptr(feat), _ptr(ts), _ptr(rays), T, R, Cn, 0 if softplus else 1, BG[bg],
+                           _ptr(alpha), _ptr(weights), _ptr(out), _stream()))
+    return out, alpha, weights
+
+
+def integrate(weights: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    weights, other = _f32(weights, "weights"), _f32(other, "other")
+    T = weights.shape[0]
+    R = weights.numel() // T
+    Cn = other.shape[-1]
+    out = torch.empty(tuple(weights.shape[1:]) + (Cn,), device=weights.device, dtype=torch.float32)
+    check(lib.na_integrate(_ptr(weights), _ptr(other), T, R, Cn, _ptr(out), _stream()))
+    return out
+
+
+def laplace_density(sdf: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    sdf = _f32(sdf, "sdf")
+    beta = _f32(beta.reshape(1), "beta")
+    out = torch.empty_like(sdf)
+    check(lib.na_laplace_density(_ptr(sdf), sdf.numel(), _ptr(beta), _ptr(out), _stream()))
+    return out
+
+
+def bezier_warp(est: torch.Tensor, pts: torch.Tensor, t: torch.Tensor, n_ctrl: int):
+    """est [...,>=1+3n] (rigidity | control points), pts [...,3], t [...] -> (pts', dp, rigidity)."""
+    lib = _lib.load()
+    est, pts, t = _f32(est, "est"), _f32(pts, "pts"), _f32(t, "t")
+    N = pts.numel() // 3
+    assert t.numel() == N and est.numel() // est.shape[-1] == N
+    out = torch.empty_like(pts)
+    dp = torch.empty_like(pts)
+    rig = torch.empty(tuple(pts.shape[:-1]) + (1,), device=pts.device, dtype=torch.float32)
+    check(lib.na_bezier_warp(_ptr(est), est.shape[-1], _ptr(pts), _ptr(t), N, n_ctrl, _ptr(out), _ptr(dp), _ptr(rig),
+                             _stream()))
+    return out, dp, rig
+
+
+# ------------------------------------------------------------------------------------------------- MLP
+def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre_act: str = "none",
+               x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = W . act([x0 | x1]) + b, exact fp32 (f32 MFMA)."""
+    lib = _lib.load()
+    x0, W = _f32(x0, "x0"), _f32(W, "W")
+    N = x0.shape[0]
+    in0 = x0.shape[1]
+    in1 = 0
+    if x1 is not None:
+        x1 = _f32(x1, "x1")
+        in1 = x1.shape[1]
+    assert W.shape[1] == in0 + in1, (W.shape, in0, in1)
+    if b is not None:
+        b = _f32(b, "b")
+    y = torch.empty(N, W.shape[0], device=x0.device, dtype=torch.float32)
+    check(lib.na_linear_f32(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(W), _ptr(b), W.shape[0], ACT[pre_act], _ptr(y),
+                            _stream()))
+    return y
+
+
+def make_desc(in_size, enc_kind, enc_dims, latent_size, num_layers, hidden, out_size, skip, activation,
+              layout="generic") -> NaMlpDesc:
+    return NaMlpDesc(in_size, ENC[enc_kind], enc_dims, latent_size, num_layers, hidden, out_size, skip,
+                     ACT[activation], LAYOUT[layout])
+
+
+def mlp_packed_bytes(desc: NaMlpDesc, precision: str) -> int:
+    return int(_lib.load().na_mlp_packed_bytes(C.byref(desc), PREC[precision]))
+
+
+def mlp_pack(desc: NaMlpDesc, precision: str, weights: Sequence[torch.Tensor],
+             biases: Sequence[torch.Tensor]) -> torch.Tensor:
+    """weights/biases in the order init, layers[0..L-1], out (nn.Linear layout).  Returns the packed stream."""
+    lib = _lib.load()
+    nbytes = mlp_packed_bytes(desc, precision)
+    if nbytes == 0:
+        raise _lib.NaError(-3, "this SkipConnMLP shape has no MFMA kernel (use linear_f32 per layer)")
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [_f32(b.detach(), "bias") for b in biases]
+    n = desc.num_layers + 2
+    assert len(ws) == n and len(bs) == n
+    packed = torch.empty(nbytes, device=ws[0].device, dtype=torch.uint8)
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+    check(lib.na_mlp_pack(C.byref(desc), PREC[precision], wp, bp, _ptr(packed), _stream()))
+    return packed
+
+
+def mlp_forward(desc: NaMlpDesc, precision: str, packed: torch.Tensor, p: torch.Tensor,
+                latent: Optional[torch.Tensor] = None, enc_params: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    p = _f32(p, "p")
+    N = p.numel() // desc.in_size
+    if latent is not None:
+        latent = _f32(latent, "latent")
+    if enc_params is not None:
+        enc_params = _f32(enc_params, "enc_params")
+    y = torch.empty(tuple(p.shape[:-1]) + (desc.out_size,), device=p.device, dtype=torch.float32)
+    check(lib.na_mlp_forward(C.byref(desc), PREC[precision], _ptr(packed), _ptr(p), _ptr(latent), _ptr(enc_params), N,
+                             _ptr(y), _stream()))
+    return y
+
+
+# ------------------------------------------------------------------------------------------------- fused renderer
+def render_plain_view(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.Tensor, packed_first: torch.Tensor,
+                      packed_view: torch.Tensor, precision: str, sigmoid_kind: str = "thin", bg: str = "black",
+                      want_weights: bool = False, workspace: Optional[torch.Tensor] = None):
+    """PlainNeRF(view) forward, fully fused (src/nerf.py:326-361).  rays [...,6] -> (rgb [...,3], alpha, weights)."""
+    lib = _lib.load()
+    rays, ts, hash_tables = _f32(rays, "rays"), _f32(ts, "ts"), _f32(hash_tables, "hash_tables")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    nbytes = int(lib.na_render_workspace_bytes(T, R))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, device=rays.device, dtype=torch.uint8)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    check(lib.na_render_plain_view(_ptr(rays), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed_first), _ptr(packed_view),
+                                   PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out),
+                                   _ptr(workspace), workspace.numel(), _stream()))
+    return out, alpha, weights

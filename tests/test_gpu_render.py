@@ -1,0 +1,92 @@
+"""GPU parity of the fused PlainNeRF(view) renderer (na_render_plain_view) against the reference goldens
+and the CPU oracle.  Tolerance: north_star's 1e-4 L-inf on RGB for the bf16x3 (parity) mode; the bf16
+fast mode is gated on PSNR vs the parity image (>= 40 dB) and L-inf <= 2e-2."""
+import math
+
+import pytest
+import torch
+
+import oracle as O
+from conftest import load_golden, golden_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from nerf_atlas_amd import ops as _ops
+    return _ops
+
+
+def pack_plain(ops, p, precision):
+    d1 = ops.make_desc(3, "hash", 35, 0, 4, 256, 65, 3, "leaky_relu", "plain_first")
+    d2 = ops.make_desc(5, "none", 0, 64, 4, 256, 3, 3, "sin", "plain_view")
+    def wb(prefix, L):
+        ws = [p[prefix + "init.weight"]] + [p[f"{prefix}layers.{i}.weight"] for i in range(L)] + [p[prefix + "out.weight"]]
+        bs = [p[prefix + "init.bias"]] + [p[f"{prefix}layers.{i}.bias"] for i in range(L)] + [p[prefix + "out.bias"]]
+        return [w.cuda() for w in ws], [b.cuda() for b in bs]
+    pf = ops.mlp_pack(d1, precision, *wb("first.", 4))
+    pv = ops.mlp_pack(d2, precision, *wb("refl.mlp.", 4))
+    tables = torch.stack([p[f"first.enc.embs.{i}.weight"] for i in range(8)]).cuda()
+    return pf, pv, tables
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_fused_render_vs_reference_golden(ops, B):
+    h = load_golden(f"g11_plain_view_b{B}")
+    p = golden_params(h)
+    T = int(h["steps"])
+    ts, _ = ops.compute_ts(float(h["near"]), float(h["far"]), T, "cuda")
+    pf, pv, tables = pack_plain(ops, p, "bf16x3")
+    out, alpha, weights = ops.render_plain_view(h["rays"].cuda(), ts, tables, pf, pv, "bf16x3", "upshifted",
+                                                str(h["bg"]), want_weights=True)
+    err = float((out.cpu() - h["out"]).abs().max())
+    assert err <= 1e-4, err
+    assert float((alpha.cpu() - h["alpha"]).abs().max()) <= 1e-4
+    assert float((weights.cpu() - h["weights"]).abs().max()) <= 1e-4
+    # fast mode: bf16 operands
+    pf, pv, tables = pack_plain(ops, p, "bf16")
+    fast, _, _ = ops.render_plain_view(h["rays"].cuda(), ts, tables, pf, pv, "bf16", "upshifted", str(h["bg"]))
+    mse = float(((fast - out) ** 2).mean())
+    assert -10 * math.log10(max(mse, 1e-20)) >= 40.0
+    assert float((fast - out).abs().max()) <= 2e-2
+
+
+def test_fused_render_tile_800_geometry(ops):
+    """One 40x40 tile of the 800^2 x 128 headline geometry vs the CPU oracle (parity mode <= 1e-4)."""
+    h = load_golden("g11_plain_view_b1")
+    p = golden_params(h)
+    size, T = 800, 128
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    crop = (380, 390, 40, 40)
+    rays = ops.raygen(c2w.cuda(), focal, size, crop)
+    ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+    pf, pv, tables = pack_plain(ops, p, "bf16x3")
+    out, alpha, weights = ops.render_plain_view(rays, ts, tables, pf, pv, "bf16x3", "upshifted", "black",
+                                                want_weights=True)
+    aux = {}
+    ref = O.plain_nerf(p, rays.cpu(), 2.0, 6.0, T, "view", act="upshifted", aux=aux)
+    assert float((out.cpu() - ref).abs().max()) <= 1e-4
+    assert float((weights.cpu() - aux["weights"]).abs().max()) <= 1e-4
+    # partition of unity (Q3) at full step count
+    assert float((weights.sum(0) - 1).abs().max()) <= 1e-5
+
+
+def test_fused_render_ragged_steps_and_workspace_error(ops):
+    from nerf_atlas_amd._lib import NaError
+    h = load_golden("g11_plain_view_b1")
+    p = golden_params(h)
+    pf, pv, tables = pack_plain(ops, p, "bf16x3")
+    rays = h["rays"].cuda()
+    for T in (1, 7, 33, 48):  # not multiples of the 32-step block
+        ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+        out, _, w = ops.render_plain_view(rays, ts, tables, pf, pv, "bf16x3", "upshifted", "white", want_weights=True)
+        aux = {}
+        ref = O.plain_nerf(p, h["rays"], 2.0, 6.0, T, "view", act="upshifted", bg="white", aux=aux)
+        assert float((out.cpu() - ref).abs().max()) <= 1e-4, T
+        assert float((w.cpu() - aux["weights"]).abs().max()) <= 1e-4, T
+    with pytest.raises(NaError):
+        ts, _ = ops.compute_ts(2.0, 6.0, 16, "cuda")
+        ops.render_plain_view(rays, ts, tables, pf, pv, "bf16x3", workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
