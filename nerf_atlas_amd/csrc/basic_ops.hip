@@ -395,14 +395,14 @@ const char* na_last_error(void) { return na::g_err; }
 
 int na_raygen(const float* c2w, int B, float focal, int size, int crop_t, int crop_l, int crop_h, int crop_w,
               const float* noise, float with_noise, float* rays, void* stream) {
-  NA_REQUIRE(c2w && rays, NA_ENULL, "na_raygen: null pointer");
   NA_REQUIRE(B > 0 && size > 0 && crop_h >= 0 && crop_w >= 0 && crop_t >= 0 && crop_l >= 0, NA_EINVAL,
              "na_raygen: bad shape B=%d size=%d crop=(%d,%d,%d,%d)", B, size, crop_t, crop_l, crop_h, crop_w);
   NA_REQUIRE(crop_t + crop_h <= size && crop_l + crop_w <= size, NA_EINVAL,
              "na_raygen: crop (%d,%d,%d,%d) exceeds image %d (clip it like the reference's slicing)", crop_t, crop_l,
              crop_h, crop_w, size);
   int64_t total = (int64_t)B * crop_h * crop_w;
-  if (total == 0) return NA_OK;
+  if (total == 0) return NA_OK;  // empty crop: nothing to write (the output pointer may be NULL)
+  NA_REQUIRE(c2w && rays, NA_ENULL, "na_raygen: null pointer");
   const float* nz = (noise != nullptr && with_noise != 0.f) ? noise : nullptr;
   hipLaunchKernelGGL(raygen_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, c2w, B, focal,
                      (float)(size * 0.5), crop_t, crop_l, crop_h, crop_w, nz, with_noise, rays);
@@ -411,10 +411,10 @@ int na_raygen(const float* c2w, int B, float focal, int size, int crop_t, int cr
 
 int na_raygen_dtu(const float* pose, const float* intrinsic, int B, int size, int crop_t, int crop_l, int crop_h,
                   int crop_w, float* rays, void* stream) {
-  NA_REQUIRE(pose && intrinsic && rays, NA_ENULL, "na_raygen_dtu: null pointer");
   NA_REQUIRE(B > 0 && size > 0 && crop_h >= 0 && crop_w >= 0, NA_EINVAL, "na_raygen_dtu: bad shape");
   int64_t total = (int64_t)B * crop_h * crop_w;
   if (total == 0) return NA_OK;
+  NA_REQUIRE(pose && intrinsic && rays, NA_ENULL, "na_raygen_dtu: null pointer");
   hipLaunchKernelGGL(raygen_dtu_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, pose,
                      intrinsic, B, size, crop_t, crop_l, crop_h, crop_w, rays);
   return check_launch("na_raygen_dtu");

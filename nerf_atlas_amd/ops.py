@@ -288,7 +288,7 @@ def render_plain_view(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.T
     if bg not in BG:
         raise NotImplementedError(bg)
     nbytes = int(lib.na_render_workspace_bytes(T, R))
-    if workspace is None or workspace.numel() < nbytes:
+    if workspace is None:
         workspace = torch.empty(nbytes, device=rays.device, dtype=torch.uint8)
     out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
     shape_t = (T,) + tuple(rays.shape[:-1])
