@@ -1,0 +1,62 @@
+"""Multi-GPU: rays shard embarrassingly.  One process per GPU; a frame is split into contiguous
+row bands (or whole tiles), every rank renders its share with replicated weights, and ONE collective gathers
+the finished RGB to rank 0 (RCCL over xGMI on the GPU box: backend "nccl"; "gloo" in CPU tests)."""
+import os
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group if world > 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def row_bands(size: int, world: int) -> List[Tuple[int, int]]:
+    """[(row0, nrows)] per rank: contiguous bands, sizes differ by at most one row, every row exactly once."""
+    base, extra = divmod(size, world)
+    bands, r0 = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        bands.append((r0, n))
+        r0 += n
+    return bands
+
+
+def shard_tiles(tiles: list, rank: int, world: int) -> list:
+    """Round-robin tile ownership g, g+G, ... (whole tiles keep mip's radii_x row differences intact)."""
+    return tiles[rank::world]
+
+
+def gather_bands(local: torch.Tensor, size: int, rank: int, world: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """local: [nrows_rank, size, C] band of this rank.  Returns the [size,size,C] frame on `dst`, None elsewhere.
+    Bands may differ by one row, so they are padded to the tallest band for the collective."""
+    if world == 1:
+        return local
+    bands = row_bands(size, world)
+    tall = max(n for _, n in bands)
+    pad = torch.zeros(tall, size, local.shape[-1], device=local.device, dtype=local.dtype)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, outs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([o[:n] for o, (_, n) in zip(outs, bands)], dim=0)
+
+
+def render_frame_sharded(render_rows: Callable[[int, int], torch.Tensor], size: int, rank: int, world: int):
+    """render_rows(row0, nrows) -> [nrows,size,3] on this rank's device; returns the frame on rank 0."""
+    r0, n = row_bands(size, world)[rank]
+    return gather_bands(render_rows(r0, n), size, rank, world)

@@ -1,0 +1,301 @@
+"""Model-variant plugins of the hot path with the reference's protocol (src/nerf.py):
+TinyNeRF, PlainNeRF, VolSDF, DynamicNeRF(spline) + the registries model_kinds / dyn_model_kinds / load_nerf /
+load_dyn.  Every forward runs HIP kernels only; PlainNeRF with the View head takes the fully fused renderer.
+
+Protocol kept for callers (runner.py): forward(rays) / forward((rays, times)), from_pts(...), .nerf, .refl,
+.set_refl, .intermediate_size, .total_latent_size(), .set_bg, .set_sigmoid, .steps/.t_near/.t_far and, after a
+forward, .ts, .alpha, .weights (+ .pts/.dp/.rigidity/.rigid_dp for dynamic models, .scale_post_act for VolSDF).
+"""
+import torch
+import torch.nn as nn
+
+from . import config, ops
+from . import refl
+from .neural_blocks import HashEncoder, SkipConnMLP
+from .utils import load_mip, load_sigmoid
+
+
+# ------------------------------------------------------------------------------------------------- operators
+def compute_ts(rays, near, far, steps, lindisp=False, perturb: float = 0, rand=None):
+    """src/nerf.py:29-47.  `rand` [steps] replaces the global-RNG draw; drawn here if perturb>0 and none given."""
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    if perturb > 0 and rand is None:
+        rand = torch.rand(steps, device=rays.device)
+    ts, mids = ops.compute_ts(near, far, steps, rays.device, lindisp, perturb, rand)
+    return r_o, r_d, ts, mids
+
+
+def compute_pts_ts(rays, near, far, steps, lindisp=False, perturb: float = 0, rand=None):
+    """src/nerf.py:50-55."""
+    r_o, r_d, ts, mids = compute_ts(rays, near, far, steps, lindisp, perturb, rand)
+    pts = ops.compute_pts(rays, ts)
+    return pts, ts, r_o, r_d, mids
+
+
+def alpha_from_density(density, ts, r_d, softplus: bool = True):
+    """src/nerf.py:60-73 (via the compositing kernel with a dummy 1-channel feature)."""
+    rays = torch.cat([torch.zeros_like(r_d), r_d], dim=-1)
+    feat = torch.ones(density.shape + (1,), device=density.device)
+    _, alpha, weights = ops.composite(density, feat, ts, rays, softplus=softplus)
+    return alpha, weights
+
+
+def volumetric_integrate(weights, other):
+    """src/nerf.py:79-80."""
+    return ops.integrate(weights, other)
+
+
+def black(_elaz_r_d, _weights): return 0
+def white(_, weights): return 1 - weights[:-1].sum(dim=0).unsqueeze(-1)
+
+
+# src/nerf.py:104-109 (same keys; "mlp" and "random" are broken/stochastic in the reference: Q12)
+sky_kinds = {"black": black, "white": white, "mlp": "MLP_MARKER", "random": None}
+
+
+def cat_not_none(a, b, dim=-1): return a if b is None else (b if a is None else torch.cat([a, b], dim=dim))
+
+
+# ------------------------------------------------------------------------------------------------- CommonNeRF
+class CommonNeRF(nn.Module):
+    """src/nerf.py:147-276."""
+
+    def __init__(self, r=None, steps: int = 64, fine_steps: int = 32, t_near: float = 0, t_far: float = 1,
+                 density_std: float = 0.01, noise_std: int = 1e-2, mip=None, instance_latent_size: int = 0,
+                 per_pixel_latent_size: int = 0, per_point_latent_size: int = 0, intermediate_size: int = 32,
+                 sigmoid_kind: str = "thin", bg: str = "black"):
+        super().__init__()
+        self.t_near, self.t_far, self.steps, self.fine_steps = t_near, t_far, steps, fine_steps
+        self.mip = mip
+        assert instance_latent_size == 0 and per_pixel_latent_size == 0 and per_point_latent_size == 0, \
+            "instance/per-pixel/per-point latents are outside the 5 configs of the hot path"
+        self.per_pixel_latent_size = self.instance_latent_size = self.per_pt_latent_size = 0
+        try: self.intermediate_size = intermediate_size
+        except AttributeError: ...
+        self.alpha = self.weights = self.ts = None
+        self.noise_std = 0.2
+        self.set_bg(bg)
+        if r is not None: self.refl = r(self.total_latent_size())
+        self.set_sigmoid(sigmoid_kind)
+
+    def set_bg(self, bg="black"):
+        if bg not in sky_kinds: raise NotImplementedError(bg)
+        if bg in ("mlp", "random"):
+            raise NotImplementedError(f"bg '{bg}' is broken/stochastic in the reference (SURVEY Q12); black|white")
+        self.bg = bg
+        self.sky_color = sky_kinds[bg]
+
+    def set_sigmoid(self, kind="thin"):
+        act = load_sigmoid(kind)
+        self.sigmoid_kind = kind
+        self.feat_act = act
+        if hasattr(self, "refl") and self.refl is not None: self.refl.act = act
+
+    def total_latent_size(self) -> int: return self.mip_size()
+
+    def set_refl(self, r):
+        if hasattr(self, "refl"): self.refl = r
+
+    @property
+    def nerf(self): return self
+
+    def mip_size(self): return 0 if self.mip is None else self.mip.size() * 6
+
+    def mip_encoding(self, rays, ts):
+        """src/nerf.py:256-261, intended layout; rays [B,H,W,6] of one crop."""
+        return None if self.mip is None else self.mip(rays, ts)
+
+    def _perturb(self): return 1 if self.training else 0
+
+    def _composite(self, density, feat, ts, rays, softplus=True, with_sky=True):
+        out, self.alpha, self.weights = ops.composite(density, feat, ts, rays, softplus=softplus,
+                                                      bg=self.bg if with_sky else "black")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------- TinyNeRF
+class TinyNeRF(CommonNeRF):
+    """src/nerf.py:278-305 with the intended semantics density = estim[...,0] (the reference class cannot be
+    constructed at HEAD: SURVEY header table)."""
+
+    def __init__(self, out_features: int = 3, **kwargs):
+        super().__init__(**kwargs)
+        self.estim = SkipConnMLP(in_size=3, out=1 + out_features, latent_size=self.total_latent_size(), num_layers=6,
+                                 hidden_size=256, init="xavier")
+
+    def forward(self, rays):
+        pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb())
+        return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
+
+    def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
+        if rays is None: rays = torch.cat([r_o, r_d], dim=-1)
+        latent = self.mip_encoding(rays, ts)
+        o = self.estim(pts, latent)
+        density, feats = o[..., 0].contiguous(), o[..., 1:].contiguous()
+        return self._composite(density, self.feat_act(feats), ts, rays)
+
+
+# ------------------------------------------------------------------------------------------------- PlainNeRF
+class PlainNeRF(CommonNeRF):
+    """src/nerf.py:310-361."""
+
+    def __init__(self, out_features: int = 3, **kwargs):
+        super().__init__(r=lambda ls: refl.View(out_features=out_features, latent_size=ls + self.intermediate_size),
+                         **kwargs)
+        self.first = SkipConnMLP(in_size=3, out=1 + self.intermediate_size, latent_size=self.total_latent_size(),
+                                 enc=HashEncoder(), num_layers=4, hidden_size=256)
+
+    def _fusable(self, refl_latent=None):
+        return (isinstance(self.refl, refl.View) and self.mip is None and refl_latent is None
+                and self.intermediate_size == 64 and self.refl.out_features == 3 and not self.training)
+
+    def forward(self, rays, want_weights: bool = True):
+        if self._fusable():
+            # sample -> hash -> first -> elaz -> View -> sigmoid -> composite in ONE kernel
+            _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
+            prec = config.precision
+            _, pf = self.first.packed(prec, "plain_first")
+            _, pv = self.refl.mlp.packed(prec, "plain_view")
+            out, self.alpha, self.weights = ops.render_plain_view(
+                rays, self.ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self.bg, want_weights)
+            return out
+        rand = None
+        pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb(),
+                                                   rand=rand)
+        return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
+
+    def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
+        if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
+        latent = self.mip_encoding(rays, ts)
+        first_out = self.first(pts, latent)
+        density = first_out[..., 0].contiguous()
+        if self.training and self.noise_std > 0:
+            density = density + torch.randn_like(density) * self.noise_std
+        intermediate = first_out[..., 1:]
+        view = r_d.unsqueeze(0).expand_as(pts).contiguous()
+        rl = cat_not_none(latent, cat_not_none(intermediate, refl_latent))
+        rgb = self.refl(x=pts, view=view, latent=rl.contiguous())
+        return self._composite(density, rgb, ts, rays)
+
+
+# ------------------------------------------------------------------------------------------------- VolSDF
+class VolSDF(CommonNeRF):
+    """src/nerf.py:861-1018, volume path only (uniform samples, Laplace density, relu, no sky term)."""
+
+    def __init__(self, sdf, out_features: int = 3, occ_kind=None, integrator_kind="direct", w_transmission: bool = False,
+                 scale_softplus: bool = False, **kwargs):
+        super().__init__(**kwargs)
+        assert occ_kind is None and not w_transmission, "occlusion / transmission are outside the volume path"
+        self.sdf = sdf
+        self.scale = nn.Parameter(torch.tensor(0.1))
+        self.secondary = None
+        self.out_features = out_features
+        self.scale_softplus = scale_softplus
+
+    def forward(self, rays):
+        pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb())
+        return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
+
+    @property
+    def intermediate_size(self): return self.sdf.intermediate_size
+
+    def set_refl(self, r): self.sdf.refl = r
+
+    @property
+    def refl(self): return self.sdf.refl
+
+    def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
+        if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
+        sdf_vals, latent = self.sdf.from_pts(pts)
+        scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
+        self.scale_post_act = scale
+        density = ops.laplace_density(sdf_vals.contiguous(), scale)
+        if self.sdf.refl.can_use_normal:
+            raise NotImplementedError("normal-dependent reflectance needs autograd normals (row N1)")
+        view = r_d.unsqueeze(0).expand_as(pts).contiguous()
+        rgb = self.sdf.refl(x=pts, view=view, normal=None, latent=latent.contiguous())
+        return self._composite(density, rgb, ts, rays, softplus=False, with_sky=False)
+
+    def set_sigmoid(self, kind="thin"):
+        if not hasattr(self, "sdf"): return
+        self.sigmoid_kind = kind
+        self.refl.act = load_sigmoid(kind)
+
+
+# ------------------------------------------------------------------------------------------------- DynamicNeRF
+class DynamicNeRF(nn.Module):
+    """src/nerf.py:1209-1303, Bezier-spline deformation (spline > 1, refl_latent = 0).  The delta path
+    (spline = 0) raises at HEAD in the reference (SURVEY header table) and raises here too."""
+
+    def __init__(self, canonical: CommonNeRF, spline: int = 0, refl_latent: int = 0):
+        super().__init__()
+        self.canonical = canonical
+        self.spline = spline
+        self.refl_latent = max(refl_latent, 0)
+        if spline <= 1:
+            raise NotImplementedError("DynamicNeRF without a spline is broken in the reference (self.dp unset); use --spline N>1")
+        if self.refl_latent != 0:
+            raise NotImplementedError("--dyn-refl-latent > 0 is outside the configs of the hot path")
+        self.spline_n = spline
+        self.mlp_out_layout = [1, 3 * spline, 0, 0]
+        self.delta_estim = SkipConnMLP(in_size=3, out=spline * 3 + 1, num_layers=5, hidden_size=256, init="xavier",
+                                       enc=HashEncoder())
+        self.delta_estim.zero_last_layer()
+
+    @property
+    def nerf(self): return self.canonical
+    @property
+    def refl(self): return self.canonical.refl
+    @property
+    def sdf(self): return getattr(self.canonical, "sdf", None)
+    @property
+    def intermediate_size(self): return self.canonical.intermediate_size + self.refl_latent
+    def total_latent_size(self): return self.canonical.total_latent_size()
+    def set_refl(self, r): self.canonical.set_refl(r)
+    def set_bg(self, bg): self.canonical.set_bg(bg)
+
+    def forward(self, rays_t):
+        rays, t = rays_t
+        c = self.canonical
+        self.pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, c.t_near, c.t_far, c.steps,
+                                                        perturb=1 if self.training else 0)
+        c.ts = self.ts
+        tt = t[None, :, None, None].expand(*self.pts.shape[:-1]).contiguous()
+        est = self.delta_estim(self.pts)
+        warped, self.dp, self.rigidity = ops.bezier_warp(est, self.pts, tt, self.spline_n)
+        self.rigid_dp = self.dp * self.rigidity
+        return c.from_pts(warped, self.ts, r_o, r_d, rays=rays)
+
+
+# ------------------------------------------------------------------------------------------------- registries
+def _experimental(name):
+    def cons(*a, **k):
+        raise NotImplementedError(f"model kind '{name}' is an experimental variant outside the hot path (SURVEY 2 row 7)")
+    return cons
+
+
+# src/nerf.py:1706-1720 / 1698-1704: same keys
+model_kinds = {"tiny": TinyNeRF, "plain": PlainNeRF, "volsdf": VolSDF,
+               **{k: _experimental(k) for k in ["ae", "coarse_fine", "mpi", "voxel", "rig", "hist"]}}
+dyn_model_kinds = {"plain": DynamicNeRF, **{k: _experimental(k) for k in ["ae", "rig", "long", "voxel"]}}
+
+
+def load_nerf(args):
+    """src/nerf.py:111-145."""
+    from .sdf import load as load_sdf
+    kwargs = {"mip": load_mip(args), "out_features": args.feature_space, "steps": args.steps, "t_near": args.near,
+              "t_far": args.far, "intermediate_size": args.shape_to_refl_size, "sigmoid_kind": args.sigmoid_kind,
+              "bg": args.bg}
+    cons = model_kinds.get(args.model, None)
+    if cons is None: raise NotImplementedError(args.model)
+    if args.model == "volsdf":
+        kwargs["sdf"] = load_sdf(args, with_integrator=False)
+        kwargs["occ_kind"] = getattr(args, "occ_kind", None)
+    return cons(**kwargs)
+
+
+def load_dyn(args, model, device=None):
+    """src/nerf.py:1680-1696."""
+    cons = dyn_model_kinds.get(args.dyn_model, None)
+    if cons is None: raise NotImplementedError(f"Unknown dyn kind: {args.dyn_model}")
+    return cons(canonical=model, spline=args.spline, refl_latent=args.dyn_refl_latent)

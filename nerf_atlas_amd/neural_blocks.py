@@ -1,0 +1,224 @@
+"""Encoders and SkipConnMLP with the reference's constructor/attribute protocol (src/neural_blocks.py:14-311).
+
+Parameters live in ordinary nn.Parameters under the reference's names (init / layers.N / out / enc.embs.N /
+enc.basis), so a reference state_dict loads unchanged.  forward() runs HIP kernels only: the fused MFMA engine
+when the shape has one (hidden 256), otherwise a chain of exact-fp32 MFMA Linears.  Inference only: outputs
+carry no autograd graph (training = SURVEY 8(f) N1).
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import config, ops
+
+
+class PositionalEncoder(nn.Module):
+    """src/neural_blocks.py:14-34."""
+
+    def __init__(self, input_dims: int = 3, max_freq: float = 6., N: int = 64, log_sampling: bool = False):
+        super().__init__()
+        if log_sampling:
+            bands = 2 ** torch.linspace(1, max_freq, steps=N, dtype=torch.float)
+        else:
+            bands = torch.linspace(1, 2 ** max_freq, steps=N, dtype=torch.float)
+        self.bands = nn.Parameter(bands, requires_grad=False)
+        self.input_dims = input_dims
+
+    def output_dims(self):
+        return self.input_dims * 2 * len(self.bands)
+
+    def forward(self, x):
+        assert x.shape[-1] == self.input_dims
+        return ops.positional_encode(x, self.bands.data)
+
+
+class FourierEncoder(nn.Module):
+    """src/neural_blocks.py:36-55; basis = sigma * randn(freqs, D).T drawn on CPU like the reference."""
+
+    def __init__(self, input_dims: int = 3, freqs: int = 128, sigma: int = 1 << 5, device="cpu"):
+        super().__init__()
+        self.input_dims = input_dims
+        self.freqs = freqs
+        self.basis = nn.Parameter(sigma * torch.randn(freqs, input_dims).T.contiguous(), requires_grad=False)
+        self.extra_scale = 1
+
+    def output_dims(self):
+        return self.freqs * 2
+
+    def forward(self, x):
+        return ops.fourier_encode(x, self.basis.data, float(self.extra_scale))
+
+    def scale_freqs(self, amt: 1 + 1e-5, cap=2):
+        self.extra_scale *= amt
+        self.extra_scale = min(self.extra_scale, cap)
+
+
+class HashEncoder(nn.Module):
+    """src/neural_blocks.py:92-193 (8 levels x 65536 x 4, resolutions 16 * 0.87497^l, Q8/Q9)."""
+
+    def __init__(self, input_dims: int = 3, emb_size: int = 1 << 16, feat_size: int = 4, levels: int = 8,
+                 include_input=True):
+        super().__init__()
+        assert input_dims == 3, "Only supports 3 inputs currently"
+        assert emb_size == 1 << 16 and feat_size == 4 and levels == 8, "the HIP hash encoder is specialised for the defaults"
+        self.register_buffer("primes", torch.tensor([1, 2654435761, 805459861, 3674653429, 2097192037, 1434869437,
+                                                     2165219737]), persistent=True)
+        self.levels, self.in_features, self.include_input = levels, input_dims, include_input
+        self.emb_size, self.feat_size = emb_size, feat_size
+        self.embs = nn.ModuleList([nn.Embedding(emb_size, feat_size) for _ in range(levels)])
+        self.low_reso, self.high_reso = 1 << 4, 1 << 14
+        self.scale = math.exp((math.log(self.high_reso) - math.log(self.low_reso)) / levels - 1)
+        self._stacked = None
+        self._stamp = None
+
+    def output_dims(self):
+        return self.levels * self.feat_size + self.include_input * self.in_features
+
+    def tables(self) -> torch.Tensor:
+        """[8,65536,4] contiguous copy of the embedding tables (rebuilt when a table changes)."""
+        stamp = tuple((e.weight._version, e.weight.data_ptr()) for e in self.embs)
+        if self._stacked is None or stamp != self._stamp:
+            self._stacked = torch.stack([e.weight.data for e in self.embs]).contiguous()
+            self._stamp = stamp
+        return self._stacked
+
+    def forward(self, x):
+        assert x.shape[-1] == self.in_features
+        return ops.hash_encode(x, self.tables(), self.include_input)
+
+
+mlp_init_kinds = {None, "zero", "kaiming", "siren", "xavier"}
+
+
+class _Act:
+    def __init__(self, name):
+        self.name = name
+
+
+class SkipConnMLP(nn.Module):
+    """src/neural_blocks.py:204-311.  `activation`: nn.LeakyReLU (default) or torch.sin."""
+
+    def __init__(self, num_layers=5, hidden_size=256, in_size=3, out=3, skip=3, activation=None, latent_size=0,
+                 enc=None, last_layer_act=False, linear=nn.Linear, init=None):
+        assert init in mlp_init_kinds, "Must use init kind"
+        super().__init__()
+        self.in_size = in_size
+        self.enc = enc
+        map_size = enc.output_dims() if enc is not None else 0
+        self.dim_p = in_size + map_size + latent_size
+        self.skip = skip
+        self.latent_size = latent_size
+        skip_size = hidden_size + self.dim_p
+        self.init = nn.Linear(self.dim_p, hidden_size)
+        self.layers = nn.ModuleList([
+            linear(skip_size if (i % skip) == 0 and i != num_layers - 1 else hidden_size, hidden_size)
+            for i in range(num_layers)])
+        self.out = nn.Linear(hidden_size, out)
+        weights = [self.init.weight, self.out.weight, *[l.weight for l in self.layers]]
+        biases = [self.init.bias, self.out.bias, *[l.bias for l in self.layers]]
+        if init == "zero":
+            for t in weights + biases: nn.init.zeros_(t)
+        elif init == "xavier":
+            for t in weights: nn.init.xavier_uniform_(t)
+            for t in biases: nn.init.zeros_(t)
+        elif init == "siren":
+            for t in weights:
+                fan_in, _ = nn.init._calculate_fan_in_and_fan_out(t)
+                a = math.sqrt(6 / fan_in)
+                nn.init._no_grad_uniform_(t, -a, a)
+            for t in biases: nn.init.zeros_(t)
+        elif init == "kaiming":
+            for t in weights: nn.init.kaiming_normal_(t, mode="fan_out")
+            for t in biases: nn.init.zeros_(t)
+        if activation is None or isinstance(activation, nn.LeakyReLU):
+            self.act_name = "leaky_relu"
+        elif activation is torch.sin:
+            self.act_name = "sin"
+        else:
+            raise NotImplementedError(f"activation {activation}: the HIP path implements LeakyReLU and sin")
+        self.activation = activation
+        self.last_layer_act = last_layer_act
+        self._packed = {}
+
+    # ---- HIP plumbing ------------------------------------------------------------------------
+    def _linears(self):
+        return [self.init, *self.layers, self.out]
+
+    def enc_kind(self):
+        if self.enc is None:
+            return "none", 0
+        if isinstance(self.enc, HashEncoder) and self.enc.include_input:
+            return "hash", 35
+        if isinstance(self.enc, FourierEncoder):
+            return "fourier", self.enc.output_dims()
+        return None, self.enc.output_dims()  # encoder without a fused prologue
+
+    def desc(self, layout="generic"):
+        kind, dims = self.enc_kind()
+        if kind is None:
+            return None
+        return ops.make_desc(self.in_size, kind, dims, self.latent_size, len(self.layers), self.init.out_features,
+                             self.out.out_features, self.skip, self.act_name, layout)
+
+    def packed(self, precision: str, layout: str = "generic"):
+        """Packed MFMA weight stream (cached; re-packed when any parameter changed), or None if this shape has
+        no fused kernel."""
+        desc = self.desc(layout)
+        if desc is None or ops.mlp_packed_bytes(desc, precision) == 0:
+            return None, None
+        lin = self._linears()
+        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        key = (precision, layout)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != stamp:
+            buf = ops.mlp_pack(desc, precision, [l.weight.data for l in lin], [l.bias.data for l in lin])
+            self._packed[key] = (stamp, buf)
+        return desc, self._packed[key][1]
+
+    def enc_params(self):
+        if isinstance(self.enc, HashEncoder):
+            return self.enc.tables()
+        if isinstance(self.enc, FourierEncoder):
+            b = self.enc.basis.data
+            return b if self.enc.extra_scale == 1 else (b * self.enc.extra_scale)
+        return None
+
+    def forward(self, p, latent: Optional[torch.Tensor] = None):
+        batches = p.shape[:-1]
+        flat = p.reshape(-1, p.shape[-1]).contiguous()
+        if self.latent_size != 0:
+            assert latent is not None, "Did not pass latent vector when some was expected"
+            lat = latent.reshape(-1, self.latent_size).contiguous()
+        else:
+            assert (latent is None) or (latent.shape[-1] == 0), "Passed latent vector when none was expected"
+            lat = None
+        out_size = self.out.out_features
+        desc, packed = (None, None) if self.last_layer_act else self.packed(config.precision)
+        if packed is not None:
+            y = ops.mlp_forward(desc, config.precision, packed, flat, lat, self.enc_params())
+            return y.reshape(batches + (out_size,))
+        # any-shape path: exact-fp32 Linears (src/neural_blocks.py:288-296)
+        init = flat
+        if self.enc is not None:
+            init = torch.cat([init, self.enc(flat)], dim=-1)
+        if lat is not None:
+            init = torch.cat([init, lat], dim=-1)
+        x = ops.linear_f32(init, self.init.weight.data, self.init.bias.data)
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            skip = i != n - 1 and (i % self.skip) == 0
+            x = ops.linear_f32(x, layer.weight.data, layer.bias.data, pre_act=self.act_name, x1=init if skip else None)
+        if self.last_layer_act:
+            setattr(self, "last_layer_out", x.reshape(batches + (-1,)))
+        y = ops.linear_f32(x, self.out.weight.data, self.out.bias.data, pre_act=self.act_name)
+        return y.reshape(batches + (out_size,))
+
+    def zero_last_layer(self):
+        nn.init.zeros_(self.out.weight)
+        nn.init.zeros_(self.out.bias)
+
+    def uniform_last_layer(self, a=1e-4):
+        nn.init.uniform_(self.out.weight, -a, a)
+        nn.init.uniform_(self.out.bias, -a, a)

@@ -1,0 +1,115 @@
+"""Colour heads on the hot path (src/refl.py:17-49,100-122,190-290,733-751): View, Positional, PosLinearView.
+The relighting heads of the reference (Basic, Diffuse, CookTorrance, Rusin*, ...) keep their registry keys and
+raise NotImplementedError (out of scope)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .neural_blocks import HashEncoder, SkipConnMLP
+from .utils import load_sigmoid
+
+
+class IdentitySpace(nn.Module):
+    def forward(self, x): return x
+    @property
+    def dims(self): return 3
+
+
+class NoSpace(nn.Module):
+    @property
+    def dims(self): return 0
+
+
+class Reflectance(nn.Module):
+    """src/refl.py:100-122."""
+
+    def __init__(self, act="thin", latent_size: int = 0, out_features: int = 3, bidirectional: bool = True, normal=None,
+                 light=None, space=None):
+        super().__init__()
+        self.latent_size = latent_size
+        self.out_features = out_features
+        self.bidirectional = bidirectional
+        self.act = load_sigmoid(act)
+
+    @property
+    def can_use_normal(self): return False
+
+    @property
+    def can_use_light(self): return False
+
+
+def _normalize(v):
+    n = torch.linalg.norm(v, dim=-1, keepdim=True).clamp_min(1e-12)
+    return v / n
+
+
+class View(Reflectance):
+    """src/refl.py:190-207: act(mlp([x | elaz(view)], latent)); 4x256, sin activations, siren init."""
+
+    def __init__(self, space=None, view="elaz", **kwargs):
+        super().__init__(**kwargs)
+        assert view == "elaz"
+        self.mlp = SkipConnMLP(in_size=5, out=self.out_features, latent_size=self.latent_size, num_layers=4,
+                               hidden_size=256, init="siren", activation=torch.sin)
+
+    def forward(self, x, view, normal=None, light=None, latent=None):
+        v = ops.view_elaz(view.contiguous())
+        return self.act(self.mlp(torch.cat([x, v], dim=-1), latent))
+
+
+class Positional(Reflectance):
+    """src/refl.py:230-245."""
+
+    def __init__(self, space=None, **kwargs):
+        super().__init__(**kwargs)
+        self.mlp = SkipConnMLP(in_size=3, out=self.out_features, latent_size=self.latent_size, enc=HashEncoder(),
+                               num_layers=5, hidden_size=256)
+
+    def forward(self, x, view, normal=None, light=None, latent=None):
+        return self.act(self.mlp(x, latent))
+
+
+class PosLinearView(Reflectance):
+    """src/refl.py:248-290 (view='raw')."""
+
+    def __init__(self, space=None, view="raw", intermediate_size=64, **kwargs):
+        super().__init__(**kwargs)
+        assert view == "raw"
+        self.im = intermediate_size
+        self.pos = SkipConnMLP(in_size=3, out=self.out_features + self.im, latent_size=self.latent_size,
+                               enc=HashEncoder(input_dims=3), num_layers=2, hidden_size=256)
+        self.view = SkipConnMLP(in_size=6, out=1, latent_size=self.latent_size + self.im, num_layers=2,
+                                hidden_size=128, init="siren", activation=torch.sin)
+
+    def forward(self, x, view, normal=None, light=None, latent=None):
+        pos, intermediate = self.act(self.pos(x, latent)).split([self.out_features, self.im], dim=-1)
+        view_latent = intermediate if latent is None else torch.cat([latent, intermediate], dim=-1)
+        linear = ops.sigmoid(self.view(torch.cat([x, _normalize(view)], dim=-1), view_latent), "normal")
+        return (linear / 2 + 0.5) * pos
+
+
+def _out_of_scope(name):
+    def cons(*a, **k):
+        raise NotImplementedError(f"refl kind '{name}' is a relighting head outside the volume-rendering hot path")
+    return cons
+
+
+# src/refl.py:733-751: same keys
+refl_kinds = {
+    "pos": Positional, "view": View, "pos-linear-view": PosLinearView,
+    **{k: _out_of_scope(k) for k in ["view-light", "basic", "diffuse", "cook-torrance", "rusin", "rusin-helmholtz",
+                                     "sph-har", "fourier", "weighted"]},
+}
+
+
+def load(args, refl_kind: str, space_kind: str, latent_size: int):
+    """src/refl.py:17-49 (the light / weighted branches are out of scope)."""
+    if space_kind not in ("identity", "surface", "none"):
+        raise NotImplementedError()
+    cons = refl_kinds.get(refl_kind, None)
+    if cons is None:
+        raise NotImplementedError(f"refl kind: {refl_kind}")
+    if getattr(args, "light_kind", None) is not None:
+        raise NotImplementedError("lights are outside the volume-rendering hot path")
+    return cons(latent_size=latent_size, act=args.sigmoid_kind, out_features=args.feature_space,
+                normal=getattr(args, "normal_kind", None), bidirectional=getattr(args, "refl_bidirectional", True))

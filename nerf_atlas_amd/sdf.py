@@ -1,0 +1,80 @@
+"""SDF models used by VolSDF's volume path (src/sdf.py:15-32,83-112,250-258,278-287,308-316)."""
+import torch
+import torch.nn as nn
+
+from . import refl as _refl
+from .neural_blocks import FourierEncoder, SkipConnMLP
+
+
+class SDFModel(nn.Module):
+    def __init__(self, intermediate_size: int = 32):
+        super().__init__()
+        self.intermediate_size = intermediate_size
+
+
+class MLP(SDFModel):
+    """src/sdf.py:250-258."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.mlp = SkipConnMLP(in_size=3, out=1 + self.intermediate_size,
+                               enc=FourierEncoder(input_dims=3, sigma=1 << 4), num_layers=6, hidden_size=256,
+                               init="xavier")
+
+    def forward(self, x): return self.mlp(x)
+
+
+class SIREN(SDFModel):
+    """src/sdf.py:278-287."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.siren = SkipConnMLP(in_size=3, out=1 + self.intermediate_size, num_layers=5, hidden_size=256,
+                                 activation=torch.sin, skip=3, init="siren")
+
+    def forward(self, x): return self.siren(x)
+
+
+class SDF(nn.Module):
+    """src/sdf.py:83-112 (the surface-intersection methods are out of scope: SURVEY 2 row 9/10)."""
+
+    def __init__(self, underlying: SDFModel, reflectance, isect=None, t_near: float = 0, t_far: float = 1, alpha: int = 1000):
+        super().__init__()
+        assert isinstance(underlying, SDFModel)
+        self.underlying = underlying
+        self.refl = reflectance
+        self.far, self.near, self.alpha, self.isect = t_far, t_near, alpha, isect
+
+    @property
+    def sdf(self): return self
+
+    @property
+    def intermediate_size(self): return self.underlying.intermediate_size
+
+    def from_pts(self, pts):
+        raw = self.underlying(pts)
+        latent = raw[..., 1:]
+        return raw[..., 0], latent if latent.shape[-1] != 0 else None
+
+    def normals(self, pts, values=None):
+        raise NotImplementedError("SDF normals need autograd through the MLP (training row N1)")
+
+
+def _out_of_scope(name):
+    def cons(*a, **k):
+        raise NotImplementedError(f"sdf kind '{name}' belongs to the surface-rendering path (out of scope)")
+    return cons
+
+
+# src/sdf.py:308-316
+sdf_kinds = {"mlp": MLP, "siren": SIREN, **{k: _out_of_scope(k) for k in ["spheres", "triangles", "local", "curl-mlp"]}}
+
+
+def load(args, with_integrator: bool = False):
+    """src/sdf.py:15-32."""
+    cons = sdf_kinds.get(args.sdf_kind, None)
+    if cons is None:
+        raise NotImplementedError(f"Unknown SDF kind: {args.sdf_kind}")
+    model = cons(intermediate_size=args.shape_to_refl_size)
+    refl_inst = _refl.load(args, args.refl_kind, getattr(args, "space_kind", "identity"), model.intermediate_size)
+    return SDF(model, refl_inst, isect=None, t_near=args.near, t_far=args.far)

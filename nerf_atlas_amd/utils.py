@@ -1,0 +1,77 @@
+"""Small helpers of the reference's src/utils.py that the hot path touches."""
+import torch
+
+from . import ops
+
+# src/utils.py:500-514 sigmoid_kinds: same string keys; values are callables running the HIP kernel
+_SIGMOID_NAMES = ["normal", "thin", "tanh", "cyclic", "upshifted", "fat", "leaky_relu", "relu", "sin",
+                  "upshifted_softplus", "upshifted_relu"]
+
+
+class _Sigmoid:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __call__(self, v):
+        return ops.sigmoid(v, self.kind)
+
+    def __repr__(self):
+        return f"sigmoid[{self.kind}]"
+
+
+sigmoid_kinds = {k: _Sigmoid(k) for k in _SIGMOID_NAMES}
+# "softmax" is a registry key of the reference (nn.Softmax) that no config on the path reaches
+sigmoid_kinds["softmax"] = None
+
+
+def load_sigmoid(kind="thin"):
+    """src/utils.py:515-518."""
+    s = sigmoid_kinds.get(kind, None)
+    if s is None:
+        raise NotImplementedError(f"Unknown sigmoid kind({kind})")
+    return s
+
+
+def mse2psnr(x):
+    """src/utils.py:184."""
+    return -10 * torch.log10(x)
+
+
+def dir_to_elev_azim(direc):
+    """src/utils.py:247-254."""
+    return ops.view_elaz(direc)
+
+
+class _Mip:
+    def __init__(self, kind, min_deg=0, max_deg=16):
+        self.kind, self.min_deg, self.max_deg = kind, min_deg, max_deg
+
+    def size(self):
+        return self.max_deg - self.min_deg
+
+    def __call__(self, rays, ts):
+        """rays [B,H,W,6] of one crop, ts [T] -> [T,B,H,W,96] (intended layout; the last interval is closed
+        at ts[-1] + (ts[-1]-ts[-2]) instead of 1e10)."""
+        t_end = float(2 * ts[-1] - ts[-2]) if ts.shape[0] > 1 else float(ts[-1]) + 1.0
+        return ops.mip_encode(rays, ts, self.kind, t_end, self.min_deg, self.max_deg)
+
+
+def CylinderGaussian(min_deg=0, max_deg=16):
+    """src/utils.py:103-117."""
+    return _Mip("cylinder", min_deg, max_deg)
+
+
+def ConicGaussian(min_deg=0, max_deg=16):
+    """src/utils.py:126-140."""
+    return _Mip("cone", min_deg, max_deg)
+
+
+def load_mip(args):
+    """src/utils.py:119-124."""
+    if args.mip is None:
+        return None
+    elif args.mip == "cone":
+        return ConicGaussian()
+    elif args.mip == "cylinder":
+        return CylinderGaussian()
+    raise NotImplementedError(f"Unknown mip kind {args.mip}")
