@@ -53,8 +53,10 @@ __global__ void raygen_kernel(const float* __restrict__ c2w, int B, float focal,
     o[2] = M[11];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+      // torch.sum accumulates from +0.0: keep that first add so an all-(-0) row sums to +0 like the reference.
+      // (The sign of a zero y decides azim = +pi vs -pi in dir_to_elev_azim for rays on the image's centre row.)
       float p0 = d0 * M[k * 4 + 0], p1 = d1 * M[k * 4 + 1], p2 = d2 * M[k * 4 + 2];
-      o[3 + k] = (p0 + p1) + p2;
+      o[3 + k] = ((0.0f + p0) + p1) + p2;
     }
   }
 }

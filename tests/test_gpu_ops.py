@@ -26,6 +26,12 @@ def dev(t):
     return t.cuda()
 
 
+def bits_equal(a, b):
+    """bit-for-bit equality (torch.equal treats -0.0 == +0.0; the sign of zero matters downstream of atan2)."""
+    a, b = a.detach().cpu().contiguous(), torch.as_tensor(b).contiguous()
+    return a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def maxdiff(a, b):
     return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
 
@@ -36,10 +42,10 @@ def test_raygen_bit_exact(ops):
     size = int(g["size"])
     for i, crop in enumerate(g["crops"].tolist()):
         rays = ops.raygen(dev(g["c2w"]), float(g["focal"]), size, tuple(crop))
-        assert torch.equal(rays.cpu(), g[f"rays{i}"]), (i, maxdiff(rays, g[f"rays{i}"]))
+        assert bits_equal(rays, g[f"rays{i}"]), (i, maxdiff(rays, g[f"rays{i}"]))
     crop = tuple(g["crops"].tolist()[1])
     rays = ops.raygen(dev(g["c2w"]), float(g["focal"]), size, crop, noise=dev(g["noise"]), with_noise=0.1)
-    assert torch.equal(rays.cpu(), g["rays_noise"])
+    assert bits_equal(rays, g["rays_noise"])
 
 
 def test_raygen_full_size_matches_oracle(ops):
@@ -49,7 +55,12 @@ def test_raygen_full_size_matches_oracle(ops):
     crop = (700, 650, 100, 100)
     rays = ops.raygen(dev(c2w), focal, size, crop)
     ref = O.nerf_camera_rays(O.pixel_grid(size, crop), c2w, focal, size)
-    assert torch.equal(rays.cpu(), ref)
+    assert bits_equal(rays, ref)
+    # identity pose, crop through the image centre: rows/cols with exact zeros (+0 vs -0 matters for azim)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    for sz, crop in ((64, (28, 28, 8, 8)), (800, (396, 396, 8, 8))):
+        f = 0.5 * sz / math.tan(0.5 * 0.6911)
+        assert bits_equal(ops.raygen(dev(c2w), f, sz, crop), O.nerf_camera_rays(O.pixel_grid(sz, crop), c2w, f, sz))
 
 
 def test_raygen_dtu(ops):

@@ -74,6 +74,24 @@ def test_fused_render_tile_800_geometry(ops):
     assert float((weights.sum(0) - 1).abs().max()) <= 1e-5
 
 
+def test_fused_render_image_centre_signed_zero(ops):
+    """Rays through the image centre have exact zeros in their direction; azim = atan2(y, x) jumps by 2*pi
+    with the SIGN of a zero y (x < 0), so ray generation must reproduce torch's zero signs."""
+    h = load_golden("g11_plain_view_b1")
+    p = golden_params(h)
+    size, T = 64, 32
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    crop = (28, 28, 8, 8)
+    rays = ops.raygen(c2w.cuda(), focal, size, crop)
+    ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+    pf, pv, tables = pack_plain(ops, p, "bf16x3")
+    out, _, _ = ops.render_plain_view(rays, ts, tables, pf, pv, "bf16x3", "upshifted", "black")
+    ref = O.plain_nerf(p, O.nerf_camera_rays(O.pixel_grid(size, crop), c2w, focal, size), 2.0, 6.0, T, "view",
+                       act="upshifted")
+    assert float((out.cpu() - ref).abs().max()) <= 1e-4
+
+
 def test_fused_render_ragged_steps_and_workspace_error(ops):
     from nerf_atlas_amd._lib import NaError
     h = load_golden("g11_plain_view_b1")
