@@ -35,9 +35,11 @@ constexpr int kMaxTilesPerMlp = 8 * 9 + 3;
 struct TileTab {
   const uint32_t* hdr0;
   const uint32_t* hdr1;
-  int32_t ntiles;
+  int32_t ntiles;  // tiles per pass (both MLPs)
   int32_t split;
 };
+// header words are read with scalar loads (s_load_dwordx2 through the constant address space)
+typedef const __attribute__((address_space(4))) uint32_t* hdr_ptr_t;
 
 template <int PREC>
 struct Frag {
@@ -62,10 +64,17 @@ __device__ __forceinline__ float sin_cw(float x) {
   return (qi & 1) ? -s : s;
 }
 
-template <int ACT>
+// Hardware sine (v_sin_f32 takes revolutions, valid for |r| <= 256 -> reduce with v_fract first).  Used by the
+// bf16 fast mode only, where its ~1e-6 absolute error is far below the bf16 operand rounding.
+__device__ __forceinline__ float sin_hw(float x) {
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f));
+}
+
+template <int ACT, int PREC = NA_PREC_BF16X3>
 __device__ __forceinline__ float act_apply(float v) {
-  if constexpr (ACT == NA_ACT_LEAKY_RELU) return fmaxf(v, v * 0.01f);
-  else if constexpr (ACT == NA_ACT_SIN) return sin_cw(v);
+  // leaky_relu(v) = max(v, 0.01 v) = median(v, 0.01 v, +big): v_med3_f32 needs no canonicalising v_max
+  if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, 3.0e38f);
+  else if constexpr (ACT == NA_ACT_SIN) return PREC == NA_PREC_BF16 ? sin_hw(v) : sin_cw(v);
   else return v;
 }
 
@@ -101,7 +110,7 @@ template <int PREC, int ACT>
 __device__ __forceinline__ void frag_activate(Frag<PREC>& f) {
   float v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = act_apply<ACT>(frag_value<PREC>(f, e));
+  for (int e = 0; e < 8; ++e) v[e] = act_apply<ACT, PREC>(frag_value<PREC>(f, e));
   f = make_frag<PREC>(v);
   pin_frag<PREC>(f);
 }
@@ -112,32 +121,56 @@ __device__ __forceinline__ void glds16(const void* g, char* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+// The stream is cyclic: every pass (one group of samples) consumes tiles 0..ntiles-1 in order, and the
+// workgroup knows up front how many passes it will run, so the prefetcher manages itself: advance() makes the
+// next tile resident and issues the DMA of the one after it (double buffer, one barrier per tile).  The header
+// entry of the tile to be issued is fetched one tile ahead with a scalar load, off the critical path.
 template <int NWAVES>
 struct WeightStream {
   const char* base0;
   const char* base1;
+  hdr_ptr_t hdr0, hdr1;
   char* lds;           // two buffers of buf_bytes each
   uint32_t buf_bytes;
-  uint32_t parity;     // buffer holding the CURRENT tile
+  uint32_t parity;     // buffer that receives the NEXT advance()'s tile
   int wave, lane;
+  int ntiles, split;
+  int issued, total;   // tiles issued so far / to issue over the whole kernel
+  int next_t;          // tile index (within a pass) of the preloaded entry
+  uint32_t e_off, e_nblk;
+  bool e_first;
 
-  __device__ __forceinline__ void issue(const TileTab& tab, int t, uint32_t par) {
-    const bool first = t < tab.split;
-    const uint32_t* e = (first ? tab.hdr0 : tab.hdr1) + 1 + 2 * (first ? t : t - tab.split);
-    const uint32_t off = __builtin_amdgcn_readfirstlane(e[0]);
-    const int nblk = __builtin_amdgcn_readfirstlane(e[1]);
-    const char* src = (first ? base0 : base1) + (size_t)off * 1024 + lane * 16;
-    char* dst = lds + par * buf_bytes;
-    for (int b = wave; b < nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
+  __device__ __forceinline__ void preload(int t) {
+    e_first = t < split;
+    hdr_ptr_t e = (e_first ? hdr0 : hdr1) + 1 + 2 * (e_first ? t : t - split);
+    e_off = e[0];
+    e_nblk = e[1];
+    next_t = t;
   }
-  // Make tile t resident (its loads were issued one tile earlier), then prefetch tile `tnext`
-  // (or nothing if tnext < 0) into the other buffer.  Returns the LDS address of tile t.
-  __device__ __forceinline__ const char* advance(const TileTab& tab, int tnext) {
+  __device__ __forceinline__ void issue_preloaded(uint32_t par) {
+    const char* src = (e_first ? base0 : base1) + (size_t)e_off * 1024 + lane * 16;
+    char* dst = lds + par * buf_bytes;
+    for (int b = wave; b < (int)e_nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
+    ++issued;
+    int t = next_t + 1;
+    preload(t == ntiles ? 0 : t);
+  }
+  __device__ __forceinline__ void start(const TileTab& tab, const char* b0, const char* b1, char* smem, uint32_t bufb,
+                                        int npasses, int wave_, int lane_) {
+    base0 = b0; base1 = b1; hdr0 = (hdr_ptr_t)tab.hdr0; hdr1 = (hdr_ptr_t)tab.hdr1;
+    lds = smem; buf_bytes = bufb; wave = wave_; lane = lane_;
+    ntiles = tab.ntiles; split = tab.split; issued = 0; total = npasses * tab.ntiles;
+    parity = 0;
+    preload(0);
+    if (total > 0) issue_preloaded(0);
+  }
+  // Make the next tile resident (its DMA was issued one tile earlier) and start the DMA of the one after it.
+  __device__ __forceinline__ const char* advance() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const char* cur = lds + parity * buf_bytes;
     parity ^= 1u;
-    if (tnext >= 0) issue(tab, tnext, parity);
+    if (issued < total) issue_preloaded(parity);
     return cur;
   }
 };
@@ -209,8 +242,8 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& acc, Frag<PREC>& f0, 
   float v0[8], v1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    v0[e] = act_apply<ACT>(acc[e]);
-    v1[e] = act_apply<ACT>(acc[8 + e]);
+    v0[e] = act_apply<ACT, PREC>(acc[e]);
+    v1[e] = act_apply<ACT, PREC>(acc[8 + e]);
   }
   f0 = make_frag<PREC>(v0);
   f1 = make_frag<PREC>(v1);
@@ -224,20 +257,17 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& acc, Frag<PREC>& f0, 
 
 // One SkipConnMLP up to (not including) the `out` Linear.  On entry I[] holds the raw init input
 // fragments; on exit H[] holds act(last hidden) ready for the out layer, I[] holds act(init).
-// `t` is the running tile index (advanced), `tlast_next` is the tile to prefetch after the final
-// tile of this call's caller-visible sequence is handled by the caller.
 template <int PREC, int ACT, int NI, int NWAVES>
-__device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, const TileTab& tab, int& t, int num_layers,
-                                                  int skip, Frag<PREC> (&I)[NI], Frag<PREC> (&H)[kHC], int lane) {
+__device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, int num_layers, int skip,
+                                                  Frag<PREC> (&I)[NI], Frag<PREC> (&H)[kHC], int lane) {
   Frag<PREC> Hn[kHC];
   // ---- init Linear: dim_p -> 256
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const char* tile = ws.advance(tab, t + 1);
+    const char* tile = ws.advance();
     f32x16 acc = load_bias<PREC>(tile, NI, lane);
     mma_chunks<PREC, NI>(acc, tile, 0, I, lane);
     acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
-    ++t;
   }
 #pragma unroll
   for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
@@ -249,21 +279,19 @@ __device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, cons
     if (sk) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const char* tile = ws.advance(tab, t + 1);
+        const char* tile = ws.advance();
         f32x16 acc = load_bias<PREC>(tile, kHC + NI, lane);
         mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
         mma_chunks<PREC, NI>(acc, tile, kHC, I, lane);
         acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
-        ++t;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const char* tile = ws.advance(tab, t + 1);
+        const char* tile = ws.advance();
         f32x16 acc = load_bias<PREC>(tile, kHC, lane);
         mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
         acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
-        ++t;
       }
     }
 #pragma unroll
@@ -273,12 +301,10 @@ __device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, cons
 
 // One 32-row tile of the `out` Linear (no activation on the result).
 template <int PREC, int NWAVES>
-__device__ __forceinline__ f32x16 mlp_out_tile(WeightStream<NWAVES>& ws, const TileTab& tab, int& t, int tnext,
-                                               const Frag<PREC> (&H)[kHC], int lane) {
-  const char* tile = ws.advance(tab, tnext);
+__device__ __forceinline__ f32x16 mlp_out_tile(WeightStream<NWAVES>& ws, const Frag<PREC> (&H)[kHC], int lane) {
+  const char* tile = ws.advance();
   f32x16 acc = load_bias<PREC>(tile, kHC, lane);
   mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
-  ++t;
   return acc;
 }
 

@@ -26,9 +26,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WeightStream<NWAVES> ws;
-  ws.base0 = a.packed + kHeaderBytes; ws.base1 = ws.base0; ws.lds = smem; ws.buf_bytes = a.buf_bytes; ws.parity = 0;
-  ws.wave = wave; ws.lane = lane;
-  ws.issue(tab, 0, 0);
+  const int npasses = ((int)blockIdx.x < a.ngroups) ? (a.ngroups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  ws.start(tab, a.packed + kHeaderBytes, a.packed + kHeaderBytes, smem, a.buf_bytes, npasses, wave, lane);
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
     const int64_t n_raw = ((int64_t)g * NWAVES + wave) * 32 + (lane & 31);
@@ -92,13 +91,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
       }
     }
     // ---------------- network
-    int t = 0;
     Frag<PREC> H[kHC];
-    mlp_hidden_layers<PREC, ACT, NI, NWAVES>(ws, tab, t, a.d.num_layers, a.d.skip, I, H, lane);
-    const bool more = g + (int)gridDim.x < a.ngroups;
+    mlp_hidden_layers<PREC, ACT, NI, NWAVES>(ws, a.d.num_layers, a.d.skip, I, H, lane);
     for (int j = 0; j < a.out_tiles; ++j) {
-      const int tnext = j + 1 < a.out_tiles ? t + 1 : (more ? 0 : -1);
-      f32x16 acc = mlp_out_tile<PREC, NWAVES>(ws, tab, t, tnext, H, lane);
+      f32x16 acc = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
       if (n_raw < a.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

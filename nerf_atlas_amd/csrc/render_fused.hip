@@ -46,9 +46,8 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, ln = lane & 31;
   WeightStream<NWAVES> ws;
-  ws.base0 = a.packed_first + kHeaderBytes; ws.base1 = a.packed_view + kHeaderBytes;
-  ws.lds = smem; ws.buf_bytes = a.buf_bytes; ws.parity = 0; ws.wave = wave; ws.lane = lane;
-  ws.issue(tab, 0, 0);
+  const int npasses = ((int)blockIdx.x < a.ngroups) ? (a.ngroups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  ws.start(tab, a.packed_first + kHeaderBytes, a.packed_view + kHeaderBytes, smem, a.buf_bytes, npasses, wave, lane);
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
     const int64_t item_raw = (int64_t)g * NWAVES + wave;
@@ -80,19 +79,18 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
       I1[1] = make_frag<PREC>(v1);
       I1[2] = make_frag<PREC>(v2);
     }
-    int tl = 0;
     Frag<PREC> H[kHC];
-    mlp_hidden_layers<PREC, NA_ACT_LEAKY_RELU, NI1, NWAVES>(ws, tab, tl, a.first_layers, 3, I1, H, lane);
+    mlp_hidden_layers<PREC, NA_ACT_LEAKY_RELU, NI1, NWAVES>(ws, a.first_layers, 3, I1, H, lane);
 
     // ---- `first` out: rows 0..63 = intermediate (-> View latent), row 64 = density
     Frag<PREC> I2[NI2];
     float density;
     {
-      f32x16 o0 = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, tl + 1, H, lane);
+      f32x16 o0 = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
       acc_to_frags<PREC, NA_ACT_NONE>(o0, I2[0], I2[1]);
-      f32x16 o1 = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, tl + 1, H, lane);
+      f32x16 o1 = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
       acc_to_frags<PREC, NA_ACT_NONE>(o1, I2[2], I2[3]);
-      f32x16 o2 = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, tl + 1, H, lane);
+      f32x16 o2 = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
       density = o2[0];  // row 64 lives in register 0 of the hi=0 lanes
       float el, az;
       elev_azim(dx, dy, dz, el, az);
@@ -103,9 +101,8 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
       I2[4] = make_frag<PREC>(v4);
     }
     // ---- View MLP (sin activations)
-    mlp_hidden_layers<PREC, NA_ACT_SIN, NI2, NWAVES>(ws, tab, tl, a.view_layers, 3, I2, H, lane);
-    const bool more = g + (int)gridDim.x < a.ngroups;
-    f32x16 oc = mlp_out_tile<PREC, NWAVES>(ws, tab, tl, more ? 0 : -1, H, lane);
+    mlp_hidden_layers<PREC, NA_ACT_SIN, NI2, NWAVES>(ws, a.view_layers, 3, I2, H, lane);
+    f32x16 oc = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
     const float cr = apply_sigmoid_kind(oc[0], a.sigmoid_kind);
     const float cg = apply_sigmoid_kind(oc[1], a.sigmoid_kind);
     const float cb = apply_sigmoid_kind(oc[2], a.sigmoid_kind);
