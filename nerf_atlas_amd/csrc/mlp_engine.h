@@ -16,6 +16,12 @@
 #pragma once
 #include "common.h"
 
+// Ablation switches for tools/ablate.py (timing experiments only; results are WRONG when any bit is set):
+//  1 no barrier/wait   2 identity activation   4 no MFMA   8 one LDS read per tile   16 no weight DMA   32 no hash
+#ifndef NA_ABLATE
+#define NA_ABLATE 0
+#endif
+
 namespace na {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -73,6 +79,7 @@ __device__ __forceinline__ float sin_hw(float x) {
 template <int ACT, int PREC = NA_PREC_BF16X3>
 __device__ __forceinline__ float act_apply(float v) {
   // leaky_relu(v) = max(v, 0.01 v) = median(v, 0.01 v, +big): v_med3_f32 needs no canonicalising v_max
+  if constexpr ((NA_ABLATE & 2) != 0) return v;
   if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, 3.0e38f);
   else if constexpr (ACT == NA_ACT_SIN) return PREC == NA_PREC_BF16 ? sin_hw(v) : sin_cw(v);
   else return v;
@@ -139,6 +146,7 @@ struct WeightStream {
   int next_t;          // tile index (within a pass) of the preloaded entry
   uint32_t e_off, e_nblk;
   bool e_first;
+  const char* cur;     // LDS address of the resident tile
 
   __device__ __forceinline__ void preload(int t) {
     e_first = t < split;
@@ -150,7 +158,8 @@ struct WeightStream {
   __device__ __forceinline__ void issue_preloaded(uint32_t par) {
     const char* src = (e_first ? base0 : base1) + (size_t)e_off * 1024 + lane * 16;
     char* dst = lds + par * buf_bytes;
-    for (int b = wave; b < (int)e_nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
+    if ((NA_ABLATE & 16) == 0 || issued < 2)
+      for (int b = wave; b < (int)e_nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
     ++issued;
     int t = next_t + 1;
     preload(t == ntiles ? 0 : t);
@@ -163,28 +172,62 @@ struct WeightStream {
     parity = 0;
     preload(0);
     if (total > 0) issue_preloaded(0);
+    advance();
   }
-  // Make the next tile resident (its DMA was issued one tile earlier) and start the DMA of the one after it.
-  __device__ __forceinline__ const char* advance() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const char* cur = lds + parity * buf_bytes;
+  // Called once per tile, after the tile's last LDS read: makes the next tile resident (its DMA was issued one
+  // tile earlier) and starts the DMA of the one after it into the buffer that was just released.
+  __device__ __forceinline__ void advance() {
+    if ((NA_ABLATE & 1) == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    cur = lds + parity * buf_bytes;
     parity ^= 1u;
     if (issued < total) issue_preloaded(parity);
-    return cur;
   }
 };
 
 // ------------------------------------------------------------------------------------------------ tile math
-// acc(32 features x 32 samples) += A[frag0 .. frag0+NCH) . B[0..NCH)
-// Software-pipelined in stages of kStage chunks: the A fragments of stage s+1 are read from LDS while the
-// MFMAs of stage s issue.  sched_barrier pins DS/MFMA order per stage (VALU/SALU may still move across)
-// so the compiler cannot hoist all 16..33 ds_read_b128 of a tile up front (that costs 64+ VGPRs and spills).
-constexpr int kStage = 4;
-#define NA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400)
+// Software pipeline inside a wave: while the MFMAs of tile j issue (a dependent accumulator chain that keeps the
+// matrix pipe busy 32 cycles per instruction), the VALU slots in between carry the activation epilogue of tile
+// j-1 (bias is already in the accumulator; activation; bf16 round; pack into next-layer B fragments).  The
+// epilogue is cut into 16 single-value steps that are spread evenly over the tile's MFMAs in program order.
+constexpr int kStage = 4;  // A fragments are read from LDS one stage (4 chunks) ahead of their MFMAs
 
-template <int PREC, int NCH>
-__device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int frag0, const Frag<PREC>* B, int lane) {
+// Activation epilogue of a finished accumulator tile, one value per step.
+template <int PREC, int ACT>
+struct Epilogue {
+  f32x16 acc;          // finished tile (bias included)
+  float v0[8], v1[8];  // activated values (become fragments 2j and 2j+1 of the next layer)
+  bool live;
+  __device__ __forceinline__ void step(int k) {
+    if (!live) return;
+    // the volatile asm orders this value with the surrounding scheduling fences, i.e. keeps it between the
+    // two MFMAs it was written between (pure VALU would otherwise sink to the end of the tile)
+    if (k < 8) { v0[k] = act_apply<ACT, PREC>(acc[k]); asm volatile("" : "+v"(v0[k])); }
+    else { v1[k - 8] = act_apply<ACT, PREC>(acc[k]); asm volatile("" : "+v"(v1[k - 8])); }
+  }
+  __device__ __forceinline__ void steps(int k0, int k1) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k >= k0 && k < k1) step(k);
+  }
+  __device__ __forceinline__ void finish(Frag<PREC>& f0, Frag<PREC>& f1) {
+    if (!live) return;
+    f0 = make_frag<PREC>(v0);
+    f1 = make_frag<PREC>(v1);
+    // the fragments are only consumed by the NEXT layer: without this pin instruction selection sinks every
+    // epilogue of a layer behind its last tile (128 live fp32 accumulators -> spills, no overlap)
+    pin_frag<PREC>(f0);
+    pin_frag<PREC>(f1);
+  }
+};
+
+// acc(32 features x 32 samples) += A[frag0 .. frag0+NCH) . B[0..NCH); after MFMA number m (counted from m0 over a
+// tile total of mtot) the pending epilogue advances by its share of the 16 steps.
+template <int PREC, int ACT, int NCH>
+__device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int frag0, const Frag<PREC>* B, int lane,
+                                           Epilogue<PREC, ACT>& epi, int m0, int mtot) {
   constexpr int FB = PREC == NA_PREC_BF16X3 ? 2048 : 1024;
   constexpr int NS = (NCH + kStage - 1) / kStage;
   bf16x8 ah[2][kStage], al[2][kStage];
@@ -202,6 +245,7 @@ __device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int fr
       for (int c = 0; c < kStage; ++c) {
         const int cc = (s + 1) * kStage + c;
         if (cc < NCH) {
+          if constexpr ((NA_ABLATE & 8) != 0) { ah[cur ^ 1][c] = ah[0][0]; al[cur ^ 1][c] = ah[0][0]; continue; }
           ah[cur ^ 1][c] = *(const bf16x8*)(a0 + cc * FB);
           if constexpr (PREC == NA_PREC_BF16X3) al[cur ^ 1][c] = *(const bf16x8*)(a0 + cc * FB + 1024);
         }
@@ -211,14 +255,20 @@ __device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int fr
     for (int c = 0; c < kStage; ++c) {
       const int cc = s * kStage + c;
       if (cc < NCH) {
-        if constexpr (PREC == NA_PREC_BF16X3) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][c], B[cc].hi, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].lo, acc, 0, 0, 0);
+        if constexpr ((NA_ABLATE & 4) != 0) {
+          asm volatile("" ::"v"(ah[cur][c]), "v"(B[cc].hi));
+        } else {
+          if constexpr (PREC == NA_PREC_BF16X3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][c], B[cc].hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].lo, acc, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].hi, acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].hi, acc, 0, 0, 0);
+        const int m = m0 + cc;
+        epi.steps(16 * m / mtot, 16 * (m + 1) / mtot);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    NA_SCHED_FENCE();
   }
 }
 
@@ -236,23 +286,35 @@ __device__ __forceinline__ f32x16 load_bias(const char* tile, int nfrag, int lan
   return acc;
 }
 
-// accumulator tile -> activated input fragments of the next layer (chunks 2j and 2j+1)
+// accumulator tile -> activated input fragments of the next layer (chunks 2j and 2j+1), not overlapped
 template <int PREC, int ACT>
 __device__ __forceinline__ void acc_to_frags(const f32x16& acc, Frag<PREC>& f0, Frag<PREC>& f1) {
-  float v0[8], v1[8];
+  Epilogue<PREC, ACT> e;
+  e.acc = acc;
+  e.live = true;
+  e.steps(0, 16);
+  e.finish(f0, f1);
+}
+
+// The eight 32-feature tiles of one Linear with 256 outputs: K = [H (NH chunks) | I (NI chunks)].
+// Tile j's MFMAs are interleaved with the epilogue of tile j-1; the last epilogue is flushed at the end.
+template <int PREC, int ACT, int NH, int NI, int NWAVES>
+__device__ __forceinline__ void linear256(WeightStream<NWAVES>& ws, const Frag<PREC>* H, const Frag<PREC>* I,
+                                          Frag<PREC> (&Hn)[kHC], int lane) {
+  Epilogue<PREC, ACT> epi;
+  epi.live = false;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    v0[e] = act_apply<ACT, PREC>(acc[e]);
-    v1[e] = act_apply<ACT, PREC>(acc[8 + e]);
+  for (int j = 0; j < 8; ++j) {
+    f32x16 acc = load_bias<PREC>(ws.cur, NH + NI, lane);
+    if constexpr (NH > 0) mma_chunks<PREC, ACT, NH>(acc, ws.cur, 0, H, lane, epi, 0, NH + NI);
+    if constexpr (NI > 0) mma_chunks<PREC, ACT, NI>(acc, ws.cur, NH, I, lane, epi, NH, NH + NI);
+    if (j > 0) epi.finish(Hn[2 * j - 2], Hn[2 * j - 1]);
+    ws.advance();
+    epi.acc = acc;
+    epi.live = true;
   }
-  f0 = make_frag<PREC>(v0);
-  f1 = make_frag<PREC>(v1);
-  // Pin the epilogue inside its tile.  The results are only consumed by the NEXT layer, so instruction
-  // selection would otherwise sink all eight epilogues of a layer behind its last tile (128 live fp32
-  // accumulators, no MFMA/VALU overlap between the waves of a SIMD).  An empty volatile asm that "modifies"
-  // the packed fragments is ordered with the barriers and forces them to exist here.
-  pin_frag<PREC>(f0);
-  pin_frag<PREC>(f1);
+  epi.steps(0, 16);
+  epi.finish(Hn[14], Hn[15]);
 }
 
 // One SkipConnMLP up to (not including) the `out` Linear.  On entry I[] holds the raw init input
@@ -262,13 +324,7 @@ __device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, int 
                                                   Frag<PREC> (&I)[NI], Frag<PREC> (&H)[kHC], int lane) {
   Frag<PREC> Hn[kHC];
   // ---- init Linear: dim_p -> 256
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const char* tile = ws.advance();
-    f32x16 acc = load_bias<PREC>(tile, NI, lane);
-    mma_chunks<PREC, NI>(acc, tile, 0, I, lane);
-    acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
-  }
+  linear256<PREC, ACT, 0, NI, NWAVES>(ws, nullptr, I, Hn, lane);
 #pragma unroll
   for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
 #pragma unroll
@@ -276,35 +332,21 @@ __device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, int 
   // ---- hidden Linears
   for (int i = 0; i < num_layers; ++i) {
     const bool sk = (i % skip) == 0 && i != num_layers - 1;
-    if (sk) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const char* tile = ws.advance();
-        f32x16 acc = load_bias<PREC>(tile, kHC + NI, lane);
-        mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
-        mma_chunks<PREC, NI>(acc, tile, kHC, I, lane);
-        acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const char* tile = ws.advance();
-        f32x16 acc = load_bias<PREC>(tile, kHC, lane);
-        mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
-        acc_to_frags<PREC, ACT>(acc, Hn[2 * j], Hn[2 * j + 1]);
-      }
-    }
+    if (sk) linear256<PREC, ACT, kHC, NI, NWAVES>(ws, H, I, Hn, lane);
+    else linear256<PREC, ACT, kHC, 0, NWAVES>(ws, H, nullptr, Hn, lane);
 #pragma unroll
     for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
   }
 }
 
-// One 32-row tile of the `out` Linear (no activation on the result).
+// One 32-row tile of the `out` Linear (no activation on the result; the caller's epilogue follows the sync).
 template <int PREC, int NWAVES>
 __device__ __forceinline__ f32x16 mlp_out_tile(WeightStream<NWAVES>& ws, const Frag<PREC> (&H)[kHC], int lane) {
-  const char* tile = ws.advance();
-  f32x16 acc = load_bias<PREC>(tile, kHC, lane);
-  mma_chunks<PREC, kHC>(acc, tile, 0, H, lane);
+  f32x16 acc = load_bias<PREC>(ws.cur, kHC, lane);
+  Epilogue<PREC, NA_ACT_NONE> none;
+  none.live = false;
+  mma_chunks<PREC, NA_ACT_NONE, kHC>(acc, ws.cur, 0, H, lane, none, 0, kHC);
+  ws.advance();
   return acc;
 }
 

@@ -70,7 +70,12 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
     Frag<PREC> I1[NI1];
     {
       float f[16];
-      hash_levels4(px, py, pz, a.tables, a.res, 4 * hi, f);
+      if constexpr ((NA_ABLATE & 32) != 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = px * (float)e;
+      } else {
+        hash_levels4(px, py, pz, a.tables, a.res, 4 * hi, f);
+      }
       float v0[8], v1[8], v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; v2[e] = 0.f; }
