@@ -21,6 +21,11 @@
 #ifndef NA_ABLATE
 #define NA_ABLATE 0
 #endif
+// NA_TRACE: waves 0 and NWAVES/2 of workgroup 0 log (s_memtime << 8 | event id) into LDS during their first two
+// passes; the render kernel dumps the log to its workspace (tools/trace.py).  Timing experiments only.
+#ifndef NA_TRACE
+#define NA_TRACE 0
+#endif
 
 namespace na {
 
@@ -44,8 +49,6 @@ struct TileTab {
   int32_t ntiles;  // tiles per pass (both MLPs)
   int32_t split;
 };
-// header words are read with scalar loads (s_load_dwordx2 through the constant address space)
-typedef const __attribute__((address_space(4))) uint32_t* hdr_ptr_t;
 
 template <int PREC>
 struct Frag {
@@ -129,107 +132,196 @@ __device__ __forceinline__ void glds16(const void* g, char* lds) {
 }
 
 // The stream is cyclic: every pass (one group of samples) consumes tiles 0..ntiles-1 in order, and the
-// workgroup knows up front how many passes it will run, so the prefetcher manages itself: advance() makes the
-// next tile resident and issues the DMA of the one after it (double buffer, one barrier per tile).  The header
-// entry of the tile to be issued is fetched one tile ahead with a scalar load, off the critical path.
-template <int NWAVES>
+// workgroup knows up front how many passes it will run, so the prefetcher manages itself.
+//
+// Three LDS slots, ONE barrier per tile placed in the MIDDLE of the tile's MFMA stream (mid_sync): at mid-tile t
+// every wave waits for its own DMA pieces of tile t+1 (issued a full tile earlier), the barrier makes tile t+1
+// resident for everybody and proves that everybody is done with tile t-1, whose slot then receives the DMA of
+// tile t+2.  Tile boundaries therefore carry no barrier and no DMA issue: the MFMA stream runs across them.
+// The (offset, size) table of the tiles is copied into LDS once so the main loop has no scalar-memory loads
+// (an outstanding SMEM load would turn every LDS wait into lgkmcnt(0)).
+// LDS slots that fit next to the tile table: 3 (mid-tile barrier) when possible, else 2 (every wave takes the
+// barrier at the end of its tile; the DMA then reuses the slot that was just consumed).
+constexpr int slots_for(int precision, int ni_max) {
+  return 3 * (((kHC + ni_max) * (precision == NA_PREC_BF16X3 ? 2 : 1) + 1) * 1024) + 8 * kMaxTiles + 24 * 1024 <= 160 * 1024
+             ? 3 : 2;
+}
+
+template <int NWAVES, int SLOTS = 3>
 struct WeightStream {
+  static constexpr int kSlots = SLOTS;
+  static constexpr bool kSplitRoles = SLOTS == 3 && NWAVES >= 8;  // second half of the waves: late barrier, no DMA
   const char* base0;
   const char* base1;
-  hdr_ptr_t hdr0, hdr1;
-  char* lds;           // two buffers of buf_bytes each
+  char* lds;            // kSlots buffers of buf_bytes each, then uint2 table[ntiles]
   uint32_t buf_bytes;
-  uint32_t parity;     // buffer that receives the NEXT advance()'s tile
   int wave, lane;
-  int ntiles, split;
-  int issued, total;   // tiles issued so far / to issue over the whole kernel
-  int next_t;          // tile index (within a pass) of the preloaded entry
-  uint32_t e_off, e_nblk;
-  bool e_first;
-  const char* cur;     // LDS address of the resident tile
-
-  __device__ __forceinline__ void preload(int t) {
-    e_first = t < split;
-    hdr_ptr_t e = (e_first ? hdr0 : hdr1) + 1 + 2 * (e_first ? t : t - split);
-    e_off = e[0];
-    e_nblk = e[1];
-    next_t = t;
+  int ntiles;
+  int issued, total;    // tiles issued so far / to issue over the whole kernel
+  int next_t;           // tile index (within a pass) of the next tile to issue
+  int cur_slot;
+  const char* cur;      // LDS address of the tile being consumed
+  bool late;            // this wave takes barrier t at the end of tile t (else in the middle of tile t)
+#if NA_TRACE
+  static constexpr int kTraceMax = 1400;
+  unsigned long long* tlog;
+  int tpos;
+  __device__ __forceinline__ void mark(int id) {
+    if (tlog != nullptr && tpos < kTraceMax) {
+      tlog[tpos++] = (__builtin_amdgcn_s_memtime() << 8) | (unsigned long long)id;
+    }
   }
-  __device__ __forceinline__ void issue_preloaded(uint32_t par) {
-    const char* src = (e_first ? base0 : base1) + (size_t)e_off * 1024 + lane * 16;
-    char* dst = lds + par * buf_bytes;
-    if ((NA_ABLATE & 16) == 0 || issued < 2)
-      for (int b = wave; b < (int)e_nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
+#else
+  __device__ __forceinline__ void mark(int) {}
+#endif
+
+  __device__ __forceinline__ void issue_next(int slot) {
+    const uint2 e = ((const uint2*)(lds + kSlots * buf_bytes))[next_t];
+    const uint32_t off = __builtin_amdgcn_readfirstlane(e.x);
+    const int nblk = __builtin_amdgcn_readfirstlane(e.y);
+    const char* src = ((off >> 31) ? base1 : base0) + (size_t)(off & 0x7fffffffu) * 1024 + lane * 16;
+    char* dst = lds + slot * buf_bytes;
+    // An LDS-DMA instruction costs ~100-200 issue cycles during which its wave cannot issue MFMAs.  With two
+    // waves per SIMD (waves w and w + NWAVES/2) only the first one issues DMA; its partner (the `late` half, which
+    // takes the per-tile barrier at the END of its tile instead of the middle and so runs half a tile ahead)
+    // keeps the matrix pipe busy meanwhile.
+    if ((NA_ABLATE & 16) == 0 || issued < 3) {
+      if constexpr (kSplitRoles) {
+        constexpr int HW = NWAVES / 2;
+        if (!late)
+          for (int b = wave; b < nblk; b += HW) glds16(src + (size_t)b * 1024, dst + b * 1024);
+      } else {
+        for (int b = wave; b < nblk; b += NWAVES) glds16(src + (size_t)b * 1024, dst + b * 1024);
+      }
+    }
     ++issued;
-    int t = next_t + 1;
-    preload(t == ntiles ? 0 : t);
+    next_t = next_t + 1 == ntiles ? 0 : next_t + 1;
   }
   __device__ __forceinline__ void start(const TileTab& tab, const char* b0, const char* b1, char* smem, uint32_t bufb,
                                         int npasses, int wave_, int lane_) {
-    base0 = b0; base1 = b1; hdr0 = (hdr_ptr_t)tab.hdr0; hdr1 = (hdr_ptr_t)tab.hdr1;
+    base0 = b0; base1 = b1;
     lds = smem; buf_bytes = bufb; wave = wave_; lane = lane_;
-    ntiles = tab.ntiles; split = tab.split; issued = 0; total = npasses * tab.ntiles;
-    parity = 0;
-    preload(0);
-    if (total > 0) issue_preloaded(0);
-    advance();
+    ntiles = tab.ntiles; issued = 0; total = npasses * tab.ntiles; next_t = 0;
+    late = SLOTS == 2 || (kSplitRoles && wave_ >= NWAVES / 2);
+    uint2* table = (uint2*)(smem + kSlots * bufb);
+#if NA_TRACE
+    tlog = nullptr;
+    tpos = 0;
+    if (blockIdx.x == 0 && lane_ == 0 && (wave_ == 0 || wave_ == NWAVES / 2))
+      tlog = (unsigned long long*)(smem + kSlots * bufb + 8 * kMaxTiles) + (wave_ ? kTraceMax : 0);
+#endif
+    for (int t = wave_ * 64 + lane_; t < tab.ntiles; t += NWAVES * 64) {
+      const bool first = t < tab.split;
+      const uint32_t* e = (first ? tab.hdr0 : tab.hdr1) + 1 + 2 * (first ? t : t - tab.split);
+      table[t] = make_uint2(e[0] | (first ? 0u : 0x80000000u), e[1]);
+    }
+    __syncthreads();
+    {
+      const bool keep = late;
+      late = false;  // every wave helps with the two start-up tiles
+      if (total > 0) issue_next(0);
+      if (total > 1) issue_next(1);
+      late = keep;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur_slot = 0;
+    cur = lds;
   }
-  // Called once per tile, after the tile's last LDS read: makes the next tile resident (its DMA was issued one
-  // tile earlier) and starts the DMA of the one after it into the buffer that was just released.
-  __device__ __forceinline__ void advance() {
+  // Once per tile, between two MFMAs of the resident tile.
+  __device__ __forceinline__ void mid_sync() {
+    mark(2);
     if ((NA_ABLATE & 1) == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      mark(3);
+      __builtin_amdgcn_s_barrier();
     }
-    cur = lds + parity * buf_bytes;
-    parity ^= 1u;
-    if (issued < total) issue_preloaded(parity);
+    mark(4);
+    if (issued < total) issue_next((cur_slot + 2) % SLOTS);
+    mark(5);
+  }
+  // Once per tile, after its last LDS read: the next tile has been resident since this tile's barrier.
+  __device__ __forceinline__ void next_tile() {
+    if (late) mid_sync();
+    mark(6);
+    cur_slot = cur_slot == SLOTS - 1 ? 0 : cur_slot + 1;
+    cur = lds + cur_slot * buf_bytes;
   }
 };
 
 // ------------------------------------------------------------------------------------------------ tile math
-// Software pipeline inside a wave: while the MFMAs of tile j issue (a dependent accumulator chain that keeps the
-// matrix pipe busy 32 cycles per instruction), the VALU slots in between carry the activation epilogue of tile
-// j-1 (bias is already in the accumulator; activation; bf16 round; pack into next-layer B fragments).  The
-// epilogue is cut into 16 single-value steps that are spread evenly over the tile's MFMAs in program order.
+// A wave owns NB blocks of 32 samples (NB = 1 or 2): every A fragment read from LDS feeds NB MFMAs (one per
+// block, independent accumulators), which halves LDS, DMA and barrier traffic per sample at NB = 2.
+//
+// Software pipeline inside a wave: while the MFMAs of tile j issue (each keeps the matrix pipe busy for 32
+// cycles), the VALU slots in between carry the activation epilogue of tile j-1 (bias is already in the
+// accumulator; activation; bf16 round; pack into next-layer B fragments).  The epilogue is cut into 8*NB
+// two-value steps that are spread evenly over the tile's MFMAs in program order.
 constexpr int kStage = 4;  // A fragments are read from LDS one stage (4 chunks) ahead of their MFMAs
 
-// Activation epilogue of a finished accumulator tile, one value per step.
-template <int PREC, int ACT>
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+
+// Activation epilogue of NB finished accumulator tiles, two values (one packed dword) per step.
+template <int PREC, int ACT, int NB>
 struct Epilogue {
-  f32x16 acc;          // finished tile (bias included)
-  float v0[8], v1[8];  // activated values (become fragments 2j and 2j+1 of the next layer)
+  f32x16 acc[NB];       // finished tiles (bias included)
+  uint32_t hi[NB][8];   // packed bf16 pairs: dwords 0..3 -> fragment 2j, 4..7 -> fragment 2j+1
+  uint32_t lo[NB][8];   // low halves (bf16x3 only)
   bool live;
-  __device__ __forceinline__ void step(int k) {
+  static constexpr int kSteps = 8 * NB;
+
+  __device__ __forceinline__ void step(int u) {  // u in [0, 8*NB): block u / 8, dword u % 8
     if (!live) return;
-    // the volatile asm orders this value with the surrounding scheduling fences, i.e. keeps it between the
-    // two MFMAs it was written between (pure VALU would otherwise sink to the end of the tile)
-    if (k < 8) { v0[k] = act_apply<ACT, PREC>(acc[k]); asm volatile("" : "+v"(v0[k])); }
-    else { v1[k - 8] = act_apply<ACT, PREC>(acc[k]); asm volatile("" : "+v"(v1[k - 8])); }
+    const int b = u >> 3, d = u & 7;
+    const float x = act_apply<ACT, PREC>(acc[b][2 * d]);
+    const float y = act_apply<ACT, PREC>(acc[b][2 * d + 1]);
+    hi[b][d] = pack_bf16x2(x, y);
+    // the volatile asm orders this dword with the surrounding scheduling fences, i.e. keeps its VALU work
+    // between the two MFMAs it was written between (pure VALU would otherwise sink to the end of the tile)
+    asm volatile("" : "+v"(hi[b][d]));
+    if constexpr (PREC == NA_PREC_BF16X3) {
+      lo[b][d] = pack_bf16x2(x - bf16_round(x), y - bf16_round(y));
+      asm volatile("" : "+v"(lo[b][d]));
+    }
   }
-  __device__ __forceinline__ void steps(int k0, int k1) {
+  __device__ __forceinline__ void steps(int u0, int u1) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (k >= k0 && k < k1) step(k);
+    for (int u = 0; u < kSteps; ++u)
+      if (u >= u0 && u < u1) step(u);
   }
-  __device__ __forceinline__ void finish(Frag<PREC>& f0, Frag<PREC>& f1) {
+  // fragments 2j and 2j+1 of block b
+  __device__ __forceinline__ void finish(int b, Frag<PREC>& f0, Frag<PREC>& f1) {
     if (!live) return;
-    f0 = make_frag<PREC>(v0);
-    f1 = make_frag<PREC>(v1);
-    // the fragments are only consumed by the NEXT layer: without this pin instruction selection sinks every
-    // epilogue of a layer behind its last tile (128 live fp32 accumulators -> spills, no overlap)
-    pin_frag<PREC>(f0);
-    pin_frag<PREC>(f1);
+    u32x4 a = {hi[b][0], hi[b][1], hi[b][2], hi[b][3]}, c = {hi[b][4], hi[b][5], hi[b][6], hi[b][7]};
+    f0.hi = __builtin_bit_cast(bf16x8, a);
+    f1.hi = __builtin_bit_cast(bf16x8, c);
+    if constexpr (PREC == NA_PREC_BF16X3) {
+      u32x4 al = {lo[b][0], lo[b][1], lo[b][2], lo[b][3]}, cl = {lo[b][4], lo[b][5], lo[b][6], lo[b][7]};
+      f0.lo = __builtin_bit_cast(bf16x8, al);
+      f1.lo = __builtin_bit_cast(bf16x8, cl);
+    }
   }
 };
 
-// acc(32 features x 32 samples) += A[frag0 .. frag0+NCH) . B[0..NCH); after MFMA number m (counted from m0 over a
-// tile total of mtot) the pending epilogue advances by its share of the 16 steps.
-template <int PREC, int ACT, int NCH>
-__device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int frag0, const Frag<PREC>* B, int lane,
-                                           Epilogue<PREC, ACT>& epi, int m0, int mtot) {
+// acc[b](32 features x 32 samples) += A[frag0 .. frag0+NCH) . B[b][0..NCH) for the NB blocks of this wave.
+// After MFMA group number m (counted from m0 over a tile total of mtot chunk-steps) the pending epilogue
+// advances by its share of its steps.
+template <int PREC, int ACT, int NB, int NCH, int BSTRIDE, class WS>
+__device__ __forceinline__ void mma_chunks(WS& ws, f32x16 (&acc)[NB], const char* tile, int frag0,
+                                           const Frag<PREC>* B, int lane, Epilogue<PREC, ACT, NB>& epi, int m0,
+                                           int mtot) {
   constexpr int FB = PREC == NA_PREC_BF16X3 ? 2048 : 1024;
   constexpr int NS = (NCH + kStage - 1) / kStage;
+  constexpr int ES = Epilogue<PREC, ACT, NB>::kSteps;
   bf16x8 ah[2][kStage], al[2][kStage];
   const char* a0 = tile + frag0 * FB + lane * 16;
 #pragma unroll
@@ -255,18 +347,27 @@ __device__ __forceinline__ void mma_chunks(f32x16& acc, const char* tile, int fr
     for (int c = 0; c < kStage; ++c) {
       const int cc = s * kStage + c;
       if (cc < NCH) {
-        if constexpr ((NA_ABLATE & 4) != 0) {
-          asm volatile("" ::"v"(ah[cur][c]), "v"(B[cc].hi));
-        } else {
-          if constexpr (PREC == NA_PREC_BF16X3) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][c], B[cc].hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].lo, acc, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const Frag<PREC>& Bf = B[b * BSTRIDE + cc];
+          if constexpr ((NA_ABLATE & 4) != 0) {
+            asm volatile("" ::"v"(ah[cur][c]), "v"(Bf.hi));
+          } else {
+            if constexpr (PREC == NA_PREC_BF16X3) {
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][c], Bf.hi, acc[b], 0, 0, 0);
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], Bf.lo, acc[b], 0, 0, 0);
+            }
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], Bf.hi, acc[b], 0, 0, 0);
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], B[cc].hi, acc, 0, 0, 0);
+          const int m = (m0 + cc) * NB + b;
+          if (m == 0) ws.mark(1);
+          epi.steps(ES * m / (mtot * NB), ES * (m + 1) / (mtot * NB));
+          __builtin_amdgcn_sched_barrier(0);
+          if (m == (mtot * NB - 1) / 2 && !ws.late) {
+            ws.mid_sync();
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-        const int m = m0 + cc;
-        epi.steps(16 * m / mtot, 16 * (m + 1) / mtot);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -289,65 +390,77 @@ __device__ __forceinline__ f32x16 load_bias(const char* tile, int nfrag, int lan
 // accumulator tile -> activated input fragments of the next layer (chunks 2j and 2j+1), not overlapped
 template <int PREC, int ACT>
 __device__ __forceinline__ void acc_to_frags(const f32x16& acc, Frag<PREC>& f0, Frag<PREC>& f1) {
-  Epilogue<PREC, ACT> e;
-  e.acc = acc;
+  Epilogue<PREC, ACT, 1> e;
+  e.acc[0] = acc;
   e.live = true;
-  e.steps(0, 16);
-  e.finish(f0, f1);
+  e.steps(0, 8);
+  e.finish(0, f0, f1);
 }
 
 // The eight 32-feature tiles of one Linear with 256 outputs: K = [H (NH chunks) | I (NI chunks)].
 // Tile j's MFMAs are interleaved with the epilogue of tile j-1; the last epilogue is flushed at the end.
-template <int PREC, int ACT, int NH, int NI, int NWAVES>
-__device__ __forceinline__ void linear256(WeightStream<NWAVES>& ws, const Frag<PREC>* H, const Frag<PREC>* I,
-                                          Frag<PREC> (&Hn)[kHC], int lane) {
-  Epilogue<PREC, ACT> epi;
+// Fragment arrays are [NB][...] flattened: block b's chunk c of H is H[b*kHC + c], of I is I[b*NIS + c].
+template <int PREC, int ACT, int NB, int NH, int NI, int NIS, class WS>
+__device__ __forceinline__ void linear256(WS& ws, const Frag<PREC>* H, const Frag<PREC>* I,
+                                          Frag<PREC>* Hn, int lane) {
+  Epilogue<PREC, ACT, NB> epi;
   epi.live = false;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    f32x16 acc = load_bias<PREC>(ws.cur, NH + NI, lane);
-    if constexpr (NH > 0) mma_chunks<PREC, ACT, NH>(acc, ws.cur, 0, H, lane, epi, 0, NH + NI);
-    if constexpr (NI > 0) mma_chunks<PREC, ACT, NI>(acc, ws.cur, NH, I, lane, epi, NH, NH + NI);
-    if (j > 0) epi.finish(Hn[2 * j - 2], Hn[2 * j - 1]);
-    ws.advance();
-    epi.acc = acc;
+    f32x16 acc[NB];
+    ws.mark(0);
+    acc[0] = load_bias<PREC>(ws.cur, NH + NI, lane);
+#pragma unroll
+    for (int b = 1; b < NB; ++b) acc[b] = acc[0];
+    if constexpr (NH > 0) mma_chunks<PREC, ACT, NB, NH, kHC>(ws, acc, ws.cur, 0, H, lane, epi, 0, NH + NI);
+    if constexpr (NI > 0) mma_chunks<PREC, ACT, NB, NI, NIS>(ws, acc, ws.cur, NH, I, lane, epi, NH, NH + NI);
+    if (j > 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) epi.finish(b, Hn[b * kHC + 2 * j - 2], Hn[b * kHC + 2 * j - 1]);
+    }
+    ws.next_tile();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) epi.acc[b] = acc[b];
     epi.live = true;
   }
-  epi.steps(0, 16);
-  epi.finish(Hn[14], Hn[15]);
+  epi.steps(0, 8 * NB);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) epi.finish(b, Hn[b * kHC + 14], Hn[b * kHC + 15]);
 }
 
 // One SkipConnMLP up to (not including) the `out` Linear.  On entry I[] holds the raw init input
 // fragments; on exit H[] holds act(last hidden) ready for the out layer, I[] holds act(init).
-template <int PREC, int ACT, int NI, int NWAVES>
-__device__ __forceinline__ void mlp_hidden_layers(WeightStream<NWAVES>& ws, int num_layers, int skip,
-                                                  Frag<PREC> (&I)[NI], Frag<PREC> (&H)[kHC], int lane) {
-  Frag<PREC> Hn[kHC];
+template <int PREC, int ACT, int NB, int NI, class WS>
+__device__ __forceinline__ void mlp_hidden_layers(WS& ws, int num_layers, int skip,
+                                                  Frag<PREC> (&I)[NB * NI], Frag<PREC> (&H)[NB * kHC], int lane) {
+  Frag<PREC> Hn[NB * kHC];
   // ---- init Linear: dim_p -> 256
-  linear256<PREC, ACT, 0, NI, NWAVES>(ws, nullptr, I, Hn, lane);
+  linear256<PREC, ACT, NB, 0, NI, NI>(ws, nullptr, I, Hn, lane);
 #pragma unroll
-  for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
+  for (int c = 0; c < NB * kHC; ++c) H[c] = Hn[c];
 #pragma unroll
-  for (int c = 0; c < NI; ++c) frag_activate<PREC, ACT>(I[c]);
+  for (int c = 0; c < NB * NI; ++c) frag_activate<PREC, ACT>(I[c]);
   // ---- hidden Linears
   for (int i = 0; i < num_layers; ++i) {
     const bool sk = (i % skip) == 0 && i != num_layers - 1;
-    if (sk) linear256<PREC, ACT, kHC, NI, NWAVES>(ws, H, I, Hn, lane);
-    else linear256<PREC, ACT, kHC, 0, NWAVES>(ws, H, nullptr, Hn, lane);
+    if (sk) linear256<PREC, ACT, NB, kHC, NI, NI>(ws, H, I, Hn, lane);
+    else linear256<PREC, ACT, NB, kHC, 0, NI>(ws, H, nullptr, Hn, lane);
 #pragma unroll
-    for (int c = 0; c < kHC; ++c) H[c] = Hn[c];
+    for (int c = 0; c < NB * kHC; ++c) H[c] = Hn[c];
   }
 }
 
-// One 32-row tile of the `out` Linear (no activation on the result; the caller's epilogue follows the sync).
-template <int PREC, int NWAVES>
-__device__ __forceinline__ f32x16 mlp_out_tile(WeightStream<NWAVES>& ws, const Frag<PREC> (&H)[kHC], int lane) {
-  f32x16 acc = load_bias<PREC>(ws.cur, kHC, lane);
-  Epilogue<PREC, NA_ACT_NONE> none;
+// One 32-row tile of the `out` Linear for the NB blocks (no activation; the caller's epilogue follows the sync).
+template <int PREC, int NB, class WS>
+__device__ __forceinline__ void mlp_out_tile(WS& ws, const Frag<PREC> (&H)[NB * kHC], int lane,
+                                             f32x16 (&acc)[NB]) {
+  acc[0] = load_bias<PREC>(ws.cur, kHC, lane);
+#pragma unroll
+  for (int b = 1; b < NB; ++b) acc[b] = acc[0];
+  Epilogue<PREC, NA_ACT_NONE, NB> none;
   none.live = false;
-  mma_chunks<PREC, NA_ACT_NONE, kHC>(acc, ws.cur, 0, H, lane, none, 0, kHC);
-  ws.advance();
-  return acc;
+  mma_chunks<PREC, NA_ACT_NONE, NB, kHC, kHC>(ws, acc, ws.cur, 0, H, lane, none, 0, kHC);
+  ws.next_tile();
 }
 
 // feature index (within a 32-row tile) held by accumulator register r of this lane

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  WeightStream<NWAVES> ws;
+  WeightStream<NWAVES, slots_for(PREC, NI)> ws;
   const int npasses = ((int)blockIdx.x < a.ngroups) ? (a.ngroups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   ws.start(tab, a.packed + kHeaderBytes, a.packed + kHeaderBytes, smem, a.buf_bytes, npasses, wave, lane);
 
@@ -92,9 +92,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
     }
     // ---------------- network
     Frag<PREC> H[kHC];
-    mlp_hidden_layers<PREC, ACT, NI, NWAVES>(ws, a.d.num_layers, a.d.skip, I, H, lane);
+    mlp_hidden_layers<PREC, ACT, 1, NI>(ws, a.d.num_layers, a.d.skip, I, H, lane);
     for (int j = 0; j < a.out_tiles; ++j) {
-      f32x16 acc = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
+      f32x16 accs[1];
+      mlp_out_tile<PREC, 1>(ws, H, lane, accs);
+      const f32x16 acc = accs[0];
       if (n_raw < a.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

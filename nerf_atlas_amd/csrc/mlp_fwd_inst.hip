@@ -18,7 +18,7 @@ static int launch_forward(const MlpArgs& a, const TileTab& tab, hipStream_t stre
     attr_done = true;
   }
   int grid = a.ngroups < 256 ? a.ngroups : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), 2 * a.buf_bytes, stream, a, tab);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), slots_for(PREC, NI) * a.buf_bytes + 8 * kMaxTiles, stream, a, tab);
   return check_launch("na_mlp_forward");
 }
 

@@ -38,114 +38,141 @@ struct RenderArgs {
   HashRes res;
 };
 
-template <int PREC, int NWAVES>
+template <int PREC, int NWAVES, int NB>
 __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderArgs a, TileTab tab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI1 = 3, NI2 = 5;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, ln = lane & 31;
-  WeightStream<NWAVES> ws;
+  WeightStream<NWAVES, 3> ws;
   const int npasses = ((int)blockIdx.x < a.ngroups) ? (a.ngroups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   ws.start(tab, a.packed_first + kHeaderBytes, a.packed_view + kHeaderBytes, smem, a.buf_bytes, npasses, wave, lane);
 
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
-    const int64_t item_raw = (int64_t)g * NWAVES + wave;
-    const bool item_ok = item_raw < a.nitems;
-    const int64_t item = item_ok ? item_raw : a.nitems - 1;
-    const int64_t ray = item / a.nb;
-    const int tb = (int)(item - ray * a.nb);
-    const int t = tb * 32 + ln;
-    const bool t_ok = t < a.T;
-    const int tc = t_ok ? t : a.T - 1;
-    // ---- sample position (src/nerf.py:53) and interval length (src/nerf.py:67-70)
-    const float* ry = a.rays + ray * 6;
-    const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
-    const float tt = a.ts[tc];
-    const float px = ox + tt * dx, py = oy + tt * dy, pz = oz + tt * dz;
-    float dist = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
-    dist = dist * sqrtf((dx * dx + dy * dy) + dz * dz);
-
-    // ---- `first` MLP input: [hash levels 4hi..4hi+3 | p, x]
-    Frag<PREC> I1[NI1];
-    {
+    ws.mark(10);
+    // NB consecutive work items (ray, 32-step block) per wave
+    int64_t item[NB], ray[NB];
+    bool item_ok[NB], t_ok[NB];
+    int t[NB];
+    float px[NB], py[NB], pz[NB], dist[NB], dirx[NB], diry[NB], dirz[NB];
+    Frag<PREC> I1[NB * NI1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int64_t item_raw = ((int64_t)g * NWAVES + wave) * NB + b;
+      item_ok[b] = item_raw < a.nitems;
+      item[b] = item_ok[b] ? item_raw : a.nitems - 1;
+      ray[b] = item[b] / a.nb;
+      const int tb = (int)(item[b] - ray[b] * a.nb);
+      t[b] = tb * 32 + ln;
+      t_ok[b] = t[b] < a.T;
+      const int tc = t_ok[b] ? t[b] : a.T - 1;
+      // ---- sample position (src/nerf.py:53) and interval length (src/nerf.py:67-70)
+      const float* ry = a.rays + ray[b] * 6;
+      const float ox = ry[0], oy = ry[1], oz = ry[2];
+      dirx[b] = ry[3]; diry[b] = ry[4]; dirz[b] = ry[5];
+      const float tt = a.ts[tc];
+      px[b] = ox + tt * dirx[b]; py[b] = oy + tt * diry[b]; pz[b] = oz + tt * dirz[b];
+      float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+      dist[b] = d * sqrtf((dirx[b] * dirx[b] + diry[b] * diry[b]) + dirz[b] * dirz[b]);
+      // ---- `first` MLP input: [hash levels 4hi..4hi+3 | p, x]
       float f[16];
       if constexpr ((NA_ABLATE & 32) != 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) f[e] = px * (float)e;
+        for (int e = 0; e < 16; ++e) f[e] = px[b] * (float)e;
       } else {
-        hash_levels4(px, py, pz, a.tables, a.res, 4 * hi, f);
+        hash_levels4(px[b], py[b], pz[b], a.tables, a.res, 4 * hi, f);
       }
       float v0[8], v1[8], v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; v2[e] = 0.f; }
-      if (hi == 0) { v2[0] = px; v2[1] = py; v2[2] = pz; v2[3] = px; v2[4] = py; v2[5] = pz; }
-      I1[0] = make_frag<PREC>(v0);
-      I1[1] = make_frag<PREC>(v1);
-      I1[2] = make_frag<PREC>(v2);
+      if (hi == 0) { v2[0] = px[b]; v2[1] = py[b]; v2[2] = pz[b]; v2[3] = px[b]; v2[4] = py[b]; v2[5] = pz[b]; }
+      I1[b * NI1 + 0] = make_frag<PREC>(v0);
+      I1[b * NI1 + 1] = make_frag<PREC>(v1);
+      I1[b * NI1 + 2] = make_frag<PREC>(v2);
     }
-    Frag<PREC> H[kHC];
-    mlp_hidden_layers<PREC, NA_ACT_LEAKY_RELU, NI1, NWAVES>(ws, a.first_layers, 3, I1, H, lane);
+    Frag<PREC> H[NB * kHC];
+    ws.mark(11);
+    mlp_hidden_layers<PREC, NA_ACT_LEAKY_RELU, NB, NI1>(ws, a.first_layers, 3, I1, H, lane);
 
     // ---- `first` out: rows 0..63 = intermediate (-> View latent), row 64 = density
-    Frag<PREC> I2[NI2];
-    float density;
+    Frag<PREC> I2[NB * NI2];
+    float density[NB];
     {
-      f32x16 o0 = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
-      acc_to_frags<PREC, NA_ACT_NONE>(o0, I2[0], I2[1]);
-      f32x16 o1 = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
-      acc_to_frags<PREC, NA_ACT_NONE>(o1, I2[2], I2[3]);
-      f32x16 o2 = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
-      density = o2[0];  // row 64 lives in register 0 of the hi=0 lanes
-      float el, az;
-      elev_azim(dx, dy, dz, el, az);
-      float v4[8];
+      f32x16 o[NB];
+      mlp_out_tile<PREC, NB>(ws, H, lane, o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v4[e] = 0.f;
-      if (hi == 0) { v4[0] = px; v4[1] = py; v4[2] = pz; v4[3] = el; v4[4] = az; }
-      I2[4] = make_frag<PREC>(v4);
+      for (int b = 0; b < NB; ++b) acc_to_frags<PREC, NA_ACT_NONE>(o[b], I2[b * NI2 + 0], I2[b * NI2 + 1]);
+      mlp_out_tile<PREC, NB>(ws, H, lane, o);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc_to_frags<PREC, NA_ACT_NONE>(o[b], I2[b * NI2 + 2], I2[b * NI2 + 3]);
+      mlp_out_tile<PREC, NB>(ws, H, lane, o);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        density[b] = o[b][0];  // row 64 lives in register 0 of the hi=0 lanes
+        float el, az;
+        elev_azim(dirx[b], diry[b], dirz[b], el, az);
+        float v4[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v4[e] = 0.f;
+        if (hi == 0) { v4[0] = px[b]; v4[1] = py[b]; v4[2] = pz[b]; v4[3] = el; v4[4] = az; }
+        I2[b * NI2 + 4] = make_frag<PREC>(v4);
+      }
     }
     // ---- View MLP (sin activations)
-    mlp_hidden_layers<PREC, NA_ACT_SIN, NI2, NWAVES>(ws, a.view_layers, 3, I2, H, lane);
-    f32x16 oc = mlp_out_tile<PREC, NWAVES>(ws, H, lane);
-    const float cr = apply_sigmoid_kind(oc[0], a.sigmoid_kind);
-    const float cg = apply_sigmoid_kind(oc[1], a.sigmoid_kind);
-    const float cb = apply_sigmoid_kind(oc[2], a.sigmoid_kind);
+    mlp_hidden_layers<PREC, NA_ACT_SIN, NB, NI2>(ws, a.view_layers, 3, I2, H, lane);
+    f32x16 oc[NB];
+    mlp_out_tile<PREC, NB>(ws, H, lane, oc);
 
-    // ---- compositing inside the block (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
-    const float sigma = softplusf_(density - 1.0f);
-    float alpha = t_ok ? 1.0f - expf(-sigma * dist) : 0.f;
-    float f = (1.0f - alpha) + 1e-10f;
-    float incl = f;  // inclusive product scan over the 32 lanes of this half
+    ws.mark(12);
+    // ---- compositing inside each block (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      float up = __shfl_up(incl, d, 32);
-      if (ln >= d) incl = incl * up;
-    }
-    float excl = __shfl_up(incl, 1, 32);
-    if (ln == 0) excl = 1.0f;
-    const float w = alpha * excl;
-    float sr = w * cr, sg = w * cg, sb = w * cb;
-    float wh = (t < a.T - 1) ? w : 0.f;
+    for (int b = 0; b < NB; ++b) {
+      const float cr = apply_sigmoid_kind(oc[b][0], a.sigmoid_kind);
+      const float cg = apply_sigmoid_kind(oc[b][1], a.sigmoid_kind);
+      const float cb = apply_sigmoid_kind(oc[b][2], a.sigmoid_kind);
+      const float sigma = softplusf_(density[b] - 1.0f);
+      float alpha = t_ok[b] ? 1.0f - expf(-sigma * dist[b]) : 0.f;
+      float f = (1.0f - alpha) + 1e-10f;
+      float incl = f;  // inclusive product scan over the 32 lanes of this half
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) {
-      sr += __shfl_xor(sr, d, 32);
-      sg += __shfl_xor(sg, d, 32);
-      sb += __shfl_xor(sb, d, 32);
-      wh += __shfl_xor(wh, d, 32);
-    }
-    const float P = __shfl(incl, 31, 32);
-    if (item_ok && hi == 0) {
-      if (ln == 0) {
-        float* o = a.partials + item * kPartialFloats;
-        o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
+      for (int d = 1; d < 32; d <<= 1) {
+        float up = __shfl_up(incl, d, 32);
+        if (ln >= d) incl = incl * up;
       }
-      if (t_ok) {
-        if (a.alpha != nullptr) a.alpha[(int64_t)t * a.R + ray] = alpha;
-        if (a.weights != nullptr) a.weights[(int64_t)t * a.R + ray] = w;
+      float excl = __shfl_up(incl, 1, 32);
+      if (ln == 0) excl = 1.0f;
+      const float w = alpha * excl;
+      float sr = w * cr, sg = w * cg, sb = w * cb;
+      float wh = (t[b] < a.T - 1) ? w : 0.f;
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) {
+        sr += __shfl_xor(sr, d, 32);
+        sg += __shfl_xor(sg, d, 32);
+        sb += __shfl_xor(sb, d, 32);
+        wh += __shfl_xor(wh, d, 32);
+      }
+      const float P = __shfl(incl, 31, 32);
+      if (item_ok[b] && hi == 0) {
+        if (ln == 0) {
+          float* o = a.partials + item[b] * kPartialFloats;
+          o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
+        }
+        if (t_ok[b]) {
+          if (a.alpha != nullptr) a.alpha[(int64_t)t[b] * a.R + ray[b]] = alpha;
+          if (a.weights != nullptr) a.weights[(int64_t)t[b] * a.R + ray[b]] = w;
+        }
       }
     }
+    ws.mark(13);
   }
+#if NA_TRACE
+  if (ws.tlog != nullptr) {  // dump behind the partials (the workspace is over-allocated by tools/trace.py)
+    unsigned long long* dst = (unsigned long long*)(a.partials + a.nitems * kPartialFloats) + (wave ? 1 + ws.kTraceMax : 0);
+    dst[0] = (unsigned long long)ws.tpos;
+    for (int i = 0; i < ws.tpos; ++i) dst[1 + i] = ws.tlog[i];
+  }
+#endif
 }
 
 #if NA_PREC_INST == 0
@@ -176,25 +203,25 @@ __global__ void render_finalize_kernel(const float* __restrict__ partials, int64
 
 #endif
 
-template <int PREC, int NWAVES>
+template <int PREC, int NWAVES, int NB>
 static int launch_render(RenderArgs& a, const TileTab& tab, hipStream_t stream) {
-  auto kern = render_plain_view_kernel<PREC, NWAVES>;
+  auto kern = render_plain_view_kernel<PREC, NWAVES, NB>;
   static thread_local bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
     attr_done = true;
   }
-  a.ngroups = (int)((a.nitems + NWAVES - 1) / NWAVES);
+  a.ngroups = (int)((a.nitems + NWAVES * NB - 1) / (NWAVES * NB));
   int grid = a.ngroups < 256 ? a.ngroups : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), 2 * a.buf_bytes, stream, a, tab);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), 3 * a.buf_bytes + 8 * kMaxTiles + (NA_TRACE ? 2 * 8 * 1400 : 0), stream, a, tab);
   return check_launch("na_render_plain_view");
 }
 
 #if NA_PREC_INST == 0
-int render_dispatch_bf16(RenderArgs& a, const TileTab& tab, hipStream_t s) { return launch_render<NA_PREC_BF16, 8>(a, tab, s); }
+int render_dispatch_bf16(RenderArgs& a, const TileTab& tab, hipStream_t s) { return launch_render<NA_PREC_BF16, 8, 1>(a, tab, s); }
 #else
-int render_dispatch_bf16x3(RenderArgs& a, const TileTab& tab, hipStream_t s) { return launch_render<NA_PREC_BF16X3, 4>(a, tab, s); }
+int render_dispatch_bf16x3(RenderArgs& a, const TileTab& tab, hipStream_t s) { return launch_render<NA_PREC_BF16X3, 4, 1>(a, tab, s); }
 #endif
 int render_dispatch_bf16(RenderArgs& a, const TileTab& tab, hipStream_t s);
 int render_dispatch_bf16x3(RenderArgs& a, const TileTab& tab, hipStream_t s);
