@@ -27,6 +27,10 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_SAMPLE = 1_192_960          # sum 2*in*out over both MLPs, unpadded
 PEAK_BF16 = 2.5e15                   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# measured with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE passes, KiB units, FETCH doubled for gfx950):
+# (2 * 51177 + 80000) KiB per launch of the full frame -> 0.19 GB vs 97.7 TFLOP: the kernel is nowhere near HBM-bound
+# (algorithmic: 15.4 MB rays + 8.4 MB tables + 1.3 MB weights read, 82 MB of per-block partials written)
+HBM_TRAFFIC_FULL_FRAME = int((2 * 51177 + 80000) * 1024)
 SIZE, STEPS_PER_RAY, FOV, NEAR, FAR = 800, 128, 0.6911, 2.0, 6.0
 
 
@@ -134,7 +138,12 @@ def main():
                        "precision": prec, "parallelism": f"rays sharded in {world} row band(s) + 1 RCCL gather"},
             "roofline": {"bound": "mfma", "kernel": "render_plain_view_kernel", "achieved": round(achieved / 1e12, 2),
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16, 4),
-                         "kernel_ms": round(kern_ms, 3), "traffic": None},
+                         "kernel_ms": round(kern_ms, 3),
+                         # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                         # (profiles/r01/pmc_*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM"); None when the
+                         # shard differs from the profiled full frame
+                         "traffic": HBM_TRAFFIC_FULL_FRAME if world == 1 else None,
+                         "traffic_unit": "bytes/launch"},
         }
         if frame is not None:
             res["config"]["frame_checksum"] = round(float(frame.double().sum()), 3)
@@ -144,6 +153,23 @@ def main():
             # same tile through the HIP path: the benchmarked kernel is the parity-checked one
             got, _, _ = ops.render_plain_view(rays_cpu.to(dev), ts, tables, pf, pv, prec, "upshifted", "black")
             res["parity_sample_linf_vs_cpu_oracle"] = float((got.cpu() - ref).abs().max())
+            # the other precision on the same frame (2 timed frames), so one line carries both modes
+            other = "bf16x3" if prec == "bf16" else "bf16"
+            _, pf2 = model.first.packed(other, "plain_first")
+            _, pv2 = model.refl.mlp.packed(other, "plain_view")
+            rays_full = ops.raygen(c2w, focal, SIZE, (0, 0, SIZE, SIZE))
+            ops.render_plain_view(rays_full, ts, tables, pf2, pv2, other, "upshifted", "black", False, ws)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                ops.render_plain_view(rays_full, ts, tables, pf2, pv2, other, "upshifted", "black", False, ws)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t1) / 2
+            got2, _, _ = ops.render_plain_view(rays_cpu.to(dev), ts, tables, pf2, pv2, other, "upshifted", "black")
+            res["other_precision"] = {"precision": other, "value": round(samples / dt2 / 1e6, 2), "unit": "Msamples/s",
+                                      "ms_per_frame": round(dt2 * 1e3, 3),
+                                      "frac_of_bf16_mfma_peak": round(samples * FLOP_PER_SAMPLE / dt2 / PEAK_BF16, 4),
+                                      "linf_vs_cpu_oracle": float((got2.cpu() - ref).abs().max())}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -261,7 +261,13 @@ struct WeightStream {
 // cycles), the VALU slots in between carry the activation epilogue of tile j-1 (bias is already in the
 // accumulator; activation; bf16 round; pack into next-layer B fragments).  The epilogue is cut into 8*NB
 // two-value steps that are spread evenly over the tile's MFMAs in program order.
-constexpr int kStage = 4;  // A fragments are read from LDS one stage (4 chunks) ahead of their MFMAs
+// A fragments are read from LDS one stage (kStage chunks) ahead of their MFMAs.  2 chunks in the 8-wave bf16
+// kernels (256-VGPR budget: depth 4 spills ~11 registers, same speed), 4 in the 4-wave bf16x3 kernels.
+#ifdef NA_KSTAGE
+template <int PREC> constexpr int stage_depth() { return NA_KSTAGE; }
+#else
+template <int PREC> constexpr int stage_depth() { return PREC == NA_PREC_BF16 ? 2 : 4; }
+#endif
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -324,6 +330,7 @@ __device__ __forceinline__ void mma_chunks(WS& ws, f32x16 (&acc)[NB], const char
                                            const Frag<PREC>* B, int lane, Epilogue<PREC, ACT, NB>& epi, int m0,
                                            int mtot) {
   constexpr int FB = PREC == NA_PREC_BF16X3 ? 2048 : 1024;
+  constexpr int kStage = stage_depth<PREC>();
   constexpr int NS = (NCH + kStage - 1) / kStage;
   constexpr int ES = Epilogue<PREC, ACT, NB>::kSteps;
   bf16x8 ah[2][kStage], al[2][kStage];

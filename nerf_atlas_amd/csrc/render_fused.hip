@@ -49,44 +49,53 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
   const int npasses = ((int)blockIdx.x < a.ngroups) ? (a.ngroups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   ws.start(tab, a.packed_first + kHeaderBytes, a.packed_view + kHeaderBytes, smem, a.buf_bytes, npasses, wave, lane);
 
+  // Geometry of this wave's work item b of group g: recomputed where needed (prologue, View input, compositing)
+  // instead of being carried in registers across both MLPs -- the kernel sits at the 256-VGPR limit and anything
+  // long-lived would be spilled to scratch.
+  struct Geom {
+    int64_t item, ray;
+    bool item_ok, t_ok;
+    int t;
+    float px, py, pz, dist, dx, dy, dz;
+  };
+  auto geom = [&](int g, int b) {
+    Geom q;
+    const int64_t item_raw = ((int64_t)g * NWAVES + wave) * NB + b;
+    q.item_ok = item_raw < a.nitems;
+    q.item = q.item_ok ? item_raw : a.nitems - 1;
+    q.ray = q.item / a.nb;
+    const int tb = (int)(q.item - q.ray * a.nb);
+    q.t = tb * 32 + ln;
+    q.t_ok = q.t < a.T;
+    const int tc = q.t_ok ? q.t : a.T - 1;
+    // sample position (src/nerf.py:53) and interval length (src/nerf.py:67-70)
+    const float* ry = a.rays + q.ray * 6;
+    q.dx = ry[3]; q.dy = ry[4]; q.dz = ry[5];
+    const float tt = a.ts[tc];
+    q.px = ry[0] + tt * q.dx; q.py = ry[1] + tt * q.dy; q.pz = ry[2] + tt * q.dz;
+    const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+    q.dist = d * sqrtf((q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz);
+    return q;
+  };
+
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
     ws.mark(10);
-    // NB consecutive work items (ray, 32-step block) per wave
-    int64_t item[NB], ray[NB];
-    bool item_ok[NB], t_ok[NB];
-    int t[NB];
-    float px[NB], py[NB], pz[NB], dist[NB], dirx[NB], diry[NB], dirz[NB];
     Frag<PREC> I1[NB * NI1];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int64_t item_raw = ((int64_t)g * NWAVES + wave) * NB + b;
-      item_ok[b] = item_raw < a.nitems;
-      item[b] = item_ok[b] ? item_raw : a.nitems - 1;
-      ray[b] = item[b] / a.nb;
-      const int tb = (int)(item[b] - ray[b] * a.nb);
-      t[b] = tb * 32 + ln;
-      t_ok[b] = t[b] < a.T;
-      const int tc = t_ok[b] ? t[b] : a.T - 1;
-      // ---- sample position (src/nerf.py:53) and interval length (src/nerf.py:67-70)
-      const float* ry = a.rays + ray[b] * 6;
-      const float ox = ry[0], oy = ry[1], oz = ry[2];
-      dirx[b] = ry[3]; diry[b] = ry[4]; dirz[b] = ry[5];
-      const float tt = a.ts[tc];
-      px[b] = ox + tt * dirx[b]; py[b] = oy + tt * diry[b]; pz[b] = oz + tt * dirz[b];
-      float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
-      dist[b] = d * sqrtf((dirx[b] * dirx[b] + diry[b] * diry[b]) + dirz[b] * dirz[b]);
+      const Geom q = geom(g, b);
       // ---- `first` MLP input: [hash levels 4hi..4hi+3 | p, x]
       float f[16];
       if constexpr ((NA_ABLATE & 32) != 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) f[e] = px[b] * (float)e;
+        for (int e = 0; e < 16; ++e) f[e] = q.px * (float)e;
       } else {
-        hash_levels4(px[b], py[b], pz[b], a.tables, a.res, 4 * hi, f);
+        hash_levels4(q.px, q.py, q.pz, a.tables, a.res, 4 * hi, f);
       }
       float v0[8], v1[8], v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; v2[e] = 0.f; }
-      if (hi == 0) { v2[0] = px[b]; v2[1] = py[b]; v2[2] = pz[b]; v2[3] = px[b]; v2[4] = py[b]; v2[5] = pz[b]; }
+      if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; v2[3] = q.px; v2[4] = q.py; v2[5] = q.pz; }
       I1[b * NI1 + 0] = make_frag<PREC>(v0);
       I1[b * NI1 + 1] = make_frag<PREC>(v1);
       I1[b * NI1 + 2] = make_frag<PREC>(v2);
@@ -110,12 +119,13 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         density[b] = o[b][0];  // row 64 lives in register 0 of the hi=0 lanes
+        const Geom q = geom(g, b);
         float el, az;
-        elev_azim(dirx[b], diry[b], dirz[b], el, az);
+        elev_azim(q.dx, q.dy, q.dz, el, az);
         float v4[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v4[e] = 0.f;
-        if (hi == 0) { v4[0] = px[b]; v4[1] = py[b]; v4[2] = pz[b]; v4[3] = el; v4[4] = az; }
+        if (hi == 0) { v4[0] = q.px; v4[1] = q.py; v4[2] = q.pz; v4[3] = el; v4[4] = az; }
         I2[b * NI2 + 4] = make_frag<PREC>(v4);
       }
     }
@@ -128,11 +138,12 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
     // ---- compositing inside each block (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      const Geom q = geom(g, b);
       const float cr = apply_sigmoid_kind(oc[b][0], a.sigmoid_kind);
       const float cg = apply_sigmoid_kind(oc[b][1], a.sigmoid_kind);
       const float cb = apply_sigmoid_kind(oc[b][2], a.sigmoid_kind);
       const float sigma = softplusf_(density[b] - 1.0f);
-      float alpha = t_ok[b] ? 1.0f - expf(-sigma * dist[b]) : 0.f;
+      float alpha = q.t_ok ? 1.0f - expf(-sigma * q.dist) : 0.f;
       float f = (1.0f - alpha) + 1e-10f;
       float incl = f;  // inclusive product scan over the 32 lanes of this half
 #pragma unroll
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
       if (ln == 0) excl = 1.0f;
       const float w = alpha * excl;
       float sr = w * cr, sg = w * cg, sb = w * cb;
-      float wh = (t[b] < a.T - 1) ? w : 0.f;
+      float wh = (q.t < a.T - 1) ? w : 0.f;
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) {
         sr += __shfl_xor(sr, d, 32);
@@ -153,14 +164,14 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
         wh += __shfl_xor(wh, d, 32);
       }
       const float P = __shfl(incl, 31, 32);
-      if (item_ok[b] && hi == 0) {
+      if (q.item_ok && hi == 0) {
         if (ln == 0) {
-          float* o = a.partials + item[b] * kPartialFloats;
+          float* o = a.partials + q.item * kPartialFloats;
           o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
         }
-        if (t_ok[b]) {
-          if (a.alpha != nullptr) a.alpha[(int64_t)t[b] * a.R + ray[b]] = alpha;
-          if (a.weights != nullptr) a.weights[(int64_t)t[b] * a.R + ray[b]] = w;
+        if (q.t_ok) {
+          if (a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
+          if (a.weights != nullptr) a.weights[(int64_t)q.t * a.R + q.ray] = w;
         }
       }
     }

@@ -31,7 +31,7 @@ def build_one(mask, prec=0):
                        ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"]), ("render_fused.hip", ["-DNA_PREC_INST=0"])]:
         # only the render kernels carry the ablation; the generic MLP units are needed for symbols
         o = os.path.join(d, src.replace(".hip", "") + "".join(extra).replace("-D", "_").replace("=", "") + ".o")
-        abl = [f"-DNA_ABLATE={mask}"] if src == "render_fused.hip" else []
+        abl = ([f"-DNA_ABLATE={mask & 63}"] + ([f"-DNA_KSTAGE={mask >> 8}"] if mask >> 8 else [])) if src == "render_fused.hip" else []
         if src == "mlp_fwd_inst.hip" and mask != 0:
             o0 = o.replace(f"obj_{mask}_", "obj_0_")
             if os.path.exists(o0):
