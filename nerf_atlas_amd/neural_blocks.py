@@ -55,6 +55,40 @@ class FourierEncoder(nn.Module):
         self.extra_scale = min(self.extra_scale, cap)
 
 
+class LearnedFourierEncoder(nn.Module):
+    """src/neural_blocks.py:57-72: Fourier features with a learnable scalar frequency scale."""
+
+    def __init__(self, input_dims: int = 3, num_freqs: int = 16, sigma: int = 1 << 5, device="cpu"):
+        super().__init__()
+        self.input_dims = input_dims
+        self.n_freqs = num_freqs
+        self.basis = nn.Parameter(sigma * torch.randn(num_freqs, input_dims).T.contiguous(), requires_grad=False)
+        self.extra_scale = nn.Parameter(torch.tensor(1.0), requires_grad=True)
+
+    def output_dims(self):
+        return self.n_freqs * 2
+
+    def forward(self, x):
+        return ops.fourier_encode(x, self.basis.data, float(self.extra_scale))
+
+
+class NNEncoder(nn.Module):
+    """src/neural_blocks.py:75-87: sin(30 * Linear(x)) (the factor is folded into the exact-fp32 Linear)."""
+
+    def __init__(self, input_dims: int = 3, out: int = 32, device=None):
+        super().__init__()
+        self.fwd = nn.Linear(input_dims, out)
+
+    def output_dims(self):
+        return self.fwd.out_features
+
+    def forward(self, x):
+        assert x.shape[-1] == self.fwd.in_features
+        flat = x.reshape(-1, x.shape[-1]).contiguous()
+        y = ops.linear_f32(flat, (30.0 * self.fwd.weight.data).contiguous(), (30.0 * self.fwd.bias.data).contiguous())
+        return ops.sigmoid(y, "sin").reshape(x.shape[:-1] + (self.fwd.out_features,))
+
+
 class HashEncoder(nn.Module):
     """src/neural_blocks.py:92-193 (8 levels x 65536 x 4, resolutions 16 * 0.87497^l, Q8/Q9)."""
 

@@ -40,6 +40,29 @@ def render_frame(model, cam, size: int, crop_size: int = 0, times=None, tiles=No
     return got
 
 
+def depth_map(model) -> torch.Tensor:
+    """runner.py:894-897: expected termination depth of the LAST forward, volumetric_integrate(weights, ts) -> [B,H,W,1]."""
+    from . import ops
+    nerf = model.nerf
+    ts = nerf.ts[:, None, None, None, None].expand(nerf.weights.shape + (1,)).contiguous()
+    return ops.integrate(nerf.weights, ts)
+
+
+def alpha_map(model) -> torch.Tensor:
+    """runner.py:523 acc_map: sum of weights[:-1] along the ray (the white-background complement)."""
+    from . import ops
+    w = model.nerf.weights
+    ones = torch.ones(w.shape + (1,), device=w.device)
+    ones[-1] = 0
+    return ops.integrate(w, ones)
+
+
+def flow_map(model) -> torch.Tensor:
+    """runner.py:908-910: volumetric_integrate(weights, rigid_dp) of a dynamic model's last forward."""
+    from . import ops
+    return ops.integrate(model.nerf.weights, model.rigid_dp.contiguous())
+
+
 def psnr(got: torch.Tensor, exp: torch.Tensor) -> float:
     """runner.py:923-924."""
     return float(mse2psnr(torch.nn.functional.mse_loss(got, exp)))

@@ -147,3 +147,31 @@ def test_mip_plain_nerf_runs(na):
     h = load_golden("g11_plain_view_b1")
     out = m(h["rays"].cuda())
     assert out.shape == (1, 6, 6, 3) and torch.isfinite(out).all()
+
+
+def test_aux_render_outputs_and_extra_encoders(na):
+    """N3-style outputs that reuse .weights (runner.py:894-920) and the low-priority encoders of A4."""
+    import oracle as O
+    from nerf_atlas_amd import neural_blocks as nb
+    h = load_golden("g9_dnerf_spline6")
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=6).cuda().eval()
+    load_params(m, golden_params(h))
+    m((h["rays"].cuda(), h["times"].cuda()))
+    w = canon.weights.cpu()
+    ts = canon.ts.cpu()
+    depth = na.render.depth_map(m).cpu()
+    assert maxdiff(depth, O.volumetric_integrate(w, ts[:, None, None, None, None].expand(w.shape + (1,)))) <= 1e-5
+    acc = na.render.alpha_map(m).cpu()
+    assert maxdiff(acc, w[:-1].sum(0).unsqueeze(-1)) <= 1e-5
+    flow = na.render.flow_map(m).cpu()
+    assert maxdiff(flow, O.volumetric_integrate(w, m.rigid_dp.cpu())) <= 1e-5
+    # encoders
+    torch.manual_seed(0)
+    x = torch.randn(50, 3)
+    e = nb.NNEncoder(3, 32).cuda()
+    ref = torch.sin(30 * torch.nn.functional.linear(x, e.fwd.weight.cpu(), e.fwd.bias.cpu()))
+    assert maxdiff(e(x.cuda()), ref) <= 2e-5
+    f = nb.LearnedFourierEncoder(3, 16, sigma=4).cuda()
+    ref = O.fourier_encode(x, f.basis.detach().cpu(), 1.0)
+    assert maxdiff(f(x.cuda()), ref) <= 5e-5 and f.output_dims() == 32
