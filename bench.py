@@ -78,6 +78,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    # NA_DIST_BACKEND=gloo lets several ranks share one GPU (flow test on a 1-GPU box); normally one rank per GPU
+    ndev = torch.cuda.device_count()
+    local = local % ndev if os.environ.get("NA_DIST_BACKEND") == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     config.set_precision(args.precision)
@@ -103,6 +106,7 @@ def main():
         return nd.gather_bands(out.reshape(nrows, SIZE, 3), SIZE, rank, world)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1: dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,11 +118,12 @@ def main():
         frame = step(i)
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev)
+    red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    tmax = torch.tensor([dt], device=red_dev)
     if world > 1: dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # this rank's fused kernel (+ finalize), HIP events
-    kt = torch.tensor([kern_ms], device=dev)
+    kt = torch.tensor([kern_ms], device=red_dev)
     if world > 1: dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kern_ms = float(kt)
 

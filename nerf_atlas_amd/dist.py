@@ -17,7 +17,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("NA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -47,13 +47,16 @@ def gather_bands(local: torch.Tensor, size: int, rank: int, world: int, dst: int
         return local
     bands = row_bands(size, world)
     tall = max(n for _, n in bands)
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()  # debug mode (several ranks on one GPU): gloo gathers through host memory
     pad = torch.zeros(tall, size, local.shape[-1], device=local.device, dtype=local.dtype)
     pad[: local.shape[0]] = local
     outs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, outs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([o[:n] for o, (_, n) in zip(outs, bands)], dim=0)
+    return torch.cat([o[:n] for o, (_, n) in zip(outs, bands)], dim=0).to(dev)
 
 
 def render_frame_sharded(render_rows: Callable[[int, int], torch.Tensor], size: int, rank: int, world: int):
