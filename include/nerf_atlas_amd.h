@@ -188,6 +188,30 @@ int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T,
                          float* alpha, float* weights, float* out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward operators (training step, runner.py:609-850: loss.backward() differentiates exactly these).
+ * fp32; every gradient buffer that is ACCUMULATED into (dW, db, tables_grad) must be zero-initialised
+ * (or hold the running .grad) by the caller.
+ *
+ * na_act_backward      g_x = g_act * act'(x) for the pre-activation input x of a Linear
+ *                      (src/neural_blocks.py:293).
+ * na_sigmoid_backward  g_x = g_y * d/dx sigmoid_kind(x) (src/utils.py:484-518).
+ * na_linear_wgrad      dW[out,in] += dY^T . act([x0|x1]);  db[out] += sum_n dY (db may be NULL).
+ *                      (the input gradient is na_linear_f32 with W^T followed by na_act_backward)
+ * na_hash_encode_backward  tables_grad[8,65536,4] += trilinear weights x g_out[N, 32(+3)]
+ *                      (src/neural_blocks.py:166-190).
+ * na_composite_backward    gradient of na_composite w.r.t. density [T,R] and feat [T,R,C] (C = 1 or 3)
+ *                      given g_out [R,C] (src/nerf.py:60-80,96-98).                              */
+int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream);
+int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, float* out, void* stream);
+int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                    int pre_act, float* dW, float* db, void* stream);
+int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input,
+                            float* tables_grad, void* stream);
+int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays,
+                          int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
+                          float* g_density, float* g_feat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

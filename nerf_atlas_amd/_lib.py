@@ -50,6 +50,13 @@ SIGNATURES = {
                               C.c_void_p, C.c_void_p]),
     "na_mlp_forward": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p,
                                  C.c_void_p]),
+    "na_act_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_sigmoid_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_linear_wgrad": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p,
+                                  C.c_void_p]),
+    "na_hash_encode_backward": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_composite_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,
+                                        c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_render_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),
     "na_render_plain_view": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,

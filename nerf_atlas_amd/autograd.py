@@ -1,0 +1,96 @@
+"""torch.autograd glue for the training step.  Every forward AND backward below is a HIP kernel
+behind the C ABI; torch only records the graph, slices/concatenates buffers and owns .grad accumulation.
+
+Used by SkipConnMLP / the model classes whenever gradients are enabled and something requires them; inference
+keeps using the fused MFMA kernels.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+def needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class LinearFn(Function):
+    """y = W . act([x0 | x1]) + b  (src/neural_blocks.py:288-296), exact fp32."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, W, b, act):
+        ctx.act = act
+        ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=x0.device), W)
+        ctx.has_x1 = x1 is not None
+        ctx.has_b = b is not None
+        return ops.linear_f32(x0, W, b, pre_act=act, x1=x1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x0, x1, W = ctx.saved_tensors
+        x1 = x1 if ctx.has_x1 else None
+        gy = gy.contiguous()
+        in0 = x0.shape[1]
+        gx0 = gx1 = gW = gb = None
+        if ctx.needs_input_grad[0] or (ctx.has_x1 and ctx.needs_input_grad[1]):
+            g_act = ops.linear_f32(gy, W.t().contiguous(), None)  # [N, in0+in1] = dL/d act(x)
+            if ctx.needs_input_grad[0]:
+                g0 = g_act[:, :in0].contiguous()
+                gx0 = ops.act_backward(x0, g0, ctx.act) if ctx.act != "none" else g0
+            if ctx.has_x1 and ctx.needs_input_grad[1]:
+                g1 = g_act[:, in0:].contiguous()
+                gx1 = ops.act_backward(x1, g1, ctx.act) if ctx.act != "none" else g1
+        if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
+            gW, gb = ops.linear_wgrad(x0, gy, ctx.act, x1, want_bias=ctx.has_b)
+        return gx0, gx1, gW, gb, None
+
+
+class HashEncodeFn(Function):
+    """HashEncoder.forward (src/neural_blocks.py:139-193); gradient w.r.t. the tables only (sample positions
+    are inputs of the canonical models on the hot path)."""
+
+    @staticmethod
+    def forward(ctx, x, tables, include_input):
+        ctx.save_for_backward(x)
+        ctx.include_input = include_input
+        return ops.hash_encode(x, tables, include_input)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("d(hash features)/d(position) is not implemented (needed only by deformation "
+                                      "models' training)")
+        return None, ops.hash_encode_backward(x, g.contiguous(), ctx.include_input), None
+
+
+class SigmoidFn(Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        ctx.kind = kind
+        ctx.save_for_backward(x)
+        return ops.sigmoid(x, kind)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.sigmoid_backward(x, g.contiguous(), ctx.kind), None
+
+
+class CompositeFn(Function):
+    """alpha_from_density + volumetric_integrate + sky (src/nerf.py:60-80,96-98).  Returns (out, alpha, weights);
+    alpha/weights are auxiliary (non-differentiable) outputs."""
+
+    @staticmethod
+    def forward(ctx, density, feat, ts, rays, softplus, bg):
+        out, alpha, weights = ops.composite(density, feat, ts, rays, softplus=softplus, bg=bg)
+        ctx.save_for_backward(density, feat, ts, rays)
+        ctx.softplus, ctx.bg = softplus, bg
+        ctx.mark_non_differentiable(alpha, weights)
+        return out, alpha, weights
+
+    @staticmethod
+    def backward(ctx, g_out, _ga, _gw):
+        density, feat, ts, rays = ctx.saved_tensors
+        gd, gf = ops.composite_backward(density, feat, ts, rays, g_out.contiguous(), ctx.softplus, ctx.bg)
+        return gd, gf, None, None, None, None

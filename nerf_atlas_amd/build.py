@@ -20,6 +20,7 @@ ARCH = "gfx950"
 UNITS = [
     ("basic_ops.hip", [], ""),
     ("linear_f32.hip", [], ""),
+    ("backward.hip", [], ""),
     ("mlp_fused.hip", [], ""),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),

@@ -1,0 +1,275 @@
+// Backward operators of the hot path (the training step of runner.py:609-850 differentiates
+// exactly these): activation, Linear (input and weight gradients), hash-table scatter, colour-head activations and
+// alpha compositing.  fp32 throughout; matrix work on the exact f32 MFMA.  Gradients are pinned against
+// torch.autograd of the CPU oracle (tests/test_gpu_backward.py).
+#include "common.h"
+
+namespace na {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == NA_ACT_LEAKY_RELU) return leaky_relu(v);
+  if (act == NA_ACT_SIN) return sinf(v);
+  return v;
+}
+__device__ __forceinline__ float act_grad(float v, int act) {
+  if (act == NA_ACT_LEAKY_RELU) return v > 0.f ? 1.f : 0.01f;
+  if (act == NA_ACT_SIN) return cosf(v);
+  return 1.f;
+}
+
+// g_x = g_act * act'(x)   (x = the pre-activation input of a Linear, src/neural_blocks.py:293)
+__global__ void act_backward_kernel(const float* __restrict__ x, const float* __restrict__ g, int64_t n, int act,
+                                    float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = g[i] * act_grad(x[i], act);
+}
+
+__device__ __forceinline__ float sigmoid_kind_grad(float v, int kind) {
+  const float s = sigmoidf_(v);
+  switch (kind) {
+    case NA_SIG_NORMAL: return s * (1.f - s);
+    case NA_SIG_THIN: return s * (1.f - s) * (1.f + 2.f * -1e-2f);
+    case NA_SIG_FAT: return s * (1.f - s) * (1.f + 2.f * 1e-2f);
+    case NA_SIG_TANH: { float t = tanhf(v); return 1.f - t * t; }
+    case NA_SIG_UPSHIFTED: return s * (1.f - s);
+    case NA_SIG_RELU: return v > 0.f ? 1.f : 0.f;
+    case NA_SIG_SIN: return cosf(v);
+    case NA_SIG_LEAKY_RELU: return v > 0.f ? 1.f : 0.01f;
+    case NA_SIG_UPSHIFTED_SOFTPLUS: return s;
+    case NA_SIG_UPSHIFTED_RELU: return v > 0.f ? 1.f : 0.f;
+    case NA_SIG_CYCLIC: return cosf(v / 5.f) / 5.f / 2.f * (1.f + 2.f * -1e-2f);
+    default: return 1.f;
+  }
+}
+
+__global__ void sigmoid_backward_kernel(const float* __restrict__ x, const float* __restrict__ g, int64_t n, int kind,
+                                        float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = g[i] * sigmoid_kind_grad(x[i], kind);
+}
+
+// ------------------------------------------------------------------------------------ Linear weight gradient
+// dW[out,in] += dY^T[out,N] . act([x0|x1])[N,in],  db[out] += sum_n dY[n,:]
+// Workgroup = 64 (out) x 64 (in) tile over one slice of N; 4 waves, each a 32x32 tile on v_mfma_f32_32x32x2_f32
+// (A[i=o][k=n], B[k=n][j=in]).  Slices are combined with fp32 atomics.
+constexpr int WG_O = 64, WG_I = 64, WG_N = 16, WG_LD = 65;
+
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ x0, int in0,
+                                                           const float* __restrict__ x1, int in1, int64_t N,
+                                                           const float* __restrict__ dY, int out, int act,
+                                                           int64_t slice, float* __restrict__ dW,
+                                                           float* __restrict__ db) {
+  __shared__ float Ys[WG_N * WG_LD];  // [n][o]
+  __shared__ float Xs[WG_N * WG_LD];  // [n][k]
+  const int in = in0 + in1;
+  const int o0 = blockIdx.x * WG_O, k0 = blockIdx.y * WG_I;
+  const int64_t n_begin = (int64_t)blockIdx.z * slice;
+  const int64_t n_end = n_begin + slice < N ? n_begin + slice : N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wo = wave >> 1, wk = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;  // thread t < 64 sums column o0 + t of dY (only blocks with blockIdx.y == 0)
+  const int ln = tid >> 4, lc = (tid & 15) * 4;  // this thread stages row ln, columns lc..lc+3 of both tiles
+  for (int64_t nb = n_begin; nb < n_end; nb += WG_N) {
+    const int64_t n = nb + ln;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float yv = 0.f, xv = 0.f;
+      if (n < n_end) {
+        const int o = o0 + lc + q, k = k0 + lc + q;
+        if (o < out) yv = dY[n * out + o];
+        if (k < in) {
+          const float raw = k < in0 ? x0[n * in0 + k] : x1[n * in1 + (k - in0)];
+          xv = act_fwd(raw, act);
+        }
+      }
+      Ys[ln * WG_LD + lc + q] = yv;
+      Xs[ln * WG_LD + lc + q] = xv;
+    }
+    __syncthreads();
+    if (db != nullptr && blockIdx.y == 0 && tid < WG_O) {
+#pragma unroll
+      for (int r = 0; r < WG_N; ++r) bsum += Ys[r * WG_LD + tid];
+    }
+    const float* ya = Ys + (lane >> 5) * WG_LD + wo * 32 + (lane & 31);
+    const float* xb = Xs + (lane >> 5) * WG_LD + wk * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < WG_N; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[kk * WG_LD], xb[kk * WG_LD], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int k = k0 + wk * 32 + (lane & 31);
+  if (k < in) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (o < out) atomicAdd(&dW[(int64_t)o * in + k], acc[r]);
+    }
+  }
+  if (db != nullptr && blockIdx.y == 0 && tid < WG_O && o0 + tid < out) atomicAdd(&db[o0 + tid], bsum);
+}
+
+// ------------------------------------------------------------------------------------ hash encoder backward
+// tables_grad[lvl][idx][:] += w_corner * g_feat[n, lvl, :]   (src/neural_blocks.py:166,190: gradient of the gather)
+__global__ void hash_backward_kernel(const float* __restrict__ x, int64_t N, const float* __restrict__ g_out,
+                                     int include_input, HashRes res, float* __restrict__ tables_grad) {
+  const int odim = 32 + 3 * include_input;
+  const int64_t total = N * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lvl = (int)(i & 7);
+    const int64_t n = i >> 3;
+    const float px = x[n * 3], py = x[n * 3 + 1], pz = x[n * 3 + 2];
+    const float Nl = res.n[lvl];
+    const float vx = px * Nl, vy = py * Nl, vz = pz * Nl;
+    const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
+    const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
+    const float wx = vx - fx, wy = vy - fy, wz = vz - fz;
+    const float iwx = 1.f - wx, iwy = 1.f - wy, iwz = 1.f - wz;
+    const float* g = g_out + n * odim + 3 * include_input + lvl * 4;
+    const float g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+    float* tab = tables_grad + (int64_t)lvl * 65536 * 4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t id = hash_index(lx + ((c >> 2) & 1), ly + ((c >> 1) & 1), lz + (c & 1));
+      const float w = (((c >> 2) & 1) ? wx : iwx) * (((c >> 1) & 1) ? wy : iwy) * ((c & 1) ? wz : iwz);
+      float* t = tab + (int64_t)id * 4;
+      atomicAdd(t + 0, w * g0);
+      atomicAdd(t + 1, w * g1);
+      atomicAdd(t + 2, w * g2);
+      atomicAdd(t + 3, w * g3);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ compositing backward
+// Forward (src/nerf.py:60-80,96-98): a_t = 1-exp(-sigma_t*dist_t), f_t = (1-a_t)+1e-10, T_t = prod_{s<t} f_s,
+// w_t = a_t*T_t, out_c = sum_t w_t*c_tc + sky.  With G_t = dL/dw_t = sum_c g_c*c_tc (- sum_c g_c for the white sky,
+// t < T-1):  dL/da_t = G_t*T_t - (sum_{s>t} G_s*w_s)/f_t,  dL/dc_tc = w_t*g_c.
+// One thread per ray: forward sweep writes T_t into g_density (used as scratch), backward sweep consumes it.
+template <int C>
+__global__ void composite_backward_kernel(const float* __restrict__ density, const float* __restrict__ feat,
+                                          const float* __restrict__ ts, const float* __restrict__ rays, int T,
+                                          int64_t R, int density_kind, int bg_kind, const float* __restrict__ g_out,
+                                          float* __restrict__ g_density, float* __restrict__ g_feat) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    const float* ry = rays + r * 6 + 3;
+    const float nrm = sqrtf((ry[0] * ry[0] + ry[1] * ry[1]) + ry[2] * ry[2]);
+    float g[C];
+    float gsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { g[c] = g_out[r * C + c]; gsum += g[c]; }
+    float trans = 1.0f;
+    for (int t = 0; t < T; ++t) {
+      const float d = density[(int64_t)t * R + r];
+      const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
+      float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
+      dist *= nrm;
+      const float a = 1.0f - expf(-sigma * dist);
+      g_density[(int64_t)t * R + r] = trans;  // scratch: T_t
+      trans = trans * ((1.0f - a) + 1e-10f);
+    }
+    float suffix = 0.f;  // sum_{s>t} G_s * w_s
+    for (int t = T - 1; t >= 0; --t) {
+      const float d = density[(int64_t)t * R + r];
+      const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
+      float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
+      dist *= nrm;
+      const float e = expf(-sigma * dist);
+      const float a = 1.0f - e;
+      const float f = (1.0f - a) + 1e-10f;
+      const float Tt = g_density[(int64_t)t * R + r];
+      const float w = a * Tt;
+      const float* ct = feat + ((int64_t)t * R + r) * C;
+      float G = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        G += g[c] * ct[c];
+        g_feat[((int64_t)t * R + r) * C + c] = w * g[c];
+      }
+      if (bg_kind == NA_BG_WHITE && t < T - 1) G -= gsum;
+      const float dLda = G * Tt - suffix / f;
+      suffix += G * w;
+      const float dsig = density_kind == NA_DENSITY_SOFTPLUS_M1 ? sigmoidf_(d - 1.0f) : (d > 0.f ? 1.f : 0.f);
+      g_density[(int64_t)t * R + r] = dLda * dist * e * dsig;
+    }
+  }
+}
+
+}  // namespace na
+
+using namespace na;
+
+extern "C" {
+
+int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream) {
+  NA_REQUIRE(x && g && out, NA_ENULL, "na_act_backward: null pointer");
+  NA_REQUIRE(act >= NA_ACT_NONE && act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_act_backward: activation %d", act);
+  if (n <= 0) return n == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(act_backward_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, g, n, act,
+                     out);
+  return check_launch("na_act_backward");
+}
+
+int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, float* out, void* stream) {
+  NA_REQUIRE(x && g && out, NA_ENULL, "na_sigmoid_backward: null pointer");
+  NA_REQUIRE(kind >= 0 && kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_sigmoid_backward: kind %d", kind);
+  if (n <= 0) return n == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(sigmoid_backward_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, g, n,
+                     kind, out);
+  return check_launch("na_sigmoid_backward");
+}
+
+int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                    int pre_act, float* dW, float* db, void* stream) {
+  NA_REQUIRE(x0 && dY && dW, NA_ENULL, "na_linear_wgrad: null pointer");
+  NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_wgrad: bad shape");
+  NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_wgrad: in1>0 needs x1");
+  NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_wgrad: activation %d", pre_act);
+  if (N == 0) return NA_OK;
+  const int in = in0 + in1;
+  // enough N-slices to fill the chip, each at least 1024 rows
+  int64_t tiles = (int64_t)((out + WG_O - 1) / WG_O) * ((in + WG_I - 1) / WG_I);
+  int64_t want = (2048 + tiles - 1) / tiles;
+  int64_t slice = (N + want - 1) / want;
+  if (slice < 1024) slice = 1024;
+  slice = (slice + WG_N - 1) / WG_N * WG_N;
+  int64_t nz = (N + slice - 1) / slice;
+  NA_REQUIRE(nz <= 65535, NA_EINVAL, "na_linear_wgrad: N too large");
+  dim3 grid((out + WG_O - 1) / WG_O, (in + WG_I - 1) / WG_I, (unsigned)nz);
+  hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x0, in0, x1, in1, N, dY, out, pre_act,
+                     slice, dW, db);
+  return check_launch("na_linear_wgrad");
+}
+
+int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input, float* tables_grad,
+                            void* stream) {
+  NA_REQUIRE(x && g_out && tables_grad, NA_ENULL, "na_hash_encode_backward: null pointer");
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
+                     g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad);
+  return check_launch("na_hash_encode_backward");
+}
+
+int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays, int T,
+                          int64_t R, int C, int density_kind, int bg_kind, const float* g_out, float* g_density,
+                          float* g_feat, void* stream) {
+  NA_REQUIRE(density && feat && ts && rays && g_out && g_density && g_feat, NA_ENULL, "na_composite_backward: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_composite_backward: bad shape");
+  NA_REQUIRE(C == 3 || C == 1, NA_EUNSUPPORTED, "na_composite_backward: C=%d (1 or 3)", C);
+  if (R == 0) return NA_OK;
+  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
+  if (C == 3)
+    hipLaunchKernelGGL(composite_backward_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
+                       density_kind, bg_kind, g_out, g_density, g_feat);
+  else
+    hipLaunchKernelGGL(composite_backward_kernel<1>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
+                       density_kind, bg_kind, g_out, g_density, g_feat);
+  return check_launch("na_composite_backward");
+}
+
+}  // extern "C"

@@ -108,8 +108,12 @@ class CommonNeRF(nn.Module):
     def _perturb(self): return 1 if self.training else 0
 
     def _composite(self, density, feat, ts, rays, softplus=True, with_sky=True):
-        out, self.alpha, self.weights = ops.composite(density, feat, ts, rays, softplus=softplus,
-                                                      bg=self.bg if with_sky else "black")
+        bg = self.bg if with_sky else "black"
+        if torch.is_grad_enabled() and (density.requires_grad or feat.requires_grad):
+            from .autograd import CompositeFn
+            out, self.alpha, self.weights = CompositeFn.apply(density.contiguous(), feat.contiguous(), ts, rays, softplus, bg)
+            return out
+        out, self.alpha, self.weights = ops.composite(density, feat, ts, rays, softplus=softplus, bg=bg)
         return out
 
 
@@ -146,8 +150,10 @@ class PlainNeRF(CommonNeRF):
                                  enc=HashEncoder(), num_layers=4, hidden_size=256)
 
     def _fusable(self, refl_latent=None):
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         return (isinstance(self.refl, refl.View) and self.mip is None and refl_latent is None
-                and self.intermediate_size == 64 and self.refl.out_features == 3 and not self.training)
+                and self.intermediate_size == 64 and self.refl.out_features == 3 and not self.training
+                and not wants_grad)
 
     def forward(self, rays, want_weights: bool = True):
         if self._fusable():

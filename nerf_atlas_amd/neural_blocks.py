@@ -11,6 +11,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import config, ops
 
 
@@ -120,6 +121,10 @@ class HashEncoder(nn.Module):
 
     def forward(self, x):
         assert x.shape[-1] == self.in_features
+        if ag.needs_grad(*[e.weight for e in self.embs]):
+            flat = x.reshape(-1, 3).contiguous()
+            tables = torch.stack([e.weight for e in self.embs])  # differentiable view of the 8 parameters
+            return ag.HashEncodeFn.apply(flat, tables, self.include_input).reshape(x.shape[:-1] + (self.output_dims(),))
         return ops.hash_encode(x, self.tables(), self.include_input)
 
 
@@ -229,6 +234,8 @@ class SkipConnMLP(nn.Module):
             assert (latent is None) or (latent.shape[-1] == 0), "Passed latent vector when none was expected"
             lat = None
         out_size = self.out.out_features
+        if ag.needs_grad(flat, lat, *self.parameters()):
+            return self._forward_train(flat, lat).reshape(batches + (out_size,))
         desc, packed = (None, None) if self.last_layer_act else self.packed(config.precision)
         if packed is not None:
             y = ops.mlp_forward(desc, config.precision, packed, flat, lat, self.enc_params())
@@ -248,6 +255,21 @@ class SkipConnMLP(nn.Module):
             setattr(self, "last_layer_out", x.reshape(batches + (-1,)))
         y = ops.linear_f32(x, self.out.weight.data, self.out.bias.data, pre_act=self.act_name)
         return y.reshape(batches + (out_size,))
+
+    def _forward_train(self, flat, lat):
+        """Differentiable forward (fp32 Linears, HIP forward and backward kernels): src/neural_blocks.py:279-296."""
+        init = flat
+        if self.enc is not None:
+            init = torch.cat([init, self.enc(flat)], dim=-1)
+        if lat is not None:
+            init = torch.cat([init, lat], dim=-1)
+        init = init.contiguous()
+        x = ag.LinearFn.apply(init, None, self.init.weight, self.init.bias, "none")
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            skip = i != n - 1 and (i % self.skip) == 0
+            x = ag.LinearFn.apply(x, init if skip else None, layer.weight, layer.bias, self.act_name)
+        return ag.LinearFn.apply(x, None, self.out.weight, self.out.bias, self.act_name)
 
     def zero_last_layer(self):
         nn.init.zeros_(self.out.weight)

@@ -233,6 +233,64 @@ def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre
     return y
 
 
+# ------------------------------------------------------------------------------------------------- backward
+def act_backward(x: torch.Tensor, g: torch.Tensor, act: str) -> torch.Tensor:
+    lib = _lib.load()
+    x, g = _f32(x, "x"), _f32(g, "g")
+    assert x.shape == g.shape
+    out = torch.empty_like(x)
+    check(lib.na_act_backward(_ptr(x), _ptr(g), x.numel(), ACT[act], _ptr(out), _stream()))
+    return out
+
+
+def sigmoid_backward(x: torch.Tensor, g: torch.Tensor, kind: str) -> torch.Tensor:
+    lib = _lib.load()
+    x, g = _f32(x, "x"), _f32(g, "g")
+    out = torch.empty_like(x)
+    check(lib.na_sigmoid_backward(_ptr(x), _ptr(g), x.numel(), SIGMOID[kind], _ptr(out), _stream()))
+    return out
+
+
+def linear_wgrad(x0: torch.Tensor, dY: torch.Tensor, pre_act: str = "none", x1: Optional[torch.Tensor] = None,
+                 want_bias: bool = True):
+    """(dW [out, in0+in1], db [out]) for y = W . act([x0|x1]) + b."""
+    lib = _lib.load()
+    x0, dY = _f32(x0, "x0"), _f32(dY, "dY")
+    N, in0 = x0.shape
+    in1 = 0
+    if x1 is not None:
+        x1 = _f32(x1, "x1")
+        in1 = x1.shape[1]
+    out = dY.shape[1]
+    dW = torch.zeros(out, in0 + in1, device=x0.device, dtype=torch.float32)
+    db = torch.zeros(out, device=x0.device, dtype=torch.float32) if want_bias else None
+    check(lib.na_linear_wgrad(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(dY), out, ACT[pre_act], _ptr(dW), _ptr(db), _stream()))
+    return dW, db
+
+
+def hash_encode_backward(x: torch.Tensor, g_out: torch.Tensor, include_input: bool = True) -> torch.Tensor:
+    lib = _lib.load()
+    x, g_out = _f32(x, "x"), _f32(g_out, "g_out")
+    N = x.numel() // 3
+    tg = torch.zeros(8, 65536, 4, device=x.device, dtype=torch.float32)
+    check(lib.na_hash_encode_backward(_ptr(x), N, _ptr(g_out), int(include_input), _ptr(tg), _stream()))
+    return tg
+
+
+def composite_backward(density, feat, ts, rays, g_out, softplus: bool = True, bg: str = "black"):
+    lib = _lib.load()
+    density, feat, ts, rays, g_out = (_f32(density, "density"), _f32(feat, "feat"), _f32(ts, "ts"), _f32(rays, "rays"),
+                                      _f32(g_out, "g_out"))
+    T = ts.shape[0]
+    Cn = feat.shape[-1]
+    R = rays.numel() // 6
+    gd = torch.empty_like(density)
+    gf = torch.empty_like(feat)
+    check(lib.na_composite_backward(_ptr(density), _ptr(feat), _ptr(ts), _ptr(rays), T, R, Cn, 0 if softplus else 1, BG[bg],
+                                    _ptr(g_out), _ptr(gd), _ptr(gf), _stream()))
+    return gd, gf
+
+
 def make_desc(in_size, enc_kind, enc_dims, latent_size, num_layers, hidden, out_size, skip, activation,
               layout="generic") -> NaMlpDesc:
     return NaMlpDesc(in_size, ENC[enc_kind], enc_dims, latent_size, num_layers, hidden, out_size, skip,

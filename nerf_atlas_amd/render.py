@@ -34,9 +34,10 @@ def render_frame(model, cam, size: int, crop_size: int = 0, times=None, tiles=No
     `tiles` restricts the work to a subset (multi-GPU sharding); untouched pixels stay zero."""
     device = next(model.parameters()).device
     got = out if out is not None else torch.zeros(size, size, 3, device=device)
-    for (c0, c1, h, w) in (tiles if tiles is not None else tile_list(size, crop_size)):
-        o, _ = render(model, cam, (c0, c1, h, w), size=size, times=times, with_noise=False)
-        got[c0:c0 + h, c1:c1 + w, :] = o.squeeze(0)
+    with torch.no_grad():  # runner.test() renders under no_grad: fused inference kernels
+        for (c0, c1, h, w) in (tiles if tiles is not None else tile_list(size, crop_size)):
+            o, _ = render(model, cam, (c0, c1, h, w), size=size, times=times, with_noise=False)
+            got[c0:c0 + h, c1:c1 + w, :] = o.squeeze(0)
     return got
 
 

@@ -13,6 +13,9 @@ class _Sigmoid:
         self.kind = kind
 
     def __call__(self, v):
+        if torch.is_grad_enabled() and v.requires_grad:
+            from .autograd import SigmoidFn
+            return SigmoidFn.apply(v.contiguous(), self.kind)
         return ops.sigmoid(v, self.kind)
 
     def __repr__(self):

@@ -10,6 +10,14 @@ from conftest import load_golden, golden_params
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Like runner.test() these checks run under no_grad; with gradients enabled the modules take the
+    differentiable fp32 path instead of the fused MFMA kernels (tests/test_gpu_backward.py covers that)."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def na():
     assert torch.cuda.is_available()
