@@ -84,7 +84,7 @@ class PosLinearView(Reflectance):
     def forward(self, x, view, normal=None, light=None, latent=None):
         pos, intermediate = self.act(self.pos(x, latent)).split([self.out_features, self.im], dim=-1)
         view_latent = intermediate if latent is None else torch.cat([latent, intermediate], dim=-1)
-        linear = ops.sigmoid(self.view(torch.cat([x, _normalize(view)], dim=-1), view_latent), "normal")
+        linear = load_sigmoid("normal")(self.view(torch.cat([x, _normalize(view)], dim=-1), view_latent))
         return (linear / 2 + 0.5) * pos
 
 
