@@ -27,7 +27,7 @@ UNITS = [
     ("render_fused.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("render_fused.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),
 ]
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("NA_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def hipcc():

@@ -334,7 +334,7 @@ __device__ __forceinline__ void mma_chunks(WS& ws, f32x16 (&acc)[NB], const char
   constexpr int NS = (NCH + kStage - 1) / kStage;
   constexpr int ES = Epilogue<PREC, ACT, NB>::kSteps;
   bf16x8 ah[2][kStage], al[2][kStage];
-  const char* a0 = tile + frag0 * FB + lane * 16;
+  const char* a0 = tile + 1024 + frag0 * FB + lane * 16;  // fragments follow the 1-KiB bias block
 #pragma unroll
   for (int c = 0; c < kStage && c < NCH; ++c) {
     ah[0][c] = *(const bf16x8*)(a0 + c * FB);
@@ -384,11 +384,9 @@ __device__ __forceinline__ void mma_chunks(WS& ws, f32x16 (&acc)[NB], const char
   }
 }
 
-// bias block of a tile: floats [hi(2)][16] right after its `nfrag` fragments
-template <int PREC>
-__device__ __forceinline__ f32x16 load_bias(const char* tile, int nfrag, int lane) {
-  constexpr int FB = PREC == NA_PREC_BF16X3 ? 2048 : 1024;
-  const f32x4* b = (const f32x4*)(tile + nfrag * FB + (lane >> 5) * 64);
+// bias block of a tile (its first KiB): floats [hi(2)][16] in accumulator order
+__device__ __forceinline__ f32x16 load_bias(const char* tile, int lane) {
+  const f32x4* b = (const f32x4*)(tile + (lane >> 5) * 64);
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -420,7 +418,7 @@ __device__ __forceinline__ void linear256(WS& ws, const Frag<PREC>* H, const Fra
   for (int j = 0; j < 8; ++j) {
     f32x16 acc[NB];
     ws.mark(0);
-    acc[0] = load_bias<PREC>(ws.cur, NH + NI, lane);
+    acc[0] = load_bias(ws.cur, lane);
 #pragma unroll
     for (int b = 1; b < NB; ++b) acc[b] = acc[0];
     if constexpr (NH > 0) mma_chunks<PREC, ACT, NB, NH, kHC>(ws, acc, ws.cur, 0, H, lane, epi, 0, NH + NI);
@@ -465,7 +463,7 @@ __device__ __forceinline__ void mlp_hidden_layers(WS& ws, int num_layers, int sk
 template <int PREC, int NB, class WS>
 __device__ __forceinline__ void mlp_out_tile(WS& ws, const Frag<PREC> (&H)[NB * kHC], int lane,
                                              f32x16 (&acc)[NB]) {
-  acc[0] = load_bias<PREC>(ws.cur, kHC, lane);
+  acc[0] = load_bias(ws.cur, lane);
 #pragma unroll
   for (int b = 1; b < NB; ++b) acc[b] = acc[0];
   Epilogue<PREC, NA_ACT_NONE, NB> none;

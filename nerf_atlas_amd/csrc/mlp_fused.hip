@@ -34,7 +34,7 @@ __global__ void pack_layer_kernel(NaMlpDesc d, int kind, const float* __restrict
       else { col = init_slot_feature(d, c - kHC, kappa); if (col >= 0) col += kHidden; }
       float w = 0.f;
       if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) w = W[(int64_t)row * in_dim + col];
-      char* p = dst + (int64_t)j * tile_bytes + (int64_t)c * planes * 1024 + l * 16 + e * 2;
+      char* p = dst + (int64_t)j * tile_bytes + 1024 + (int64_t)c * planes * 1024 + l * 16 + e * 2;
       __bf16 h = (__bf16)w;
       *(uint16_t*)p = __builtin_bit_cast(uint16_t, h);
       if (planes == 2) *(uint16_t*)(p + 1024) = bf16_bits(w - (float)h);
@@ -48,7 +48,7 @@ __global__ void pack_layer_kernel(NaMlpDesc d, int kind, const float* __restrict
         int row = kind == LK_OUT ? out_row_map(d, rho) : rho;
         if (row >= 0 && row < out_dim && bias != nullptr) v = bias[row];
       }
-      *(float*)(dst + (int64_t)j * tile_bytes + (int64_t)nfrag * planes * 1024 + k * 4) = v;
+      *(float*)(dst + (int64_t)j * tile_bytes + k * 4) = v;
     }
   }
 }

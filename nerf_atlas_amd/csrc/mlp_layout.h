@@ -1,8 +1,8 @@
 // Weight-stream layout shared by the packer (mlp_pack.hip), the generic fused MLP (mlp_fused.hip) and
 // the fused PlainNeRF renderer (render_fused.hip).
 //
-// Stream = tiles in consumption order.  Tile (layer, j) = `nfrag` A-fragments (one per 16-wide K chunk;
-// `planes` KiB each: bf16 hi [, bf16 lo]) followed by a 1-KiB bias block (floats [hi(2)][16]).
+// Stream = tiles in consumption order.  Tile (layer, j) = a 1-KiB bias block (floats [hi(2)][16]) followed by
+// `nfrag` A-fragments (one per 16-wide K chunk; `planes` KiB each: bf16 hi [, bf16 lo]).
 //   init layer   : 8 tiles x NI fragments              (K = init input, "slot map" order)
 //   hidden layer : 8 tiles x 16 (+NI if skip) fragments (K = hidden in pi-order [, init slots])
 //   out layer    : ceil(out/32) tiles x 16 fragments
