@@ -200,6 +200,12 @@ int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T,
  *                      (the input gradient is na_linear_f32 with W^T followed by na_act_backward)
  * na_hash_encode_backward  tables_grad[8,65536,4] += trilinear weights x g_out[N, 32(+3)]
  *                      (src/neural_blocks.py:166-190).
+ * na_hash_encode_backward_input  g_x[N,3] = d(features)/d(position) . g_out (+ g_out[:, :3] with
+ *                      include_input); floor() carries no gradient, as in torch.autograd of the same lines.
+ * na_laplace_density_backward    g_sdf[N] and (optional, ACCUMULATED into one float the caller zeroed) g_beta of
+ *                      na_laplace_density (src/utils.py:50-58, src/nerf.py:985-990).
+ * na_bezier_warp_backward        g_est[N, est_stride] of na_bezier_warp given any of g_out_pts [N,3], g_dp [N,3],
+ *                      g_rigidity [N] (null = zero) (src/nerf.py:1173-1178,1201-1206,1267-1278).
  * na_composite_backward    gradient of na_composite w.r.t. density [T,R] and feat [T,R,C] (C = 1 or 3)
  *                      given g_out [R,C] (src/nerf.py:60-80,96-98).                              */
 int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream);
@@ -208,6 +214,13 @@ int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t 
                     int pre_act, float* dW, float* db, void* stream);
 int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input,
                             float* tables_grad, void* stream);
+int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,
+                                  int include_input, float* g_x, void* stream);
+int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, const float* g, float* g_sdf,
+                                float* g_beta, void* stream);
+int na_bezier_warp_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl,
+                            const float* g_out_pts, const float* g_dp, const float* g_rigidity, float* g_est,
+                            void* stream);
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays,
                           int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
                           float* g_density, float* g_feat, void* stream);

@@ -55,6 +55,10 @@ SIGNATURES = {
     "na_linear_wgrad": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p,
                                   C.c_void_p]),
     "na_hash_encode_backward": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_hash_encode_backward_input": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_laplace_density_backward": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "na_bezier_warp_backward": (C.c_int, [c_f32p, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          C.c_void_p]),
     "na_composite_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,
                                         c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_render_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),

@@ -46,22 +46,57 @@ class LinearFn(Function):
 
 
 class HashEncodeFn(Function):
-    """HashEncoder.forward (src/neural_blocks.py:139-193); gradient w.r.t. the tables only (sample positions
-    are inputs of the canonical models on the hot path)."""
+    """HashEncoder.forward (src/neural_blocks.py:139-193): gradients w.r.t. the tables (scatter) and, for
+    deformation models whose canonical positions are predicted, w.r.t. the positions."""
 
     @staticmethod
     def forward(ctx, x, tables, include_input):
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, tables)
         ctx.include_input = include_input
         return ops.hash_encode(x, tables, include_input)
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
+        x, tables = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gt = None
         if ctx.needs_input_grad[0]:
-            raise NotImplementedError("d(hash features)/d(position) is not implemented (needed only by deformation "
-                                      "models' training)")
-        return None, ops.hash_encode_backward(x, g.contiguous(), ctx.include_input), None
+            gx = ops.hash_encode_backward_input(x, tables, g, ctx.include_input)
+        if ctx.needs_input_grad[1]:
+            gt = ops.hash_encode_backward(x, g, ctx.include_input)
+        return gx, gt, None
+
+
+class LaplaceDensityFn(Function):
+    """VolSDF density 1/beta * laplace_cdf(-sdf, beta) (src/nerf.py:985-990, src/utils.py:50-58)."""
+
+    @staticmethod
+    def forward(ctx, sdf, beta):
+        ctx.save_for_backward(sdf, beta)
+        return ops.laplace_density(sdf, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        sdf, beta = ctx.saved_tensors
+        g_sdf, g_beta = ops.laplace_density_backward(sdf, beta, g.contiguous(), want_beta=ctx.needs_input_grad[1])
+        return g_sdf, (g_beta.reshape(beta.shape) if g_beta is not None else None)
+
+
+class BezierWarpFn(Function):
+    """DynamicNeRF spline warp (src/nerf.py:1267-1278) -> (warped pts, dp, rigidity); gradient w.r.t. the
+    estimator output and the (pass-through) points."""
+
+    @staticmethod
+    def forward(ctx, est, pts, t, n_ctrl):
+        ctx.save_for_backward(est, t)
+        ctx.n_ctrl = n_ctrl
+        return ops.bezier_warp(est, pts, t, n_ctrl)
+
+    @staticmethod
+    def backward(ctx, g_pts, g_dp, g_rig):
+        est, t = ctx.saved_tensors
+        g_est = ops.bezier_warp_backward(est, t, ctx.n_ctrl, g_pts, g_dp, g_rig)
+        return g_est, (g_pts if ctx.needs_input_grad[1] else None), None, None
 
 
 class SigmoidFn(Function):

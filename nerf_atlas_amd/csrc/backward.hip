@@ -146,6 +146,124 @@ __global__ void hash_backward_kernel(const float* __restrict__ x, int64_t N, con
   }
 }
 
+// d(hash features)/d(position): the trilinear weights are linear in each fractional coordinate, floor() has zero
+// gradient (torch.autograd of src/neural_blocks.py:166-190 sees exactly this), so
+//   g_x[a] = g_in[a] (include_input) + sum_lvl N_lvl * sum_corner dW_corner/dw_a * <emb_corner, g_lvl>.
+// One thread per (sample, level); the 8 levels of a sample sit in 8 adjacent lanes and are summed with DPP-free
+// shuffles before a single store.
+__global__ void hash_backward_input_kernel(const float* __restrict__ x, int64_t N, const float* __restrict__ tables,
+                                           const float* __restrict__ g_out, int include_input, HashRes res,
+                                           float* __restrict__ g_x) {
+  const int odim = 32 + 3 * include_input;
+  const int64_t total = (N * 8 + 63) / 64 * 64;  // whole waves, so the shuffles below are convergent
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lvl = (int)(i & 7);
+    const int64_t n = i >> 3;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (n < N) {
+      const float px = x[n * 3], py = x[n * 3 + 1], pz = x[n * 3 + 2];
+      const float Nl = res.n[lvl];
+      const float vx = px * Nl, vy = py * Nl, vz = pz * Nl;
+      const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
+      const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
+      const float wx = vx - fx, wy = vy - fy, wz = vz - fz;
+      const float iwx = 1.f - wx, iwy = 1.f - wy, iwz = 1.f - wz;
+      const float* g = g_out + n * odim + 3 * include_input + lvl * 4;
+      const float g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+      const float* tab = tables + (int64_t)lvl * 65536 * 4;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+        const uint32_t id = hash_index(lx + bx, ly + by, lz + bz);
+        const float4 e = *(const float4*)(tab + (int64_t)id * 4);
+        const float d = ((e.x * g0 + e.y * g1) + e.z * g2) + e.w * g3;
+        const float sx = bx ? 1.f : -1.f, sy = by ? 1.f : -1.f, sz = bz ? 1.f : -1.f;
+        const float ux = bx ? wx : iwx, uy = by ? wy : iwy, uz = bz ? wz : iwz;
+        gx += d * (sx * uy * uz);
+        gy += d * (ux * sy * uz);
+        gz += d * (ux * uy * sz);
+      }
+      gx *= Nl; gy *= Nl; gz *= Nl;
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      gx += __shfl_xor(gx, m);
+      gy += __shfl_xor(gy, m);
+      gz += __shfl_xor(gz, m);
+    }
+    if (lvl == 0 && n < N) {
+      if (include_input) {
+        gx += g_out[n * odim]; gy += g_out[n * odim + 1]; gz += g_out[n * odim + 2];
+      }
+      g_x[n * 3] = gx; g_x[n * 3 + 1] = gy; g_x[n * 3 + 2] = gz;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ VolSDF Laplace density
+// density = cdf(s)/beta, s = -sdf/beta (src/utils.py:50-58, src/nerf.py:985-990); pdf = exp(-|s|)/2.
+//   d/dsdf = -pdf/beta^2,   d/dbeta = -cdf/beta^2 + pdf*sdf/beta^3   (block-reduced, one atomic per workgroup)
+__global__ __launch_bounds__(256) void laplace_density_backward_kernel(const float* __restrict__ sdf, int64_t N,
+                                                                       const float* __restrict__ beta,
+                                                                       const float* __restrict__ g,
+                                                                       float* __restrict__ g_sdf,
+                                                                       float* __restrict__ g_beta) {
+  __shared__ float part[4];
+  const float sc = beta[0];
+  const float r = 1.0f / sc, r2 = r * r;
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = sdf[i], gi = g[i];
+    const float s = -v / sc;
+    const float e = expf(-fabsf(s)) * 0.5f;
+    const float cdf = s <= 0.f ? e : 1.f - e;
+    g_sdf[i] = -gi * e * r2;
+    acc += gi * (e * v * r2 * r - cdf * r2);
+  }
+  if (g_beta == nullptr) return;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(g_beta, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// ------------------------------------------------------------------------------------ spline warp
+// Forward (src/nerf.py:1173-1178,1201-1206,1267-1278): rig = sigmoid(e0/2), dp = sum_k B_k(t) P_k,
+// out = pts + dp*rig.  Bezier curves are linear in their control points with the Bernstein weights B_k(t).
+__global__ void bezier_warp_backward_kernel(const float* __restrict__ est, int est_stride,
+                                            const float* __restrict__ tt, int64_t N, int n,
+                                            const float* __restrict__ g_pts, const float* __restrict__ g_dp,
+                                            const float* __restrict__ g_rig, float* __restrict__ g_est) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* e = est + i * est_stride;
+    float* ge = g_est + i * est_stride;
+    const float rig = sigmoidf_(e[0] / 2.f);
+    const float t = tt[i], m1t = 1.f - t;
+    float B[8];
+    B[0] = 1.f;
+    for (int it = 1; it < n; ++it) {
+      B[it] = B[it - 1] * t;
+      for (int k = it - 1; k >= 1; --k) B[k] = B[k] * m1t + B[k - 1] * t;
+      B[0] *= m1t;
+    }
+    float dp[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < n; ++k)
+      for (int a = 0; a < 3; ++a) dp[a] += B[k] * e[1 + 3 * k + a];
+    float d_rig = g_rig != nullptr ? g_rig[i] : 0.f;
+    float d_dp[3];
+    for (int a = 0; a < 3; ++a) {
+      const float gw = g_pts != nullptr ? g_pts[i * 3 + a] : 0.f;
+      d_rig += gw * dp[a];
+      d_dp[a] = gw * rig + (g_dp != nullptr ? g_dp[i * 3 + a] : 0.f);
+    }
+    ge[0] = d_rig * rig * (1.f - rig) * 0.5f;
+    for (int k = 0; k < n; ++k)
+      for (int a = 0; a < 3; ++a) ge[1 + 3 * k + a] = B[k] * d_dp[a];
+    for (int c = 1 + 3 * n; c < est_stride; ++c) ge[c] = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------------------------ compositing backward
 // Forward (src/nerf.py:60-80,96-98): a_t = 1-exp(-sigma_t*dist_t), f_t = (1-a_t)+1e-10, T_t = prod_{s<t} f_s,
 // w_t = a_t*T_t, out_c = sum_t w_t*c_tc + sky.  With G_t = dL/dw_t = sum_c g_c*c_tc (- sum_c g_c for the white sky,
@@ -253,6 +371,36 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
   hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
                      g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad);
   return check_launch("na_hash_encode_backward");
+}
+
+int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,
+                                  int include_input, float* g_x, void* stream) {
+  NA_REQUIRE(x && tables && g_out && g_x, NA_ENULL, "na_hash_encode_backward_input: null pointer");
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(hash_backward_input_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                     x, N, tables, g_out, include_input ? 1 : 0, hash_resolutions(), g_x);
+  return check_launch("na_hash_encode_backward_input");
+}
+
+int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, const float* g, float* g_sdf,
+                                float* g_beta, void* stream) {
+  NA_REQUIRE(sdf && beta && g && g_sdf, NA_ENULL, "na_laplace_density_backward: null pointer");
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(laplace_density_backward_kernel, dim3(grid_for(N, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     sdf, N, beta, g, g_sdf, g_beta);
+  return check_launch("na_laplace_density_backward");
+}
+
+int na_bezier_warp_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl,
+                            const float* g_out_pts, const float* g_dp, const float* g_rigidity, float* g_est,
+                            void* stream) {
+  NA_REQUIRE(est && t && g_est, NA_ENULL, "na_bezier_warp_backward: null pointer");
+  NA_REQUIRE(n_ctrl >= 2 && n_ctrl <= 8 && est_stride >= 1 + 3 * n_ctrl, NA_EINVAL,
+             "na_bezier_warp_backward: n_ctrl=%d (2..8) stride=%d", n_ctrl, est_stride);
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(bezier_warp_backward_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
+                     est_stride, t, N, n_ctrl, g_out_pts, g_dp, g_rigidity, g_est);
+  return check_launch("na_bezier_warp_backward");
 }
 
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays, int T,

@@ -9,6 +9,7 @@ forward, .ts, .alpha, .weights (+ .pts/.dp/.rigidity/.rigid_dp for dynamic model
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import config, ops
 from . import refl
 from .neural_blocks import HashEncoder, SkipConnMLP
@@ -213,9 +214,13 @@ class VolSDF(CommonNeRF):
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
         sdf_vals, latent = self.sdf.from_pts(pts)
-        scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
+        if ag.needs_grad(sdf_vals, self.scale):
+            scale = torch.nn.functional.softplus(self.scale) if self.scale_softplus else self.scale
+            density = ag.LaplaceDensityFn.apply(sdf_vals.contiguous(), scale)
+        else:
+            scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
+            density = ops.laplace_density(sdf_vals.contiguous(), scale)
         self.scale_post_act = scale
-        density = ops.laplace_density(sdf_vals.contiguous(), scale)
         if self.sdf.refl.can_use_normal:
             raise NotImplementedError("normal-dependent reflectance needs autograd normals (row N1)")
         view = r_d.unsqueeze(0).expand_as(pts).contiguous()
@@ -268,7 +273,10 @@ class DynamicNeRF(nn.Module):
         c.ts = self.ts
         tt = t[None, :, None, None].expand(*self.pts.shape[:-1]).contiguous()
         est = self.delta_estim(self.pts)
-        warped, self.dp, self.rigidity = ops.bezier_warp(est, self.pts, tt, self.spline_n)
+        if ag.needs_grad(est):
+            warped, self.dp, self.rigidity = ag.BezierWarpFn.apply(est.contiguous(), self.pts, tt, self.spline_n)
+        else:
+            warped, self.dp, self.rigidity = ops.bezier_warp(est, self.pts, tt, self.spline_n)
         self.rigid_dp = self.dp * self.rigidity
         return c.from_pts(warped, self.ts, r_o, r_d, rays=rays)
 

@@ -2,8 +2,8 @@
 
 Parameters live in ordinary nn.Parameters under the reference's names (init / layers.N / out / enc.embs.N /
 enc.basis), so a reference state_dict loads unchanged.  forward() runs HIP kernels only: the fused MFMA engine
-when the shape has one (hidden 256), otherwise a chain of exact-fp32 MFMA Linears.  Inference only: outputs
-carry no autograd graph (training = SURVEY 8(f) N1).
+when the shape has one (hidden 256), otherwise a chain of exact-fp32 MFMA Linears.  With gradients enabled the
+same operators run through nerf_atlas_amd/autograd.py (HIP forward + backward kernels).
 """
 import math
 from typing import Optional
@@ -32,6 +32,8 @@ class PositionalEncoder(nn.Module):
 
     def forward(self, x):
         assert x.shape[-1] == self.input_dims
+        if ag.needs_grad(x):
+            raise NotImplementedError("d(%s)/d(position) has no HIP backward yet (DESIGN.md 9a)" % type(self).__name__)
         return ops.positional_encode(x, self.bands.data)
 
 
@@ -49,6 +51,8 @@ class FourierEncoder(nn.Module):
         return self.freqs * 2
 
     def forward(self, x):
+        if ag.needs_grad(x):
+            raise NotImplementedError("d(%s)/d(position) has no HIP backward yet (DESIGN.md 9a)" % type(self).__name__)
         return ops.fourier_encode(x, self.basis.data, float(self.extra_scale))
 
     def scale_freqs(self, amt: 1 + 1e-5, cap=2):
@@ -70,6 +74,8 @@ class LearnedFourierEncoder(nn.Module):
         return self.n_freqs * 2
 
     def forward(self, x):
+        if ag.needs_grad(x, self.extra_scale):
+            raise NotImplementedError("LearnedFourierEncoder has no HIP backward yet (DESIGN.md 9a)")
         return ops.fourier_encode(x, self.basis.data, float(self.extra_scale))
 
 
@@ -121,7 +127,7 @@ class HashEncoder(nn.Module):
 
     def forward(self, x):
         assert x.shape[-1] == self.in_features
-        if ag.needs_grad(*[e.weight for e in self.embs]):
+        if ag.needs_grad(x, *[e.weight for e in self.embs]):
             flat = x.reshape(-1, 3).contiguous()
             tables = torch.stack([e.weight for e in self.embs])  # differentiable view of the 8 parameters
             return ag.HashEncodeFn.apply(flat, tables, self.include_input).reshape(x.shape[:-1] + (self.output_dims(),))

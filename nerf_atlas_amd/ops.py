@@ -277,6 +277,43 @@ def hash_encode_backward(x: torch.Tensor, g_out: torch.Tensor, include_input: bo
     return tg
 
 
+def hash_encode_backward_input(x: torch.Tensor, tables: torch.Tensor, g_out: torch.Tensor,
+                               include_input: bool = True) -> torch.Tensor:
+    lib = _lib.load()
+    x, tables, g_out = _f32(x, "x"), _f32(tables, "tables"), _f32(g_out, "g_out")
+    N = x.numel() // 3
+    gx = torch.empty_like(x)
+    check(lib.na_hash_encode_backward_input(_ptr(x), N, _ptr(tables), _ptr(g_out), int(include_input), _ptr(gx),
+                                            _stream()))
+    return gx
+
+
+def laplace_density_backward(sdf: torch.Tensor, beta: torch.Tensor, g: torch.Tensor, want_beta: bool = True):
+    """-> (g_sdf, g_beta [1] or None)."""
+    lib = _lib.load()
+    sdf, g = _f32(sdf, "sdf"), _f32(g, "g")
+    beta = _f32(beta.reshape(1), "beta")
+    g_sdf = torch.empty_like(sdf)
+    g_beta = torch.zeros(1, device=sdf.device, dtype=torch.float32) if want_beta else None
+    check(lib.na_laplace_density_backward(_ptr(sdf), sdf.numel(), _ptr(beta), _ptr(g), _ptr(g_sdf),
+                                          _ptr(g_beta) if want_beta else None, _stream()))
+    return g_sdf, g_beta
+
+
+def bezier_warp_backward(est: torch.Tensor, t: torch.Tensor, n_ctrl: int, g_pts=None, g_dp=None, g_rig=None):
+    lib = _lib.load()
+    est, t = _f32(est, "est"), _f32(t, "t")
+    N = t.numel()
+    g_pts = None if g_pts is None else _f32(g_pts, "g_pts")
+    g_dp = None if g_dp is None else _f32(g_dp, "g_dp")
+    g_rig = None if g_rig is None else _f32(g_rig, "g_rig")
+    g_est = torch.empty_like(est)
+    check(lib.na_bezier_warp_backward(_ptr(est), est.shape[-1], _ptr(t), N, n_ctrl,
+                                      None if g_pts is None else _ptr(g_pts), None if g_dp is None else _ptr(g_dp),
+                                      None if g_rig is None else _ptr(g_rig), _ptr(g_est), _stream()))
+    return g_est
+
+
 def composite_backward(density, feat, ts, rays, g_out, softplus: bool = True, bg: str = "black"):
     lib = _lib.load()
     density, feat, ts, rays, g_out = (_f32(density, "density"), _f32(feat, "feat"), _f32(ts, "ts"), _f32(rays, "rays"),

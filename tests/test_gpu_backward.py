@@ -121,3 +121,118 @@ def test_plain_nerf_training_gradients_match_oracle_autograd(ops):
         opt.step()
     with torch.no_grad():
         assert float(torch.nn.functional.mse_loss(m(h["rays"].cuda()), target.cuda())) < float(loss.detach())
+
+
+def test_hash_backward_wrt_positions(ops):
+    """d(features)/d(x): needed once positions are predicted (D-NeRF canonical warp).  floor() carries no gradient."""
+    g = load_golden("g4_hash")
+    p = golden_params(g)
+    tabs = [p[f"embs.{i}.weight"] for i in range(8)]
+    for inc in (True, False):
+        x = torch.from_numpy(proc_uniform((5001, 3), 19, 3.0)).requires_grad_()
+        go = torch.from_numpy(proc_uniform((5001, 32 + 3 * inc), 20, 1.0))
+        (O.hash_encode(x, tabs, include_input=inc) * go).sum().backward()
+        gx = ops.hash_encode_backward_input(x.detach().cuda(), torch.stack(tabs).cuda(), go.cuda(), inc)
+        assert rel(gx, x.grad) <= 2e-5, inc
+
+
+def test_laplace_density_backward(ops):
+    sdf = torch.from_numpy(proc_uniform((70001,), 21, 0.6))
+    sdf[:3] = torch.tensor([0.0, -0.0, 1e-9])
+    go = torch.from_numpy(proc_uniform((70001,), 22, 1.0))
+    for beta in (0.1, 0.37):
+        s = sdf.clone().requires_grad_()
+        b = torch.tensor(beta, requires_grad=True)
+        ((1 / b * O.laplace_cdf(-s, b)) * go).sum().backward()
+        gs, gb = ops.laplace_density_backward(sdf.cuda(), torch.tensor(beta).cuda(), go.cuda())
+        assert rel(gs, s.grad) <= 2e-5
+        assert abs(float(gb) - float(b.grad)) <= 2e-4 * abs(float(b.grad)) + 1e-2  # 70k-term fp32 sum, other order
+        gs2, none = ops.laplace_density_backward(sdf.cuda(), torch.tensor(beta).cuda(), go.cuda(), want_beta=False)
+        assert none is None and torch.equal(gs, gs2)
+
+
+@pytest.mark.parametrize("n", [2, 4, 6, 8])
+def test_bezier_warp_backward(ops, n):
+    N = 3001
+    est = torch.from_numpy(proc_uniform((N, 1 + 3 * n), 23, 1.5))
+    pts = torch.from_numpy(proc_uniform((N, 3), 24, 2.0))
+    t = torch.from_numpy(proc_uniform((N,), 25, 0.5)) + 0.5
+    gs = [torch.from_numpy(proc_uniform(s, 26 + i, 1.0)) for i, s in enumerate([(N, 3), (N, 3), (N, 1)])]
+    e = est.clone().requires_grad_()
+    rig = (e[..., :1] / 2).sigmoid()
+    ps = torch.stack(e[..., 1:].split([3] * n, dim=-1), dim=0)
+    dp = (O.cubic_bezier if n == 4 else O.de_casteljau)(ps, t[:, None], n)
+    warped = pts + dp * rig
+    ((warped * gs[0]).sum() + (dp * gs[1]).sum() + (rig * gs[2]).sum()).backward()
+    ge = ops.bezier_warp_backward(est.cuda(), t.cuda(), n, *[g.cuda() for g in gs])
+    assert rel(ge, e.grad) <= 2e-5
+    # only the warped points carry a gradient (the rendering loss)
+    e.grad = None
+    rig = (e[..., :1] / 2).sigmoid()
+    dp = (O.cubic_bezier if n == 4 else O.de_casteljau)(torch.stack(e[..., 1:].split([3] * n, dim=-1), dim=0), t[:, None], n)
+    ((pts + dp * rig) * gs[0]).sum().backward()
+    assert rel(ops.bezier_warp_backward(est.cuda(), t.cuda(), n, gs[0].cuda()), e.grad) <= 2e-5
+
+
+def _grad_parity(m, ref_p, out, ref_out, target, min_checked, tol=5e-4):
+    loss = torch.nn.functional.mse_loss(out, target.cuda())
+    loss.backward()
+    ref_loss = torch.nn.functional.mse_loss(ref_out, target)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, rp in ref_p.items():
+        if rp.grad is None or k not in named:
+            continue
+        assert named[k].grad is not None, k
+        assert rel(named[k].grad, rp.grad) <= tol, (k, rel(named[k].grad, rp.grad))
+        checked += 1
+    assert checked >= min_checked, checked
+
+
+@pytest.mark.parametrize("kind", ["mlp", "siren"])
+def test_volsdf_training_gradients_match_oracle_autograd(ops, kind):
+    """VolSDF (Laplace density, learnable beta) end to end against torch.autograd of the CPU oracle."""
+    import nerf_atlas_amd as na
+    import nerf_atlas_amd.nerf, nerf_atlas_amd.refl, nerf_atlas_amd.sdf  # noqa: F401,E401
+    h = load_golden(f"g10_volsdf_{kind}")
+    params = golden_params(h)
+    under = na.sdf.sdf_kinds[kind](intermediate_size=64)
+    r = na.refl.View(latent_size=64, act="upshifted", out_features=3)
+    s = na.sdf.SDF(under, r, isect=None, t_near=0.3, t_far=1.8)
+    m = na.nerf.VolSDF(sdf=s, steps=int(h["steps"]), t_near=0.3, t_far=1.8, sigmoid_kind="upshifted").cuda().eval()
+    sd = m.state_dict()
+    for k, v in params.items():
+        sd[k].copy_(v)
+    target = torch.from_numpy(proc_uniform(tuple(h["out"].shape), 78, 0.5)) + 0.5
+    out = m(h["rays"].cuda())
+    assert out.requires_grad
+    ref_p = {k: (v.clone().requires_grad_() if v.is_floating_point() and "basis" not in k else v) for k, v in params.items()}
+    ref_p["scale"] = torch.as_tensor(h["scale"]).clone().float().requires_grad_()
+    ref_out = O.volsdf(ref_p, h["rays"], 0.3, 1.8, int(h["steps"]), kind, "view", act="upshifted")
+    _grad_parity(m, ref_p, out, ref_out, target, 20, tol=2e-3 if kind == "mlp" else 5e-4)
+    assert m.scale.grad is not None and float(m.scale.grad.abs()) > 0
+
+
+@pytest.mark.parametrize("spline", [6, 4])
+def test_dnerf_training_gradients_match_oracle_autograd(ops, spline):
+    """D-NeRF: loss -> canonical PlainNeRF -> d/d(warped points) (hash + first MLP input gradients) -> spline warp
+    -> deformation MLP, all through HIP backward kernels."""
+    import nerf_atlas_amd as na
+    import nerf_atlas_amd.nerf, nerf_atlas_amd.refl, nerf_atlas_amd.sdf  # noqa: F401,E401
+    h = load_golden(f"g9_dnerf_spline{spline}")
+    params = golden_params(h)
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=spline).cuda().eval()
+    sd = m.state_dict()
+    for k, v in params.items():
+        sd[k].copy_(v)
+    target = torch.from_numpy(proc_uniform(tuple(h["out"].shape), 79, 0.5)) + 0.5
+    out = m((h["rays"].cuda(), h["times"].cuda()))
+    assert out.requires_grad
+    ref_p = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in params.items()}
+    ref_out = O.dynamic_nerf_spline(ref_p, h["rays"], h["times"], 2.0, 6.0, int(h["steps"]), spline, "view", act="upshifted")
+    _grad_parity(m, ref_p, out, ref_out, target, 50, tol=2e-3)
+    g = dict(m.named_parameters())["delta_estim.init.weight"].grad
+    assert float(g.abs().max()) > 0  # the deformation network really received a gradient through the warp
