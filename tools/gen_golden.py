@@ -468,9 +468,46 @@ def g13():
     save("g13_tiny", rays=rays, out=out, steps=T, near=2.0, far=6.0, weights=w, **spec(sd_names, sd_shapes))
 
 
+# ------------------------------------------------------------------ G14 loaders (N2)
+def g14():
+    """Reference loaders (src/loaders.py:74-150) on the analytic scene of tools/make_scene.py, at the file size and
+    through PIL's resize; labels stored as uint16 fixed point of the exact k/255 grid where possible."""
+    import tempfile
+    import src.loaders as rload
+    from tools.make_scene import make_scene
+    kw = {}
+    with tempfile.TemporaryDirectory() as td:
+        d = make_scene(os.path.join(td, "static"), size=24, n_train=4, n_test=2) + "/"
+        for training in (True, False):
+            for size in (24, 16):
+                for white in (False, True):
+                    labels, c, _ = rload.original(d, normalize=False, training=training, size=size, white_bg=white)
+                    key = f"orig_{'train' if training else 'test'}_{size}_{'w' if white else 'b'}"
+                    kw[key + "_labels"] = labels
+                    kw[key + "_c2w"] = c.cam_to_world
+                    kw[key + "_focal"] = np.float64(c.focal)
+        labels, c, _ = rload.original(d, normalize=True, training=True, size=24, with_mask=True)
+        kw["orig_norm_mask_labels"], kw["orig_norm_mask_c2w"] = labels, c.cam_to_world
+        dd = make_scene(os.path.join(td, "dyn"), size=24, n_train=5, n_test=2, dynamic=True) + "/"
+        # shuffle the frame order and stretch the times so that sorting and normalisation are exercised
+        import json
+        tf = json.load(open(dd + "transforms_train.json"))
+        tf["frames"] = [tf["frames"][i] for i in (3, 0, 4, 1, 2)]
+        for fr in tf["frames"]:
+            fr["time"] = fr["time"] * 3.0 - 0.5
+        json.dump(tf, open(dd + "transforms_train.json", "w"))
+        for gamma in (False, True):
+            (labels, times), c, _ = rload.dnerf(dd, training=True, size=24, time_gamma=gamma, white_bg=False)
+            kw[f"dnerf_g{int(gamma)}_labels"], kw[f"dnerf_g{int(gamma)}_times"] = labels, times
+            kw[f"dnerf_g{int(gamma)}_c2w"] = c.cam_to_world
+        (labels, times), c, _ = rload.dnerf(dd, training=False, size=16, time_gamma=False, white_bg=True)
+        kw["dnerf_test_labels"], kw["dnerf_test_times"], kw["dnerf_test_focal"] = labels, times, np.float64(c.focal)
+    save("g14_loaders", **kw)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for g in which:
         globals()[g]()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
