@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, utils
 
 
 class Camera(nn.Module):
@@ -48,7 +48,8 @@ class NeRFCamera(Camera):
         uniform draws replace the reference's global-RNG rand_like; drawn here if jitter is on and none given."""
         crop = position_samples if isinstance(position_samples, tuple) else _crop_of(position_samples, size)
         if with_noise and noise is None:
-            noise = torch.rand(crop[2], crop[3], 2, device=self.cam_to_world.device)
+            dev = self.cam_to_world.device  # u first, then v: the reference's draw order (src/cameras.py:55-58)
+            noise = torch.cat([utils.rand((crop[2], crop[3], 1), dev), utils.rand((crop[2], crop[3], 1), dev)], dim=-1)
         return ops.raygen(self.cam_to_world.data, self.focal, size, crop, noise, float(with_noise or 0.0))
 
 

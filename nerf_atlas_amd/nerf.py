@@ -13,6 +13,7 @@ from . import autograd as ag
 from . import config, ops
 from . import refl
 from .neural_blocks import HashEncoder, SkipConnMLP
+from . import utils
 from .utils import load_mip, load_sigmoid
 
 
@@ -21,7 +22,7 @@ def compute_ts(rays, near, far, steps, lindisp=False, perturb: float = 0, rand=N
     """src/nerf.py:29-47.  `rand` [steps] replaces the global-RNG draw; drawn here if perturb>0 and none given."""
     r_o, r_d = rays.split([3, 3], dim=-1)
     if perturb > 0 and rand is None:
-        rand = torch.rand(steps, device=rays.device)
+        rand = utils.rand((steps,), rays.device)
     ts, mids = ops.compute_ts(near, far, steps, rays.device, lindisp, perturb, rand)
     return r_o, r_d, ts, mids
 
@@ -177,7 +178,7 @@ class PlainNeRF(CommonNeRF):
         first_out = self.first(pts, latent)
         density = first_out[..., 0].contiguous()
         if self.training and self.noise_std > 0:
-            density = density + torch.randn_like(density) * self.noise_std
+            density = density + utils.randn(density.shape, density.device) * self.noise_std
         intermediate = first_out[..., 1:]
         view = r_d.unsqueeze(0).expand_as(pts).contiguous()
         rl = cat_not_none(latent, cat_not_none(intermediate, refl_latent))
@@ -220,7 +221,7 @@ class VolSDF(CommonNeRF):
         else:
             scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
             density = ops.laplace_density(sdf_vals.contiguous(), scale)
-        self.scale_post_act = scale
+        object.__setattr__(self, "scale_post_act", scale)  # plain attribute: never a second registration of the Parameter
         if self.sdf.refl.can_use_normal:
             raise NotImplementedError("normal-dependent reflectance needs autograd normals (row N1)")
         view = r_d.unsqueeze(0).expand_as(pts).contiguous()

@@ -1,0 +1,226 @@
+"""Training and evaluation loops with the reference's recipe (runner.py:609-850 train, :855-995 test,
+:1221-1322 main), restricted to what the five hot-path configs use: l2/l1/rmse loss in RGB, Adam(eps 1e-7) with the
+cosine schedule, random crops/views from Python's `random`, pixel jitter 0.1, stratified sampling and density noise
+in training mode, `--volsdf-scale-decay`, `--delta-x-decay`; regularisers that need second derivatives (eikonal,
+FFJORD divergence) raise.
+
+Every forward and backward is a HIP kernel (nerf_atlas_amd/autograd.py); torch.optim owns the parameter update, like
+in the reference.  With `replay_reference_rng=True` the stochastic tensors come from torch's CPU generator in the
+reference's order, so a run is comparable with the reference's iteration by iteration (tests/test_gpu_train.py
+against tests/golden/train_parity_*.json).
+"""
+import argparse
+import math
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import loaders, nerf, refl, utils
+from .render import render, render_frame
+
+# the reference's CLI defaults for the fields used here (runner.py:38-424)
+DEFAULTS = dict(
+    data=None, data_kind="original", derive_kind=True, size=32, render_size=16, epochs=30000, batch_size=8,
+    crop_size=16, test_crop_size=0, steps=64, mip=None, sigmoid_kind="upshifted", feature_space=3, model="plain",
+    dyn_model=None, bg="black", learning_rate=5e-4, seed=1337, decay=0.0, loss_fns=["l2"], sched_min=5e-5,
+    no_sched=False, shape_to_refl_size=64, refl_kind="view", space_kind="identity", normal_kind=None,
+    refl_bidirectional=True, sdf_kind="mlp", near=2.0, far=6.0, spline=0, dyn_refl_latent=0, time_gamma=False,
+    volsdf_scale_decay=0.0, delta_x_decay=0.0, opt_step=1, clip_gradients=0.0, train_imgs=-1, serial_idxs=False,
+    higher_end_chance=0, opt_kind="adam", light_kind=None, occ_kind=None, volsdf_alternate=False, test_white_bg=False,
+    sdf_eikonal=0.0, ffjord_div_decay=0.0, offset_decay=0.0, dyn_diverge_decay=0.0, smooth_normals=0.0,
+    neural_upsample=False, quiet=True,
+)
+
+loss_map = {
+    "l2": F.mse_loss,
+    "l1": F.l1_loss,
+    "rmse": lambda x, ref: F.mse_loss(x, ref).clamp(min=1e-10).sqrt(),
+}
+
+
+def make_args(**overrides) -> SimpleNamespace:
+    """Namespace with the reference's defaults; mirrors the post-processing of runner.arguments() (:430-437)."""
+    unknown = set(overrides) - set(DEFAULTS)
+    assert not unknown, f"unknown arguments {sorted(unknown)}"
+    a = SimpleNamespace(**{**DEFAULTS, **overrides})
+    if not a.neural_upsample:
+        a.render_size = a.size
+        a.feature_space = 3
+    if a.test_crop_size <= 0:
+        a.test_crop_size = a.crop_size
+    return a
+
+
+def args_from_argv(argv) -> SimpleNamespace:
+    """Parse the subset of the reference's command line that maps onto DEFAULTS (flags keep their spelling)."""
+    p = argparse.ArgumentParser(allow_abbrev=False)
+    p.add_argument("-d", "--data")
+    for k, v in DEFAULTS.items():
+        if k == "data":
+            continue
+        flag = "--" + k.replace("_", "-")
+        if k == "learning_rate":
+            p.add_argument("-lr", flag, type=float, default=v)
+        elif isinstance(v, bool):
+            p.add_argument(flag, action="store_true", default=v)
+        elif isinstance(v, list):
+            p.add_argument(flag, nargs="+", default=v)
+        elif v is None:
+            p.add_argument(flag, default=None, type=(int if k == "spline" else str))
+        else:
+            p.add_argument(flag, type=type(v), default=v)
+    p.add_argument("--nosave", action="store_true")
+    p.add_argument("--notraintest", action="store_true")
+    p.add_argument("--valid-freq", type=int, default=500)
+    p.add_argument("--outdir", default="outputs/")
+    ns = vars(p.parse_args(argv))
+    return make_args(**{k: ns[k] for k in DEFAULTS if k in ns})
+
+
+def seed(s):
+    """runner.py:1214-1218."""
+    if s == -1:
+        return
+    torch.manual_seed(s)
+    random.seed(s)
+    np.random.seed(s)
+
+
+def load_model(args, is_dyn=False, device="cuda"):
+    """runner.py:1169-1211 for the supported kinds."""
+    if args.model == "sdf":
+        raise NotImplementedError("--model sdf (surface rendering) is outside the volume-rendering hot path")
+    model = nerf.load_nerf(args)
+    if is_dyn:
+        model = nerf.load_dyn(args, model, device)
+    model.set_refl(refl.load(args, args.refl_kind, args.space_kind, model.intermediate_size))
+    return model.to(device)
+
+
+def load_loss_fn(args):
+    fns = [loss_map[k] for k in args.loss_fns]
+    assert len(fns) > 0, "must provide at least 1 loss function"
+    if len(fns) == 1:
+        return fns[0]
+    return lambda x, ref: sum(fn(x, ref) for fn in fns) / len(fns)
+
+
+def load_optim(args, params):
+    """runner.py:448-458."""
+    if args.opt_kind != "adam":
+        raise NotImplementedError(f"opt kind {args.opt_kind}")
+    return torch.optim.Adam(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay)
+
+
+def train(model, cam, labels, opt, args, sched=None, on_iter=None):
+    """runner.py:609-850.  Returns the list of per-iteration l2 losses (what save_losses() plots)."""
+    if args.epochs == 0:
+        return []
+    for k in ("sdf_eikonal", "ffjord_div_decay", "dyn_diverge_decay", "smooth_normals"):
+        if getattr(args, k, 0) > 0:
+            raise NotImplementedError(f"--{k.replace('_', '-')} needs second derivatives of the MLPs (DESIGN.md 9a)")
+    if getattr(args, "offset_decay", 0) > 0:
+        raise NotImplementedError("--offset-decay is not implemented")
+    device = next(model.parameters()).device
+    loss_fn = load_loss_fn(args)
+    times = None
+    if type(labels) is tuple:
+        times = labels[-1].to(device)
+        labels = labels[0]
+    batch_size = min(args.batch_size, labels.shape[0])
+    cs = args.crop_size
+    if cs != 0:
+        get_crop = lambda: (random.randint(0, args.render_size - cs), random.randint(0, args.render_size - cs), cs, cs)
+    else:
+        get_crop = lambda: (0, 0, args.size, args.size)
+    train_choices = range(labels.shape[0])
+    if args.higher_end_chance > 0:
+        train_choices = list(train_choices) + [0] * args.higher_end_chance + [labels.shape[0] - 1] * args.higher_end_chance
+    next_idxs = (lambda i: [i % len(cam)] * batch_size) if args.serial_idxs else (lambda _: random.sample(train_choices, batch_size))
+
+    losses = []
+    model.train()
+    opt.zero_grad()
+    for i in range(args.epochs):
+        idxs = next_idxs(i)
+        ts = None if times is None else times[idxs]
+        c0, c1, c2, c3 = crop = get_crop()
+        ref = labels[idxs][:, c0:c0 + c2, c1:c1 + c3, :3].to(device)
+        out, _rays = render(model, cam[idxs], crop, size=args.render_size, times=ts)
+        loss = loss_fn(out, ref)
+        assert loss.isfinite(), f"Got {loss.item()} loss"
+        losses.append(loss.item())
+        if args.volsdf_scale_decay > 0 and isinstance(model, nerf.VolSDF):
+            loss = loss + args.volsdf_scale_decay * model.scale_post_act
+        if args.delta_x_decay > 0:
+            loss = loss + args.delta_x_decay * model.dp.norm(dim=-1).mean()
+        if args.opt_step != 1:
+            loss = loss / args.opt_step
+        loss.backward()
+        if args.clip_gradients > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_gradients)
+        if i % args.opt_step == 0:
+            opt.step()
+            opt.zero_grad()
+        if sched is not None:
+            sched.step()
+        if on_iter is not None:
+            on_iter(i, losses[-1])
+    return losses
+
+
+def test(model, cam, labels, args):
+    """runner.py:855-995: every view rendered in test_crop_size tiles without jitter; per-image PSNR."""
+    device = next(model.parameters()).device
+    times = None
+    if type(labels) is tuple:
+        times = labels[-1].to(device)
+        labels = labels[0]
+    if args.test_crop_size <= 0:
+        args.test_crop_size = args.render_size
+    psnrs, gots = [], []
+    model.eval()
+    for i in range(labels.shape[0]):
+        ts = None if times is None else times[i:i + 1]
+        exp = labels[i, ..., :3].to(device)
+        got = render_frame(model, cam[i:i + 1], args.render_size, args.test_crop_size, times=ts)
+        gots.append(got)
+        psnrs.append(float(utils.mse2psnr(F.mse_loss(got, exp))))
+    return psnrs, gots
+
+
+def fit(args, device="cuda", replay_reference_rng=False, init=None, on_iter=None):
+    """runner.main() (:1221-1322): seed, load the training set, build model + optimiser + schedule, train, load the
+    test set, evaluate.  `init(model)` may overwrite the initial parameters (parity runs use procedural weights);
+    with replay_reference_rng the torch stream is re-seeded with seed+1 after it, as tools/ref_train_fixture.py does."""
+    seed(args.seed)
+    labels, cam, _ = loaders.load(args, training=True)
+    cam = cam.to(device)
+    is_dyn = type(labels) is tuple
+    model = load_model(args, is_dyn, device)
+    if init is not None:
+        init(model)
+    prev = utils.random_source
+    if replay_reference_rng:
+        utils.set_random_source(utils.ReferenceStreamRandom())
+        torch.manual_seed(args.seed + 1)
+    try:
+        if args.train_imgs > 0:
+            labels = tuple(l[:args.train_imgs] for l in labels) if is_dyn else labels[:args.train_imgs]
+            cam = cam[:args.train_imgs]
+        model.nerf.steps, model.nerf.t_near, model.nerf.t_far = args.steps, args.near, args.far  # set_per_run :1048-1050
+        opt = load_optim(args, model.parameters())
+        sched = None if args.no_sched else torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.epochs,
+                                                                                       eta_min=args.sched_min)
+        losses = train(model, cam, labels, opt, args, sched=sched, on_iter=on_iter)
+    finally:
+        utils.set_random_source(prev)
+    test_labels, test_cam, _ = loaders.load(args, training=False)
+    test_cam = test_cam.to(device)
+    if args.test_white_bg:
+        model.set_bg("white")
+    psnrs, gots = test(model, test_cam, test_labels, args)
+    return dict(model=model, losses=losses, test_psnr=psnrs, test_psnr_mean=float(np.mean(psnrs)), frames=gots)

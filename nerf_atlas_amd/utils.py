@@ -78,3 +78,34 @@ def load_mip(args):
     elif args.mip == "cylinder":
         return CylinderGaussian()
     raise NotImplementedError(f"Unknown mip kind {args.mip}")
+
+
+# ------------------------------------------------------------------------------------------------- random source
+class DeviceRandom:
+    """Stochastic training terms (pixel jitter, stratified offsets, density noise) drawn on the tensor's device."""
+
+    def rand(self, shape, device): return torch.rand(shape, device=device)
+    def randn(self, shape, device): return torch.randn(shape, device=device)
+
+
+class ReferenceStreamRandom:
+    """The same draws taken from torch's global CPU generator in the reference's call order and copied to the
+    device: after `torch.manual_seed(s)` a training run consumes exactly the stream the reference consumes on CPU
+    (runner.py:609-850 -> cameras.py:55-58, nerf.py:42-46, nerf.py:347-348), which makes trajectories comparable
+    iteration by iteration (tools/ref_train_fixture.py)."""
+
+    def rand(self, shape, device): return torch.rand(shape).to(device)
+    def randn(self, shape, device): return torch.randn(shape).to(device)
+
+
+random_source = DeviceRandom()
+
+
+def set_random_source(src):
+    global random_source
+    random_source = src if src is not None else DeviceRandom()
+    return random_source
+
+
+def rand(shape, device): return random_source.rand(tuple(shape), device)
+def randn(shape, device): return random_source.randn(tuple(shape), device)
