@@ -196,8 +196,14 @@ int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T,
  * na_act_backward      g_x = g_act * act'(x) for the pre-activation input x of a Linear
  *                      (src/neural_blocks.py:293).
  * na_sigmoid_backward  g_x = g_y * d/dx sigmoid_kind(x) (src/utils.py:484-518).
- * na_linear_wgrad      dW[out,in] += dY^T . act([x0|x1]);  db[out] += sum_n dY (db may be NULL).
- *                      (the input gradient is na_linear_f32 with W^T followed by na_act_backward)
+ * na_linear_wgrad      dW[out,in] += dY^T . act([x0|x1]);  db[out] += sum_n dY (db may be NULL), exact fp32
+ *                      (the exact input gradient is na_linear_f32 with W^T followed by na_act_backward).
+ * Fast training precision: the three GEMMs of a layer on the bf16 matrix core with a 2-way operand split
+ * (hi = bf16(x), lo = bf16(x - hi); lo*hi + hi*lo + hi*hi accumulated in fp32: relative error ~2^-16):
+ * na_linear_bf16x3        same contract as na_linear_f32 (y = W . act([x0|x1]) + b).
+ * na_linear_dgrad_bf16x3  g_x0[N,in0] | g_x1[N,in1] = (dY[N,out] . W) * act'([x0|x1]); Wt = W^T as
+ *                         [in0+in1, out] row-major; either output may be NULL; x0/x1 = the forward inputs.
+ * na_linear_wgrad_bf16x3  same contract as na_linear_wgrad.
  * na_hash_encode_backward  tables_grad[8,65536,4] += trilinear weights x g_out[N, 32(+3)]
  *                      (src/neural_blocks.py:166-190).
  * na_hash_encode_backward_input  g_x[N,3] = d(features)/d(position) . g_out (+ g_out[:, :3] with
@@ -210,6 +216,12 @@ int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T,
  *                      given g_out [R,C] (src/nerf.py:60-80,96-98).                              */
 int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream);
 int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, float* out, void* stream);
+int na_linear_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* W, const float* b,
+                     int out, int pre_act, float* y, void* stream);
+int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt, const float* x0, int in0,
+                           const float* x1, int in1, int pre_act, float* g_x0, float* g_x1, void* stream);
+int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                           int pre_act, float* dW, float* db, void* stream);
 int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
                     int pre_act, float* dW, float* db, void* stream);
 int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input,

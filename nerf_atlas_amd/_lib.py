@@ -52,8 +52,14 @@ SIGNATURES = {
                                  C.c_void_p]),
     "na_act_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_sigmoid_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_linear_bf16x3": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p,
+                                   C.c_void_p]),
+    "na_linear_dgrad_bf16x3": (C.c_int, [c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, c_f32p,
+                                  c_f32p, C.c_void_p]),
     "na_linear_wgrad": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p,
                                   C.c_void_p]),
+    "na_linear_wgrad_bf16x3": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p,
+                                         c_f32p, C.c_void_p]),
     "na_hash_encode_backward": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_hash_encode_backward_input": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_laplace_density_backward": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -7,7 +7,7 @@ keeps using the fused MFMA kernels.
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import config, ops
 
 
 def needs_grad(*tensors) -> bool:
@@ -15,15 +15,18 @@ def needs_grad(*tensors) -> bool:
 
 
 class LinearFn(Function):
-    """y = W . act([x0 | x1]) + b  (src/neural_blocks.py:288-296), exact fp32."""
+    """y = W . act([x0 | x1]) + b  (src/neural_blocks.py:288-296).  config.train_precision selects the three GEMMs:
+    "bf16x3": split-bf16 MFMA kernels of csrc/train_gemm.hip (activation derivative fused into the input gradient);
+    "fp32": exact f32-MFMA Linear, act_backward and weight-gradient kernels."""
 
     @staticmethod
     def forward(ctx, x0, x1, W, b, act):
         ctx.act = act
+        ctx.fast = config.train_precision == "bf16x3"
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=x0.device), W)
         ctx.has_x1 = x1 is not None
         ctx.has_b = b is not None
-        return ops.linear_f32(x0, W, b, pre_act=act, x1=x1)
+        return ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=ctx.fast)
 
     @staticmethod
     def backward(ctx, gy):
@@ -32,16 +35,19 @@ class LinearFn(Function):
         gy = gy.contiguous()
         in0 = x0.shape[1]
         gx0 = gx1 = gW = gb = None
-        if ctx.needs_input_grad[0] or (ctx.has_x1 and ctx.needs_input_grad[1]):
+        want0, want1 = ctx.needs_input_grad[0], ctx.has_x1 and ctx.needs_input_grad[1]
+        if (want0 or want1) and ctx.fast:
+            gx0, gx1 = ops.linear_dgrad(gy, W, x0, ctx.act, x1, want0, want1)
+        elif want0 or want1:
             g_act = ops.linear_f32(gy, W.t().contiguous(), None)  # [N, in0+in1] = dL/d act(x)
-            if ctx.needs_input_grad[0]:
+            if want0:
                 g0 = g_act[:, :in0].contiguous()
                 gx0 = ops.act_backward(x0, g0, ctx.act) if ctx.act != "none" else g0
-            if ctx.has_x1 and ctx.needs_input_grad[1]:
+            if want1:
                 g1 = g_act[:, in0:].contiguous()
                 gx1 = ops.act_backward(x1, g1, ctx.act) if ctx.act != "none" else g1
         if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
-            gW, gb = ops.linear_wgrad(x0, gy, ctx.act, x1, want_bias=ctx.has_b)
+            gW, gb = ops.linear_wgrad(x0, gy, ctx.act, x1, want_bias=ctx.has_b, split_bf16=ctx.fast)
         return gx0, gx1, gW, gb, None
 
 

@@ -21,6 +21,7 @@ UNITS = [
     ("basic_ops.hip", [], ""),
     ("linear_f32.hip", [], ""),
     ("backward.hip", [], ""),
+    ("train_gemm.hip", [], ""),
     ("mlp_fused.hip", [], ""),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),

@@ -10,3 +10,16 @@ def set_precision(p: str):
     if p not in ("bf16", "bf16x3"):
         raise ValueError(p)
     precision = p
+
+
+# Training-step GEMMs (forward / input gradient / weight gradient of every Linear while gradients are recorded):
+# "bf16x3" = the same 2-way split on the bf16 matrix core (relative error ~2^-16 per GEMM, HBM-bound kernels);
+# "fp32" = exact fp32 on the f32 matrix core (gradient-parity mode, ~4x slower per step).
+train_precision = "bf16x3"
+
+
+def set_train_precision(p: str):
+    global train_precision
+    if p not in ("fp32", "bf16x3"):
+        raise ValueError(p)
+    train_precision = p

@@ -1,5 +1,5 @@
 // Backward operators of the hot path (the training step of runner.py:609-850 differentiates
-// exactly these): activation, Linear (input and weight gradients), hash-table scatter, colour-head activations and
+// exactly these): activation, exact-fp32 Linear weight gradient (the split-bf16 GEMMs live in train_gemm.hip), hash-table scatter, colour-head activations and
 // alpha compositing.  fp32 throughout; matrix work on the exact f32 MFMA.  Gradients are pinned against
 // torch.autograd of the CPU oracle (tests/test_gpu_backward.py).
 #include "common.h"
@@ -116,32 +116,66 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------ hash encoder backward
 // tables_grad[lvl][idx][:] += w_corner * g_feat[n, lvl, :]   (src/neural_blocks.py:166,190: gradient of the gather)
-__global__ void hash_backward_kernel(const float* __restrict__ x, int64_t N, const float* __restrict__ g_out,
-                                     int include_input, HashRes res, float* __restrict__ tables_grad) {
+//
+// The grids are coarse (16 ... 6.3 cells per unit) and consecutive samples are neighbouring pixels at one depth, so
+// most of a wave lands in the same few cells: plain per-lane atomics serialise on a handful of addresses (measured
+// 10.2 ms for 262 144 samples).  One wave handles 64 consecutive samples of ONE level; per corner the lanes that share
+// a table row are combined first (leader loop: readfirstlane -> match mask -> wave reduction) and only the leader
+// issues the 4 atomics.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restrict__ x, int64_t N,
+                                                            const float* __restrict__ g_out, int include_input,
+                                                            HashRes res, float* __restrict__ tables_grad) {
   const int odim = 32 + 3 * include_input;
-  const int64_t total = N * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int lvl = (int)(i & 7);
-    const int64_t n = i >> 3;
-    const float px = x[n * 3], py = x[n * 3 + 1], pz = x[n * 3 + 2];
-    const float Nl = res.n[lvl];
-    const float vx = px * Nl, vy = py * Nl, vz = pz * Nl;
-    const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
-    const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
-    const float wx = vx - fx, wy = vy - fy, wz = vz - fz;
+  const int lvl = blockIdx.y;
+  const float Nl = res.n[lvl];
+  float* tab = tables_grad + (int64_t)lvl * 65536 * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (N + stride - 1) / stride;
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t n = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = n < N;
+    float wx = 0.f, wy = 0.f, wz = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    int lx = 0, ly = 0, lz = 0;
+    if (live) {
+      const float vx = x[n * 3] * Nl, vy = x[n * 3 + 1] * Nl, vz = x[n * 3 + 2] * Nl;
+      const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
+      lx = (int)fx; ly = (int)fy; lz = (int)fz;
+      wx = vx - fx; wy = vy - fy; wz = vz - fz;
+      const float* g = g_out + n * odim + 3 * include_input + lvl * 4;
+      g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
+    }
     const float iwx = 1.f - wx, iwy = 1.f - wy, iwz = 1.f - wz;
-    const float* g = g_out + n * odim + 3 * include_input + lvl * 4;
-    const float g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-    float* tab = tables_grad + (int64_t)lvl * 65536 * 4;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t id = hash_index(lx + ((c >> 2) & 1), ly + ((c >> 1) & 1), lz + (c & 1));
       const float w = (((c >> 2) & 1) ? wx : iwx) * (((c >> 1) & 1) ? wy : iwy) * ((c & 1) ? wz : iwz);
-      float* t = tab + (int64_t)id * 4;
-      atomicAdd(t + 0, w * g0);
-      atomicAdd(t + 1, w * g1);
-      atomicAdd(t + 2, w * g2);
-      atomicAdd(t + 3, w * g3);
+      const float a0 = w * g0, a1 = w * g1, a2 = w * g2, a3 = w * g3;
+      bool todo = live;
+      // at most 4 leader rounds (covers the common case of a wave straddling a cell face), then per-lane atomics
+      for (int round = 0; round < 4; ++round) {
+        const uint64_t pending = __ballot(todo);
+        if (pending == 0) break;
+        const int leader = __ffsll((unsigned long long)pending) - 1;
+        const uint32_t lid = __shfl(id, leader);
+        const bool mine = todo && id == lid;
+        const float s0 = wave_sum(mine ? a0 : 0.f), s1 = wave_sum(mine ? a1 : 0.f);
+        const float s2 = wave_sum(mine ? a2 : 0.f), s3 = wave_sum(mine ? a3 : 0.f);
+        if ((int)(threadIdx.x & 63) == leader) {
+          float* t = tab + (int64_t)lid * 4;
+          atomicAdd(t + 0, s0); atomicAdd(t + 1, s1); atomicAdd(t + 2, s2); atomicAdd(t + 3, s3);
+        }
+        todo = todo && !mine;
+      }
+      if (todo) {
+        float* t = tab + (int64_t)id * 4;
+        atomicAdd(t + 0, a0); atomicAdd(t + 1, a1); atomicAdd(t + 2, a2); atomicAdd(t + 3, a3);
+      }
     }
   }
 }
@@ -368,7 +402,7 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
                             void* stream) {
   NA_REQUIRE(x && g_out && tables_grad, NA_ENULL, "na_hash_encode_backward: null pointer");
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
-  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
                      g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad);
   return check_launch("na_hash_encode_backward");
 }

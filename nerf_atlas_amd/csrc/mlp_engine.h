@@ -57,22 +57,7 @@ struct Frag {
 };
 
 // ------------------------------------------------------------------------------------------------ activations
-// sin with a 2-term Cody-Waite reduction by pi and a degree-9 odd polynomial (least-squares on
-// Chebyshev nodes of [-pi/2,pi/2]): max |err| 1.6e-7 for |x| <= 3e3 (checked against fp64).
-__device__ __forceinline__ float sin_cw(float x) {
-  float q = rintf(x * 0.318309886183790672f);
-  float r = fmaf(q, -3.140625f, x);
-  r = fmaf(q, -9.67502593994140625e-4f, r);
-  r = fmaf(q, -1.509957990978376432e-7f, r);
-  float r2 = r * r;
-  float p = fmaf(r2, 2.5962193818e-06f, -1.9804804431e-04f);
-  p = fmaf(p, r2, 8.3329907333e-03f);
-  p = fmaf(p, r2, -1.6666655917e-01f);
-  float s = fmaf(p * r2, r, r);
-  int qi = (int)q;
-  return (qi & 1) ? -s : s;
-}
-
+// sin_cw (Cody-Waite + degree-9 polynomial, 1.6e-7) lives in common.h
 // Hardware sine (v_sin_f32 takes revolutions, valid for |r| <= 256 -> reduce with v_fract first).  Used by the
 // bf16 fast mode only, where its ~1e-6 absolute error is far below the bf16 operand rounding.
 __device__ __forceinline__ float sin_hw(float x) {

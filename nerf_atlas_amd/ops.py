@@ -214,8 +214,9 @@ def bezier_warp(est: torch.Tensor, pts: torch.Tensor, t: torch.Tensor, n_ctrl: i
 
 # ------------------------------------------------------------------------------------------------- MLP
 def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre_act: str = "none",
-               x1: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = W . act([x0 | x1]) + b, exact fp32 (f32 MFMA)."""
+               x1: Optional[torch.Tensor] = None, split_bf16: bool = False) -> torch.Tensor:
+    """y = W . act([x0 | x1]) + b: exact fp32 (f32 MFMA), or with split_bf16 the 3-product bf16 split used by the
+    training step (relative error ~2^-16, 5x the matrix-core rate)."""
     lib = _lib.load()
     x0, W = _f32(x0, "x0"), _f32(W, "W")
     N = x0.shape[0]
@@ -228,9 +229,31 @@ def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre
     if b is not None:
         b = _f32(b, "b")
     y = torch.empty(N, W.shape[0], device=x0.device, dtype=torch.float32)
-    check(lib.na_linear_f32(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(W), _ptr(b), W.shape[0], ACT[pre_act], _ptr(y),
-                            _stream()))
+    fn = lib.na_linear_bf16x3 if split_bf16 else lib.na_linear_f32
+    check(fn(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(W), _ptr(b), W.shape[0], ACT[pre_act], _ptr(y), _stream()))
     return y
+
+
+def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, x0: torch.Tensor, pre_act: str = "none",
+                 x1: Optional[torch.Tensor] = None, want0: bool = True, want1: bool = True):
+    """(g_x0 [N,in0] | None, g_x1 [N,in1] | None) = (dY . W) * act'([x0|x1]) for y = W . act([x0|x1]) + b."""
+    lib = _lib.load()
+    dY, W, x0 = _f32(dY, "dY"), _f32(W, "W"), _f32(x0, "x0")
+    N, in0 = x0.shape
+    in1 = 0
+    if x1 is not None:
+        x1 = _f32(x1, "x1")
+        in1 = x1.shape[1]
+    out = dY.shape[1]
+    assert W.shape == (out, in0 + in1) and dY.shape[0] == N
+    Wt = W.t().contiguous()  # [in, out]: the K-contiguous operand of the input-gradient GEMM (<= 0.6 MB)
+    g0 = torch.empty_like(x0) if want0 else None
+    g1 = torch.empty_like(x1) if (want1 and x1 is not None) else None
+    if g0 is None and g1 is None:
+        return None, None
+    check(lib.na_linear_dgrad_bf16x3(_ptr(dY), out, N, _ptr(Wt), _ptr(x0), in0, _ptr(x1), in1, ACT[pre_act], _ptr(g0), _ptr(g1),
+                              _stream()))
+    return g0, g1
 
 
 # ------------------------------------------------------------------------------------------------- backward
@@ -252,8 +275,8 @@ def sigmoid_backward(x: torch.Tensor, g: torch.Tensor, kind: str) -> torch.Tenso
 
 
 def linear_wgrad(x0: torch.Tensor, dY: torch.Tensor, pre_act: str = "none", x1: Optional[torch.Tensor] = None,
-                 want_bias: bool = True):
-    """(dW [out, in0+in1], db [out]) for y = W . act([x0|x1]) + b."""
+                 want_bias: bool = True, split_bf16: bool = False):
+    """(dW [out, in0+in1], db [out]) for y = W . act([x0|x1]) + b; exact fp32 or the split-bf16 GEMM."""
     lib = _lib.load()
     x0, dY = _f32(x0, "x0"), _f32(dY, "dY")
     N, in0 = x0.shape
@@ -264,7 +287,8 @@ def linear_wgrad(x0: torch.Tensor, dY: torch.Tensor, pre_act: str = "none", x1: 
     out = dY.shape[1]
     dW = torch.zeros(out, in0 + in1, device=x0.device, dtype=torch.float32)
     db = torch.zeros(out, device=x0.device, dtype=torch.float32) if want_bias else None
-    check(lib.na_linear_wgrad(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(dY), out, ACT[pre_act], _ptr(dW), _ptr(db), _stream()))
+    fn = lib.na_linear_wgrad_bf16x3 if split_bf16 else lib.na_linear_wgrad
+    check(fn(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(dY), out, ACT[pre_act], _ptr(dW), _ptr(db), _stream()))
     return dW, db
 
 

@@ -19,6 +19,47 @@ def ops():
     return _ops
 
 
+# End-to-end gradient bars per training precision (config.train_precision).  "fp32": exact GEMMs, L-inf 5e-4 / 2e-3 of
+# the largest entry per tensor (fp32 summation order only).  "bf16x3": each GEMM carries ~2^-16 relative error which the
+# sine layers amplify along the chain, and under predicted positions (D-NeRF) a 1e-5 shift moves a sample across a hash
+# cell face, i.e. into other table rows -- an L-inf bar per tensor is meaningless there, so that mode is held to the
+# relative L2 error per tensor instead.
+E2E_TOL = {"fp32": 1.0, "bf16x3": 40.0}
+
+
+def rel_l2(a, b):
+    b = torch.as_tensor(b).double()
+    return float((a.detach().cpu().double() - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def check_grads(named, ref_p, train_prec, linf_tol, l2_tol, what):
+    checked, worst = 0, 0.0
+    for k, rp in ref_p.items():
+        if rp.grad is None or k not in named:
+            continue
+        gp = named[k].grad
+        assert gp is not None, k
+        if train_prec == "fp32":
+            e = rel(gp, rp.grad)
+            assert e <= linf_tol, (k, e)
+        else:
+            e = rel_l2(gp, rp.grad)
+            assert e <= l2_tol, (k, e)
+        worst = max(worst, e)
+        checked += 1
+    print(f"\n[{what}/{train_prec}] worst per-tensor gradient error {worst:.2e} over {checked} tensors")
+    return checked
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def train_prec(request):
+    from nerf_atlas_amd import config
+    prev = config.train_precision
+    config.set_train_precision(request.param)
+    yield request.param
+    config.set_train_precision(prev)
+
+
 def rel(a, b):
     b = torch.as_tensor(b)
     return float((a.detach().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12))
@@ -42,7 +83,7 @@ def test_composite_backward(ops):
 
 
 @pytest.mark.parametrize("act", ["none", "leaky_relu", "sin"])
-def test_linear_backward(ops, act):
+def test_linear_backward(ops, act, train_prec):
     from nerf_atlas_amd.autograd import LinearFn
     N, in0, in1, out = 3000, 70, 37, 90
     x0 = torch.from_numpy(proc_uniform((N, in0), 1, 2.0))
@@ -81,7 +122,7 @@ def test_sigmoid_backward(ops):
         assert rel(ops.sigmoid_backward(v.cuda(), go.cuda(), k), x.grad) <= 2e-5, k
 
 
-def test_plain_nerf_training_gradients_match_oracle_autograd(ops):
+def test_plain_nerf_training_gradients_match_oracle_autograd(ops, train_prec):
     """End to end: d(MSE loss)/d(every parameter) of PlainNeRF(view) through the HIP backward kernels vs
     torch.autograd through the CPU oracle (eval-mode sampling, no density noise)."""
     import nerf_atlas_amd.nerf as nerf
@@ -101,16 +142,8 @@ def test_plain_nerf_training_gradients_match_oracle_autograd(ops):
     ref_out = O.plain_nerf(ref_p, h["rays"], 2.0, 6.0, T, "view", act="upshifted")
     ref_loss = torch.nn.functional.mse_loss(ref_out, target)
     ref_loss.backward()
-    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6
-    named = dict(m.named_parameters())
-    checked = 0
-    for k, rp in ref_p.items():
-        if rp.grad is None or k not in named:
-            continue
-        gp = named[k].grad
-        assert gp is not None, k
-        assert rel(gp, rp.grad) <= 5e-4, (k, rel(gp, rp.grad))
-        checked += 1
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6 * E2E_TOL[train_prec]
+    checked = check_grads(dict(m.named_parameters()), ref_p, train_prec, 5e-4, 2e-2, "plain")  # measured 3.8e-6 / 4.9e-3
     assert checked >= 30
     # a few optimiser steps through torch.optim (plumbing) lower the loss
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
@@ -174,25 +207,19 @@ def test_bezier_warp_backward(ops, n):
     assert rel(ops.bezier_warp_backward(est.cuda(), t.cuda(), n, gs[0].cuda()), e.grad) <= 2e-5
 
 
-def _grad_parity(m, ref_p, out, ref_out, target, min_checked, tol=5e-4):
+def _grad_parity(m, ref_p, out, ref_out, target, min_checked, tol=5e-4, loss_tol=1e-6, train_prec="fp32", what="",
+                 l2_tol=0.3):
     loss = torch.nn.functional.mse_loss(out, target.cuda())
     loss.backward()
     ref_loss = torch.nn.functional.mse_loss(ref_out, target)
     ref_loss.backward()
-    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6
-    named = dict(m.named_parameters())
-    checked = 0
-    for k, rp in ref_p.items():
-        if rp.grad is None or k not in named:
-            continue
-        assert named[k].grad is not None, k
-        assert rel(named[k].grad, rp.grad) <= tol, (k, rel(named[k].grad, rp.grad))
-        checked += 1
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= loss_tol
+    checked = check_grads(dict(m.named_parameters()), ref_p, train_prec, tol, l2_tol, what)
     assert checked >= min_checked, checked
 
 
 @pytest.mark.parametrize("kind", ["mlp", "siren"])
-def test_volsdf_training_gradients_match_oracle_autograd(ops, kind):
+def test_volsdf_training_gradients_match_oracle_autograd(ops, kind, train_prec):
     """VolSDF (Laplace density, learnable beta) end to end against torch.autograd of the CPU oracle."""
     import nerf_atlas_amd as na
     import nerf_atlas_amd.nerf, nerf_atlas_amd.refl, nerf_atlas_amd.sdf  # noqa: F401,E401
@@ -211,12 +238,14 @@ def test_volsdf_training_gradients_match_oracle_autograd(ops, kind):
     ref_p = {k: (v.clone().requires_grad_() if v.is_floating_point() and "basis" not in k else v) for k, v in params.items()}
     ref_p["scale"] = torch.as_tensor(h["scale"]).clone().float().requires_grad_()
     ref_out = O.volsdf(ref_p, h["rays"], 0.3, 1.8, int(h["steps"]), kind, "view", act="upshifted")
-    _grad_parity(m, ref_p, out, ref_out, target, 20, tol=2e-3 if kind == "mlp" else 5e-4)
+    _grad_parity(m, ref_p, out, ref_out, target, 20, tol=2e-3 if kind == "mlp" else 5e-4,
+                 loss_tol=1e-6 * E2E_TOL[train_prec], train_prec=train_prec, what=f"volsdf-{kind}",
+                 l2_tol=1e-3)  # measured 5e-6 (fp32, L-inf) / 1.2e-4 (bf16x3, L2)
     assert m.scale.grad is not None and float(m.scale.grad.abs()) > 0
 
 
 @pytest.mark.parametrize("spline", [6, 4])
-def test_dnerf_training_gradients_match_oracle_autograd(ops, spline):
+def test_dnerf_training_gradients_match_oracle_autograd(ops, spline, train_prec):
     """D-NeRF: loss -> canonical PlainNeRF -> d/d(warped points) (hash + first MLP input gradients) -> spline warp
     -> deformation MLP, all through HIP backward kernels."""
     import nerf_atlas_amd as na
@@ -233,6 +262,45 @@ def test_dnerf_training_gradients_match_oracle_autograd(ops, spline):
     assert out.requires_grad
     ref_p = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in params.items()}
     ref_out = O.dynamic_nerf_spline(ref_p, h["rays"], h["times"], 2.0, 6.0, int(h["steps"]), spline, "view", act="upshifted")
-    _grad_parity(m, ref_p, out, ref_out, target, 50, tol=2e-3)
+    _grad_parity(m, ref_p, out, ref_out, target, 50, tol=2e-3, loss_tol=1e-6 * E2E_TOL[train_prec],
+                 train_prec=train_prec, what=f"dnerf-{spline}", l2_tol=0.3)  # measured 4.4e-5 / 7.5e-2 (cell flips)
     g = dict(m.named_parameters())["delta_estim.init.weight"].grad
     assert float(g.abs().max()) > 0  # the deformation network really received a gradient through the warp
+
+
+@pytest.mark.parametrize("shape", [(5000, 256, 0, 256), (4097, 256, 38, 256), (1000, 38, 0, 256), (3001, 256, 0, 65),
+                                   (2000, 256, 0, 3), (777, 69, 0, 256), (513, 256, 260, 515), (64, 3, 0, 4)])
+@pytest.mark.parametrize("act", ["leaky_relu", "sin"])
+def test_split_bf16_training_gemms(ops, shape, act):
+    """The three training GEMMs (csrc/train_gemm.hip) against fp64 torch on every layer shape of the five configs,
+    including unaligned K (38, 69, 294), ragged N and column counts on both sides of the 64/128/256 tile choice.
+    Bar: 1e-4 of the largest output (split-bf16 products carry ~2^-16 relative error)."""
+    N, in0, in1, out = shape
+    x0 = torch.from_numpy(proc_uniform((N, in0), 31, 2.0))
+    x1 = torch.from_numpy(proc_uniform((N, in1), 32, 2.0)) if in1 else None
+    W = torch.from_numpy(proc_uniform((out, in0 + in1), 33, (6.0 / (in0 + in1)) ** 0.5))
+    b = torch.from_numpy(proc_uniform((out,), 34, 0.1))
+    gy = torch.from_numpy(proc_uniform((N, out), 35, 1.0))
+    f = {"leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.01), "sin": torch.sin}[act]
+    r0 = x0.double().requires_grad_()
+    r1 = x1.double().requires_grad_() if in1 else None
+    rW, rb = W.double().requires_grad_(), b.double().requires_grad_()
+    xin = f(torch.cat([r0, r1], -1) if in1 else r0)
+    y_ref = torch.nn.functional.linear(xin, rW, rb)
+    (y_ref * gy.double()).sum().backward()
+    c = lambda t: None if t is None else t.cuda()
+    y = ops.linear_f32(c(x0), c(W), c(b), pre_act=act, x1=c(x1), split_bf16=True)
+    assert rel(y, y_ref.detach().float()) <= 1e-4
+    g0, g1 = ops.linear_dgrad(c(gy), c(W), c(x0), act, c(x1))
+    assert rel(g0, r0.grad.float()) <= 1e-4
+    if in1:
+        assert rel(g1, r1.grad.float()) <= 1e-4
+        only1 = ops.linear_dgrad(c(gy), c(W), c(x0), act, c(x1), want0=False)
+        assert only1[0] is None and torch.equal(only1[1], g1)
+    else:
+        assert g1 is None
+    dW, db = ops.linear_wgrad(c(x0), c(gy), act, c(x1))
+    assert rel(dW, rW.grad.float()) <= 1e-4
+    assert rel(db, rb.grad.float()) <= 1e-4
+    dW2, none = ops.linear_wgrad(c(x0), c(gy), act, c(x1), want_bias=False)
+    assert none is None and rel(dW2, rW.grad.float()) <= 1e-4

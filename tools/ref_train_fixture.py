@@ -70,6 +70,8 @@ def fill_procedural(module):
         for name, t in sd.items():
             if name.endswith("primes") or t.numel() == 0 or name == "scale" or name.endswith(".scale"):
                 continue
+            if name.startswith("delta_estim.out."):
+                continue  # the deformation head keeps the reference's zero initialisation (src/nerf.py:1256)
             v = torch.from_numpy(proc_param(name, tuple(t.shape)))
             if name.endswith("basis"):
                 v = v * (16.0 if "sdf" in name else 32.0)
