@@ -95,6 +95,27 @@ __device__ __forceinline__ float cos_cw(float x) {
   return (qi & 1) ? -c : c;
 }
 
+// sin and cos on one shared reduction (Fourier-feature prologue: 2 x 128 of them per sample)
+__device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
+  float q = rintf(x * 0.318309886183790672f);
+  float r = fmaf(q, -3.140625f, x);
+  r = fmaf(q, -9.67502593994140625e-4f, r);
+  r = fmaf(q, -1.509957990978376432e-7f, r);
+  float r2 = r * r;
+  float p = fmaf(r2, 2.5962193818e-06f, -1.9804804431e-04f);
+  p = fmaf(p, r2, 8.3329907333e-03f);
+  p = fmaf(p, r2, -1.6666655917e-01f);
+  float s = fmaf(p * r2, r, r);
+  float c = fmaf(r2, -2.7557319224e-07f, 2.4801587302e-05f);
+  c = fmaf(c, r2, -1.3888888889e-03f);
+  c = fmaf(c, r2, 4.1666666667e-02f);
+  c = fmaf(c, r2, -0.5f);
+  c = fmaf(c, r2, 1.0f);
+  const bool odd = ((int)q) & 1;
+  sn = odd ? -s : s;
+  cs = odd ? -c : c;
+}
+
 // Reference hash (src/neural_blocks.py:135-139,166): ((x*1) ^ (y*2654435761) ^ (z*805459861)) mod 2^16
 // in int64 with a non-negative remainder.  Only the low 16 bits survive the mod and the low bits of
 // a two's-complement product/xor depend only on the low bits of the operands, so uint32 arithmetic
