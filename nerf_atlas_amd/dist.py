@@ -63,3 +63,40 @@ def render_frame_sharded(render_rows: Callable[[int, int], torch.Tensor], size: 
     """render_rows(row0, nrows) -> [nrows,size,3] on this rank's device; returns the frame on rank 0."""
     r0, n = row_bands(size, world)[rank]
     return gather_bands(render_rows(r0, n), size, rank, world)
+
+
+# ------------------------------------------------------------------------------------------------- training replicas
+def shard_batch(idxs: list, rank: int, world: int) -> list:
+    """Views of one training batch owned by this rank (idxs[rank::world]).  With batch_size % world == 0 the mean of
+    the per-rank mean losses equals the single-process loss over the whole batch."""
+    return idxs[rank::world]
+
+
+def allreduce_gradients(params, world: Optional[int] = None) -> int:
+    """Average .grad over the replicas with ONE flat all-reduce (replicas + all-reduce of grads).
+    PlainNeRF's parameters are ~11 MB of fp32, 8 MiB of it hash tables: a single bucket, which on the xGMI ring is
+    latency- rather than bandwidth-bound, so there is nothing to overlap with backward.  Parameters without a gradient
+    on this rank contribute zeros (every rank must flatten the same set).  Returns the number of elements reduced."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    params = [p for p in params if p.requires_grad]
+    if world == 1 or not params:
+        return 0
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    on_cuda = flat.is_cuda
+    if dist.get_backend() == "gloo" and on_cuda:
+        flat = flat.cpu()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat = flat / world
+    if on_cuda and not flat.is_cuda:
+        flat = flat.to(params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return off

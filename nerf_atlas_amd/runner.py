@@ -1,0 +1,68 @@
+"""Command-line entry with the reference's flags for the supported subset (runner.py:38-424, :1221-1322):
+
+    python -m nerf_atlas_amd.runner -d data/nerf_synthetic/lego/ --data-kind original --size 64 --crop-size 24 \\
+        --epochs 5000 --model plain --refl-kind view --near 2 --far 6 --batch-size 4 --outdir outputs/ [--save model.pt]
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m nerf_atlas_amd.runner ...   # replicas + gradient all-reduce
+
+seeds, loads the dataset (loaders.py), builds the model through the registries, trains (train.py), renders the test set
+with the fused kernels and writes `results.txt` in the reference's format (runner.py:977-995) plus `test_NNN.png`
+(expected | rendered, side by side).  Flags outside the hot path are rejected by argparse rather than ignored."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import train as T
+
+
+def summary(name, psnrs, training=False):
+    return (f"[Summary {name} ({'training' if training else 'test'}) @ nerf_atlas_amd]:\n"
+            f"\tmean {np.mean(psnrs):.03f}\n\tmedian {np.median(psnrs):.03f}\n\tmin {min(psnrs):.03f}\n"
+            f"\tmax {max(psnrs):.03f}\n\tvar {np.var(psnrs):.03f}")
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    outdir, save, keep = "outputs/", None, []
+    it = iter(argv)
+    for a in it:  # flags owned by this wrapper
+        if a == "--outdir": outdir = next(it)
+        elif a == "--save": save = next(it)
+        else: keep.append(a)
+    args = T.args_from_argv(keep)
+    quiet = args.quiet
+
+    def on_iter(i, l2):
+        if not quiet and (i % 50 == 0 or i == args.epochs - 1):
+            print(f"[{i:06}] l2 {l2:.04f}", flush=True)
+    res = T.fit(args, on_iter=on_iter)
+    if res["rank"] != 0:
+        return res
+    os.makedirs(outdir, exist_ok=True)
+    lines = []
+    labels = res["test_labels"][0] if type(res["test_labels"]) is tuple else res["test_labels"]
+    for i, (p, got) in enumerate(zip(res["test_psnr"], res["frames"])):
+        mse = 10 ** (-p / 10)
+        lines.append(f"[{i:03}]: L2 {mse:.03f} PSNR {p:.03f}")
+        print(lines[-1])
+        try:
+            from PIL import Image
+            both = torch.cat([labels[i, ..., :3].cpu(), got.clamp(0, 1).cpu()], dim=1)
+            Image.fromarray((both.numpy() * 255).round().astype(np.uint8)).save(os.path.join(outdir, f"test_{i:03}.png"))
+        except ImportError:
+            pass
+    s = summary("", res["test_psnr"])
+    print(s)
+    with open(os.path.join(outdir, "results.txt"), "w") as f:
+        f.write(s)
+        for l in lines:
+            f.write("\n" + l)
+    if save:
+        torch.save(res["model"].state_dict(), save)  # state_dict keys = the reference's
+        print(f"Saved to {save}")
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ against tests/golden/train_parity_*.json).
 """
 import argparse
 import math
+import os
 import random
 from types import SimpleNamespace
 
@@ -18,6 +19,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import dist as na_dist
 from . import loaders, nerf, refl, utils
 from .render import render, render_frame
 
@@ -115,8 +117,11 @@ def load_optim(args, params):
     return torch.optim.Adam(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay)
 
 
-def train(model, cam, labels, opt, args, sched=None, on_iter=None):
-    """runner.py:609-850.  Returns the list of per-iteration l2 losses (what save_losses() plots)."""
+def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0, world: int = 1):
+    """runner.py:609-850.  Returns the list of per-iteration l2 losses (what save_losses() plots).
+    world > 1: data-parallel replicas (one process per GPU, identical seeds): every rank draws the same views and
+    crop, renders views idxs[rank::world], and the gradients are averaged with one flat RCCL all-reduce before the
+    optimiser step (dist.allreduce_gradients); the reference's own --data-parallel is broken (SURVEY header table)."""
     if args.epochs == 0:
         return []
     for k in ("sdf_eikonal", "ffjord_div_decay", "dyn_diverge_decay", "smooth_normals"):
@@ -146,6 +151,9 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None):
     opt.zero_grad()
     for i in range(args.epochs):
         idxs = next_idxs(i)
+        if world > 1:
+            idxs = na_dist.shard_batch(idxs, rank, world)
+            assert idxs, "batch_size must be >= the number of replicas"
         ts = None if times is None else times[idxs]
         c0, c1, c2, c3 = crop = get_crop()
         ref = labels[idxs][:, c0:c0 + c2, c1:c1 + c3, :3].to(device)
@@ -160,6 +168,8 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None):
         if args.opt_step != 1:
             loss = loss / args.opt_step
         loss.backward()
+        if world > 1:
+            na_dist.allreduce_gradients(model.parameters(), world)
         if args.clip_gradients > 0:
             torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_gradients)
         if i % args.opt_step == 0:
@@ -196,6 +206,11 @@ def fit(args, device="cuda", replay_reference_rng=False, init=None, on_iter=None
     """runner.main() (:1221-1322): seed, load the training set, build model + optimiser + schedule, train, load the
     test set, evaluate.  `init(model)` may overwrite the initial parameters (parity runs use procedural weights);
     with replay_reference_rng the torch stream is re-seeded with seed+1 after it, as tools/ref_train_fixture.py does."""
+    rank, world = 0, 1
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # torchrun: one replica per GPU
+        rank, world, local = na_dist.init_from_env()
+        device = f"cuda:{local if torch.cuda.device_count() > local else 0}"  # debug: several replicas on one GPU
+        torch.cuda.set_device(torch.device(device))
     seed(args.seed)
     labels, cam, _ = loaders.load(args, training=True)
     cam = cam.to(device)
@@ -215,7 +230,7 @@ def fit(args, device="cuda", replay_reference_rng=False, init=None, on_iter=None
         opt = load_optim(args, model.parameters())
         sched = None if args.no_sched else torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.epochs,
                                                                                        eta_min=args.sched_min)
-        losses = train(model, cam, labels, opt, args, sched=sched, on_iter=on_iter)
+        losses = train(model, cam, labels, opt, args, sched=sched, on_iter=on_iter, rank=rank, world=world)
     finally:
         utils.set_random_source(prev)
     test_labels, test_cam, _ = loaders.load(args, training=False)
@@ -223,4 +238,5 @@ def fit(args, device="cuda", replay_reference_rng=False, init=None, on_iter=None
     if args.test_white_bg:
         model.set_bg("white")
     psnrs, gots = test(model, test_cam, test_labels, args)
-    return dict(model=model, losses=losses, test_psnr=psnrs, test_psnr_mean=float(np.mean(psnrs)), frames=gots)
+    return dict(model=model, losses=losses, test_psnr=psnrs, test_psnr_mean=float(np.mean(psnrs)), frames=gots,
+                test_labels=test_labels, rank=rank, world=world)

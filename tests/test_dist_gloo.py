@@ -63,3 +63,38 @@ def test_sharded_frame_gather_gloo_world2():
         results = [q.get(timeout=120) for _ in procs]
         for p in procs: p.join(timeout=60)
         assert all(results), results
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from nerf_atlas_amd import dist as nd
+    r, w, _ = nd.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
+              torch.nn.Parameter(torch.zeros(2, 2), requires_grad=False), torch.nn.Parameter(torch.zeros(4))]
+    params[0].grad = torch.full((5, 3), float(r + 1))
+    params[1].grad = torch.arange(7, dtype=torch.float32) * (r + 1)
+    if r == 0:
+        params[3].grad = torch.ones(4)  # rank 1 has no gradient for this one: treated as zeros
+    n = nd.allreduce_gradients(params, w)
+    ok = n == 15 + 7 + 4
+    ok &= bool(torch.allclose(params[0].grad, torch.full((5, 3), 1.5)))
+    ok &= bool(torch.allclose(params[1].grad, torch.arange(7, dtype=torch.float32) * 1.5))
+    ok &= params[2].grad is None and bool(torch.allclose(params[3].grad, torch.full((4,), 0.5)))
+    ok &= nd.shard_batch([4, 9, 2, 7], r, w) == ([4, 2] if r == 0 else [9, 7])
+    q.put(ok)
+    torch.distributed.destroy_process_group()
+
+
+def test_world2_gradient_allreduce_and_batch_shards():
+    """Data-parallel training replicas: one flat all-reduce averages the gradients; views shard round-robin."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(res), res
