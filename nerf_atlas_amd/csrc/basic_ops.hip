@@ -241,13 +241,24 @@ __global__ void sigmoid_kernel(const float* __restrict__ x, int64_t N, int kind,
 // ------------------------------------------------------------------------------------ mip IPE (intended layout)
 // src/utils.py:23-27,39-48,60-101 with cov laid out like mean ([T,B,H,W,3]); radii_x differences rows of
 // the crop (src/utils.py:77-81; the appended last row repeats the second-to-last difference).
+// One thread per (sample, 4 consecutive features): the [.., 6*nd] rows leave as coalesced float4 stores (a thread per
+// sample wrote 96 floats 384 bytes apart from its neighbour: 0.45 TB/s); the few dozen flops of cone/cylinder geometry
+// are recomputed per thread.
+__device__ __forceinline__ float mip_sin(float y) {
+  return fabsf(y) <= 3.0e3f ? sin_cw(y) : sinf(y);  // sin_cw: 1.6e-7 inside its range; 2^15 * x needs libm's reduction
+}
+
+template <int VEC>
 __global__ void mip_kernel(const float* __restrict__ rays, int B, int H, int W, const float* __restrict__ ts, int T,
                            int kind, float t_end, int min_deg, int max_deg, float* __restrict__ out) {
   const int nd = max_deg - min_deg;
   const int F = 6 * nd;
+  const int per = F / VEC;
   int64_t R = (int64_t)B * H * W;
-  int64_t total = (int64_t)T * R;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  int64_t total = (int64_t)T * R * per;
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = j / per;
+    const int f0 = (int)(j % per) * VEC;
     int64_t r = i % R;
     int t = (int)(i / R);
     int wq = (int)(r % W);
@@ -279,20 +290,29 @@ __global__ void mip_kernel(const float* __restrict__ rays, int B, int H, int W, 
     }
     float dsq[3] = {ry[3] * ry[3], ry[4] * ry[4], ry[5] * ry[5]};
     float magn = fmaxf((dsq[0] + dsq[1]) + dsq[2], 1e-10f);
-    float* o = out + i * F;
+    float mean[3], cov[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      float mean = ry[3 + a] * t_mean + ry[a];
-      float cov = t_var * dsq[a] + r_var * (1.f - dsq[a] / magn);
-      for (int k = 0; k < nd; ++k) {
-        float sc = exp2f((float)(min_deg + k));
-        float y = mean * sc;
-        float yv = cov * (sc * sc);
-        float damp = expf(-0.5f * yv);
-        o[k * 3 + a] = damp * sinf(y);
-        o[3 * nd + k * 3 + a] = damp * sinf(y + 0.5f * 3.14159265358979323846f);
-      }
+      mean[a] = ry[3 + a] * t_mean + ry[a];
+      cov[a] = t_var * dsq[a] + r_var * (1.f - dsq[a] / magn);
     }
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int f = f0 + e;
+      const int part = f >= 3 * nd;            // 0: sin(y), 1: sin(y + pi/2)
+      const int rem = f - part * 3 * nd;
+      const int k = rem / 3, a = rem - 3 * k;
+      const float m = a == 0 ? mean[0] : (a == 1 ? mean[1] : mean[2]);
+      const float c = a == 0 ? cov[0] : (a == 1 ? cov[1] : cov[2]);
+      const float sc = exp2f((float)(min_deg + k));
+      const float y = m * sc;
+      const float damp = expf(-0.5f * (c * (sc * sc)));
+      v[e] = damp * mip_sin(part ? y + 0.5f * 3.14159265358979323846f : y);
+    }
+    float* o = out + i * F + f0;
+    if (VEC == 4) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+    else o[0] = v[0];
   }
 }
 
@@ -493,9 +513,14 @@ int na_mip_encode(const float* rays, int B, int H, int W, const float* ts, int T
   NA_REQUIRE(B >= 1 && H >= 2 && W >= 1 && T >= 1 && max_deg > min_deg, NA_EINVAL,
              "na_mip_encode: bad shape (radii_x needs H>=2 rows)");
   NA_REQUIRE(kind == 0 || kind == 1, NA_EUNSUPPORTED, "na_mip_encode: kind %d", kind);
+  const int F = 6 * (max_deg - min_deg);
   int64_t total = (int64_t)T * B * H * W;
-  hipLaunchKernelGGL(mip_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, rays, B, H, W, ts,
-                     T, kind, t_end, min_deg, max_deg, out);
+  if (F % 4 == 0)
+    hipLaunchKernelGGL(mip_kernel<4>, dim3(grid_for(total * (F / 4), 256, 1 << 18)), dim3(256), 0, (hipStream_t)stream,
+                       rays, B, H, W, ts, T, kind, t_end, min_deg, max_deg, out);
+  else
+    hipLaunchKernelGGL(mip_kernel<1>, dim3(grid_for(total * F, 256, 1 << 18)), dim3(256), 0, (hipStream_t)stream, rays,
+                       B, H, W, ts, T, kind, t_end, min_deg, max_deg, out);
   return check_launch("na_mip_encode");
 }
 

@@ -32,7 +32,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
   for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
     const int64_t n_raw = ((int64_t)g * NWAVES + wave) * 32 + (lane & 31);
     const int64_t n = n_raw < a.N ? n_raw : a.N - 1;
-    const int hi = lane >> 5;
+    // `hi` is laundered once per group: everything the prologue derives from it (slot -> feature maps, basis
+    // addresses) is otherwise loop-invariant, gets hoisted out of the group loop and lives in scratch (up to 344
+    // spilled registers measured)
+    int hi = lane >> 5;
+    asm volatile("" : "+v"(hi));
     Frag<PREC> I[NI];
     // ---------------- init input fragments
     {

@@ -36,11 +36,11 @@ static int dispatch_forward(MlpArgs& a, const TileTab& tab, int NI, hipStream_t 
   NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_NONE, 3, NWS)
   NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 3, NWS)
   NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 7, NWS)
-  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 9, 4)
-  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_FOURIER, 17, 4)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 9, NWS)
+  NA_CASE(NA_ACT_LEAKY_RELU, NA_ENC_FOURIER, 17, NWS)
   NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 1, NWS)
   NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 5, NWS)
-  NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 11, 4)
+  NA_CASE(NA_ACT_SIN, NA_ENC_NONE, 11, NWS)
 #undef NA_CASE
   set_error("na_mlp_forward: no kernel for activation %d, encoder %d, NI %d", act, a.d.enc_kind, NI);
   return NA_EUNSUPPORTED;
