@@ -237,6 +237,28 @@ int na_composite_backward(const float* density, const float* feat, const float* 
                           int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
                           float* g_density, float* g_feat, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SDF ray marching (src/march.py).  Per-ray state lives in caller-owned device arrays; the SDF network
+ * is evaluated for ALL rays by na_mlp_forward between the updates (no mask compaction, no host sync) and the updates
+ * touch only the rays the reference's boolean-mask code would have touched.  `sdf` is column 0 of an [R, stride] MLP
+ * output.  hits/rem/todo are 0/1 bytes.
+ *
+ * na_ray_points           pts[R,3] = r_o + r_d * t, t per ray (t_ray[R]) or t_scalar when t_ray is NULL.
+ * na_sphere_march_update  one iteration of sphere_march (src/march.py:39-45): for rem rays  hits |= (sdf < eps) &
+ *                         (dist <= far);  dist += sdf;  rem &= !(hits | dist > far).
+ * na_sign_change_update   one uniform step `step` of throughput_with_sign_change (src/march.py:96-103): running
+ *                         minimum + its step index, first sign change (last_pos / first_neg step indices, -1 = none).
+ * na_bisection_update     bisection (src/march.py:159-179): sdf_mid NULL initialises todo and z = (low+high)/2 from
+ *                         low/high/sdf_low/sdf_high; otherwise one iteration with the SDF at z.                        */
+int na_ray_points(const float* r_o, const float* r_d, const float* t_ray, float t_scalar, int64_t R, float* pts,
+                  void* stream);
+int na_sphere_march_update(const float* sdf, int stride, int64_t R, float eps, float far, float* dist, uint8_t* hits,
+                           uint8_t* rem, void* stream);
+int na_sign_change_update(const float* sdf, int stride, int64_t R, int step, float* curr_min, int32_t* idxs,
+                          int32_t* last_pos, int32_t* first_neg, void* stream);
+int na_bisection_update(const float* sdf_mid, int stride, int64_t R, float eps, float* low, float* high, float* sdf_low,
+                        float* sdf_high, float* z, uint8_t* todo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,13 @@ SIGNATURES = {
                               C.c_void_p, C.c_void_p]),
     "na_mlp_forward": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p,
                                  C.c_void_p]),
+    "na_ray_points": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_float, c_i64, c_f32p, C.c_void_p]),
+    "na_sphere_march_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, C.c_float, c_f32p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "na_sign_change_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "na_bisection_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                      C.c_void_p, C.c_void_p]),
     "na_act_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_sigmoid_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_linear_bf16x3": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p,

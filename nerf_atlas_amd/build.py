@@ -22,6 +22,7 @@ UNITS = [
     ("linear_f32.hip", [], ""),
     ("backward.hip", [], ""),
     ("train_gemm.hip", [], ""),
+    ("march.hip", [], ""),
     ("mlp_fused.hip", [], ""),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),

@@ -212,6 +212,50 @@ def bezier_warp(est: torch.Tensor, pts: torch.Tensor, t: torch.Tensor, n_ctrl: i
     return out, dp, rig
 
 
+# ------------------------------------------------------------------------------------------------- SDF marching
+def ray_points(r_o: torch.Tensor, r_d: torch.Tensor, t) -> torch.Tensor:
+    """r_o + r_d * t; t a float or a per-ray tensor [..., 1] / [...]."""
+    lib = _lib.load()
+    r_o, r_d = _f32(r_o, "r_o"), _f32(r_d, "r_d")
+    R = r_o.numel() // 3
+    pts = torch.empty_like(r_o)
+    if torch.is_tensor(t):
+        t = _f32(t, "t")
+        assert t.numel() == R
+        check(lib.na_ray_points(_ptr(r_o), _ptr(r_d), _ptr(t), 0.0, R, _ptr(pts), _stream()))
+    else:
+        check(lib.na_ray_points(_ptr(r_o), _ptr(r_d), None, float(t), R, _ptr(pts), _stream()))
+    return pts
+
+
+def _sdf_col(sdf: torch.Tensor):
+    sdf = _f32(sdf, "sdf")
+    return sdf, (sdf.shape[-1] if sdf.dim() > 1 else 1)
+
+
+def sphere_march_update(sdf, eps: float, far: float, dist, hits, rem):
+    lib = _lib.load()
+    sdf, stride = _sdf_col(sdf)
+    check(lib.na_sphere_march_update(_ptr(sdf), stride, dist.numel(), float(eps), float(far), _ptr(dist), _ptr(hits),
+                                     _ptr(rem), _stream()))
+
+
+def sign_change_update(sdf, step: int, curr_min, idxs, last_pos, first_neg):
+    lib = _lib.load()
+    sdf, stride = _sdf_col(sdf)
+    check(lib.na_sign_change_update(_ptr(sdf), stride, curr_min.numel(), int(step), _ptr(curr_min), _ptr(idxs),
+                                    _ptr(last_pos), _ptr(first_neg), _stream()))
+
+
+def bisection_update(sdf_mid, eps: float, low, high, sdf_low, sdf_high, z, todo):
+    lib = _lib.load()
+    stride = 1
+    if sdf_mid is not None:
+        sdf_mid, stride = _sdf_col(sdf_mid)
+    check(lib.na_bisection_update(_ptr(sdf_mid), stride, low.numel(), float(eps), _ptr(low), _ptr(high), _ptr(sdf_low),
+                                  _ptr(sdf_high), _ptr(z), _ptr(todo), _stream()))
+
+
 # ------------------------------------------------------------------------------------------------- MLP
 def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre_act: str = "none",
                x1: Optional[torch.Tensor] = None, split_bf16: bool = False) -> torch.Tensor:

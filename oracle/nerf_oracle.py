@@ -23,7 +23,7 @@ __all__ = [
     "cone_moments", "lift_gaussian_intended", "mip_latent_intended", "de_casteljau",
     "cubic_bezier", "laplace_cdf", "tiny_nerf", "plain_nerf", "volsdf", "dynamic_nerf_spline",
     "view_refl", "positional_refl", "pos_linear_view_refl", "mse2psnr", "render_tiled",
-    "HASH_PRIMES",
+    "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
 ]
 
 # ----------------------------------------------------------------------------- A1 pixels
@@ -565,3 +565,71 @@ def render_tiled(model_fn, c2w, focal, size: int, crop_size: int):
             rays = nerf_camera_rays(pos, c2w, focal, size)
             got[c0:c0 + crop_size, c1:c1 + crop_size, :] = model_fn(rays).squeeze(0)
     return got
+
+
+# ----------------------------------------------------------------------------- N4 SDF marching (src/march.py)
+# Dense restatements: the reference gathers the active rays with boolean masks; updating only where the mask is set
+# is the same computation ray by ray.  `sdf_fn(pts[..., 3]) -> [..., >=1]`, column 0 = signed distance.
+
+
+def sphere_march(sdf_fn, r_o, r_d, iters: int = 32, eps: float = 1e-3, near: float = 0, far: float = 1):
+    """src/march.py:27-47."""
+    hits = torch.zeros(r_o.shape[:-1] + (1,), dtype=torch.bool)
+    rem = torch.ones(r_o.shape[:-1], dtype=torch.bool)
+    curr_dist = torch.full(r_o.shape[:-1] + (1,), float(near))
+    for _ in range(iters):
+        dist = sdf_fn(r_o + r_d * curr_dist)[..., 0:1]
+        act = rem.unsqueeze(-1)
+        hits = hits | (act & (dist < eps) & (curr_dist <= far))
+        curr_dist = torch.where(act, curr_dist + dist, curr_dist)
+        rem = rem & ~(hits.squeeze(-1) | (curr_dist > far).squeeze(-1))
+    return r_o + r_d * curr_dist, hits.squeeze(-1), curr_dist, None
+
+
+def throughput_with_sign_change(sdf_fn, r_o, r_d, near: float, far: float, batch_size: int = 128, jitter: float = 0.0):
+    """src/march.py:78-110; `jitter` stands for the reference's random.random() draw."""
+    max_t = far - near + jitter * (2 / batch_size)
+    step = max_t / batch_size
+    curr_min = sdf_fn(r_o + near)[..., 0]  # sic (src/march.py:90): the scalar is added to the origin
+    idxs = torch.zeros_like(curr_min, dtype=torch.long)
+    last_pos = torch.full_like(idxs, -1)
+    first_neg = torch.full_like(idxs, -1)
+    for i in range(batch_size):
+        t = near + step * (i + 1)
+        sd = sdf_fn(r_o + t * r_d)[..., 0]
+        idxs = torch.where(sd < curr_min, i + 1, idxs)
+        curr_min = torch.minimum(curr_min, sd)
+        mask = (first_neg == -1) & (sd < 0)
+        last_pos = torch.where(mask, i, last_pos)
+        first_neg = torch.where(mask, i + 1, first_neg)
+    best_pos = r_o + (near + idxs.unsqueeze(-1) * step) * r_d
+    return sdf_fn(best_pos)[..., 0], best_pos, last_pos.unsqueeze(-1) * step, first_neg.unsqueeze(-1) * step
+
+
+def bisection(sdf_fn, r_o, r_d, near, far, iters: int = 32, eps: float = 1e-6):
+    """src/march.py:147-180 (near/far: per-ray [..., 1] tensors; not modified here)."""
+    low, high = near.clone(), far.clone()
+    sdf_low = sdf_fn(r_o + low * r_d)[..., 0, None]
+    sdf_high = sdf_fn(r_o + high * r_d)[..., 0, None]
+    todo = ((high - low) > eps) & (sdf_low > 0) & (sdf_high < 0) & (high > low)
+    z = (low + high) / 2
+    for _ in range(iters):
+        if not todo.any():
+            break
+        sdf_mid = sdf_fn(r_o + z * r_d)[..., 0, None]
+        lm = (sdf_mid > 0) & todo
+        low = torch.where(lm, z, low)
+        sdf_low = torch.where(lm, sdf_mid, sdf_low)
+        hm = (sdf_mid < 0) & todo
+        high = torch.where(hm, z, high)
+        sdf_high = torch.where(hm, sdf_mid, sdf_high)
+        z = (low + high) / 2
+        todo = todo & ((high - low) > eps) & (sdf_low > 0) & (sdf_high < 0) & (high > low)
+    return r_o + z * r_d
+
+
+def bisect(sdf_fn, r_o, r_d, iters: int = 128, near: float = 0, far: float = 1, jitter: float = 0.0):
+    """src/march.py:63-75."""
+    tput, best_pos, last_pos, first_neg = throughput_with_sign_change(sdf_fn, r_o, r_d, near, far, iters, jitter)
+    pts = bisection(sdf_fn, r_o, r_d, last_pos, first_neg, iters=min(32, iters))
+    return pts, tput < 0, best_pos, tput.unsqueeze(-1)

@@ -21,7 +21,7 @@ def load_golden(name):
     out = {}
     for k in z.files:
         v = z[k]
-        if v.dtype.kind in "fiu" :
+        if v.dtype.kind in "fiub":
             out[k] = torch.from_numpy(v)
         else:
             out[k] = v

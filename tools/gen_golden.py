@@ -505,9 +505,43 @@ def g14():
     save("g14_loaders", **kw)
 
 
+# ------------------------------------------------------------------ G15 SDF marching (N4)
+def g15():
+    """Reference src/march.py on (a) an analytic two-sphere SDF (pins the marching logic exactly) and (b) the reference
+    SIREN SDF model with procedural weights (pins it through a network)."""
+    import random
+    import src.march as rmarch
+    c2w = POSES[1:2]
+    camr, _ = cam(c2w, 12)
+    rays = camr.sample_positions(ref_pixel_grid(12, (0, 0, 12, 12)), size=12, with_noise=False)[0]
+    r_o, r_d = rays[..., :3].contiguous(), torch.nn.functional.normalize(rays[..., 3:], dim=-1)
+
+    def analytic(p):
+        a = torch.linalg.norm(p - torch.tensor([0.1, -0.2, 0.0]), dim=-1) - 1.1
+        b = torch.linalg.norm(p - torch.tensor([0.9, 0.6, 0.3]), dim=-1) - 0.5
+        return torch.minimum(a, b).unsqueeze(-1)
+    siren = rsdf.SIREN(intermediate_size=0)
+    names, shapes = fill_procedural(siren)
+    kw = dict(r_o=r_o, r_d=r_d, **spec(names, shapes))
+    for tag, fn, near, far in (("an", analytic, 1.0, 6.0), ("nn", siren, 0.5, 5.0)):
+        pts, hits, dist, _ = rmarch.sphere_march(fn, r_o, r_d, iters=24, eps=1e-3, near=near, far=far)
+        kw.update({f"{tag}_sm_pts": pts, f"{tag}_sm_hits": hits, f"{tag}_sm_dist": dist})
+        random.seed(7)
+        jit = random.random()
+        random.seed(7)
+        tput, best, lastp, firstn = rmarch.throughput_with_sign_change(fn, r_o, r_d, near, far, batch_size=40)
+        kw.update({f"{tag}_tp": tput, f"{tag}_best": best, f"{tag}_last": lastp, f"{tag}_first": firstn})
+        random.seed(7)
+        pts, hits, best2, tput2 = rmarch.bisect(fn, r_o, r_d, iters=40, near=near, far=far)
+        kw.update({f"{tag}_bi_pts": pts, f"{tag}_bi_hits": hits, f"{tag}_bi_tput": tput2})
+        kw[f"{tag}_near"], kw[f"{tag}_far"] = np.float64(near), np.float64(far)
+    kw["jitter"] = np.float64(jit)
+    save("g15_march", **kw)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for g in which:
         globals()[g]()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
