@@ -98,3 +98,19 @@ def test_unsupported_regularisers_raise(tmp_path):
     args = T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, sdf_eikonal=0.1)
     with pytest.raises(NotImplementedError):
         T.fit(args)
+
+
+def test_runner_cli_writes_results(tmp_path):
+    """python -m nerf_atlas_amd.runner with the reference's flags: trains a few iterations, renders the test set with
+    the fused kernels, writes results.txt in the reference's format and the state_dict under the reference's keys."""
+    from nerf_atlas_amd import runner
+    data = make_scene(str(tmp_path / "s"), size=32, n_train=4, n_test=2) + "/"
+    out = tmp_path / "out"
+    res = runner.main(["-d", data, "--size", "32", "--crop-size", "16", "--test-crop-size", "32", "--batch-size", "2",
+                       "--steps", "24", "--epochs", "12", "--quiet", "--model", "plain", "--refl-kind", "view",
+                       "--outdir", str(out), "--save", str(tmp_path / "m.pt")])
+    txt = (out / "results.txt").read_text()
+    assert "[Summary" in txt and "mean" in txt and txt.count("PSNR") == 2
+    assert (out / "test_000.png").exists() and len(res["losses"]) == 12
+    sd = torch.load(tmp_path / "m.pt")
+    assert "first.init.weight" in sd and "refl.mlp.out.bias" in sd and "first.enc.embs.7.weight" in sd
