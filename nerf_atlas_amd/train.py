@@ -1,8 +1,8 @@
 """Training and evaluation loops with the reference's recipe (runner.py:609-850 train, :855-995 test,
 :1221-1322 main), restricted to what the five hot-path configs use: l2/l1/rmse loss in RGB, Adam(eps 1e-7) with the
 cosine schedule, random crops/views from Python's `random`, pixel jitter 0.1, stratified sampling and density noise
-in training mode, `--volsdf-scale-decay`, `--delta-x-decay`; regularisers that need second derivatives (eikonal,
-FFJORD divergence) raise.
+in training mode, `--volsdf-scale-decay`, `--delta-x-decay`, `--offset-decay`; regularisers that need second
+derivatives (eikonal, FFJORD divergence) raise.
 
 Every forward and backward is a HIP kernel (nerf_atlas_amd/autograd.py); torch.optim owns the parameter update, like
 in the reference.  With `replay_reference_rng=True` the stochastic tensors come from torch's CPU generator in the
@@ -117,6 +117,17 @@ def load_optim(args, params):
     return torch.optim.Adam(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay)
 
 
+def offset_decay_term(model, curr_percent: float):
+    """NR-NeRF offset regulariser of `make dnerf` (runner.py:633-636,777-781): exp_ratio * mean(weights.detach() *
+    (|dp|^(2 - rigidity) + 3e-3 * rigidity)), exp_ratio = (1/100)^(1 - progress).  Elementwise loss arithmetic on the
+    model's stored [T,B,H,W,*] outputs; its gradient enters the HIP backward through BezierWarpFn's dp / rigidity
+    inputs."""
+    exp_ratio = (1 / 100) ** (1 - curr_percent)
+    norm_dp = torch.linalg.vector_norm(model.dp, dim=-1, keepdim=True).pow(2 - model.rigidity)
+    reg = model.canonical.weights.detach()[None, ..., None] * (norm_dp + 3e-3 * model.rigidity)
+    return exp_ratio * reg.mean()
+
+
 def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0, world: int = 1):
     """runner.py:609-850.  Returns the list of per-iteration l2 losses (what save_losses() plots).
     world > 1: data-parallel replicas (one process per GPU, identical seeds): every rank draws the same views and
@@ -127,8 +138,6 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
     for k in ("sdf_eikonal", "ffjord_div_decay", "dyn_diverge_decay", "smooth_normals"):
         if getattr(args, k, 0) > 0:
             raise NotImplementedError(f"--{k.replace('_', '-')} needs second derivatives of the MLPs (DESIGN.md 9a)")
-    if getattr(args, "offset_decay", 0) > 0:
-        raise NotImplementedError("--offset-decay is not implemented")
     device = next(model.parameters()).device
     loss_fn = load_loss_fn(args)
     times = None
@@ -165,6 +174,8 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
             loss = loss + args.volsdf_scale_decay * model.scale_post_act
         if args.delta_x_decay > 0:
             loss = loss + args.delta_x_decay * model.dp.norm(dim=-1).mean()
+        if args.offset_decay > 0:
+            loss = loss + offset_decay_term(model, i / args.epochs) * args.offset_decay
         if args.opt_step != 1:
             loss = loss / args.opt_step
         loss.backward()

@@ -304,3 +304,37 @@ def test_split_bf16_training_gemms(ops, shape, act):
     assert rel(db, rb.grad.float()) <= 1e-4
     dW2, none = ops.linear_wgrad(c(x0), c(gy), act, c(x1), want_bias=False)
     assert none is None and rel(dW2, rW.grad.float()) <= 1e-4
+
+
+def test_offset_decay_regulariser_gradients(ops):
+    """`make dnerf`'s --offset-decay term (runner.py:777-781): its gradient reaches the deformation MLP through the dp and
+    rigidity outputs of the spline-warp backward kernel."""
+    import types
+    import nerf_atlas_amd as na
+    import nerf_atlas_amd.nerf, nerf_atlas_amd.train  # noqa: F401,E401
+    from nerf_atlas_amd import config
+    h = load_golden("g9_dnerf_spline4")
+    params = golden_params(h)
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=4).cuda().eval()
+    sd = m.state_dict()
+    for k, v in params.items():
+        sd[k].copy_(v)
+    prev = config.train_precision
+    config.set_train_precision("fp32")
+    try:
+        out = m((h["rays"].cuda(), h["times"].cuda()))
+        loss = out.square().mean() + 0.7 * na.train.offset_decay_term(m, 0.25)
+        loss.backward()
+    finally:
+        config.set_train_precision(prev)
+    ref_p = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in params.items()}
+    aux = {}
+    ref_out = O.dynamic_nerf_spline(ref_p, h["rays"], h["times"], 2.0, 6.0, int(h["steps"]), 4, "view", act="upshifted", aux=aux)
+    norm_dp = torch.linalg.vector_norm(aux["dp"], dim=-1, keepdim=True).pow(2 - aux["rigidity"])
+    reg = aux["weights"].detach()[None, ..., None] * (norm_dp + 3e-3 * aux["rigidity"])
+    ref_loss = ref_out.square().mean() + 0.7 * (1 / 100) ** 0.75 * reg.mean()
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6
+    checked = check_grads(dict(m.named_parameters()), ref_p, "fp32", 2e-3, 0.3, "dnerf+offset-decay")
+    assert checked >= 50
