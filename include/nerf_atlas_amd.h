@@ -187,6 +187,13 @@ int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T,
                          int precision, int sigmoid_kind, int bg_kind,
                          float* alpha, float* weights, float* out,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Same kernel with explicit sample positions pts[T,R,3] (PlainNeRF.from_pts, src/nerf.py:340-361, as called by
+ * DynamicNeRF with the spline-warped canonical points, src/nerf.py:1301-1303); directions and interval lengths still
+ * come from rays / ts.                                                                                              */
+int na_render_plain_view_pts(const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                             const float* hash_tables, const void* packed_first, const void* packed_view,
+                             int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward operators (training step, runner.py:609-850: loss.backward() differentiates exactly these).

@@ -78,6 +78,9 @@ SIGNATURES = {
     "na_render_plain_view": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                        C.c_void_p]),
+    "na_render_plain_view_pts": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]),
 }
 
 _lib = None

@@ -22,6 +22,7 @@ constexpr int kPartialFloats = 8;  // P, S_r, S_g, S_b, W_head, pad
 struct RenderArgs {
   const float* rays;     // [R,6]
   const float* ts;       // [T]
+  const float* pts;      // nullable [T,R,3]: explicit sample positions (deformed canonical points) instead of o + t d
   const float4* tables;  // [8,65536]
   const char* packed_first;
   const char* packed_view;
@@ -72,7 +73,12 @@ __global__ __launch_bounds__(NWAVES * 64) void render_plain_view_kernel(RenderAr
     const float* ry = a.rays + q.ray * 6;
     q.dx = ry[3]; q.dy = ry[4]; q.dz = ry[5];
     const float tt = a.ts[tc];
-    q.px = ry[0] + tt * q.dx; q.py = ry[1] + tt * q.dy; q.pz = ry[2] + tt * q.dz;
+    if (a.pts != nullptr) {
+      const float* p = a.pts + ((int64_t)tc * a.R + q.ray) * 3;
+      q.px = p[0]; q.py = p[1]; q.pz = p[2];
+    } else {
+      q.px = ry[0] + tt * q.dx; q.py = ry[1] + tt * q.dy; q.pz = ry[2] + tt * q.dz;
+    }
     const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
     q.dist = d * sqrtf((q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz);
     return q;
@@ -249,10 +255,10 @@ extern "C" size_t na_render_workspace_bytes(int T, int64_t R) {
   return (size_t)(R * nb * kPartialFloats * sizeof(float)) + 256;
 }
 
-extern "C" int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T, const float* hash_tables,
-                                    const void* packed_first, const void* packed_view, int precision, int sigmoid_kind,
-                                    int bg_kind, float* alpha, float* weights, float* out, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+static int render_plain_view_impl(const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                                  const float* hash_tables, const void* packed_first, const void* packed_view,
+                                  int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
   NA_REQUIRE(rays && ts && hash_tables && packed_first && packed_view && out && workspace, NA_ENULL,
              "na_render_plain_view: null pointer");
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view: bad shape T=%d R=%lld", T, (long long)R);
@@ -268,7 +274,7 @@ extern "C" int na_render_plain_view(const float* rays, int64_t R, const float* t
   NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
   NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
   RenderArgs a;
-  a.rays = rays; a.ts = ts; a.tables = (const float4*)hash_tables;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
   a.packed_first = (const char*)packed_first; a.packed_view = (const char*)packed_view;
   a.alpha = alpha; a.weights = weights;
   a.partials = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -288,5 +294,22 @@ extern "C" int na_render_plain_view(const float* rays, int64_t R, const float* t
   hipLaunchKernelGGL(render_finalize_kernel, dim3(grid_for(R, 128, 1 << 16)), dim3(128), 0, (hipStream_t)stream,
                      a.partials, R, a.nb, T, bg_kind, weights, out);
   return check_launch("na_render_finalize");
+}
+
+extern "C" int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T, const float* hash_tables,
+                                    const void* packed_first, const void* packed_view, int precision, int sigmoid_kind,
+                                    int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return render_plain_view_impl(rays, nullptr, R, ts, T, hash_tables, packed_first, packed_view, precision, sigmoid_kind,
+                                bg_kind, alpha, weights, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int na_render_plain_view_pts(const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                                        const float* hash_tables, const void* packed_first, const void* packed_view,
+                                        int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights,
+                                        float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(pts, NA_ENULL, "na_render_plain_view_pts: null pts");
+  return render_plain_view_impl(rays, pts, R, ts, T, hash_tables, packed_first, packed_view, precision, sigmoid_kind,
+                                bg_kind, alpha, weights, out, workspace, workspace_bytes, stream);
 }
 #endif

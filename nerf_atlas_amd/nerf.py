@@ -174,6 +174,14 @@ class PlainNeRF(CommonNeRF):
 
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
+        if self._fusable(refl_latent) and not ag.needs_grad(pts):
+            # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
+            prec = config.precision
+            _, pf = self.first.packed(prec, "plain_first")
+            _, pv = self.refl.mlp.packed(prec, "plain_view")
+            out, self.alpha, self.weights = ops.render_plain_view(
+                rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self.bg, True, pts=pts.contiguous())
+            return out
         latent = self.mip_encoding(rays, ts)
         first_out = self.first(pts, latent)
         density = first_out[..., 0].contiguous()

@@ -442,8 +442,10 @@ def mlp_forward(desc: NaMlpDesc, precision: str, packed: torch.Tensor, p: torch.
 # ------------------------------------------------------------------------------------------------- fused renderer
 def render_plain_view(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.Tensor, packed_first: torch.Tensor,
                       packed_view: torch.Tensor, precision: str, sigmoid_kind: str = "thin", bg: str = "black",
-                      want_weights: bool = False, workspace: Optional[torch.Tensor] = None):
-    """PlainNeRF(view) forward, fully fused (src/nerf.py:326-361).  rays [...,6] -> (rgb [...,3], alpha, weights)."""
+                      want_weights: bool = False, workspace: Optional[torch.Tensor] = None,
+                      pts: Optional[torch.Tensor] = None):
+    """PlainNeRF(view) forward, fully fused (src/nerf.py:326-361).  rays [...,6] -> (rgb [...,3], alpha, weights).
+    pts [T,...,3]: explicit sample positions (from_pts with deformed points) instead of o + t d."""
     lib = _lib.load()
     rays, ts, hash_tables = _f32(rays, "rays"), _f32(ts, "ts"), _f32(hash_tables, "hash_tables")
     R = rays.numel() // 6
@@ -457,6 +459,13 @@ def render_plain_view(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.T
     shape_t = (T,) + tuple(rays.shape[:-1])
     alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
     weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3, (pts.shape, T, R)
+        check(lib.na_render_plain_view_pts(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed_first),
+                                           _ptr(packed_view), PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha),
+                                           _ptr(weights), _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
+        return out, alpha, weights
     check(lib.na_render_plain_view(_ptr(rays), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed_first), _ptr(packed_view),
                                    PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out),
                                    _ptr(workspace), workspace.numel(), _stream()))

@@ -21,7 +21,7 @@ __all__ = [
     "positional_encode", "skip_mlp", "mlp_linear_shapes", "dir_to_elev_azim", "sigmoid",
     "expected_sin", "integrated_pos_enc_diag", "radii_x", "cylinder_moments",
     "cone_moments", "lift_gaussian_intended", "mip_latent_intended", "de_casteljau",
-    "cubic_bezier", "laplace_cdf", "tiny_nerf", "plain_nerf", "volsdf", "dynamic_nerf_spline",
+    "cubic_bezier", "laplace_cdf", "tiny_nerf", "plain_nerf", "plain_nerf_from_pts", "volsdf", "dynamic_nerf_spline",
     "view_refl", "positional_refl", "pos_linear_view_refl", "mse2psnr", "render_tiled",
     "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
 ]

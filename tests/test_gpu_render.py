@@ -147,3 +147,31 @@ def test_coarse_plus_fine_budget_T192(ops):
     ref = O.plain_nerf(p, h["rays"], 2.0, 6.0, 192, "view", act="upshifted", aux=aux)
     assert float((out.cpu() - ref).abs().max()) <= 1e-4
     assert float((w.cpu() - aux["weights"]).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_fused_render_with_explicit_points(ops, prec):
+    """na_render_plain_view_pts (PlainNeRF.from_pts, what D-NeRF calls with warped points): with pts = o + t d it is the
+    same computation as the ray form, bit for bit; with shifted points it matches the oracle's from_pts."""
+    h = load_golden("g11_plain_view_b2")
+    p = golden_params(h)
+    T = int(h["steps"])
+    rays = h["rays"].cuda()
+    ts, _ = ops.compute_ts(float(h["near"]), float(h["far"]), T, "cuda")
+    pf, pv, tables = pack_plain(ops, p, prec)
+    base = ops.render_plain_view(rays, ts, tables, pf, pv, prec, "upshifted", "black", want_weights=True)
+    pts = ops.compute_pts(rays, ts)
+    same = ops.render_plain_view(rays, ts, tables, pf, pv, prec, "upshifted", "black", want_weights=True, pts=pts)
+    for a, b in zip(base, same):
+        assert torch.equal(a, b)
+    if prec == "bf16x3":
+        shift = torch.tensor([0.03, -0.05, 0.02], device="cuda")
+        warped = (pts + shift * torch.sin(pts[..., :1] * 3)).contiguous()
+        got, _, w = ops.render_plain_view(rays, ts, tables, pf, pv, prec, "upshifted", "black", want_weights=True, pts=warped)
+        r_o, r_d = h["rays"].split([3, 3], dim=-1)
+        aux = {}
+        ref = O.plain_nerf_from_pts(p, warped.cpu(), ts.cpu(), r_o, r_d, "view", "upshifted", "black", aux=aux)
+        assert float((got.cpu() - ref).abs().max()) <= 1e-4
+        assert float((w.cpu() - aux["weights"]).abs().max()) <= 1e-4
+    with pytest.raises(AssertionError):
+        ops.render_plain_view(rays, ts, tables, pf, pv, prec, pts=pts[:-1])
