@@ -64,6 +64,41 @@ def flow_map(model) -> torch.Tensor:
     return ops.integrate(model.nerf.weights, model.rigid_dp.contiguous())
 
 
+def rigidity_map(model) -> torch.Tensor:
+    """runner.py:911-913: volumetric_integrate(weights, rigidity) of a dynamic model's last forward."""
+    from . import ops
+    return ops.integrate(model.nerf.weights, model.rigidity.contiguous())
+
+
+def depth_to_normals(depth_img: torch.Tensor) -> torch.Tensor:
+    """src/utils.py:421-427: forward differences of a depth image [H,W,1] -> unit normals [H-1,W-1,3] (image-space
+    post-processing of a finished frame, not a per-sample operator)."""
+    dz_dx = depth_img[1:, 1:, ...] - depth_img[:-1, 1:, ...]
+    dz_dy = depth_img[1:, 1:, ...] - depth_img[1:, :-1, ...]
+    d = torch.cat([dz_dx / 2, dz_dy / 2, torch.ones_like(dz_dx)], dim=-1)
+    return torch.nn.functional.normalize(d, dim=-1)
+
+
+def render_over_time(model, cam, size: int, crop_size: int, times, with_alpha: bool = False, rank: int = 0,
+                     world: int = 1):
+    """runner.py:998-1017: one camera, a sweep of times through a dynamic model; frame i is rendered in test()-style
+    tiles at times[i].  Frames are independent, so with world > 1 this rank renders frames rank, rank+world, ...
+    (D-NeRF time sweeps shard by frame); returns [(index, frame [size,size,3(+1)])]."""
+    device = next(model.parameters()).device
+    frames = []
+    with torch.no_grad():
+        for i in range(rank, len(times), world):
+            t = times[i].reshape(1).to(device)
+            got = torch.zeros(size, size, 3 + int(with_alpha), device=device)
+            for (c0, c1, h, w) in tile_list(size, crop_size):
+                o, _ = render(model, cam, (c0, c1, h, w), size=size, times=t, with_noise=False)
+                got[c0:c0 + h, c1:c1 + w, :3] = o.squeeze(0)
+                if with_alpha:
+                    got[c0:c0 + h, c1:c1 + w, 3] = alpha_map(model)[0, ..., 0]
+            frames.append((i, got))
+    return frames
+
+
 def psnr(got: torch.Tensor, exp: torch.Tensor) -> float:
     """runner.py:923-924."""
     return float(mse2psnr(torch.nn.functional.mse_loss(got, exp)))

@@ -174,6 +174,20 @@ def test_aux_render_outputs_and_extra_encoders(na):
     assert maxdiff(acc, w[:-1].sum(0).unsqueeze(-1)) <= 1e-5
     flow = na.render.flow_map(m).cpu()
     assert maxdiff(flow, O.volumetric_integrate(w, m.rigid_dp.cpu())) <= 1e-5
+    rig = na.render.rigidity_map(m).cpu()
+    assert maxdiff(rig, O.volumetric_integrate(w, m.rigidity.cpu())) <= 1e-5
+    nrm = na.render.depth_to_normals(depth[0])
+    assert nrm.shape == (depth.shape[1] - 1, depth.shape[2] - 1, 3) and maxdiff(nrm.norm(dim=-1), torch.ones(nrm.shape[:-1])) <= 1e-5
+    # time sweep (runner.py:998-1017): frame i == a tiled frame at times[i]; two "ranks" split the frames
+    cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]), focal=40.0).cuda()
+    times = torch.tensor([0.1, 0.5, 0.9])
+    sweep = na.render.render_over_time(m, cam, 12, 8, times, with_alpha=True)
+    assert [i for i, _ in sweep] == [0, 1, 2] and sweep[0][1].shape == (12, 12, 4)
+    single = na.render.render_frame(m, cam, 12, 8, times=times[1:2].cuda())
+    assert torch.equal(sweep[1][1][..., :3], single)
+    part = na.render.render_over_time(m, cam, 12, 8, times, rank=1, world=2)
+    assert [i for i, _ in part] == [1] and torch.equal(part[0][1], single)
+    assert float((sweep[0][1][..., :3] - sweep[2][1][..., :3]).abs().max()) > 1e-4  # the scene really moves
     # encoders
     torch.manual_seed(0)
     x = torch.randn(50, 3)
