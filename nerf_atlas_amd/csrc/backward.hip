@@ -359,6 +359,7 @@ using namespace na;
 extern "C" {
 
 int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream) {
+  if (n == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(x && g && out, NA_ENULL, "na_act_backward: null pointer");
   NA_REQUIRE(act >= NA_ACT_NONE && act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_act_backward: activation %d", act);
   if (n <= 0) return n == 0 ? NA_OK : NA_EINVAL;
@@ -368,6 +369,7 @@ int na_act_backward(const float* x, const float* g, int64_t n, int act, float* o
 }
 
 int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, float* out, void* stream) {
+  if (n == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(x && g && out, NA_ENULL, "na_sigmoid_backward: null pointer");
   NA_REQUIRE(kind >= 0 && kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_sigmoid_backward: kind %d", kind);
   if (n <= 0) return n == 0 ? NA_OK : NA_EINVAL;
@@ -400,6 +402,7 @@ int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t 
 
 int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input, float* tables_grad,
                             void* stream) {
+  if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(x && g_out && tables_grad, NA_ENULL, "na_hash_encode_backward: null pointer");
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
   hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
@@ -409,6 +412,7 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
 
 int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,
                                   int include_input, float* g_x, void* stream) {
+  if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(x && tables && g_out && g_x, NA_ENULL, "na_hash_encode_backward_input: null pointer");
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
   hipLaunchKernelGGL(hash_backward_input_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
@@ -418,6 +422,7 @@ int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables
 
 int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, const float* g, float* g_sdf,
                                 float* g_beta, void* stream) {
+  if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(sdf && beta && g && g_sdf, NA_ENULL, "na_laplace_density_backward: null pointer");
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
   hipLaunchKernelGGL(laplace_density_backward_kernel, dim3(grid_for(N, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
@@ -428,6 +433,7 @@ int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, 
 int na_bezier_warp_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl,
                             const float* g_out_pts, const float* g_dp, const float* g_rigidity, float* g_est,
                             void* stream) {
+  if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(est && t && g_est, NA_ENULL, "na_bezier_warp_backward: null pointer");
   NA_REQUIRE(n_ctrl >= 2 && n_ctrl <= 8 && est_stride >= 1 + 3 * n_ctrl, NA_EINVAL,
              "na_bezier_warp_backward: n_ctrl=%d (2..8) stride=%d", n_ctrl, est_stride);

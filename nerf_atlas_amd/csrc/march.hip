@@ -83,6 +83,7 @@ extern "C" {
 
 int na_ray_points(const float* r_o, const float* r_d, const float* t_ray, float t_scalar, int64_t R, float* pts,
                   void* stream) {
+  if (R == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(r_o && r_d && pts, NA_ENULL, "na_ray_points: null pointer");
   if (R <= 0) return R == 0 ? NA_OK : NA_EINVAL;
   hipLaunchKernelGGL(ray_points_kernel, dim3(grid_for(R * 3, 256, 8192)), dim3(256), 0, (hipStream_t)stream, r_o, r_d,
@@ -92,6 +93,7 @@ int na_ray_points(const float* r_o, const float* r_d, const float* t_ray, float 
 
 int na_sphere_march_update(const float* sdf, int stride, int64_t R, float eps, float far, float* dist, uint8_t* hits,
                            uint8_t* rem, void* stream) {
+  if (R == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(sdf && dist && hits && rem, NA_ENULL, "na_sphere_march_update: null pointer");
   NA_REQUIRE(stride >= 1, NA_EINVAL, "na_sphere_march_update: stride %d", stride);
   if (R <= 0) return R == 0 ? NA_OK : NA_EINVAL;
@@ -102,6 +104,7 @@ int na_sphere_march_update(const float* sdf, int stride, int64_t R, float eps, f
 
 int na_sign_change_update(const float* sdf, int stride, int64_t R, int step, float* curr_min, int32_t* idxs,
                           int32_t* last_pos, int32_t* first_neg, void* stream) {
+  if (R == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(sdf && curr_min && idxs && last_pos && first_neg, NA_ENULL, "na_sign_change_update: null pointer");
   NA_REQUIRE(stride >= 1 && step >= 0, NA_EINVAL, "na_sign_change_update: stride %d step %d", stride, step);
   if (R <= 0) return R == 0 ? NA_OK : NA_EINVAL;
@@ -112,6 +115,7 @@ int na_sign_change_update(const float* sdf, int stride, int64_t R, int step, flo
 
 int na_bisection_update(const float* sdf_mid, int stride, int64_t R, float eps, float* low, float* high, float* sdf_low,
                         float* sdf_high, float* z, uint8_t* todo, void* stream) {
+  if (R == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(low && high && sdf_low && sdf_high && z && todo, NA_ENULL, "na_bisection_update: null pointer");
   NA_REQUIRE(stride >= 1, NA_EINVAL, "na_bisection_update: stride %d", stride);
   if (R <= 0) return R == 0 ? NA_OK : NA_EINVAL;

@@ -473,11 +473,11 @@ extern "C" {
 
 int na_linear_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* W, const float* b,
                      int out, int pre_act, float* y, void* stream) {
+  if (N == 0) return NA_OK;  // empty batch: nothing to read or write (zero-size tensors carry null pointers)
   NA_REQUIRE(x0 && W && y, NA_ENULL, "na_linear_bf16x3: null pointer");
   NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_bf16x3: bad shape");
   NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_bf16x3: in1>0 needs x1");
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bf16x3: activation %d", pre_act);
-  if (N == 0) return NA_OK;
   NtArgs a{};
   a.a = RowSrc{x0, x1, in0, in1, N};
   a.b = RowSrc{W, nullptr, in0 + in1, 0, out};
@@ -490,12 +490,12 @@ int na_linear_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t
 
 int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt, const float* x0, int in0, const float* x1,
                     int in1, int pre_act, float* g_x0, float* g_x1, void* stream) {
+  if (N == 0) return NA_OK;  // empty batch: nothing to read or write (zero-size tensors carry null pointers)
   NA_REQUIRE(dY && Wt && (g_x0 || g_x1), NA_ENULL, "na_linear_dgrad_bf16x3: null pointer");
   NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_dgrad_bf16x3: bad shape");
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_dgrad_bf16x3: activation %d", pre_act);
   NA_REQUIRE(pre_act == NA_ACT_NONE || ((g_x0 == nullptr || x0) && (g_x1 == nullptr || in1 == 0 || x1)), NA_ENULL,
              "na_linear_dgrad_bf16x3: the activation derivative needs the forward inputs");
-  if (N == 0) return NA_OK;
   NtArgs a{};
   a.a = RowSrc{dY, nullptr, out, 0, N};
   a.b = RowSrc{Wt, nullptr, out, 0, in0 + in1};
@@ -511,11 +511,11 @@ int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt,
 
 int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
                     int pre_act, float* dW, float* db, void* stream) {
+  if (N == 0) return NA_OK;  // empty batch: nothing to read or write (zero-size tensors carry null pointers)
   NA_REQUIRE(x0 && dY && dW, NA_ENULL, "na_linear_wgrad_bf16x3: null pointer");
   NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_wgrad_bf16x3: bad shape");
   NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_wgrad_bf16x3: in1>0 needs x1");
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_wgrad_bf16x3: activation %d", pre_act);
-  if (N == 0) return NA_OK;
   constexpr int WM = 2, WN = 4, BM = 64 * WM, BN = 64 * WN;
   const int in = in0 + in1;
   TnArgs a{};

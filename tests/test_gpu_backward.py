@@ -338,3 +338,43 @@ def test_offset_decay_regulariser_gradients(ops):
     assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6
     checked = check_grads(dict(m.named_parameters()), ref_p, "fp32", 2e-3, 0.3, "dnerf+offset-decay")
     assert checked >= 50
+
+
+def test_backward_and_march_edge_cases(ops):
+    """Empty inputs are no-ops, null pointers and bad shapes return NA_E* with a message (no exception crosses the C ABI,
+    no silent success)."""
+    from nerf_atlas_amd import _lib
+    from nerf_atlas_amd._lib import NaError
+    lib = _lib.load()
+    dev = "cuda"
+    z = lambda *s: torch.zeros(*s, device=dev)
+    # empty batches
+    assert ops.linear_f32(z(0, 8), z(4, 8), z(4), split_bf16=True).shape == (0, 4)
+    g0, g1 = ops.linear_dgrad(z(0, 4), z(4, 8), z(0, 8), "sin")
+    assert g0.shape == (0, 8) and g1 is None
+    dW, db = ops.linear_wgrad(z(0, 8), z(0, 4), "sin", split_bf16=True)
+    assert float(dW.abs().sum()) == 0 and float(db.abs().sum()) == 0
+    assert float(ops.hash_encode_backward(z(0, 3), z(0, 35)).abs().sum()) == 0
+    assert ops.hash_encode_backward_input(z(0, 3), z(8, 65536, 4), z(0, 35)).shape == (0, 3)
+    gs, gb = ops.laplace_density_backward(z(0), torch.tensor(0.1, device=dev), z(0))
+    assert gs.numel() == 0 and float(gb) == 0
+    assert ops.bezier_warp_backward(z(0, 13), z(0), 4, z(0, 3)).shape == (0, 13)
+    assert ops.ray_points(z(0, 3), z(0, 3), 1.0).shape == (0, 3)
+    # errors: null pointers / bad arguments -> negative code + message
+    s = torch.cuda.current_stream().cuda_stream
+    x = z(16, 8)
+    for rc in (lib.na_linear_bf16x3(None, 8, None, 0, 16, x.data_ptr(), None, 4, 0, x.data_ptr(), s),
+               lib.na_linear_bf16x3(x.data_ptr(), 8, None, 3, 16, x.data_ptr(), None, 4, 0, x.data_ptr(), s),   # in1 > 0 without x1
+               lib.na_linear_bf16x3(x.data_ptr(), 8, None, 0, 16, x.data_ptr(), None, 4, 7, x.data_ptr(), s),   # unknown activation
+               lib.na_linear_dgrad_bf16x3(x.data_ptr(), 4, 16, x.data_ptr(), None, 8, None, 0, 2, x.data_ptr(), None, s),  # sin needs x0
+               lib.na_linear_wgrad_bf16x3(x.data_ptr(), 8, None, 0, 16, None, 4, 0, x.data_ptr(), None, s),
+               lib.na_bezier_warp_backward(x.data_ptr(), 5, x.data_ptr(), 16, 4, None, None, None, x.data_ptr(), s),  # stride < 1+3n
+               lib.na_sphere_march_update(x.data_ptr(), 0, 16, 1e-3, 1.0, x.data_ptr(), x.data_ptr(), x.data_ptr(), s),
+               lib.na_sign_change_update(x.data_ptr(), 1, 16, -1, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), s),
+               lib.na_bisection_update(None, 1, 16, 1e-6, None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), s),
+               lib.na_render_plain_view_pts(x.data_ptr(), None, 1, x.data_ptr(), 4, x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 0, 0,
+                                            None, None, x.data_ptr(), x.data_ptr(), 1 << 20, s)):
+        assert rc < 0 and len(lib.na_last_error()) > 0
+    with pytest.raises(NaError):
+        ops.check(lib.na_hash_encode_backward_input(None, 4, None, None, 1, None, s))
+    torch.cuda.synchronize()
