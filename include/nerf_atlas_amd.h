@@ -173,6 +173,11 @@ int na_mlp_pack(const NaMlpDesc* desc, int precision, const float* const* weight
 int na_mlp_forward(const NaMlpDesc* desc, int precision, const void* packed,
                    const float* p, const float* latent, const float* enc_params, int64_t N,
                    float* y, void* stream);
+/* Same with explicit row pitches (in floats) for p and latent: the inputs may be column slices of wider buffers, e.g.
+ * latent = first_out + 1 with pitch 65 (src/nerf.py:349-352 `intermediate = first_out[..., 1:]`) -- no copy.          */
+int na_mlp_forward_ld(const NaMlpDesc* desc, int precision, const void* packed,
+                      const float* p, int64_t p_ld, const float* latent, int64_t latent_ld,
+                      const float* enc_params, int64_t N, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A10 PlainNeRF.forward with the View head (src/nerf.py:326-361, src/refl.py:190-207), fully

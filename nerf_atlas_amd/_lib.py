@@ -50,6 +50,8 @@ SIGNATURES = {
                               C.c_void_p, C.c_void_p]),
     "na_mlp_forward": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p,
                                  C.c_void_p]),
+    "na_mlp_forward_ld": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64, c_f32p,
+                                    c_i64, c_f32p, C.c_void_p]),
     "na_ray_points": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_float, c_i64, c_f32p, C.c_void_p]),
     "na_sphere_march_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, C.c_float, c_f32p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),

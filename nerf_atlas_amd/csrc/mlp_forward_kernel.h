@@ -11,6 +11,7 @@ struct MlpArgs {
   const char* packed;
   const float* p;
   const float* latent;
+  int64_t p_ld, latent_ld;  // row pitches in floats (>= in_size / latent_size): inputs may be column slices of wider buffers
   const float* enc;
   float* y;
   int64_t N;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
       int c0 = 0;  // first "rest" chunk
       float px = 0.f, py = 0.f, pz = 0.f;
       if constexpr (ENC == NA_ENC_HASH) {
-        px = a.p[n * 3]; py = a.p[n * 3 + 1]; pz = a.p[n * 3 + 2];
+        px = a.p[n * a.p_ld]; py = a.p[n * a.p_ld + 1]; pz = a.p[n * a.p_ld + 2];
         float f[16];
         hash_levels4(px, py, pz, (const float4*)a.enc, a.res, 4 * hi, f);
         float v0[8], v1[8];
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
       } else if constexpr (ENC == NA_ENC_FOURIER) {
         const int F = d.enc_dims / 2, D = d.in_size;
         float xv[8];
-        for (int q = 0; q < 8; ++q) xv[q] = q < D ? a.p[n * D + q] : 0.f;
+        for (int q = 0; q < 8; ++q) xv[q] = q < D ? a.p[n * a.p_ld + q] : 0.f;
 #pragma unroll
         for (int c = 0; c < NI; ++c) {
           if ((c & 1) == 0 && c + 1 < F / 8) {
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
             int f = init_slot_feature(d, c, 8 * hi + e);
             float x = 0.f;
             if (f >= 0) {
-              if (f < d.in_size) x = a.p[n * d.in_size + f];
-              else if (f < d.in_size + d.enc_dims) x = a.p[n * d.in_size + (f - d.in_size)];  // enc's include_input copy of p
-              else x = a.latent[n * d.latent_size + (f - d.in_size - d.enc_dims)];
+              if (f < d.in_size) x = a.p[n * a.p_ld + f];
+              else if (f < d.in_size + d.enc_dims) x = a.p[n * a.p_ld + (f - d.in_size)];  // enc's include_input copy of p
+              else x = a.latent[n * a.latent_ld + (f - d.in_size - d.enc_dims)];
             }
             v[e] = x;
           }

@@ -116,7 +116,17 @@ int na_mlp_pack(const NaMlpDesc* desc, int precision, const float* const* weight
 
 int na_mlp_forward(const NaMlpDesc* desc, int precision, const void* packed, const float* p, const float* latent,
                    const float* enc_params, int64_t N, float* y, void* stream) {
+  return na_mlp_forward_ld(desc, precision, packed, p, desc ? desc->in_size : 0, latent, desc ? desc->latent_size : 0,
+                           enc_params, N, y, stream);
+}
+
+int na_mlp_forward_ld(const NaMlpDesc* desc, int precision, const void* packed, const float* p, int64_t p_ld,
+                      const float* latent, int64_t latent_ld, const float* enc_params, int64_t N, float* y,
+                      void* stream) {
   NA_REQUIRE(desc && packed && p && y, NA_ENULL, "na_mlp_forward: null pointer");
+  NA_REQUIRE(p_ld >= desc->in_size && (desc->latent_size == 0 || latent_ld >= desc->latent_size), NA_EINVAL,
+             "na_mlp_forward: row pitch smaller than the row (p_ld=%lld, latent_ld=%lld)", (long long)p_ld,
+             (long long)latent_ld);
   NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_mlp_forward: precision %d",
              precision);
   const char* why = mlp_unsupported_reason(*desc);
@@ -129,6 +139,7 @@ int na_mlp_forward(const NaMlpDesc* desc, int precision, const void* packed, con
   if (N == 0) return NA_OK;
   MlpArgs a;
   a.d = *desc; a.packed = (const char*)packed; a.p = p; a.latent = latent; a.enc = enc_params; a.y = y; a.N = N;
+  a.p_ld = p_ld; a.latent_ld = latent_ld;
   a.out_tiles = out_tiles(*desc);
   a.res = hash_resolutions();
   TileTab tab;

@@ -188,9 +188,9 @@ class PlainNeRF(CommonNeRF):
         if self.training and self.noise_std > 0:
             density = density + utils.randn(density.shape, density.device) * self.noise_std
         intermediate = first_out[..., 1:]
-        view = r_d.unsqueeze(0).expand_as(pts).contiguous()
+        view = r_d.unsqueeze(0).expand_as(pts)
         rl = cat_not_none(latent, cat_not_none(intermediate, refl_latent))
-        rgb = self.refl(x=pts, view=view, latent=rl.contiguous())
+        rgb = self.refl(x=pts, view=view, latent=rl)  # `intermediate` is a column slice of first_out: passed by pitch
         return self._composite(density, rgb, ts, rays)
 
 
@@ -232,8 +232,8 @@ class VolSDF(CommonNeRF):
         object.__setattr__(self, "scale_post_act", scale)  # plain attribute: never a second registration of the Parameter
         if self.sdf.refl.can_use_normal:
             raise NotImplementedError("normal-dependent reflectance needs autograd normals (row N1)")
-        view = r_d.unsqueeze(0).expand_as(pts).contiguous()
-        rgb = self.sdf.refl(x=pts, view=view, normal=None, latent=latent.contiguous())
+        view = r_d.unsqueeze(0).expand_as(pts)
+        rgb = self.sdf.refl(x=pts, view=view, normal=None, latent=latent)  # column slice of the SDF output: by pitch
         return self._composite(density, rgb, ts, rays, softplus=False, with_sky=False)
 
     def set_sigmoid(self, kind="thin"):

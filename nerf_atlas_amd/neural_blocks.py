@@ -232,20 +232,23 @@ class SkipConnMLP(nn.Module):
 
     def forward(self, p, latent: Optional[torch.Tensor] = None):
         batches = p.shape[:-1]
-        flat = p.reshape(-1, p.shape[-1]).contiguous()
         if self.latent_size != 0:
             assert latent is not None, "Did not pass latent vector when some was expected"
-            lat = latent.reshape(-1, self.latent_size).contiguous()
         else:
             assert (latent is None) or (latent.shape[-1] == 0), "Passed latent vector when none was expected"
-            lat = None
+            latent = None
         out_size = self.out.out_features
+        if not ag.needs_grad(p, latent, *self.parameters()):
+            desc, packed = (None, None) if self.last_layer_act else self.packed(config.precision)
+            if packed is not None:
+                # column slices of wider buffers (`first_out[..., 1:]`) go down with their row pitch: no copy
+                y = ops.mlp_forward(desc, config.precision, packed, p.reshape(-1, p.shape[-1]),
+                                    None if latent is None else latent.reshape(-1, self.latent_size), self.enc_params())
+                return y.reshape(batches + (out_size,))
+        flat = p.reshape(-1, p.shape[-1]).contiguous()
+        lat = None if latent is None else latent.reshape(-1, self.latent_size).contiguous()
         if ag.needs_grad(flat, lat, *self.parameters()):
             return self._forward_train(flat, lat).reshape(batches + (out_size,))
-        desc, packed = (None, None) if self.last_layer_act else self.packed(config.precision)
-        if packed is not None:
-            y = ops.mlp_forward(desc, config.precision, packed, flat, lat, self.enc_params())
-            return y.reshape(batches + (out_size,))
         # any-shape path: exact-fp32 Linears (src/neural_blocks.py:288-296)
         init = flat
         if self.enc is not None:

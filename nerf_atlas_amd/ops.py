@@ -424,18 +424,36 @@ def mlp_pack(desc: NaMlpDesc, precision: str, weights: Sequence[torch.Tensor],
     return packed
 
 
+def _rows(t: torch.Tensor, width: int, name: str):
+    """[N, width] rows of a float32 CUDA tensor WITHOUT copying when it is a column slice of a wider row-major buffer
+    (unit stride along the last dim, one constant row pitch); returns (tensor, pitch in floats)."""
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA(HIP) tensor: the hot path has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    v = t.reshape(-1, width)  # a view whenever the strides allow it
+    if v.numel() == 0 or (v.stride(1) == 1 and v.stride(0) >= width):
+        return v, (v.stride(0) if v.shape[0] > 1 else max(v.stride(0), width))
+    v = v.contiguous()
+    return v, width
+
+
 def mlp_forward(desc: NaMlpDesc, precision: str, packed: torch.Tensor, p: torch.Tensor,
                 latent: Optional[torch.Tensor] = None, enc_params: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused SkipConnMLP forward.  p [..., in_size] and latent [..., latent_size] may be column slices of wider
+    buffers (e.g. `first_out[..., 1:]`): their row pitch is passed down instead of making them contiguous."""
     lib = _lib.load()
-    p = _f32(p, "p")
-    N = p.numel() // desc.in_size
+    p2, p_ld = _rows(p, desc.in_size, "p")
+    N = p2.shape[0]
+    lat2, lat_ld = (None, 0)
     if latent is not None:
-        latent = _f32(latent, "latent")
+        lat2, lat_ld = _rows(latent, desc.latent_size, "latent")
+        assert lat2.shape[0] == N
     if enc_params is not None:
         enc_params = _f32(enc_params, "enc_params")
     y = torch.empty(tuple(p.shape[:-1]) + (desc.out_size,), device=p.device, dtype=torch.float32)
-    check(lib.na_mlp_forward(C.byref(desc), PREC[precision], _ptr(packed), _ptr(p), _ptr(latent), _ptr(enc_params), N,
-                             _ptr(y), _stream()))
+    check(lib.na_mlp_forward_ld(C.byref(desc), PREC[precision], _ptr(packed), _ptr(p2), p_ld, _ptr(lat2), lat_ld,
+                                _ptr(enc_params), N, _ptr(y), _stream()))
     return y
 
 

@@ -53,7 +53,11 @@ class View(Reflectance):
                                hidden_size=256, init="siren", activation=torch.sin)
 
     def forward(self, x, view, normal=None, light=None, latent=None):
-        v = ops.view_elaz(view.contiguous())
+        if view.dim() > 1 and view.stride(0) == 0:
+            # directions broadcast along the sample axis (r_d.unsqueeze(0).expand_as(pts)): one elev/azim per RAY
+            v = ops.view_elaz(view[0].contiguous()).unsqueeze(0).expand(view.shape[:-1] + (2,))
+        else:
+            v = ops.view_elaz(view.contiguous())
         return self.act(self.mlp(torch.cat([x, v], dim=-1), latent))
 
 
