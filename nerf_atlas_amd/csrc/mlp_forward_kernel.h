@@ -84,20 +84,30 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
         }
         c0 = F / 8;
       }
+      // remaining chunks: slots hold consecutive features of the virtual row [p | (x again for hash) | latent].  The
+      // slot -> feature map is written out per encoder with compile-time chunk/element indices and the loads are
+      // select-based (clamped address, unconditional load, zero by select): the generic init_slot_feature() call
+      // per element compiled to ~900 branches in this prologue.
+      const int dim_rest = ENC == NA_ENC_HASH ? 6 + d.latent_size : d.in_size + d.latent_size;
+      const float* prow = a.p + n * a.p_ld;
+      const float* lrow = d.latent_size > 0 ? a.latent + n * a.latent_ld : prow;
+      const int npos = ENC == NA_ENC_HASH ? 6 : d.in_size;  // leading position slots (hash: p then x, both = p)
 #pragma unroll
       for (int c = 0; c < NI; ++c) {
         if (c >= c0) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            int f = init_slot_feature(d, c, 8 * hi + e);
-            float x = 0.f;
-            if (f >= 0) {
-              if (f < d.in_size) x = a.p[n * a.p_ld + f];
-              else if (f < d.in_size + d.enc_dims) x = a.p[n * a.p_ld + (f - d.in_size)];  // enc's include_input copy of p
-              else x = a.latent[n * a.latent_ld + (f - d.in_size - d.enc_dims)];
-            }
-            v[e] = x;
+            const int rho = 16 * (c - c0) + 8 * hi + e;  // index into the virtual row
+            const bool ok = rho < dim_rest;
+            const bool is_pos = rho < npos;
+            int pi = ENC == NA_ENC_HASH ? (rho >= 3 ? rho - 3 : rho) : rho;
+            pi = is_pos ? pi : 0;
+            int li = rho - npos;
+            li = (!is_pos && ok) ? li : 0;
+            const float xp = prow[pi];
+            const float xl = lrow[li];
+            v[e] = ok ? (is_pos ? xp : xl) : 0.f;
           }
           I[c] = make_frag<PREC>(v);
         }
