@@ -14,7 +14,6 @@ restates the published algorithm (RQ decomposition of P[:, :3] with a positive d
 of P).  Parity for that function is UNPINNED (no cv2 to run against); it is checked by recomposition instead.
 """
 import json
-import math
 import os
 
 import numpy as np

@@ -10,7 +10,6 @@ reference's order, so a run is comparable with the reference's iteration by iter
 against tests/golden/train_parity_*.json).
 """
 import argparse
-import math
 import os
 import random
 from types import SimpleNamespace

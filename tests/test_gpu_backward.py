@@ -1,7 +1,5 @@
 """GPU parity of the backward operators against torch.autograd of the CPU oracle.
 Tolerance: 2e-4 of the largest gradient entry (fp32 accumulation order differs between MFMA and BLAS)."""
-import math
-
 import pytest
 import torch
 
@@ -309,7 +307,6 @@ def test_split_bf16_training_gemms(ops, shape, act):
 def test_offset_decay_regulariser_gradients(ops):
     """`make dnerf`'s --offset-decay term (runner.py:777-781): its gradient reaches the deformation MLP through the dp and
     rigidity outputs of the spline-warp backward kernel."""
-    import types
     import nerf_atlas_amd as na
     import nerf_atlas_amd.nerf, nerf_atlas_amd.train  # noqa: F401,E401
     from nerf_atlas_amd import config

@@ -1,6 +1,5 @@
 """GPU parity of the host model layer (reference plugin protocol) against the reference goldens.
 RGB tolerance 1e-4 L-inf (north_star) in the default bf16x3 precision."""
-import math
 
 import pytest
 import torch

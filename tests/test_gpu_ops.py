@@ -2,7 +2,6 @@
 Tolerances: indices / pixel grid / rays / ts bit-exact; fp32 operators <= 2e-6; see each test."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

@@ -1,7 +1,6 @@
 """N4 SDF marching (src/march.py): the oracle restatement against outputs of the reference's own functions
 (tests/golden/g15_march.npz: analytic two-sphere SDF and the reference SIREN SDF with procedural weights), and the HIP
 path (nerf_atlas_amd/march.py + csrc/march.hip) against the oracle."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """Pin the CPU oracle (oracle/) against fixtures generated from the REAL reference
 (tools/gen_golden.py).  CPU-only; runs under -m "not gpu"."""
-import math
 
 import numpy as np
 import pytest

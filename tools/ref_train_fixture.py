@@ -19,7 +19,6 @@ Runs only in the build container; nothing of the reference is copied or travels.
 import argparse
 import json
 import os
-import random
 import sys
 import tempfile
 import time
