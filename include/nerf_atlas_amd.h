@@ -127,6 +127,12 @@ int na_composite(const float* density, const float* feat, const float* ts, const
 int na_integrate(const float* weights, const float* other, int T, int64_t R, int C, float* out,
                  void* stream);
 
+/* PosLinearView pieces (src/refl.py:248-290): unit view directions (F.normalize, eps 1e-12), and the final
+ * out[N,C] = (sigmoid(lin[N]) / 2 + 0.5) * pos[N rows of pitch pos_ld, first C columns].                            */
+int na_normalize3(const float* v, int64_t N, float* out, void* stream);
+int na_pos_linear_combine(const float* lin, const float* pos, int64_t pos_ld, int64_t N, int C, float* out,
+                          void* stream);
+
 /* A12 VolSDF density = 1/beta * laplace_cdf(-sdf, beta) (src/utils.py:50-58, src/nerf.py:1000-1003);
  * beta is a device scalar (learned parameter).                                                */
 int na_laplace_density(const float* sdf, int64_t N, const float* beta, float* density, void* stream);

@@ -40,6 +40,8 @@ SIGNATURES = {
     "na_composite": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, c_f32p,
                                c_f32p, c_f32p, C.c_void_p]),
     "na_integrate": (C.c_int, [c_f32p, c_f32p, C.c_int, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_normalize3": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
+    "na_pos_linear_combine": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_laplace_density": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),
     "na_bezier_warp": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_f32p,
                                  C.c_void_p]),

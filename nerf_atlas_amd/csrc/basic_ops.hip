@@ -405,6 +405,25 @@ __global__ void bezier_warp_kernel(const float* __restrict__ est, int est_stride
   }
 }
 
+// F.normalize(v, dim=-1) (eps 1e-12), src/refl.py:281: the raw-view input of PosLinearView
+__global__ void normalize3_kernel(const float* __restrict__ v, int64_t N, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = v[i * 3], y = v[i * 3 + 1], z = v[i * 3 + 2];
+    const float n = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-12f);
+    out[i * 3] = x / n; out[i * 3 + 1] = y / n; out[i * 3 + 2] = z / n;
+  }
+}
+
+// PosLinearView combine (src/refl.py:288-290): out[n,c] = (sigmoid(lin[n]) / 2 + 0.5) * pos[n * pos_ld + c]
+__global__ void pos_linear_combine_kernel(const float* __restrict__ lin, const float* __restrict__ pos, int64_t pos_ld,
+                                          int64_t N, int C, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N * C; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / C;
+    const int c = (int)(i - n * C);
+    out[i] = (sigmoidf_(lin[n]) / 2.f + 0.5f) * pos[n * pos_ld + c];
+  }
+}
+
 }  // namespace na
 
 // ================================================================================================ C ABI
@@ -568,6 +587,24 @@ int na_bezier_warp(const float* est, int est_stride, const float* pts, const flo
   hipLaunchKernelGGL(bezier_warp_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
                      est_stride, pts, t, N, n_ctrl, out_pts, dp, rigidity_out);
   return check_launch("na_bezier_warp");
+}
+
+int na_normalize3(const float* v, int64_t N, float* out, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(v && out, NA_ENULL, "na_normalize3: null pointer");
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_normalize3: N=%lld", (long long)N);
+  hipLaunchKernelGGL(normalize3_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, v, N, out);
+  return check_launch("na_normalize3");
+}
+
+int na_pos_linear_combine(const float* lin, const float* pos, int64_t pos_ld, int64_t N, int C, float* out,
+                          void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(lin && pos && out, NA_ENULL, "na_pos_linear_combine: null pointer");
+  NA_REQUIRE(N > 0 && C >= 1 && pos_ld >= C, NA_EINVAL, "na_pos_linear_combine: bad shape");
+  hipLaunchKernelGGL(pos_linear_combine_kernel, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, lin,
+                     pos, pos_ld, N, C, out);
+  return check_launch("na_pos_linear_combine");
 }
 
 }  // extern "C"

@@ -274,6 +274,12 @@ class DynamicNeRF(nn.Module):
     def set_refl(self, r): self.canonical.set_refl(r)
     def set_bg(self, bg): self.canonical.set_bg(bg)
 
+    @property
+    def rigid_dp(self):
+        """dp * rigidity (src/nerf.py:1278), only read by the flow visualisation and regularisers: formed on demand so
+        the render path carries no extra elementwise pass over the samples."""
+        return self.dp * self.rigidity
+
     def forward(self, rays_t):
         rays, t = rays_t
         c = self.canonical
@@ -286,7 +292,6 @@ class DynamicNeRF(nn.Module):
             warped, self.dp, self.rigidity = ag.BezierWarpFn.apply(est.contiguous(), self.pts, tt, self.spline_n)
         else:
             warped, self.dp, self.rigidity = ops.bezier_warp(est, self.pts, tt, self.spline_n)
-        self.rigid_dp = self.dp * self.rigidity
         return c.from_pts(warped, self.ts, r_o, r_d, rays=rays)
 
 

@@ -189,6 +189,26 @@ def integrate(weights: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def normalize3(v: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    v = _f32(v, "v")
+    out = torch.empty_like(v)
+    check(lib.na_normalize3(_ptr(v), v.numel() // 3, _ptr(out), _stream()))
+    return out
+
+
+def pos_linear_combine(lin: torch.Tensor, pos: torch.Tensor, C_out: int) -> torch.Tensor:
+    """(sigmoid(lin)/2 + 0.5) * pos[..., :C_out]; pos may be wider (its first C_out columns are used, by row pitch)."""
+    lib = _lib.load()
+    lin = _f32(lin, "lin")
+    pos2, ld = _rows(pos, pos.shape[-1], "pos")
+    N = lin.numel()
+    assert pos2.shape[0] == N and C_out <= pos.shape[-1]
+    out = torch.empty(tuple(lin.shape[:-1]) + (C_out,), device=lin.device, dtype=torch.float32)
+    check(lib.na_pos_linear_combine(_ptr(lin), _ptr(pos2), ld, N, C_out, _ptr(out), _stream()))
+    return out
+
+
 def laplace_density(sdf: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     sdf = _f32(sdf, "sdf")

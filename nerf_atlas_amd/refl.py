@@ -39,8 +39,11 @@ class Reflectance(nn.Module):
 
 
 def _normalize(v):
-    n = torch.linalg.norm(v, dim=-1, keepdim=True).clamp_min(1e-12)
-    return v / n
+    """F.normalize(view, dim=-1) on the GPU; one normalisation per RAY when the directions are broadcast along the
+    sample axis."""
+    if v.dim() > 1 and v.stride(0) == 0:
+        return ops.normalize3(v[0].contiguous()).unsqueeze(0).expand(v.shape)
+    return ops.normalize3(v.contiguous())
 
 
 class View(Reflectance):
@@ -86,10 +89,11 @@ class PosLinearView(Reflectance):
                                 hidden_size=128, init="siren", activation=torch.sin)
 
     def forward(self, x, view, normal=None, light=None, latent=None):
-        pos, intermediate = self.act(self.pos(x, latent)).split([self.out_features, self.im], dim=-1)
+        pos_all = self.act(self.pos(x, latent))  # [..., out_features + im]
+        intermediate = pos_all[..., self.out_features:]
         view_latent = intermediate if latent is None else torch.cat([latent, intermediate], dim=-1)
-        linear = load_sigmoid("normal")(self.view(torch.cat([x, _normalize(view)], dim=-1), view_latent))
-        return (linear / 2 + 0.5) * pos
+        raw = self.view(torch.cat([x, _normalize(view)], dim=-1), view_latent)
+        return ops.pos_linear_combine(raw, pos_all, self.out_features)  # (sigmoid(raw)/2 + 0.5) * pos_all[..., :out]
 
 
 def _out_of_scope(name):
