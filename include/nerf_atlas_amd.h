@@ -214,6 +214,9 @@ int na_render_plain_view_pts(const float* rays, const float* pts, int64_t R, con
  * na_act_backward      g_x = g_act * act'(x) for the pre-activation input x of a Linear
  *                      (src/neural_blocks.py:293).
  * na_sigmoid_backward  g_x = g_y * d/dx sigmoid_kind(x) (src/utils.py:484-518).
+ * na_pos_linear_combine_backward  gradient of na_pos_linear_combine (src/refl.py:288-290) w.r.t. lin [N] (g_lin,
+ *                      nullable) and pos (g_pos [N, gpos_ld], nullable: columns < C receive g * (sigmoid/2 + 0.5),
+ *                      columns C..gpos_ld-1 are zeroed) given g [N, C].
  * na_linear_wgrad      dW[out,in] += dY^T . act([x0|x1]);  db[out] += sum_n dY (db may be NULL), exact fp32
  *                      (the exact input gradient is na_linear_f32 with W^T followed by na_act_backward).
  * Fast training precision: the three GEMMs of a layer on the bf16 matrix core with a 2-way operand split
@@ -234,6 +237,8 @@ int na_render_plain_view_pts(const float* rays, const float* pts, int64_t R, con
  *                      given g_out [R,C] (src/nerf.py:60-80,96-98).                              */
 int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream);
 int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, float* out, void* stream);
+int na_pos_linear_combine_backward(const float* lin, const float* pos, int64_t pos_ld, const float* g, int64_t N, int C,
+                                   float* g_lin, float* g_pos, int64_t gpos_ld, void* stream);
 int na_linear_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* W, const float* b,
                      int out, int pre_act, float* y, void* stream);
 int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt, const float* x0, int in0,
@@ -254,6 +259,24 @@ int na_bezier_warp_backward(const float* est, int est_stride, const float* t, in
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays,
                           int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
                           float* g_density, float* g_feat, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layer-synchronous fused renderer (csrc/render_ls.hip): the same operator as na_render_plain_view
+ * (PlainNeRF.forward with the View head, src/nerf.py:326-361, src/refl.py:190-207) on the engine that keeps
+ * activations in LDS and streams weights straight into registers.  Both MLPs are packed into ONE stream:
+ *   w_first / b_first = {init, layers.0..3, out} of PlainNeRF.first  (hash encoder, 4x256, out 65; src/nerf.py:320-324)
+ *   w_view  / b_view  = {init, layers.0..3, out} of View.mlp         (5 + 64 latent -> 4x256 -> 3; src/refl.py:201-204)
+ * in nn.Linear layout (fp32, device pointers; biases may be NULL).  `pts` ([T,R,3], nullable) replaces o + t d by
+ * explicit sample positions (PlainNeRF.from_pts with deformed points, src/nerf.py:337-361).  Workspace: partials of
+ * the per-block compositing + a 16-KiB-per-workgroup scratch.                                                    */
+size_t na_render_ls_packed_bytes(int precision);
+int na_render_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                      const float* const* w_view, const float* const* b_view, void* packed, void* stream);
+size_t na_render_ls_workspace_bytes(int T, int64_t R);
+int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                            const float* hash_tables, const void* packed, int precision, int sigmoid_kind, int bg_kind,
+                            float* alpha, float* weights, float* out, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SDF ray marching (src/march.py).  Per-ray state lives in caller-owned device arrays; the SDF network

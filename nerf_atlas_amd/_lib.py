@@ -63,6 +63,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p]),
     "na_act_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_sigmoid_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_pos_linear_combine_backward": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_i64,
+                                                 C.c_void_p]),
     "na_linear_bf16x3": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p,
                                    C.c_void_p]),
     "na_linear_dgrad_bf16x3": (C.c_int, [c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, c_f32p,
@@ -85,6 +87,12 @@ SIGNATURES = {
     "na_render_plain_view_pts": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                            C.c_void_p]),
+    "na_render_ls_packed_bytes": (C.c_size_t, [C.c_int]),
+    "na_render_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "na_render_ls_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),
+    "na_render_plain_view_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

@@ -118,6 +118,24 @@ class SigmoidFn(Function):
         return ops.sigmoid_backward(x, g.contiguous(), ctx.kind), None
 
 
+class PosLinearCombineFn(Function):
+    """(sigmoid(lin)/2 + 0.5) * pos[..., :C] (src/refl.py:288-290)."""
+
+    @staticmethod
+    def forward(ctx, lin, pos, c_out):
+        ctx.c_out = c_out
+        ctx.save_for_backward(lin, pos)
+        with torch.no_grad():
+            return ops.pos_linear_combine(lin, pos, c_out)
+
+    @staticmethod
+    def backward(ctx, g):
+        lin, pos = ctx.saved_tensors
+        g_lin, g_pos = ops.pos_linear_combine_backward(lin, pos, g.contiguous(), ctx.c_out, ctx.needs_input_grad[0],
+                                                       ctx.needs_input_grad[1])
+        return g_lin, g_pos, None
+
+
 class CompositeFn(Function):
     """alpha_from_density + volumetric_integrate + sky (src/nerf.py:60-80,96-98).  Returns (out, alpha, weights);
     alpha/weights are auxiliary (non-differentiable) outputs."""

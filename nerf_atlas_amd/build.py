@@ -5,6 +5,8 @@ missing the package raises on first use.
 """
 import argparse
 import concurrent.futures as cf
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -28,6 +30,8 @@ UNITS = [
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),
     ("render_fused.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("render_fused.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),
+    ("render_ls.hip", ["-DNA_PREC_INST=0"], "_bf16"),
+    ("render_ls.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),
 ]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("NA_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -39,17 +43,35 @@ def hipcc():
     return exe
 
 
-def _deps_mtime():
-    m = 0.0
+def _headers_digest() -> str:
+    """sha256 over every header a unit can include (csrc/*.h, include/*.h): content, not mtime."""
+    h = hashlib.sha256()
     for root in (CSRC, os.path.join(HERE, "..", "include")):
-        for f in os.listdir(root):
-            m = max(m, os.path.getmtime(os.path.join(root, f)))
-    return m
+        for f in sorted(os.listdir(root)):
+            if f.endswith(".h"):
+                h.update(f.encode())
+                with open(os.path.join(root, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
+def _unit_digest(unit, headers: str) -> str:
+    src, extra, suffix = unit
+    h = hashlib.sha256(headers.encode())
+    h.update(" ".join(FLAGS + extra).encode())
+    with open(os.path.join(CSRC, src), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+def _obj_path(unit):
+    src, _, suffix = unit
+    return os.path.join(OBJ, os.path.splitext(src)[0] + suffix + ".o")
 
 
 def _compile(unit):
     src, extra, suffix = unit
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + suffix + ".o")
+    obj = _obj_path(unit)
     cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -58,19 +80,36 @@ def _compile(unit):
 
 
 def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
+    """Compile the units whose (source, headers, flags) digest changed since the object was built, then link.
+    Up-to-date-ness is decided by content hashes recorded next to the objects (build/digests.json), never by mtime:
+    a fresh checkout, an edited header and a changed flag all rebuild exactly what they touch."""
     units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[0]))]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
-        return LIB
     os.makedirs(OBJ, exist_ok=True)
-    jobs = jobs or min(len(units), os.cpu_count() or 4)
+    stamp = os.path.join(OBJ, "digests.json")
+    try:
+        with open(stamp) as fh:
+            old = json.load(fh)
+    except (OSError, ValueError):
+        old = {}
+    headers = _headers_digest()
+    new = {os.path.basename(_obj_path(u)): _unit_digest(u, headers) for u in units}
+    stale = [u for u in units if force or not os.path.exists(_obj_path(u))
+             or old.get(os.path.basename(_obj_path(u))) != new[os.path.basename(_obj_path(u))]]
+    if not stale and os.path.exists(LIB) and old.get("__lib__") == hashlib.sha256("".join(sorted(new.values())).encode()).hexdigest():
+        return LIB
+    jobs = jobs or min(max(len(stale), 1), os.cpu_count() or 4)
     if verbose:
-        print(f"[nerf_atlas_amd] compiling {len(units)} units for {ARCH} with {jobs} jobs", file=sys.stderr)
+        print(f"[nerf_atlas_amd] compiling {len(stale)} of {len(units)} units for {ARCH} with {jobs} jobs", file=sys.stderr)
     with cf.ThreadPoolExecutor(jobs) as ex:
-        objs = list(ex.map(_compile, units))
+        list(ex.map(_compile, stale))
+    objs = [_obj_path(u) for u in units]
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    new["__lib__"] = hashlib.sha256("".join(sorted(v for k, v in new.items())).encode()).hexdigest()
+    with open(stamp, "w") as fh:
+        json.dump(new, fh, indent=1)
     return LIB
 
 

@@ -23,3 +23,15 @@ def set_train_precision(p: str):
     if p not in ("fp32", "bf16x3"):
         raise ValueError(p)
     train_precision = p
+
+
+# Fused PlainNeRF(view) renderer: "ls" = layer-synchronous engine (csrc/render_ls.hip: activations in LDS, weights
+# streamed into registers, two sample groups in antiphase), "reg" = register-resident engine (csrc/render_fused.hip).
+engine = "ls"
+
+
+def set_engine(e: str):
+    global engine
+    if e not in ("ls", "reg"):
+        raise ValueError(e)
+    engine = e

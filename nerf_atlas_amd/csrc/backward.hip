@@ -352,6 +352,27 @@ __global__ void composite_backward_kernel(const float* __restrict__ density, con
   }
 }
 
+// out = (sigmoid(lin)/2 + 0.5) * pos[:, :C]  (src/refl.py:288-290): one thread per row.
+//   g_lin[n]    = sum_c g[n,c] * pos[n,c] * s (1 - s) / 2
+//   g_pos[n, c] = g[n,c] * (s/2 + 0.5) for c < C, 0 for the remaining (pass-through) columns
+__global__ void pos_linear_combine_backward_kernel(const float* __restrict__ lin, const float* __restrict__ pos,
+                                                   int64_t pos_ld, const float* __restrict__ g, int64_t N, int C,
+                                                   float* __restrict__ g_lin, float* __restrict__ g_pos, int64_t gpos_ld) {
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    const float s = sigmoidf_(lin[n]);
+    const float scale = s / 2.f + 0.5f;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float gc = g[n * C + c];
+      acc = acc + gc * pos[n * pos_ld + c];
+      if (g_pos != nullptr) g_pos[n * gpos_ld + c] = gc * scale;
+    }
+    if (g_pos != nullptr)
+      for (int64_t c = C; c < gpos_ld; ++c) g_pos[n * gpos_ld + c] = 0.f;
+    if (g_lin != nullptr) g_lin[n] = acc * (s * (1.f - s) / 2.f);
+  }
+}
+
 }  // namespace na
 
 using namespace na;
@@ -376,6 +397,17 @@ int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, flo
   hipLaunchKernelGGL(sigmoid_backward_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, g, n,
                      kind, out);
   return check_launch("na_sigmoid_backward");
+}
+
+int na_pos_linear_combine_backward(const float* lin, const float* pos, int64_t pos_ld, const float* g, int64_t N, int C,
+                                   float* g_lin, float* g_pos, int64_t gpos_ld, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(lin && pos && g, NA_ENULL, "na_pos_linear_combine_backward: null pointer");
+  NA_REQUIRE(N > 0 && C >= 1 && pos_ld >= C && (g_pos == nullptr || gpos_ld >= C), NA_EINVAL,
+             "na_pos_linear_combine_backward: bad shape");
+  hipLaunchKernelGGL(pos_linear_combine_backward_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     lin, pos, pos_ld, g, N, C, g_lin, g_pos, gpos_ld);
+  return check_launch("na_pos_linear_combine_backward");
 }
 
 int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,

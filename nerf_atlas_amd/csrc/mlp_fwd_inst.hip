@@ -1,5 +1,6 @@
 // Instantiations of the generic fused MLP forward kernel for ONE precision (NA_PREC_INST = 0 | 1); built as
 // two translation units so the heavy kernels compile in parallel.
+#include <atomic>
 #include "mlp_forward_kernel.h"
 
 #ifndef NA_PREC_INST
@@ -11,11 +12,17 @@ namespace na {
 template <int PREC, int ACT, int ENC, int NI, int NWAVES>
 static int launch_forward(const MlpArgs& a, const TileTab& tab, hipStream_t stream) {
   auto kern = mlp_forward_kernel<PREC, ACT, ENC, NI, NWAVES>;
-  static thread_local bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
-    attr_done = true;
+  // the attribute is per DEVICE (not per thread): one bit per device ordinal
+  static std::atomic<uint64_t> attr_done{0};
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return NA_EHIP; }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
+      attr_done.fetch_or(bit, std::memory_order_release);
+    }
   }
   int grid = a.ngroups < 256 ? a.ngroups : 256;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), slots_for(PREC, NI) * a.buf_bytes + 8 * kMaxTiles, stream, a, tab);

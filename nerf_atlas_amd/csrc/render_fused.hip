@@ -8,6 +8,7 @@
 // combined by a tiny second kernel (na_render_finalize), which also adds the background term.
 //
 // Compiled once per precision (-DNA_PREC_INST=0|1).
+#include <atomic>
 #include "mlp_layout.h"
 #include "encoders.h"
 
@@ -218,17 +219,32 @@ __global__ void render_finalize_kernel(const float* __restrict__ partials, int64
   }
 }
 
+
+int launch_render_finalize(const float* partials, int64_t R, int nb, int T, int bg_kind, float* weights, float* out,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(render_finalize_kernel, dim3(grid_for(R, 128, 1 << 16)), dim3(128), 0, stream, partials, R, nb, T,
+                     bg_kind, weights, out);
+  return check_launch("na_render_finalize");
+}
 #endif
+
+// hipFuncSetAttribute is per DEVICE: remember which devices already carry the 160-KiB dynamic-LDS limit
+inline int ensure_max_lds(const void* kern, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return NA_EHIP; }
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return NA_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
+  done.fetch_or(bit, std::memory_order_release);
+  return NA_OK;
+}
 
 template <int PREC, int NWAVES, int NB>
 static int launch_render(RenderArgs& a, const TileTab& tab, hipStream_t stream) {
   auto kern = render_plain_view_kernel<PREC, NWAVES, NB>;
-  static thread_local bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_max_lds((const void*)kern, attr_done); rc != NA_OK) return rc;
   a.ngroups = (int)((a.nitems + NWAVES * NB - 1) / (NWAVES * NB));
   int grid = a.ngroups < 256 ? a.ngroups : 256;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), 3 * a.buf_bytes + 8 * kMaxTiles + (NA_TRACE ? 2 * 8 * 1400 : 0), stream, a, tab);
@@ -291,9 +307,7 @@ static int render_plain_view_impl(const float* rays, const float* pts, int64_t R
   int rc = precision == NA_PREC_BF16 ? render_dispatch_bf16(a, tab, (hipStream_t)stream)
                                      : render_dispatch_bf16x3(a, tab, (hipStream_t)stream);
   if (rc != NA_OK) return rc;
-  hipLaunchKernelGGL(render_finalize_kernel, dim3(grid_for(R, 128, 1 << 16)), dim3(128), 0, (hipStream_t)stream,
-                     a.partials, R, a.nb, T, bg_kind, weights, out);
-  return check_launch("na_render_finalize");
+  return launch_render_finalize(a.partials, R, a.nb, T, bg_kind, weights, out, (hipStream_t)stream);
 }
 
 extern "C" int na_render_plain_view(const float* rays, int64_t R, const float* ts, int T, const float* hash_tables,

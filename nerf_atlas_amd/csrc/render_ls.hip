@@ -1,0 +1,705 @@
+// na_render_plain_view_ls: PlainNeRF.forward with the View head (src/nerf.py:326-361, src/refl.py:190-207) as ONE
+// kernel on the LAYER-SYNCHRONOUS engine.  Same arithmetic and work items as render_fused.hip
+// (a block = 32 consecutive steps of one ray, lane&31 = step, compositing = in-wave scan), different data flow:
+//
+//  * 8 waves = 4 row groups (64 output rows = two 32-row MFMA tiles) x 2 sample groups (NBLK blocks each).
+//  * Activations live in LDS as ready-made MFMA B fragments, [group][block][chunk][lane] x 16 B: the lane that
+//    produces 8 values of a chunk is the lane that consumes them, so ds_write_b128 / ds_read_b128 are lane-linear and
+//    conflict-free; the implied k permutation is the engine's pi_perm, folded into the weight packing.
+//  * A layer = an MFMA phase that is CHUNK-major: per 16-wide k chunk the wave streams its two A fragments straight
+//    from global memory into registers (a 4-deep software-prefetched ring that runs across layer, MLP and pass
+//    boundaries: no LDS-DMA, no weight ring in LDS) and feeds them to 2 x NBLK MFMAs whose B fragments come from LDS:
+//    every LDS fragment read feeds TWO MFMAs (the one-read-per-MFMA structure of mlp_engine.h caps the matrix pipe
+//    near 57 %).  All 2 x NBLK accumulator tiles stay in registers until the layer is complete; the activation
+//    epilogue then overwrites the LDS fragments in place.
+//  * The two sample groups run in ANTIPHASE, one workgroup barrier per phase: while one group streams MFMAs the
+//    other runs its epilogue / encoder / compositing (VALU + LDS writes) on the same SIMDs, so VALU work never sits
+//    between a wave's own MFMAs and each SIMD always has one MFMA-only wave.
+//  * LDS: per group NBLK x (16 hidden + 4 init) chunks = 80 KiB, 160 KiB per workgroup (bf16: NBLK = 4; bf16x3 keeps
+//    hi and lo planes: NBLK = 2).  The fifth init chunk of the View MLP (x, y, z, elev, azim) does not fit: its
+//    fragments go through a 16-KiB per-workgroup global scratch (L2) and are prefetched like weights.
+//  * `first.out` / `view.out` (65 and 3 rows) run block-per-wave (wave rg = block rg, all out tiles), which is also the
+//    assignment of the hash-encoder prologue and of compositing, so density and colour never leave their wave.
+//
+// Compiled once per precision (-DNA_PREC_INST=0|1).
+#include <atomic>
+#include "mlp_layout.h"
+#include "encoders.h"
+
+#ifndef NA_PREC_INST
+#error "compile with -DNA_PREC_INST=0 (bf16) or 1 (bf16x3)"
+#endif
+// NA_LS_TRACE: waves 0 and 4 of workgroup 0 stamp s_memtime before and after every barrier of their second pass
+// (tools/ls_trace.py).  Timing experiments only.
+#ifndef NA_LS_TRACE
+#define NA_LS_TRACE 0
+#endif
+
+namespace na {
+
+int launch_render_finalize(const float* partials, int64_t R, int nb, int T, int bg_kind, float* weights, float* out,
+                           hipStream_t stream);  // render_fused.hip
+
+namespace ls {
+
+constexpr int kPF = 4;       // weight prefetch depth, in fragment pairs
+constexpr int kNPhase = 12;  // MFMA phases per pass
+// fragment pairs a wave consumes per phase: first.init, first.L0 (3 skip + 16), L1..L3, first.out (16 x 3 tiles / 2),
+// view.init (4 latent + geometry), view.L0 (5 skip + 16), L1..L3, view.out (16 / 2)
+__host__ __device__ constexpr int phase_pairs(int p) {
+  return p == 0 ? 3 : p == 1 ? 19 : p == 5 ? 24 : p == 6 ? 5 : p == 7 ? 21 : p == 11 ? 8 : 16;
+}
+constexpr int kPairsPerPass = 176;
+constexpr int kHeaderBytes = 1024;
+constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB blocks: floats [slot][hi(2)][16]
+constexpr uint32_t kMagic = 0x4C533031u;        // "LS01"
+constexpr int kPartialFloats = 8;
+
+template <int PREC>
+struct Cfg {
+  static constexpr int P = PREC == NA_PREC_BF16X3 ? 2 : 1;
+  static constexpr int NBLK = PREC == NA_PREC_BF16X3 ? 2 : 4;  // 32-sample blocks per sample group
+  static constexpr int FRAG = 1024 * P;                         // bytes of one fragment (hi plane [, lo plane])
+  static constexpr int PAIR = 2 * FRAG;
+  static constexpr int HREG = NBLK * 16 * FRAG;                 // hidden activations of one group
+  static constexpr int IREG = NBLK * 4 * FRAG;                  // init-input chunks of one group
+  static constexpr int GROUP = HREG + IREG;                     // 80 KiB
+  static constexpr int STREAM = kPairsPerPass * PAIR;           // weight stream of one row group
+  static constexpr int SCRATCH = 2 * NBLK * 2 * FRAG;           // geometry chunk fragments (raw, sin) per workgroup
+};
+
+inline size_t packed_bytes(int precision) {
+  const int pair = 2048 * (precision == NA_PREC_BF16X3 ? 2 : 1);
+  return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)kPairsPerPass * pair;
+}
+
+struct Args {
+  const float* rays;     // [R,6]
+  const float* ts;       // [T]
+  const float* pts;      // nullable [T,R,3]
+  const float4* tables;  // [8,65536]
+  const char* packed;    // LS stream (na_render_ls_pack)
+  float* alpha;          // nullable [T,R]
+  float* weights;        // nullable [T,R] (block-local; finalize applies the cross-block prefix)
+  float* partials;       // [R*nb, 8]
+  char* scratch;         // [grid][Cfg::SCRATCH]
+  int64_t R;
+  int64_t nitems;        // R * nb
+  int T, nb;
+  int npass;             // ceil(nitems / (2*NBLK))
+  int sigmoid_kind;
+  uint32_t packed_size;
+  HashRes res;
+  unsigned long long* trace;  // NA_LS_TRACE builds only: [2 groups][128] s_memtime stamps of workgroup 0, second pass
+};
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+template <int PREC>
+__device__ __forceinline__ Frag<PREC> wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  Frag<PREC> f;
+  f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  if constexpr (PREC == NA_PREC_BF16X3)
+    f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024, 0));
+  return f;
+}
+
+template <int PREC>
+__device__ __forceinline__ Frag<PREC> fread(const char* p) {
+  Frag<PREC> f;
+  f.hi = *(const bf16x8*)p;
+  if constexpr (PREC == NA_PREC_BF16X3) f.lo = *(const bf16x8*)(p + 1024);
+  return f;
+}
+
+template <int PREC>
+__device__ __forceinline__ void fwrite(char* p, const Frag<PREC>& f) {
+  *(bf16x8*)p = f.hi;
+  if constexpr (PREC == NA_PREC_BF16X3) *(bf16x8*)(p + 1024) = f.lo;
+}
+
+template <int PREC>
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<PREC>& A, const Frag<PREC>& B) {
+  if constexpr (PREC == NA_PREC_BF16X3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
+}
+
+// floats [slot][hi(2)][16] of one phase's bias block -> accumulator init of tile `slot`.  Buffer loads with the
+// wave-uniform part in the scalar offset: no per-lane 64-bit pointers to hoist and spill.
+__device__ __forceinline__ f32x16 bias_tile(__amdgpu_buffer_rsrc_t rs, int bias_soff, int slot, int lane) {
+  const int voff = (lane >> 5) * 64;
+  f32x16 a;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, bias_soff + slot * 128 + q * 16, 0));
+    a[q * 4 + 0] = v[0]; a[q * 4 + 1] = v[1]; a[q * 4 + 2] = v[2]; a[q * 4 + 3] = v[3];
+  }
+  return a;
+}
+
+// ---- MFMA phase of a 256-row Linear: K = [NI init chunks from LDS | geometry chunk | NH hidden chunks from LDS]
+template <int PREC, int RING0, int NI, bool GEO, int NH, bool WRAP>
+__device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag<PREC> (&ring)[kPF][2], int& cur,
+                                         __amdgpu_buffer_rsrc_t rs, int wvoff, const char* hb, const char* ib, int lane,
+                                         const Frag<PREC> (&geoB)[Cfg<PREC>::NBLK]) {
+  constexpr int NB = Cfg<PREC>::NBLK, FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
+  constexpr int NCH = NI + (GEO ? 1 : 0) + NH;
+  Frag<PREC> Bq[2][NB];
+  auto bsrc = [&](int q, int b) -> Frag<PREC> {
+    if (q < NI) return fread<PREC>(ib + (b * 4 + q) * FR + lane * 16);
+    if (GEO && q == NI) return geoB[b];
+    return fread<PREC>(hb + (b * 16 + (q - NI - (GEO ? 1 : 0))) * FR + lane * 16);
+  };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) Bq[0][b] = bsrc(0, b);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const Frag<PREC> A0 = ring[(RING0 + q) % kPF][0], A1 = ring[(RING0 + q) % kPF][1];
+    if (q + 1 < NCH) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) Bq[(q + 1) & 1][b] = bsrc(q + 1, b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      mma<PREC>(acc[0][b], A0, Bq[q & 1][b]);
+      mma<PREC>(acc[1][b], A1, Bq[q & 1][b]);
+      if (b == 0) {
+        int nx = cur + q + kPF;
+        if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
+        ring[(RING0 + q) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
+        ring[(RING0 + q) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cur += NCH;
+}
+
+// ---- MFMA phase of an out Linear, block-per-wave: NT 32-row tiles x 16 chunks for block `blk`; fragment f = c*NT + j
+template <int PREC, int RING0, int NT, bool WRAP>
+__device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2], int& cur, __amdgpu_buffer_rsrc_t rs,
+                                      int wvoff, const char* hb, int lane, int blk) {
+  constexpr int FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
+  Frag<PREC> Bq[2];
+  const char* src = hb + blk * 16 * FR + lane * 16;
+  Bq[0] = fread<PREC>(src);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c + 1 < 16) Bq[(c + 1) & 1] = fread<PREC>(src + (c + 1) * FR);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int f = c * NT + j, p = f >> 1, t = f & 1;
+      mma<PREC>(o[j], ring[(RING0 + p) % kPF][t], Bq[c & 1]);
+      if (t == 1) {
+        int nx = cur + p + kPF;
+        if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
+        ring[(RING0 + p) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
+        ring[(RING0 + p) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cur += NT * 8;
+}
+
+// ---- epilogue of a 256-row Linear: act(acc) -> the group's hidden fragments in LDS (in place)
+template <int PREC, int ACT>
+__device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][Cfg<PREC>::NBLK], char* hb, int rg, int lane) {
+  constexpr int NB = Cfg<PREC>::NBLK, FR = Cfg<PREC>::FRAG;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      Frag<PREC> f0, f1;
+      acc_to_frags<PREC, ACT>(acc[t][b], f0, f1);
+      char* dst = hb + (b * 16 + 2 * (2 * rg + t)) * FR + lane * 16;
+      fwrite<PREC>(dst, f0);
+      fwrite<PREC>(dst + FR, f1);
+    }
+}
+
+// the skip connection re-enters through the activation (src/neural_blocks.py:291-293): act() on the init chunks of
+// block `blk`, in place, once the init Linear has consumed the raw values
+template <int PREC, int ACT, int NCH>
+__device__ __forceinline__ void activate_init(char* ib, int blk, int lane) {
+  constexpr int FR = Cfg<PREC>::FRAG;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    char* p = ib + (blk * 4 + c) * FR + lane * 16;
+    Frag<PREC> f = fread<PREC>(p);
+    frag_activate<PREC, ACT>(f);
+    fwrite<PREC>(p, f);
+  }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using C = Cfg<PREC>;
+  constexpr int NB = C::NBLK, FR = C::FRAG;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rg = wv & 3, g = wv >> 2;
+  const int hi = lane >> 5, ln = lane & 31;
+  char* hb = smem + g * C::GROUP;
+  char* ib = hb + C::HREG;
+  const bool owner = rg < NB;           // this wave owns block rg of its group (encoder, out layers, compositing)
+  const int blk = owner ? rg : rg - NB;  // non-owners (bf16x3: rg 2,3) shadow a block to keep their weight ring in step
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, a.packed_size, 0x00020000);
+  const int wvoff = kHeaderBytes + kBiasBytes + rg * C::STREAM + lane * 16;
+  const int bias_rg = kHeaderBytes + rg * (kNPhase * 1024);  // scalar offset of this row group's bias blocks
+  // geometry-chunk scratch of this workgroup / sample group: [block][raw, sin] fragments
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.scratch + (size_t)blockIdx.x * C::SCRATCH), 0, C::SCRATCH, 0x00020000);
+  const int scr = g * (NB * 2 * FR);
+  auto scr_store = [&](int soff, const Frag<PREC>& f) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, f.hi), srs, lane * 16, soff, 0);
+    if constexpr (PREC == NA_PREC_BF16X3)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, f.lo), srs, lane * 16, soff + 1024, 0);
+  };
+
+  struct Geom {
+    int64_t item, ray;
+    bool item_ok, t_ok;
+    int t;
+    float px, py, pz, dist, dx, dy, dz;
+  };
+  auto geom = [&](int pass, int b) {
+    Geom q;
+    const int64_t item_raw = ((int64_t)pass * 2 + g) * NB + b;
+    q.item_ok = item_raw < a.nitems;
+    q.item = q.item_ok ? item_raw : a.nitems - 1;
+    q.ray = q.item / a.nb;
+    const int tb = (int)(q.item - q.ray * a.nb);
+    q.t = tb * 32 + ln;
+    q.t_ok = q.t < a.T;
+    const int tc = q.t_ok ? q.t : a.T - 1;
+    const float* ry = a.rays + q.ray * 6;
+    q.dx = ry[3]; q.dy = ry[4]; q.dz = ry[5];
+    const float tt = a.ts[tc];
+    if (a.pts != nullptr) {
+      const float* p = a.pts + ((int64_t)tc * a.R + q.ray) * 3;
+      q.px = p[0]; q.py = p[1]; q.pz = p[2];
+    } else {
+      q.px = ry[0] + tt * q.dx; q.py = ry[1] + tt * q.dy; q.pz = ry[2] + tt * q.dz;
+    }
+    const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+    q.dist = d * sqrtf((q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz);
+    return q;
+  };
+
+  // compositing of block rg of pass `pass` (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
+  auto composite = [&](int pass, const f32x16& oc, float density) {
+    const Geom q = geom(pass, blk);
+    const float cr = apply_sigmoid_kind(oc[0], a.sigmoid_kind);
+    const float cg = apply_sigmoid_kind(oc[1], a.sigmoid_kind);
+    const float cb = apply_sigmoid_kind(oc[2], a.sigmoid_kind);
+    const float sigma = softplusf_(density - 1.0f);
+    float alpha = q.t_ok ? 1.0f - expf(-sigma * q.dist) : 0.f;
+    float f = (1.0f - alpha) + 1e-10f;
+    float incl = f;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      float up = __shfl_up(incl, d, 32);
+      if (ln >= d) incl = incl * up;
+    }
+    float excl = __shfl_up(incl, 1, 32);
+    if (ln == 0) excl = 1.0f;
+    const float w = alpha * excl;
+    float sr = w * cr, sg = w * cg, sb = w * cb;
+    float wh = (q.t < a.T - 1) ? w : 0.f;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+      sr += __shfl_xor(sr, d, 32);
+      sg += __shfl_xor(sg, d, 32);
+      sb += __shfl_xor(sb, d, 32);
+      wh += __shfl_xor(wh, d, 32);
+    }
+    const float P = __shfl(incl, 31, 32);
+    if (owner && q.item_ok && hi == 0) {
+      if (ln == 0) {
+        float* o = a.partials + q.item * kPartialFloats;
+        o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
+      }
+      if (q.t_ok) {
+        if (a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
+        if (a.weights != nullptr) a.weights[(int64_t)q.t * a.R + q.ray] = w;
+      }
+    }
+  };
+
+#if NA_LS_TRACE
+  unsigned long long* tlog = (a.trace != nullptr && blockIdx.x == 0 && lane == 0 && rg == 0) ? a.trace + g * 128 : nullptr;
+  int tpos = 0;
+  bool ton = false;
+#define SYNC()                                                                              \
+  do {                                                                                      \
+    if (tlog != nullptr && ton && tpos < 126) tlog[tpos++] = __builtin_amdgcn_s_memtime();  \
+    __syncthreads();                                                                        \
+    if (tlog != nullptr && ton && tpos < 126) tlog[tpos++] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define SYNC() __syncthreads()
+#endif
+  Frag<PREC> ring[kPF][2];
+#pragma unroll
+  for (int p = 0; p < kPF; ++p) {
+    ring[p][0] = wload<PREC>(wrs, wvoff, p * C::PAIR);
+    ring[p][1] = wload<PREC>(wrs, wvoff, p * C::PAIR + FR);
+  }
+  Frag<PREC> geoB[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) geoB[b] = ring[0][0];  // defined value; only phases 6 and 7 read it
+
+  f32x16 acc[2][NB];
+  f32x16 oc[1];
+  float density = 0.f;
+  int prev = -1;
+  if (g == 1) __syncthreads();  // group 1 runs one phase behind group 0
+
+  for (int pass = blockIdx.x; pass < a.npass; pass += gridDim.x) {
+    int cur = 0;
+#if NA_LS_TRACE
+    ton = pass == (int)blockIdx.x + (int)gridDim.x;
+#endif
+    // ================= EP: compositing of the previous pass, hash encoder of this one
+    if (prev >= 0) composite(prev, oc[0], density);
+    if (owner) {
+      const Geom q = geom(pass, blk);
+      float f[16];
+      hash_levels4(q.px, q.py, q.pz, a.tables, a.res, 4 * hi, f);
+      float v0[8], v1[8], v2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; v2[e] = 0.f; }
+      if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; v2[3] = q.px; v2[4] = q.py; v2[5] = q.pz; }
+      char* dst = ib + blk * 4 * FR + lane * 16;
+      fwrite<PREC>(dst, make_frag<PREC>(v0));
+      fwrite<PREC>(dst + FR, make_frag<PREC>(v1));
+      fwrite<PREC>(dst + 2 * FR, make_frag<PREC>(v2));
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x16 bv = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[t][b] = bv;
+    }
+    SYNC();
+    // ================= `first` MLP (LeakyReLU)
+    m_hidden<PREC, 0, 3, false, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    SYNC();
+    {
+      f32x16 bv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 1 * 1024, t, lane);
+      store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
+      if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+    }
+    SYNC();
+    m_hidden<PREC, 3, 3, false, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    SYNC();
+    for (int i = 0; i < 3; ++i) {
+      f32x16 bv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (2 + i) * 1024, t, lane);
+      store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      SYNC();
+      m_hidden<PREC, 2, 0, false, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+      SYNC();
+    }
+    f32x16 o3[3];
+    {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o3[j] = bias_tile(wrs, bias_rg + 5 * 1024, j, lane);
+      store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
+    }
+    SYNC();
+    // first.out: rows 0..63 = intermediate (-> View latent), row 64 = density
+    m_out<PREC, 2, 3, false>(o3, ring, cur, wrs, wvoff, hb, lane, blk);
+    SYNC();
+    {
+      f32x16 bv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 6 * 1024, t, lane);
+      if (owner) {
+        density = o3[2][0];  // row 64 lives in register 0 of the hi=0 lanes
+        char* dst = ib + blk * 4 * FR + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          Frag<PREC> f0, f1;
+          acc_to_frags<PREC, NA_ACT_NONE>(o3[j], f0, f1);
+          fwrite<PREC>(dst + (2 * j) * FR, f0);
+          fwrite<PREC>(dst + (2 * j + 1) * FR, f1);
+        }
+        // fifth init chunk of the View MLP: x, y, z, elev, azim (raw for view.init, sin() for the skip layer)
+        const Geom q = geom(pass, blk);
+        float el, az;
+        elev_azim(q.dx, q.dy, q.dz, el, az);
+        float v4[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v4[e] = 0.f;
+        if (hi == 0) { v4[0] = q.px; v4[1] = q.py; v4[2] = q.pz; v4[3] = el; v4[4] = az; }
+        Frag<PREC> raw = make_frag<PREC>(v4);
+        Frag<PREC> act = raw;
+        frag_activate<PREC, NA_ACT_SIN>(act);
+        scr_store(scr + (blk * 2) * FR, raw);
+        scr_store(scr + (blk * 2 + 1) * FR, act);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the scratch stores are read by the other waves after the barrier
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+    }
+    SYNC();
+    // ================= View MLP (sin)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) geoB[b] = wload<PREC>(srs, lane * 16, scr + (b * 2) * FR);
+    m_hidden<PREC, 2, 4, true, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    SYNC();
+    {
+      f32x16 bv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 7 * 1024, t, lane);
+      store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+      if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+    }
+    SYNC();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) geoB[b] = wload<PREC>(srs, lane * 16, scr + (b * 2 + 1) * FR);
+    m_hidden<PREC, 3, 4, true, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    SYNC();
+    for (int i = 0; i < 3; ++i) {
+      f32x16 bv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (8 + i) * 1024, t, lane);
+      store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      SYNC();
+      m_hidden<PREC, 0, 0, false, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+      SYNC();
+    }
+    {
+      oc[0] = bias_tile(wrs, bias_rg + 11 * 1024, 0, lane);
+      store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+    }
+    SYNC();
+    m_out<PREC, 0, 1, true>(oc, ring, cur, wrs, wvoff, hb, lane, blk);
+    SYNC();
+    prev = pass;
+  }
+  if (prev >= 0) composite(prev, oc[0], density);
+  if (g == 0) __syncthreads();  // group 0 takes its extra barrier at the end
+}
+
+// ================================================================================================ pack
+#if NA_PREC_INST == 0
+struct PackArgs {
+  const float* w_first[6];  // init, layers.0..3, out   (nn.Linear layout [out,in])
+  const float* b_first[6];
+  const float* w_view[6];
+  const float* b_view[6];
+};
+
+__host__ __device__ inline int phase_first_frag(int p) {
+  int s = 0;
+  for (int i = 0; i < p; ++i) s += 2 * phase_pairs(i);
+  return s;
+}
+
+// One thread per bf16 element of the hi plane of every fragment, plus the bias blocks.
+__global__ void pack_ls_kernel(PackArgs w, int planes, char* __restrict__ dst) {
+  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  const int frag_bytes = 1024 * planes;
+  const int64_t nfrag_rg = 2 * kPairsPerPass;
+  const int64_t nelem = 4 * nfrag_rg * 512;
+  const int64_t nbias = 4 * kNPhase * 256;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nelem + nbias; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nelem) {
+      const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+      const int64_t fg = i >> 9;
+      const int rg = (int)(fg / nfrag_rg);
+      int f = (int)(fg % nfrag_rg);
+      int p = 0;
+      while (f >= 2 * phase_pairs(p)) { f -= 2 * phase_pairs(p); ++p; }
+      const int kappa = 8 * (l >> 5) + e;
+      const bool view = p >= 6;
+      const NaMlpDesc& d = view ? d2 : d1;
+      const int lp = view ? p - 6 : p;  // 0 init, 1 skip layer, 2..4 hidden, 5 out
+      const float* W = view ? w.w_view[lp] : w.w_first[lp];
+      const int NIc = view ? 5 : 3;     // init chunks
+      const int dim_p = d.in_size + d.enc_dims + d.latent_size;
+      int row, col, in_dim, out_dim;
+      if (lp == 5) {  // out layer: fragment f = c*NT + j
+        const int NT = view ? 1 : 3;
+        const int c = f / NT, j = f % NT;
+        row = out_row_map(d, 32 * j + (l & 31));
+        col = 16 * c + pi_perm(kappa);
+        in_dim = kHidden; out_dim = d.out_size;
+      } else {
+        const int q = f >> 1, t = f & 1;
+        row = 32 * (2 * rg + t) + (l & 31);
+        out_dim = kHidden;
+        if (lp == 0) { col = init_slot_feature(d, q, kappa); in_dim = dim_p; }
+        else if (lp == 1) {
+          if (q < NIc) { col = init_slot_feature(d, q, kappa); if (col >= 0) col += kHidden; }
+          else col = 16 * (q - NIc) + pi_perm(kappa);
+          in_dim = kHidden + dim_p;
+        } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
+      }
+      float v = 0.f;
+      if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + ((int64_t)rg * nfrag_rg + (fg % nfrag_rg)) * frag_bytes + l * 16 + e * 2;
+      const __bf16 h = (__bf16)v;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
+      if (planes == 2) {
+        const __bf16 lo = (__bf16)(v - (float)h);
+        *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
+      }
+    } else {
+      const int64_t q = i - nelem;
+      const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
+      const bool view = p >= 6;
+      const NaMlpDesc& d = view ? d2 : d1;
+      const int lp = view ? p - 6 : p;
+      const float* B = view ? w.b_view[lp] : w.b_first[lp];
+      const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
+      const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v = 0.f;
+      if (lp == 5) {
+        const int row = slot < (view ? 1 : 3) ? out_row_map(d, 32 * slot + rin) : -1;
+        if (row >= 0 && row < d.out_size && B != nullptr) v = B[row];
+      } else if (slot < 2 && B != nullptr) {
+        v = B[32 * (2 * rg + slot) + rin];
+      }
+      *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
+    }
+  }
+}
+
+__global__ void pack_ls_header_kernel(uint32_t magic, uint32_t precision, uint32_t* __restrict__ dst) {
+  if (threadIdx.x == 0) { dst[0] = magic; dst[1] = precision; dst[2] = kPairsPerPass; dst[3] = kNPhase; }
+}
+
+#endif  // NA_PREC_INST == 0
+
+// per-device hipFuncSetAttribute bookkeeping (the attribute is per device, not per thread)
+template <int PREC>
+static int launch(Args& a, hipStream_t stream) {
+  using C = Cfg<PREC>;
+  auto kern = render_ls_kernel<PREC>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return NA_EHIP; }
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  a.npass = (int)((a.nitems + 2 * C::NBLK - 1) / (2 * C::NBLK));
+  const int grid = a.npass < 256 ? a.npass : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * C::GROUP, stream, a);
+  return check_launch("na_render_plain_view_ls");
+}
+
+}  // namespace ls
+
+#if NA_PREC_INST == 0
+int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_BF16>(a, s); }
+#else
+int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_BF16X3>(a, s); }
+#endif
+int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s);
+int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s);
+
+}  // namespace na
+
+#if NA_PREC_INST == 0
+using namespace na;
+
+extern "C" size_t na_render_ls_packed_bytes(int precision) {
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3) return 0;
+  return ls::packed_bytes(precision);
+}
+
+extern "C" int na_render_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                 const float* const* w_view, const float* const* b_view, void* packed, void* stream) {
+  NA_REQUIRE(w_first && b_first && w_view && b_view && packed, NA_ENULL, "na_render_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_render_ls_pack: precision %d",
+             precision);
+  ls::PackArgs w;
+  for (int i = 0; i < 6; ++i) {
+    NA_REQUIRE(w_first[i] && w_view[i], NA_ENULL, "na_render_ls_pack: weights[%d] is null", i);
+    w.w_first[i] = w_first[i]; w.b_first[i] = b_first[i];
+    w.w_view[i] = w_view[i]; w.b_view[i] = b_view[i];
+  }
+  const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
+  hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
+                     (uint32_t*)packed);
+  const int64_t total = 4 * 2 * (int64_t)ls::kPairsPerPass * 512 + 4 * ls::kNPhase * 256;
+  hipLaunchKernelGGL(ls::pack_ls_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, planes,
+                     (char*)packed);
+  return check_launch("na_render_ls_pack");
+}
+
+extern "C" size_t na_render_ls_workspace_bytes(int T, int64_t R) {
+  if (T < 1 || R < 0) return 0;
+  const int64_t nb = (T + 31) / 32;
+  return (size_t)(R * nb * ls::kPartialFloats * sizeof(float)) + 256 + 256 * (size_t)ls::Cfg<NA_PREC_BF16>::SCRATCH + 256 +
+         (NA_LS_TRACE ? 4096 : 0);
+}
+
+extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                                       const float* hash_tables, const void* packed, int precision, int sigmoid_kind,
+                                       int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;  // empty batch: a no-op before any pointer check (zero-size tensors carry null pointers)
+  NA_REQUIRE(rays && ts && hash_tables && packed && out && workspace, NA_ENULL, "na_render_plain_view_ls: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED,
+             "na_render_plain_view_ls: precision %d", precision);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_plain_view_ls: sigmoid %d",
+             sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_plain_view_ls: bg %d", bg_kind);
+  NA_REQUIRE(workspace_bytes >= na_render_ls_workspace_bytes(T, R), NA_EWORKSPACE,
+             "na_render_plain_view_ls: workspace %zu < %zu bytes", workspace_bytes, na_render_ls_workspace_bytes(T, R));
+  if (R == 0) return NA_OK;
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision);
+  a.alpha = alpha; a.weights = weights;
+  a.partials = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.R = R; a.T = T; a.nb = (T + 31) / 32; a.nitems = R * a.nb;
+  a.scratch = (char*)(((uintptr_t)(a.partials + a.nitems * ls::kPartialFloats) + 255) & ~(uintptr_t)255);
+  a.sigmoid_kind = sigmoid_kind;
+  a.res = hash_resolutions();
+  a.trace = NA_LS_TRACE ? (unsigned long long*)(a.scratch + 256 * (size_t)ls::Cfg<NA_PREC_BF16>::SCRATCH) : nullptr;
+  int rc = precision == NA_PREC_BF16 ? render_ls_dispatch_bf16(a, (hipStream_t)stream)
+                                     : render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
+  if (rc != NA_OK) return rc;
+  return launch_render_finalize(a.partials, R, a.nb, T, bg_kind, weights, out, (hipStream_t)stream);
+}
+#endif

@@ -157,15 +157,34 @@ class PlainNeRF(CommonNeRF):
                 and self.intermediate_size == 64 and self.refl.out_features == 3 and not self.training
                 and not wants_grad)
 
+    def packed_ls(self, precision: str):
+        """Weight stream of the layer-synchronous renderer (both MLPs in one buffer; cached, re-packed when any
+        parameter changed)."""
+        lin = self.first._linears() + self.refl.mlp._linears()
+        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        cache = self.__dict__.setdefault("_packed_ls", {})
+        hit = cache.get(precision)
+        if hit is None or hit[0] != stamp:
+            wb = lambda m: ([l.weight.data for l in m._linears()], [l.bias.data for l in m._linears()])
+            cache[precision] = (stamp, ops.render_ls_pack(precision, wb(self.first), wb(self.refl.mlp)))
+        return cache[precision][1]
+
+    def _render_fused(self, rays, ts, want_weights, pts=None):
+        """sample -> hash -> first -> elaz -> View -> sigmoid -> composite in ONE kernel (config.engine picks the
+        layer-synchronous engine or the register-resident one)."""
+        prec = config.precision
+        if config.engine == "ls":
+            return ops.render_plain_view_ls(rays, ts, self.first.enc.tables(), self.packed_ls(prec), prec,
+                                            self.sigmoid_kind, self.bg, want_weights, pts=pts)
+        _, pf = self.first.packed(prec, "plain_first")
+        _, pv = self.refl.mlp.packed(prec, "plain_view")
+        return ops.render_plain_view(rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self.bg,
+                                     want_weights, pts=pts)
+
     def forward(self, rays, want_weights: bool = True):
         if self._fusable():
-            # sample -> hash -> first -> elaz -> View -> sigmoid -> composite in ONE kernel
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
-            prec = config.precision
-            _, pf = self.first.packed(prec, "plain_first")
-            _, pv = self.refl.mlp.packed(prec, "plain_view")
-            out, self.alpha, self.weights = ops.render_plain_view(
-                rays, self.ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self.bg, want_weights)
+            out, self.alpha, self.weights = self._render_fused(rays, self.ts, want_weights)
             return out
         rand = None
         pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb(),
@@ -176,11 +195,7 @@ class PlainNeRF(CommonNeRF):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
         if self._fusable(refl_latent) and not ag.needs_grad(pts):
             # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
-            prec = config.precision
-            _, pf = self.first.packed(prec, "plain_first")
-            _, pv = self.refl.mlp.packed(prec, "plain_view")
-            out, self.alpha, self.weights = ops.render_plain_view(
-                rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self.bg, True, pts=pts.contiguous())
+            out, self.alpha, self.weights = self._render_fused(rays, ts, True, pts=pts.contiguous())
             return out
         latent = self.mip_encoding(rays, ts)
         first_out = self.first(pts, latent)

@@ -199,6 +199,8 @@ def normalize3(v: torch.Tensor) -> torch.Tensor:
 
 def pos_linear_combine(lin: torch.Tensor, pos: torch.Tensor, C_out: int) -> torch.Tensor:
     """(sigmoid(lin)/2 + 0.5) * pos[..., :C_out]; pos may be wider (its first C_out columns are used, by row pitch)."""
+    if torch.is_grad_enabled() and (lin.requires_grad or pos.requires_grad):
+        raise RuntimeError("ops.pos_linear_combine is not differentiable: go through autograd.PosLinearCombineFn")
     lib = _lib.load()
     lin = _f32(lin, "lin")
     pos2, ld = _rows(pos, pos.shape[-1], "pos")
@@ -207,6 +209,21 @@ def pos_linear_combine(lin: torch.Tensor, pos: torch.Tensor, C_out: int) -> torc
     out = torch.empty(tuple(lin.shape[:-1]) + (C_out,), device=lin.device, dtype=torch.float32)
     check(lib.na_pos_linear_combine(_ptr(lin), _ptr(pos2), ld, N, C_out, _ptr(out), _stream()))
     return out
+
+
+def pos_linear_combine_backward(lin: torch.Tensor, pos: torch.Tensor, g: torch.Tensor, C_out: int, want_lin=True,
+                                want_pos=True):
+    """Gradients of pos_linear_combine w.r.t. lin [...,1] and pos [...,W] (columns >= C_out get zeros)."""
+    lib = _lib.load()
+    lin, g = _f32(lin, "lin"), _f32(g, "g")
+    pos2, ld = _rows(pos, pos.shape[-1], "pos")
+    N = lin.numel()
+    g_lin = torch.empty_like(lin) if want_lin else None
+    g_pos = torch.empty(pos.shape, device=pos.device, dtype=torch.float32) if want_pos else None
+    check(lib.na_pos_linear_combine_backward(_ptr(lin), _ptr(pos2), ld, _ptr(g), N, C_out,
+                                             _ptr(g_lin) if want_lin else None, _ptr(g_pos) if want_pos else None,
+                                             pos.shape[-1], _stream()))
+    return g_lin, g_pos
 
 
 def laplace_density(sdf: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
@@ -507,4 +524,50 @@ def render_plain_view(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.T
     check(lib.na_render_plain_view(_ptr(rays), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed_first), _ptr(packed_view),
                                    PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out),
                                    _ptr(workspace), workspace.numel(), _stream()))
+    return out, alpha, weights
+
+
+def render_ls_pack(precision: str, first_wb, view_wb) -> torch.Tensor:
+    """Pack PlainNeRF.first and View.mlp ({init, layers.0..3, out} weights and biases each) into the weight stream of
+    the layer-synchronous renderer (na_render_ls_pack)."""
+    lib = _lib.load()
+    (w1, b1), (w2, b2) = first_wb, view_wb
+    assert len(w1) == 6 and len(w2) == 6, "the LS renderer is specialised for 4 hidden layers per MLP"
+    dev = w1[0].device
+    keep = [[_f32(w.detach(), "weight") for w in w1], [None if b is None else _f32(b.detach(), "bias") for b in b1],
+            [_f32(w.detach(), "weight") for w in w2], [None if b is None else _f32(b.detach(), "bias") for b in b2]]
+    shapes1 = [(256, 38), (256, 294), (256, 256), (256, 256), (256, 256), (65, 256)]
+    shapes2 = [(256, 69), (256, 325), (256, 256), (256, 256), (256, 256), (3, 256)]
+    for w, shp in zip(keep[0] + keep[2], shapes1 + shapes2):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS renderer: weight shape {tuple(w.shape)} != {shp}")
+    arrs = [(C.c_void_p * 6)(*[0 if t is None else t.data_ptr() for t in lst]) for lst in keep]
+    packed = torch.empty(int(lib.na_render_ls_packed_bytes(PREC[precision])), device=dev, dtype=torch.uint8)
+    check(lib.na_render_ls_pack(PREC[precision], arrs[0], arrs[1], arrs[2], arrs[3], _ptr(packed), _stream()))
+    return packed
+
+
+def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.Tensor, packed: torch.Tensor,
+                         precision: str, sigmoid_kind: str = "thin", bg: str = "black", want_weights: bool = False,
+                         workspace: Optional[torch.Tensor] = None, pts: Optional[torch.Tensor] = None):
+    """PlainNeRF(view) forward on the layer-synchronous engine (same contract as render_plain_view)."""
+    lib = _lib.load()
+    rays, ts, hash_tables = _f32(rays, "rays"), _f32(ts, "ts"), _f32(hash_tables, "hash_tables")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    nbytes = int(lib.na_render_ls_workspace_bytes(T, R))
+    if workspace is None:
+        workspace = torch.empty(nbytes, device=rays.device, dtype=torch.uint8)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3, (pts.shape, T, R)
+    check(lib.na_render_plain_view_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed),
+                                      PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights),
+                                      _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
     return out, alpha, weights

@@ -4,6 +4,7 @@ raise NotImplementedError (out of scope)."""
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .neural_blocks import HashEncoder, SkipConnMLP
 from .utils import load_sigmoid
@@ -93,7 +94,10 @@ class PosLinearView(Reflectance):
         intermediate = pos_all[..., self.out_features:]
         view_latent = intermediate if latent is None else torch.cat([latent, intermediate], dim=-1)
         raw = self.view(torch.cat([x, _normalize(view)], dim=-1), view_latent)
-        return ops.pos_linear_combine(raw, pos_all, self.out_features)  # (sigmoid(raw)/2 + 0.5) * pos_all[..., :out]
+        # (sigmoid(raw)/2 + 0.5) * pos_all[..., :out]
+        if ag.needs_grad(raw, pos_all):
+            return ag.PosLinearCombineFn.apply(raw, pos_all, self.out_features)
+        return ops.pos_linear_combine(raw, pos_all, self.out_features)
 
 
 def _out_of_scope(name):

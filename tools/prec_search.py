@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""CPU search for the cheapest MFMA operand format that keeps the fused renderer within 1e-4 L-inf of the fp32
+oracle.  Emulates operand rounding of every Linear in the oracle's PlainNeRF(view) forward
+(products of rounded operands are exact in fp32; accumulation stays fp32 like the MFMA accumulator) on the bench
+tile, random-init bench weights (seed 2).
+
+    python tools/prec_search.py [--hw 48] [--schemes f16,f16_x2w,...]
+
+Scheme grammar: a '+'-separated list of products "<xfmt>*<wfmt>", where a format is
+    f16 | bf16                    operand rounded to that type
+    f16lo | bf16lo                the residual (v - round(v)) rounded to the same type
+    e4m3 | e2m1 | e2m3 | e3m2     MX block format (32-element blocks along K, power-of-two scale) of the operand
+    e4m3lo(f16) ...               MX block format of the residual after f16 (or bf16) rounding
+"""
+import argparse
+import math
+import os
+import re
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def _grid_quant(v, grid):
+    """round |v| to the nearest value of the sorted positive grid (ties to the lower index: irrelevant here)"""
+    a = v.abs()
+    idx = torch.bucketize(a, grid)
+    idx = idx.clamp(1, len(grid) - 1)
+    lo, hi = grid[idx - 1], grid[idx]
+    q = torch.where(a - lo <= hi - a, lo, hi)
+    q = torch.where(a >= grid[-1], grid[-1], q)
+    return q * v.sign()
+
+
+def _fp_grid(ebits, mbits, bias, emax_clip=None, ieee_inf=False):
+    vals = {0.0}
+    for e in range(0, 2 ** ebits):
+        for m in range(0, 2 ** mbits):
+            if e == 0:
+                vals.add(m / 2 ** mbits * 2.0 ** (1 - bias))
+            else:
+                vals.add((1 + m / 2 ** mbits) * 2.0 ** (e - bias))
+    g = sorted(vals)
+    if emax_clip is not None:
+        g = [x for x in g if x <= emax_clip]
+    return torch.tensor(g, dtype=torch.float32)
+
+
+GRIDS = {
+    "e2m1": (_fp_grid(2, 1, 1), 2),            # max 6 = 1.5 * 2^2
+    "e2m3": (_fp_grid(2, 3, 1), 2),            # max 7.5
+    "e3m2": (_fp_grid(3, 2, 3), 4),            # max 28 = 1.75 * 2^4
+    "e4m3": (_fp_grid(4, 3, 7, emax_clip=448.0), 8),
+}
+
+
+def mx_quant(v, kind, block=32):
+    """OCP MX: per 32-element block along the last dim, scale = 2^(floor(log2(amax)) - emax_elem)."""
+    grid, emax = GRIDS[kind]
+    K = v.shape[-1]
+    pad = (-K) % block
+    vp = F.pad(v, (0, pad)) if pad else v
+    vb = vp.reshape(*vp.shape[:-1], -1, block)
+    amax = vb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp(min=1e-38))) - emax
+    s = torch.exp2(e)
+    q = _grid_quant(vb / s, grid) * s
+    q = q.reshape(vp.shape)
+    return q[..., :K] if pad else q
+
+
+def rnd(v, t):
+    return v.to(t).float()
+
+
+def fmt_apply(v, fmt):
+    m = re.fullmatch(r"(\w+?)lo\((\w+)\)", fmt)
+    if m:
+        base = {"f16": torch.float16, "bf16": torch.bfloat16}[m.group(2)]
+        return mx_quant(v - rnd(v, base), m.group(1))
+    if fmt in ("f16", "bf16"):
+        return rnd(v, torch.float16 if fmt == "f16" else torch.bfloat16)
+    if fmt in ("f16lo", "bf16lo"):
+        t = torch.float16 if fmt == "f16lo" else torch.bfloat16
+        return rnd(v - rnd(v, t), t)
+    if fmt == "f32":
+        return v
+    return mx_quant(v, fmt)
+
+
+class Scheme:
+    """spec = "<default products>[;<regex on the layer name>=<products>]..." (first matching override wins)"""
+
+    def __init__(self, spec, names=None):
+        self.spec = spec
+        parts = spec.split(";")
+        self.products = [tuple(p.split("*")) for p in parts[0].split("+")]
+        self.over = [(re.compile(a), [tuple(p.split("*")) for p in b.split("+")])
+                     for a, b in (q.split("=") for q in parts[1:])]
+        self.names = names or {}
+        self.wcache = {}
+
+    def linear(self, x, w, b):
+        y = None
+        xc = {}
+        prods = self.products
+        name = self.names.get(id(w), "?")
+        for rx, pr in self.over:
+            if rx.search(name):
+                prods = pr
+                break
+        for xf, wf in prods:
+            if xf not in xc:
+                xc[xf] = fmt_apply(x, xf)
+            key = (id(w), wf)
+            if key not in self.wcache:
+                self.wcache[key] = fmt_apply(w, wf)
+            t = xc[xf] @ self.wcache[key].t()
+            y = t if y is None else y + t
+        return y + b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hw", type=int, default=40)
+    ap.add_argument("--schemes", default="")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--weights", default="random", choices=["random", "procedural"])
+    args = ap.parse_args()
+    import bench
+    import oracle as O
+    import oracle.nerf_oracle as NO
+    model = bench.build_model("cpu", seed=args.seed)
+    params = {k: v.detach() for k, v in model.state_dict().items()}
+    if args.weights == "procedural":  # the weights of the reference goldens / the GPU parity tests (O(1) activations)
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from conftest import load_golden, golden_params
+        params = golden_params(load_golden("g11_plain_view_b1"))
+    focal = 0.5 * bench.SIZE / math.tan(0.5 * bench.FOV)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    hw = args.hw
+    crop = (bench.SIZE // 2 - hw // 2, bench.SIZE // 2 - hw // 2, hw, hw)
+    rays = O.nerf_camera_rays(O.pixel_grid(bench.SIZE, crop), c2w, focal, bench.SIZE)
+
+    def run():
+        return O.plain_nerf(params, rays, bench.NEAR, bench.FAR, bench.STEPS_PER_RAY, "view", act="upshifted")
+
+    ref = run()
+    names = {id(v): k for k, v in params.items()}
+    real_linear = F.linear
+    default = [
+        "bf16*bf16", "f16*f16",
+        "f16*f16+f16lo*f16", "f16*f16+f16*f16lo",
+        "f16*f16+f16lo*f16+f16*f16lo",
+        "bf16*bf16+bf16lo*bf16+bf16*bf16lo",
+        "f16*f16+e4m3lo(f16)*e4m3+e4m3*e4m3lo(f16)",
+        "f16*f16+e2m3lo(f16)*e2m3+e2m3*e2m3lo(f16)",
+        "f16*f16+e2m1lo(f16)*e2m1+e2m1*e2m1lo(f16)",
+        "f16*f16+e3m2lo(f16)*e3m2+e3m2*e3m2lo(f16)",
+    ]
+    schemes = [s for s in args.schemes.split(",") if s] or default
+    for spec in schemes:
+        sch = Scheme(spec, names)
+
+        class _F:  # the oracle calls F.linear; swap the module attribute for the run
+            pass
+        NO.F.linear = lambda x, w, b=None: sch.linear(x, w, b)
+        t0 = time.time()
+        try:
+            out = run()
+        finally:
+            NO.F.linear = real_linear
+        d = (out - ref).abs()
+        print(f"{spec:60s} Linf {d.max().item():.3e}  mean {d.mean().item():.3e}  p99.9 "
+              f"{d.flatten().kthvalue(int(0.999 * d.numel())).values.item():.3e}  ({time.time() - t0:.1f}s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

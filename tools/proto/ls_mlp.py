@@ -24,9 +24,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libls_proto.so")
 
 
-def build(variant="w8s", ablate=0):
+def build(variant="w8s", ablate=0, *extra):
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared",
-                    f"-DLS_ABLATE={ablate}", os.path.join(HERE, f"ls_mlp_{variant}.hip"), "-o", LIB], check=True)
+                    f"-DLS_ABLATE={ablate}", *extra, os.path.join(HERE, f"ls_mlp_{variant}.hip"), "-o", LIB], check=True)
+    with open(LIB + ".variant", "w") as f:
+        f.write(variant)
     print(LIB)
 
 
@@ -44,7 +46,25 @@ def pack_rows(W, row0):
     return out
 
 
-def run(L=6):
+def pack_rows_perm(W, row0):
+    """Like pack_rows, for the w8g variant: the k order inside chunk 2*tile+q is the producer's accumulator register
+    order (lane half h, element e -> feature 32*tile + (r&3) + 8*(r>>2) + 4*h with r = 8*q + e)."""
+    import torch
+    K = W.shape[1]
+    lanes = torch.arange(64)
+    rows = row0 + (lanes & 31)
+    h = lanes >> 5
+    out = torch.empty(K // 16, 64, 8, dtype=torch.bfloat16)
+    for c in range(K // 16):
+        tile, q = c >> 1, c & 1
+        for e in range(8):
+            r = 8 * q + e
+            cols = 32 * tile + (r & 3) + 8 * (r >> 2) + 4 * h
+            out[c, :, e] = W[rows, cols].to(torch.bfloat16)
+    return out
+
+
+def run(L=6, perm=False):
     import torch
     torch.manual_seed(0)
     dev = "cuda"
@@ -54,8 +74,13 @@ def run(L=6):
     Wo = torch.randn(32, 256) * (1 / 256) ** 0.5
     bi, bh, bo = torch.randn(256) * 0.1, torch.randn(L, 256) * 0.1, torch.randn(32) * 0.1
     w_init = torch.stack([pack_rows(Wi, 32 * w) for w in range(8)]).contiguous().to(dev)
-    w_hid = torch.stack([torch.stack([pack_rows(Wh[l], 32 * w) for w in range(8)]) for l in range(L)]).contiguous().to(dev)
-    w_out = pack_rows(Wo, 0).contiguous().to(dev)
+    pk = pack_rows_perm if perm else pack_rows
+    w_hid = torch.stack([torch.stack([pk(Wh[l], 32 * w) for w in range(8)]) for l in range(L)]).contiguous().to(dev)
+    w_out = pk(Wo, 0).contiguous().to(dev)
+    if perm:  # w8g: one weight buffer, the out layer stored as layer L / tile 0
+        pad = torch.zeros(1, 8, 16, 64, 8, dtype=torch.bfloat16, device=dev)
+        pad[0, 0] = w_out
+        w_hid = torch.cat([w_hid, pad]).contiguous()
     x = torch.randn(N, 16, device=dev)
     y = torch.empty(N, 32, device=dev)
     lib = C.CDLL(LIB)
@@ -84,10 +109,23 @@ def run(L=6):
     e1.record(); torch.cuda.synchronize()
     dt = e0.elapsed_time(e1) / 10 * 1e-3
     flop = 2 * (16 * 256 + L * 256 * 256 + 256 * 32)
+    if perm and hasattr(lib, "ls_mlp_forward_trace"):
+        tr = torch.zeros(2 * 5 * 64, dtype=torch.int64, device=dev)
+        ft = lib.ls_mlp_forward_trace
+        ft.argtypes = fn.argtypes + [C.c_void_p]
+        ft(*args, tr.data_ptr())
+        torch.cuda.synchronize()
+        t = tr.cpu().reshape(2, 5, 64)[:, :, 2:L - 1].double()
+        for g in range(2):
+            E, bw1, M, bw2 = (t[g, 1] - t[g, 0]).mean(), (t[g, 2] - t[g, 1]).mean(), (t[g, 3] - t[g, 2]).mean(), (t[g, 4] - t[g, 3]).mean()
+            per = (t[g, 0, 1:] - t[g, 0, :-1]).mean()
+            print(f"  trace group {g}: E {E:.0f}  wait {bw1:.0f}  M {M:.0f}  wait {bw2:.0f}  period {per:.0f} (s_memtime ticks, 100 MHz?)")
     print(f"L={L}: {dt * 1e3:.2f} ms for {N} samples = {N / dt / 1e6:.0f} Msamples/s, {N * flop / dt / 1e12:.0f} TFLOP/s "
           f"= {N * flop / dt / 2.5e15:.1%} of the bf16 MFMA peak")
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "build": build(*(sys.argv[2:3] or ["w8s"]), *(int(x) for x in sys.argv[3:4]))
-    else: run(int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    if sys.argv[1] == "build": build(*(sys.argv[2:3] or ["w8s"]), *(int(x) for x in sys.argv[3:4]), *sys.argv[4:])
+    else:
+        variant = open(LIB + ".variant").read().strip() if os.path.exists(LIB + ".variant") else ""
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 6, perm=variant.startswith("w8g"))
