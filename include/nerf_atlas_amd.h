@@ -235,6 +235,30 @@ int na_render_plain_view_pts(const float* rays, const float* pts, int64_t R, con
  *                      g_rigidity [N] (null = zero) (src/nerf.py:1173-1178,1201-1206,1267-1278).
  * na_composite_backward    gradient of na_composite w.r.t. density [T,R] and feat [T,R,C] (C = 1 or 3)
  *                      given g_out [R,C] (src/nerf.py:60-80,96-98).                              */
+ /* Deterministic accumulation.  The gradients summed across workgroups (dW/db of the two na_linear_wgrad* kernels,
+ * the hash-table scatter, d/dbeta of the Laplace density) use fp32 atomics by default: fast, but the rounding depends
+ * on the arrival order, so two runs differ in the last bits (and a chaotic training trajectory such as D-NeRF's
+ * diverges from there).  After na_set_deterministic(ws, bytes) -- a caller-owned device buffer of at least
+ * 8 * (largest accumulated output) bytes = 16 MiB for the hash tables -- those operators accumulate in 64-bit fixed
+ * point (2^-40 resolution): integer addition is associative, so results are bitwise reproducible.  The setting is
+ * process-wide (autograd engines call the backward operators from their own threads); the workspace is used by one
+ * operator at a time, in stream order, so all deterministic work must share one stream.  NULL switches it off.       */
+int na_set_deterministic(void* workspace, size_t bytes);
+
+/* Forward-mode tangents for SDF normals and the eikonal regulariser (src/sdf.py:43,108, runner.py:685-692,
+ * src/utils.py:31): d sdf / d x is propagated forward through the MLP as three tangent rows per sample,
+ * t_{l+1} = W_l . (act'(z_l) * t_l), so the loss on the normals is a first-order graph of the operators below plus
+ * na_linear_*; no double backward is needed.
+ * na_act_deriv          out = act'(x) (order 1) or act''(x) (order 2) for NA_ACT_* (leaky: 0.01|1, 0; sin: cos, -sin).
+ * na_mul_bcast          out[j,i] = a[i] * b[j,i], a [n], b/out [J,n]: one multiplier row shared by J tangent rows.
+ * na_mul_reduce         out[i] = sum_j g[j,i] * b[j,i] (gradient of na_mul_bcast w.r.t. a).
+ * na_eikonal_loss       loss[0] += mean_n (|normals[:,n]| - 1)^2, normals [3,N] tangent-major; loss zeroed by caller.
+ * na_eikonal_loss_backward  g_normals [3,N] = g[0] * d loss / d normals.                                          */
+int na_act_deriv(const float* x, int64_t n, int act, int order, float* out, void* stream);
+int na_mul_bcast(const float* a, const float* b, int64_t n, int J, float* out, void* stream);
+int na_mul_reduce(const float* g, const float* b, int64_t n, int J, float* out, void* stream);
+int na_eikonal_loss(const float* normals, int64_t N, float* loss, void* stream);
+int na_eikonal_loss_backward(const float* normals, int64_t N, const float* g, float* g_normals, void* stream);
 int na_act_backward(const float* x, const float* g, int64_t n, int act, float* out, void* stream);
 int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, float* out, void* stream);
 int na_pos_linear_combine_backward(const float* lin, const float* pos, int64_t pos_ld, const float* g, int64_t N, int C,

@@ -61,6 +61,12 @@ SIGNATURES = {
                                         C.c_void_p]),
     "na_bisection_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                       C.c_void_p, C.c_void_p]),
+    "na_set_deterministic": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "na_act_deriv": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "na_mul_bcast": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_mul_reduce": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_eikonal_loss": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
+    "na_eikonal_loss_backward": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),
     "na_act_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_sigmoid_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_pos_linear_combine_backward": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_i64,

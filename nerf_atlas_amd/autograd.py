@@ -136,6 +136,54 @@ class PosLinearCombineFn(Function):
         return g_lin, g_pos, None
 
 
+class ActDerivFn(Function):
+    """m = act'(x) as a differentiable node (its own derivative is act''(x): -sin for sin, 0 for LeakyReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.act = act
+        ctx.save_for_backward(x)
+        return ops.act_deriv(x, act, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        if ctx.act != "sin":
+            return torch.zeros_like(x), None
+        return ops.mul_bcast(ops.act_deriv(x, ctx.act, 2), g.contiguous().unsqueeze(0)).squeeze(0), None
+
+
+class MulBcastFn(Function):
+    """out[j] = a * b[j]: the multiplier row a [N,K] is shared by the J tangent rows b [J,N,K]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.mul_bcast(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = ops.mul_reduce(g, b) if ctx.needs_input_grad[0] else None
+        gb = ops.mul_bcast(a, g) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+class EikonalFn(Function):
+    """utils.eikonal_loss (src/utils.py:31) on tangent-major normals [3, N]."""
+
+    @staticmethod
+    def forward(ctx, normals):
+        ctx.save_for_backward(normals)
+        return ops.eikonal_loss(normals)
+
+    @staticmethod
+    def backward(ctx, g):
+        (normals,) = ctx.saved_tensors
+        return ops.eikonal_loss_backward(normals, g.contiguous())
+
+
 class CompositeFn(Function):
     """alpha_from_density + volumetric_integrate + sky (src/nerf.py:60-80,96-98).  Returns (out, alpha, weights);
     alpha/weights are auxiliary (non-differentiable) outputs."""

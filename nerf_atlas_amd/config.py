@@ -35,3 +35,28 @@ def set_engine(e: str):
     if e not in ("ls", "reg"):
         raise ValueError(e)
     engine = e
+
+
+# Reproducible training: gradients summed across workgroups (weight/bias gradients, hash-table scatter, d/dbeta)
+# accumulate in 64-bit fixed point instead of fp32 atomics (na_set_deterministic): bitwise run-to-run reproducibility
+# at ~the same speed.  Off by default (the fp32 atomics are the reference-like fast path).
+_det_ws = None
+
+
+def set_deterministic(on: bool, device="cuda"):
+    """Process-wide.  Keeps a 16-MiB device workspace alive while on."""
+    global _det_ws
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    if on:
+        if _det_ws is None or str(_det_ws.device) != str(torch.device(device)):
+            _det_ws = torch.empty(8 * 65536 * 4 * 8 + 4096, device=device, dtype=torch.uint8)
+        _lib.check(lib.na_set_deterministic(_det_ws.data_ptr(), _det_ws.numel()))
+    else:
+        _lib.check(lib.na_set_deterministic(None, 0))
+        _det_ws = None
+
+
+def deterministic() -> bool:
+    return _det_ws is not None

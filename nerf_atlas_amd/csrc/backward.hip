@@ -27,6 +27,62 @@ __global__ void act_backward_kernel(const float* __restrict__ x, const float* __
     out[i] = g[i] * act_grad(x[i], act);
 }
 
+// ------------------------------------------------------------------------------------ forward-mode tangents
+// SDF normals d sdf / d x (src/sdf.py:43,108) are propagated FORWARD through the MLP, three tangent rows per sample
+// next to the value row: t_{l+1} = W_l . (act'(z_l) * t_l).  That keeps the eikonal term (runner.py:685-692) a
+// first-order graph of Linear / multiply / act' nodes, so its gradient w.r.t. the weights needs no double backward.
+__device__ __forceinline__ float act_deriv(float v, int act, int order) {  // order 1: act', order 2: act''
+  if (act == NA_ACT_SIN) return order == 1 ? cosf(v) : -sinf(v);
+  if (act == NA_ACT_LEAKY_RELU) return order == 1 ? (v > 0.f ? 1.f : 0.01f) : 0.f;
+  return order == 1 ? 1.f : 0.f;
+}
+__global__ void act_deriv_kernel(const float* __restrict__ x, int64_t n, int act, int order, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = act_deriv(x[i], act, order);
+}
+// out[j, i] = a[i] * b[j, i]   (a [n], b / out [J, n]: one multiplier row shared by the J tangent rows)
+__global__ void mul_bcast_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int J,
+                                 float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * J; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i % n] * b[i];
+}
+// out[i] = sum_j g[j, i] * b[j, i]   (gradient of mul_bcast w.r.t. the shared row; j summed in order)
+__global__ void mul_reduce_kernel(const float* __restrict__ g, const float* __restrict__ b, int64_t n, int J,
+                                  float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < J; ++j) s = s + g[(int64_t)j * n + i] * b[(int64_t)j * n + i];
+    out[i] = s;
+  }
+}
+// eikonal_loss(normals) = mean((|n| - 1)^2) over N rows of 3 (src/utils.py:31); n stored [3, N] (tangent-major)
+__global__ __launch_bounds__(256) void eikonal_kernel(const float* __restrict__ nrm, int64_t N, float inv_n,
+                                                      float* __restrict__ loss, long long* __restrict__ fix) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = nrm[i], y = nrm[N + i], z = nrm[2 * N + i];
+    const float d = sqrtf((x * x + y * y) + z * z) - 1.f;
+    acc += d * d;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) accumulate(loss, fix, 0, ((part[0] + part[1]) + (part[2] + part[3])) * inv_n);
+}
+// d loss / d n = g * 2 (|n| - 1) / |n| * n / N
+__global__ void eikonal_backward_kernel(const float* __restrict__ nrm, int64_t N, const float* __restrict__ g,
+                                        float inv_n, float* __restrict__ g_n) {
+  const float gs = g[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = nrm[i], y = nrm[N + i], z = nrm[2 * N + i];
+    const float len = sqrtf((x * x + y * y) + z * z);
+    const float c = len > 0.f ? gs * 2.f * (len - 1.f) / len * inv_n : 0.f;
+    g_n[i] = c * x; g_n[N + i] = c * y; g_n[2 * N + i] = c * z;
+  }
+}
+
 __device__ __forceinline__ float sigmoid_kind_grad(float v, int kind) {
   const float s = sigmoidf_(v);
   switch (kind) {
@@ -61,7 +117,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
                                                            const float* __restrict__ x1, int in1, int64_t N,
                                                            const float* __restrict__ dY, int out, int act,
                                                            int64_t slice, float* __restrict__ dW,
-                                                           float* __restrict__ db) {
+                                                           float* __restrict__ db, long long* __restrict__ fixW,
+                                                           long long* __restrict__ fixb) {
   __shared__ float Ys[WG_N * WG_LD];  // [n][o]
   __shared__ float Xs[WG_N * WG_LD];  // [n][k]
   const int in = in0 + in1;
@@ -108,10 +165,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (o < out) atomicAdd(&dW[(int64_t)o * in + k], acc[r]);
+      if (o < out) accumulate(dW, fixW, (int64_t)o * in + k, acc[r]);
     }
   }
-  if (db != nullptr && blockIdx.y == 0 && tid < WG_O && o0 + tid < out) atomicAdd(&db[o0 + tid], bsum);
+  if (db != nullptr && blockIdx.y == 0 && tid < WG_O && o0 + tid < out) accumulate(db, fixb, o0 + tid, bsum);
 }
 
 // ------------------------------------------------------------------------------------ hash encoder backward
@@ -130,11 +187,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restrict__ x, int64_t N,
                                                             const float* __restrict__ g_out, int include_input,
-                                                            HashRes res, float* __restrict__ tables_grad) {
+                                                            HashRes res, float* __restrict__ tables_grad,
+                                                            long long* __restrict__ fix) {
   const int odim = 32 + 3 * include_input;
   const int lvl = blockIdx.y;
   const float Nl = res.n[lvl];
   float* tab = tables_grad + (int64_t)lvl * 65536 * 4;
+  long long* ftab = fix != nullptr ? fix + (int64_t)lvl * 65536 * 4 : nullptr;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t rounds = (N + stride - 1) / stride;
   for (int64_t it = 0; it < rounds; ++it) {
@@ -167,14 +226,16 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
         const float s0 = wave_sum(mine ? a0 : 0.f), s1 = wave_sum(mine ? a1 : 0.f);
         const float s2 = wave_sum(mine ? a2 : 0.f), s3 = wave_sum(mine ? a3 : 0.f);
         if ((int)(threadIdx.x & 63) == leader) {
-          float* t = tab + (int64_t)lid * 4;
-          atomicAdd(t + 0, s0); atomicAdd(t + 1, s1); atomicAdd(t + 2, s2); atomicAdd(t + 3, s3);
+          const int64_t t = (int64_t)lid * 4;
+          accumulate(tab, ftab, t + 0, s0); accumulate(tab, ftab, t + 1, s1);
+          accumulate(tab, ftab, t + 2, s2); accumulate(tab, ftab, t + 3, s3);
         }
         todo = todo && !mine;
       }
       if (todo) {
-        float* t = tab + (int64_t)id * 4;
-        atomicAdd(t + 0, a0); atomicAdd(t + 1, a1); atomicAdd(t + 2, a2); atomicAdd(t + 3, a3);
+        const int64_t t = (int64_t)id * 4;
+        accumulate(tab, ftab, t + 0, a0); accumulate(tab, ftab, t + 1, a1);
+        accumulate(tab, ftab, t + 2, a2); accumulate(tab, ftab, t + 3, a3);
       }
     }
   }
@@ -241,7 +302,8 @@ __global__ __launch_bounds__(256) void laplace_density_backward_kernel(const flo
                                                                        const float* __restrict__ beta,
                                                                        const float* __restrict__ g,
                                                                        float* __restrict__ g_sdf,
-                                                                       float* __restrict__ g_beta) {
+                                                                       float* __restrict__ g_beta,
+                                                                       long long* __restrict__ fix) {
   __shared__ float part[4];
   const float sc = beta[0];
   const float r = 1.0f / sc, r2 = r * r;
@@ -259,7 +321,7 @@ __global__ __launch_bounds__(256) void laplace_density_backward_kernel(const flo
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(g_beta, (part[0] + part[1]) + (part[2] + part[3]));
+  if (threadIdx.x == 0) accumulate(g_beta, fix, 0, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 // ------------------------------------------------------------------------------------ spline warp
@@ -399,6 +461,50 @@ int na_sigmoid_backward(const float* x, const float* g, int64_t n, int kind, flo
   return check_launch("na_sigmoid_backward");
 }
 
+int na_act_deriv(const float* x, int64_t n, int act, int order, float* out, void* stream) {
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(x && out, NA_ENULL, "na_act_deriv: null pointer");
+  NA_REQUIRE(n > 0 && (order == 1 || order == 2) && act >= NA_ACT_NONE && act <= NA_ACT_SIN, NA_EINVAL, "na_act_deriv: bad argument");
+  hipLaunchKernelGGL(act_deriv_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, n, act, order, out);
+  return check_launch("na_act_deriv");
+}
+
+int na_mul_bcast(const float* a, const float* b, int64_t n, int J, float* out, void* stream) {
+  if (n == 0 || J == 0) return NA_OK;
+  NA_REQUIRE(a && b && out, NA_ENULL, "na_mul_bcast: null pointer");
+  NA_REQUIRE(n > 0 && J > 0, NA_EINVAL, "na_mul_bcast: bad shape");
+  hipLaunchKernelGGL(mul_bcast_kernel, dim3(grid_for(n * J, 256, 16384)), dim3(256), 0, (hipStream_t)stream, a, b, n, J, out);
+  return check_launch("na_mul_bcast");
+}
+
+int na_mul_reduce(const float* g, const float* b, int64_t n, int J, float* out, void* stream) {
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(g && b && out, NA_ENULL, "na_mul_reduce: null pointer");
+  NA_REQUIRE(n > 0 && J > 0, NA_EINVAL, "na_mul_reduce: bad shape");
+  hipLaunchKernelGGL(mul_reduce_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, g, b, n, J, out);
+  return check_launch("na_mul_reduce");
+}
+
+int na_eikonal_loss(const float* normals, int64_t N, float* loss, void* stream) {
+  NA_REQUIRE(normals && loss, NA_ENULL, "na_eikonal_loss: null pointer");
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_eikonal_loss: N=%lld", (long long)N);
+  int rc;
+  long long* fix = det_begin(1, (hipStream_t)stream, "na_eikonal_loss", &rc);
+  if (rc != NA_OK) return rc;
+  hipLaunchKernelGGL(eikonal_kernel, dim3(grid_for(N, 256, 1024)), dim3(256), 0, (hipStream_t)stream, normals, N,
+                     1.0f / (float)N, loss, fix);
+  if (fix != nullptr) return det_finish(fix, 1, loss, (hipStream_t)stream, "na_eikonal_loss");
+  return check_launch("na_eikonal_loss");
+}
+
+int na_eikonal_loss_backward(const float* normals, int64_t N, const float* g, float* g_normals, void* stream) {
+  NA_REQUIRE(normals && g && g_normals, NA_ENULL, "na_eikonal_loss_backward: null pointer");
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_eikonal_loss_backward: N=%lld", (long long)N);
+  hipLaunchKernelGGL(eikonal_backward_kernel, dim3(grid_for(N, 256, 4096)), dim3(256), 0, (hipStream_t)stream, normals, N, g,
+                     1.0f / (float)N, g_normals);
+  return check_launch("na_eikonal_loss_backward");
+}
+
 int na_pos_linear_combine_backward(const float* lin, const float* pos, int64_t pos_ld, const float* g, int64_t N, int C,
                                    float* g_lin, float* g_pos, int64_t gpos_ld, void* stream) {
   if (N == 0) return NA_OK;
@@ -427,8 +533,17 @@ int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t 
   int64_t nz = (N + slice - 1) / slice;
   NA_REQUIRE(nz <= 65535, NA_EINVAL, "na_linear_wgrad: N too large");
   dim3 grid((out + WG_O - 1) / WG_O, (in + WG_I - 1) / WG_I, (unsigned)nz);
+  int rc;
+  const size_t nW = (size_t)out * in, nfix = nW + (db ? out : 0);
+  long long* fix = det_begin(nfix, (hipStream_t)stream, "na_linear_wgrad", &rc);
+  if (rc != NA_OK) return rc;
   hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x0, in0, x1, in1, N, dY, out, pre_act,
-                     slice, dW, db);
+                     slice, dW, db, fix, fix ? fix + nW : nullptr);
+  if (fix != nullptr) {
+    if ((rc = det_finish(fix, nW, dW, (hipStream_t)stream, "na_linear_wgrad")) != NA_OK) return rc;
+    if (db != nullptr) return det_finish(fix + nW, (size_t)out, db, (hipStream_t)stream, "na_linear_wgrad");
+    return NA_OK;
+  }
   return check_launch("na_linear_wgrad");
 }
 
@@ -437,8 +552,13 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
   if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(x && g_out && tables_grad, NA_ENULL, "na_hash_encode_backward: null pointer");
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  int rc;
+  const size_t ntab = (size_t)8 * 65536 * 4;
+  long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_backward", &rc);
+  if (rc != NA_OK) return rc;
   hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
-                     g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad);
+                     g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix);
+  if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_backward");
   return check_launch("na_hash_encode_backward");
 }
 
@@ -457,8 +577,12 @@ int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, 
   if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
   NA_REQUIRE(sdf && beta && g && g_sdf, NA_ENULL, "na_laplace_density_backward: null pointer");
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  int rc;
+  long long* fix = g_beta != nullptr ? det_begin(1, (hipStream_t)stream, "na_laplace_density_backward", &rc) : (rc = NA_OK, nullptr);
+  if (rc != NA_OK) return rc;
   hipLaunchKernelGGL(laplace_density_backward_kernel, dim3(grid_for(N, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     sdf, N, beta, g, g_sdf, g_beta);
+                     sdf, N, beta, g, g_sdf, g_beta, fix);
+  if (fix != nullptr) return det_finish(fix, 1, g_beta, (hipStream_t)stream, "na_laplace_density_backward");
   return check_launch("na_laplace_density_backward");
 }
 

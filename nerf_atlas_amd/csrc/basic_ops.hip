@@ -9,6 +9,38 @@ namespace na {
 
 static thread_local char g_err[512] = "";
 
+static DetWs g_det = {nullptr, 0};  // process-wide: autograd runs backward kernels on its own threads
+DetWs det_workspace() { return g_det; }
+
+__global__ void det_fold_kernel(const long long* __restrict__ fix, int64_t n, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long v = fix[i];
+    if (v != 0) out[i] = out[i] + (float)((double)v * (1.0 / 1099511627776.0));
+  }
+}
+
+// zeroed int64 accumulator for n outputs, or nullptr (rc = NA_OK: mode off; rc != NA_OK: workspace too small)
+long long* det_begin(size_t n, hipStream_t stream, const char* who, int* rc) {
+  *rc = NA_OK;
+  if (g_det.ptr == nullptr) return nullptr;
+  if (g_det.bytes < n * sizeof(long long)) {
+    set_error("%s: deterministic workspace %zu < %zu bytes (na_set_deterministic)", who, g_det.bytes, n * sizeof(long long));
+    *rc = NA_EWORKSPACE;
+    return nullptr;
+  }
+  if (hipMemsetAsync(g_det.ptr, 0, n * sizeof(long long), stream) != hipSuccess) {
+    set_error("%s: hipMemsetAsync failed", who);
+    *rc = NA_EHIP;
+    return nullptr;
+  }
+  return g_det.ptr;
+}
+
+int det_finish(const long long* fix, size_t n, float* out, hipStream_t stream, const char* who) {
+  hipLaunchKernelGGL(det_fold_kernel, dim3(grid_for((int64_t)n, 256, 4096)), dim3(256), 0, stream, fix, (int64_t)n, out);
+  return check_launch(who);
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -432,6 +464,13 @@ using namespace na;
 extern "C" {
 
 int na_version(void) { return NA_VERSION; }
+
+int na_set_deterministic(void* workspace, size_t bytes) {
+  NA_REQUIRE(workspace == nullptr || ((uintptr_t)workspace % 8 == 0 && bytes >= 8), NA_EINVAL,
+             "na_set_deterministic: workspace must be 8-byte aligned");
+  na::g_det = {(long long*)workspace, workspace ? bytes : 0};
+  return NA_OK;
+}
 const char* na_last_error(void) { return na::g_err; }
 
 int na_raygen(const float* c2w, int B, float focal, int size, int crop_t, int crop_l, int crop_h, int crop_w,

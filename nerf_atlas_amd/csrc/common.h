@@ -34,12 +34,28 @@ inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
   return (unsigned)g;
 }
 
+// Deterministic accumulation (na_set_deterministic): gradients that are summed across workgroups go through 64-bit
+// FIXED-POINT atomics (2^-40 resolution, +-8.4e6 range) instead of fp32 atomics: integer addition is associative, so
+// the result is bitwise independent of the order in which workgroups arrive.  The int64 accumulator lives in a caller
+// workspace that the entry point zeroes, fills and folds into the fp32 output (det_begin / det_finish).
+constexpr float kFixScale = 1099511627776.0f;  // 2^40
+struct DetWs { long long* ptr; size_t bytes; };
+DetWs det_workspace();  // {nullptr, 0} when the deterministic mode is off (basic_ops.hip)
+long long* det_begin(size_t n, hipStream_t stream, const char* who, int* rc);
+int det_finish(const long long* fix, size_t n, float* out, hipStream_t stream, const char* who);
+
 // Python-double level resolutions of the reference hash encoder (src/neural_blocks.py:126-128,146):
 // N_l = 16 * exp((ln 16384 - ln 16)/8 - 1)^l, then cast to fp32 when multiplied with the fp32 input.
 struct HashRes { float n[8]; };
 HashRes hash_resolutions();
 
 // ---- device helpers ---------------------------------------------------------------------------
+// out[idx] += v: fp32 atomic (fast, order-dependent rounding) or fixed-point atomic (deterministic)
+__device__ __forceinline__ void accumulate(float* out, long long* fix, int64_t idx, float v) {
+  if (fix != nullptr) atomicAdd((unsigned long long*)(fix + idx), (unsigned long long)__float2ll_rn(v * kFixScale));
+  else atomicAdd(out + idx, v);
+}
+
 __device__ __forceinline__ float leaky_relu(float v) { return v > 0.f ? v : v * 0.01f; }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }

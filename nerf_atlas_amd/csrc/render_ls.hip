@@ -34,7 +34,6 @@
 #ifndef NA_LS_TRACE
 #define NA_LS_TRACE 0
 #endif
-
 namespace na {
 
 int launch_render_finalize(const float* partials, int64_t R, int nb, int T, int bg_kind, float* weights, float* out,
@@ -95,14 +94,15 @@ struct Args {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-template <int PREC>
+template <int PREC, int AUX = 0>
 __device__ __forceinline__ Frag<PREC> wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
   Frag<PREC> f;
-  f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
   if constexpr (PREC == NA_PREC_BF16X3)
-    f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024, 0));
+    f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024, AUX));
   return f;
 }
+
 
 template <int PREC>
 __device__ __forceinline__ Frag<PREC> fread(const char* p) {
@@ -147,6 +147,8 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
                                          const Frag<PREC> (&geoB)[Cfg<PREC>::NBLK]) {
   constexpr int NB = Cfg<PREC>::NBLK, FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
   constexpr int NCH = NI + (GEO ? 1 : 0) + NH;
+  // the partner wave on this SIMD is in a VALU-dense epilogue: MFMA issue must win the arbitration
+  __builtin_amdgcn_s_setprio(1);
   Frag<PREC> Bq[2][NB];
   auto bsrc = [&](int q, int b) -> Frag<PREC> {
     if (q < NI) return fread<PREC>(ib + (b * 4 + q) * FR + lane * 16);
@@ -177,6 +179,7 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  __builtin_amdgcn_s_setprio(0);
   cur += NCH;
 }
 
@@ -185,6 +188,7 @@ template <int PREC, int RING0, int NT, bool WRAP>
 __device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2], int& cur, __amdgpu_buffer_rsrc_t rs,
                                       int wvoff, const char* hb, int lane, int blk) {
   constexpr int FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
+  __builtin_amdgcn_s_setprio(1);
   Frag<PREC> Bq[2];
   const char* src = hb + blk * 16 * FR + lane * 16;
   Bq[0] = fread<PREC>(src);
@@ -206,15 +210,16 @@ __device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  __builtin_amdgcn_s_setprio(0);
   cur += NT * 8;
 }
 
 // ---- epilogue of a 256-row Linear: act(acc) -> the group's hidden fragments in LDS (in place)
-template <int PREC, int ACT>
+template <int PREC, int ACT, int T0 = 0, int T1 = 2>
 __device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][Cfg<PREC>::NBLK], char* hb, int rg, int lane) {
   constexpr int NB = Cfg<PREC>::NBLK, FR = Cfg<PREC>::FRAG;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = T0; t < T1; ++t)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       Frag<PREC> f0, f1;
@@ -348,6 +353,22 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #else
 #define SYNC() __syncthreads()
 #endif
+  f32x16 acc[2][NB];
+  // One hash level (4*hi + k) of a sample -> bytes 8*(k&1)..+7 of this lane's 16 B of init chunk k>>1 (LDS).
+  auto hash_finish = [&](int k, const HashGather& hg) {
+    float f[4];
+    hash_level_finish(hg, f);
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (__bf16)f[e];
+      l[e] = (__bf16)(f[e] - (float)h[e]);
+    }
+    char* dst = ib + (blk * 4 + (k >> 1)) * FR + lane * 16 + (k & 1) * 8;
+    *(bf16x4*)dst = h;
+    if constexpr (PREC == NA_PREC_BF16X3) *(bf16x4*)(dst + 1024) = l;
+  };
   Frag<PREC> ring[kPF][2];
 #pragma unroll
   for (int p = 0; p < kPF; ++p) {
@@ -358,7 +379,6 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) geoB[b] = ring[0][0];  // defined value; only phases 6 and 7 read it
 
-  f32x16 acc[2][NB];
   f32x16 oc[1];
   float density = 0.f;
   int prev = -1;
@@ -370,19 +390,30 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     ton = pass == (int)blockIdx.x + (int)gridDim.x;
 #endif
     // ================= EP: compositing of the previous pass, hash encoder of this one
-    if (prev >= 0) composite(prev, oc[0], density);
-    if (owner) {
+    // All 4 x 8 table gathers of this lane half are issued FIRST (the accumulators are dead here, so 128 registers are
+    // free): the gathers are TA-bound (64 distinct 128-B lines per instruction, 8 MiB of tables) and a dependent round
+    // costs ~2-3k cycles under load -- one round, with the compositing of the previous pass in its shadow, instead of
+    // four.  (Spreading the levels over the epilogues of the other layers was measured slower: every gathering wave
+    // stalls ~3k cycles per round and the epilogues have ~1.8k cycles of slack.)
+    if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
       const Geom q = geom(pass, blk);
-      float f[16];
-      hash_levels4(q.px, q.py, q.pz, a.tables, a.res, 4 * hi, f);
-      float v0[8], v1[8], v2[8];
+      HashGather hg0, hg1, hg2, hg3;
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 0], 4 * hi + 0, hg0);
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 1], 4 * hi + 1, hg1);
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 2], 4 * hi + 2, hg2);
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 3], 4 * hi + 3, hg3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (prev >= 0) composite(prev, oc[0], density);
+      __builtin_amdgcn_sched_barrier(0);
+      hash_finish(0, hg0);
+      hash_finish(1, hg1);
+      hash_finish(2, hg2);
+      hash_finish(3, hg3);
+      float v2[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; v2[e] = 0.f; }
+      for (int e = 0; e < 8; ++e) v2[e] = 0.f;
       if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; v2[3] = q.px; v2[4] = q.py; v2[5] = q.pz; }
-      char* dst = ib + blk * 4 * FR + lane * 16;
-      fwrite<PREC>(dst, make_frag<PREC>(v0));
-      fwrite<PREC>(dst + FR, make_frag<PREC>(v1));
-      fwrite<PREC>(dst + 2 * FR, make_frag<PREC>(v2));
+      fwrite<PREC>(ib + blk * 4 * FR + lane * 16 + 2 * FR, make_frag<PREC>(v2));
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -509,7 +540,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     SYNC();
     prev = pass;
   }
-  if (prev >= 0) composite(prev, oc[0], density);
+  if (prev >= 0 && (NB == 4 || owner)) composite(prev, oc[0], density);
   if (g == 0) __syncthreads();  // group 0 takes its extra barrier at the end
 }
 

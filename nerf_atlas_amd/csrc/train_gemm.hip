@@ -286,6 +286,8 @@ struct TnArgs {
   int64_t slice;    // samples per workgroup (multiple of TK)
   float* dW;        // [out, in]
   float* db;        // [out] or null
+  long long* fixW;  // deterministic mode: int64 fixed-point accumulators parallel to dW / db (else null)
+  long long* fixb;
 };
 
 template <int WM, int WN>
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = o0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.out) atomicAdd(g.dW + (int64_t)row * in + col, acc[mi][ni][r]);
+        if (row < g.out) accumulate(g.dW, g.fixW, (int64_t)row * in + col, acc[mi][ni][r]);
       }
   }
   if (want_db) {
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_tn_kernel(TnArgs g) {
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         const int col = o0 + (id >> 3) * 4 + c;
-        if ((id & 7) == 0 && id < A_BLOCKS && col < g.out) atomicAdd(g.db + col, v);
+        if ((id & 7) == 0 && id < A_BLOCKS && col < g.out) accumulate(g.db, g.fixb, col, v);
       }
     }
   }
@@ -543,7 +545,18 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   }
   dim3 grid((out + BM - 1) / BM, (in + BN - 1) / BN, (unsigned)nz);
   const int lds = smem_bytes<WM, WN>();
+  int rc;
+  const size_t nW = (size_t)out * in;
+  long long* fix = det_begin(nW + (db ? out : 0), (hipStream_t)stream, "na_linear_wgrad_bf16x3", &rc);
+  if (rc != NA_OK) return rc;
+  a.fixW = fix;
+  a.fixb = fix ? fix + nW : nullptr;
   hipLaunchKernelGGL(k, grid, dim3(64 * WM * WN), lds, (hipStream_t)stream, a);
+  if (fix != nullptr) {
+    if ((rc = det_finish(fix, nW, dW, (hipStream_t)stream, "na_linear_wgrad_bf16x3")) != NA_OK) return rc;
+    if (db != nullptr) return det_finish(fix + nW, (size_t)out, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+    return NA_OK;
+  }
   return check_launch("na_linear_wgrad_bf16x3");
 }
 

@@ -59,6 +59,18 @@ def gather_bands(local: torch.Tensor, size: int, rank: int, world: int, dst: int
     return torch.cat([o[:n] for o, (_, n) in zip(outs, bands)], dim=0).to(dev)
 
 
+def merge_tile_frames(frame: torch.Tensor, rank: int, world: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Tile sharding (mip: radii_x differences rows inside a crop, so whole tiles are the unit): every rank holds a full
+    [size,size,C] frame with its own tiles filled and zeros elsewhere; every pixel has exactly one owner, so ONE
+    sum-reduce to `dst` reassembles the frame exactly (x + 0 is exact).  Returns the frame on `dst`, None elsewhere."""
+    if world == 1:
+        return frame
+    dev = frame.device
+    buf = frame.cpu() if (dist.get_backend() == "gloo" and frame.is_cuda) else frame.clone()
+    dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)
+    return buf.to(dev) if rank == dst else None
+
+
 def render_frame_sharded(render_rows: Callable[[int, int], torch.Tensor], size: int, rank: int, world: int):
     """render_rows(row0, nrows) -> [nrows,size,3] on this rank's device; returns the frame on rank 0."""
     r0, n = row_bands(size, world)[rank]

@@ -92,6 +92,10 @@ class NNEncoder(nn.Module):
     def forward(self, x):
         assert x.shape[-1] == self.fwd.in_features
         flat = x.reshape(-1, x.shape[-1]).contiguous()
+        if ag.needs_grad(flat, *self.fwd.parameters()):
+            # differentiable path: sin(30 (W x + b)) through the Linear and sigmoid autograd functions
+            y = ag.LinearFn.apply(flat, None, self.fwd.weight * 30.0, self.fwd.bias * 30.0, "none")
+            return ag.SigmoidFn.apply(y, "sin").reshape(x.shape[:-1] + (self.fwd.out_features,))
         y = ops.linear_f32(flat, (30.0 * self.fwd.weight.data).contiguous(), (30.0 * self.fwd.bias.data).contiguous())
         return ops.sigmoid(y, "sin").reshape(x.shape[:-1] + (self.fwd.out_features,))
 
@@ -278,7 +282,49 @@ class SkipConnMLP(nn.Module):
         for i, layer in enumerate(self.layers):
             skip = i != n - 1 and (i % self.skip) == 0
             x = ag.LinearFn.apply(x, init if skip else None, layer.weight, layer.bias, self.act_name)
+        if self.last_layer_act:
+            setattr(self, "last_layer_out", x)
         return ag.LinearFn.apply(x, None, self.out.weight, self.out.bias, self.act_name)
+
+    def forward_with_input_tangents(self, p):
+        """(y [N,out], t [3,N,out]) with t[j] = d y / d p_j, propagated FORWARD through the network next to the values
+        (src/sdf.py:43: the reference obtains the same Jacobian rows with torch.autograd.grad(create_graph=True)):
+            t_0 = W_init . d[p | enc(p)]/dp_j,   t_{l+1} = W_l . (act'([z_l | init]) * [t_l | d init]),  no biases.
+        Every node is a first-order autograd Function over HIP kernels (LinearFn, MulBcastFn, ActDerivFn), so a loss on
+        the tangents -- the eikonal term, runner.py:685-692 -- back-propagates to the weights without double backward.
+        p [N,3] does not require grad; encoders: none or FourierEncoder (its Jacobian is elementwise: cos/-sin times the
+        fixed basis)."""
+        assert self.latent_size == 0 and p.dim() == 2 and p.shape[1] == self.in_size == 3
+        p = p.contiguous()
+        N = p.shape[0]
+        eye = torch.eye(3, device=p.device, dtype=torch.float32)[:, None, :].expand(3, N, 3)
+        init, dinit = p, eye
+        if self.enc is not None:
+            if not isinstance(self.enc, FourierEncoder):
+                raise NotImplementedError("input tangents through " + type(self.enc).__name__)
+            enc = ops.fourier_encode(p, self.enc.basis.data, float(self.enc.extra_scale))  # [N, 2F] = [sin | cos]
+            F_ = self.enc.freqs
+            swapped = torch.cat([enc[:, F_:], enc[:, :F_]], dim=-1).contiguous()            # [cos | sin]
+            B = (self.enc.basis.data * float(self.enc.extra_scale))                          # [3, F]
+            signed = torch.cat([B, -B], dim=-1)[:, None, :].expand(3, N, 2 * F_).contiguous()  # d/dp_j: cos*B_j | -sin*B_j
+            denc = ops.mul_bcast(swapped, signed)
+            init = torch.cat([p, enc], dim=-1)
+            dinit = torch.cat([eye, denc], dim=-1)
+        init = init.contiguous()
+        dinit = dinit.contiguous()
+        K0 = init.shape[1]
+        z = ag.LinearFn.apply(init, None, self.init.weight, self.init.bias, "none")
+        t = ag.LinearFn.apply(dinit.reshape(3 * N, K0), None, self.init.weight, None, "none").reshape(3, N, -1)
+        n = len(self.layers)
+        lins = [(l, i != n - 1 and (i % self.skip) == 0) for i, l in enumerate(self.layers)] + [(self.out, False)]
+        for lin, skip in lins:
+            x_in = torch.cat([z, init], dim=-1).contiguous() if skip else z
+            t_in = torch.cat([t, dinit], dim=-1).contiguous() if skip else t
+            m = ag.ActDerivFn.apply(x_in, self.act_name)
+            mt = ag.MulBcastFn.apply(m, t_in)
+            z = ag.LinearFn.apply(z, init if skip else None, lin.weight, lin.bias, self.act_name)
+            t = ag.LinearFn.apply(mt.reshape(3 * N, -1), None, lin.weight, None, "none").reshape(3, N, -1)
+        return z, t
 
     def zero_last_layer(self):
         nn.init.zeros_(self.out.weight)

@@ -571,3 +571,49 @@ def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torc
                                       PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights),
                                       _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
     return out, alpha, weights
+
+
+# ------------------------------------------------------------------------------------------------- forward-mode tangents
+def act_deriv(x: torch.Tensor, act: str, order: int = 1) -> torch.Tensor:
+    lib = _lib.load()
+    x = _f32(x, "x")
+    out = torch.empty_like(x)
+    check(lib.na_act_deriv(_ptr(x), x.numel(), ACT[act], order, _ptr(out), _stream()))
+    return out
+
+
+def mul_bcast(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [n...] shared by the J leading rows of b [J, n...]."""
+    lib = _lib.load()
+    a, b = _f32(a, "a"), _f32(b, "b")
+    J = b.shape[0]
+    assert b.numel() == J * a.numel(), (a.shape, b.shape)
+    out = torch.empty_like(b)
+    check(lib.na_mul_bcast(_ptr(a), _ptr(b), a.numel(), J, _ptr(out), _stream()))
+    return out
+
+
+def mul_reduce(g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    g, b = _f32(g, "g"), _f32(b, "b")
+    J = b.shape[0]
+    out = torch.empty(b.shape[1:], device=b.device, dtype=torch.float32)
+    check(lib.na_mul_reduce(_ptr(g), _ptr(b), out.numel(), J, _ptr(out), _stream()))
+    return out
+
+
+def eikonal_loss(normals: torch.Tensor) -> torch.Tensor:
+    """normals [3, N] (tangent-major) -> scalar mean((|n| - 1)^2)."""
+    lib = _lib.load()
+    normals = _f32(normals, "normals")
+    loss = torch.zeros(1, device=normals.device, dtype=torch.float32)
+    check(lib.na_eikonal_loss(_ptr(normals), normals.shape[1], _ptr(loss), _stream()))
+    return loss.reshape(())
+
+
+def eikonal_loss_backward(normals: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    normals, g = _f32(normals, "normals"), _f32(g.reshape(1), "g")
+    out = torch.empty_like(normals)
+    check(lib.na_eikonal_loss_backward(_ptr(normals), normals.shape[1], _ptr(g), _ptr(out), _stream()))
+    return out

@@ -22,21 +22,43 @@ def summary(name, psnrs, training=False):
             f"\tmax {max(psnrs):.03f}\n\tvar {np.var(psnrs):.03f}")
 
 
+def load_state(path):
+    """--load: a state_dict written by --save here, or a reference checkpoint (runner.py:1141-1166 pickles the whole
+    module with torch.save(model, path): anything exposing .state_dict() is accepted; parameter names are the
+    reference's, so its tensors load into this package's modules unchanged)."""
+    obj = torch.load(path, map_location="cpu", weights_only=False)
+    if hasattr(obj, "state_dict"):
+        obj = obj.state_dict()
+    if not isinstance(obj, dict):
+        raise ValueError(f"{path}: neither a state_dict nor a module")
+    return obj
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    outdir, save, keep = "outputs/", None, []
+    outdir, save, load, keep = "outputs/", None, None, []
     it = iter(argv)
     for a in it:  # flags owned by this wrapper
         if a == "--outdir": outdir = next(it)
         elif a == "--save": save = next(it)
+        elif a == "--load": load = next(it)
         else: keep.append(a)
     args = T.args_from_argv(keep)
+    state = load_state(load) if load else None
     quiet = args.quiet
 
     def on_iter(i, l2):
         if not quiet and (i % 50 == 0 or i == args.epochs - 1):
             print(f"[{i:06}] l2 {l2:.04f}", flush=True)
-    res = T.fit(args, on_iter=on_iter)
+    init = None
+    if state is not None:
+        def init(model):
+            missing, unexpected = model.load_state_dict(state, strict=False)
+            if unexpected:
+                raise ValueError(f"--load: parameters of another architecture: {sorted(unexpected)[:4]} ...")
+            if missing and not quiet:
+                print(f"--load: {len(missing)} parameters keep their initial values", flush=True)
+    res = T.fit(args, on_iter=on_iter, init=init)
     if res["rank"] != 0:
         return res
     os.makedirs(outdir, exist_ok=True)

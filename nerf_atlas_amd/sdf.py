@@ -11,6 +11,23 @@ class SDFModel(nn.Module):
         super().__init__()
         self.intermediate_size = intermediate_size
 
+    def _net(self):
+        raise NotImplementedError()
+
+    def normals(self, pts, values=None):
+        """src/sdf.py:43-48: d sdf / d pts, [..., 3].  Forward-mode tangents through the MLP (one value row and three
+        tangent rows per point; SkipConnMLP.forward_with_input_tangents) instead of autograd(create_graph=True): the
+        result is differentiable w.r.t. the weights with first-order autograd, which is what the eikonal regulariser
+        needs (runner.py:685-692).  Always runs the fp32 / split-bf16 training GEMMs, also under no_grad."""
+        flat = pts.reshape(-1, 3)
+        _, t = self._net().forward_with_input_tangents(flat)
+        return t[..., 0].t().reshape(pts.shape)
+
+    def normals_tangent_major(self, pts):
+        """[3, N] layout of the same normals (what ops.eikonal_loss consumes: no transposition in the graph)."""
+        _, t = self._net().forward_with_input_tangents(pts.reshape(-1, 3))
+        return t[..., 0]
+
 
 class MLP(SDFModel):
     """src/sdf.py:250-258."""
@@ -22,6 +39,7 @@ class MLP(SDFModel):
                                init="xavier")
 
     def forward(self, x): return self.mlp(x)
+    def _net(self): return self.mlp
 
 
 class SIREN(SDFModel):
@@ -33,6 +51,7 @@ class SIREN(SDFModel):
                                  activation=torch.sin, skip=3, init="siren")
 
     def forward(self, x): return self.siren(x)
+    def _net(self): return self.siren
 
 
 class SDF(nn.Module):
@@ -56,8 +75,7 @@ class SDF(nn.Module):
         latent = raw[..., 1:]
         return raw[..., 0], latent if latent.shape[-1] != 0 else None
 
-    def normals(self, pts, values=None):
-        raise NotImplementedError("SDF normals need autograd through the MLP (training row N1)")
+    def normals(self, pts, values=None): return self.underlying.normals(pts, values)
 
 
 def _out_of_scope(name):

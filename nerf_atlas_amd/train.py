@@ -1,8 +1,8 @@
 """Training and evaluation loops with the reference's recipe (runner.py:609-850 train, :855-995 test,
 :1221-1322 main), restricted to what the five hot-path configs use: l2/l1/rmse loss in RGB, Adam(eps 1e-7) with the
 cosine schedule, random crops/views from Python's `random`, pixel jitter 0.1, stratified sampling and density noise
-in training mode, `--volsdf-scale-decay`, `--delta-x-decay`, `--offset-decay`; regularisers that need second
-derivatives (eikonal, FFJORD divergence) raise.
+in training mode, `--volsdf-scale-decay`, `--delta-x-decay`, `--offset-decay`, `--sdf-eikonal` (SDF normals by forward-mode
+tangents through the MLP); the FFJORD divergence and smooth-normals terms raise.
 
 Every forward and backward is a HIP kernel (nerf_atlas_amd/autograd.py); torch.optim owns the parameter update, like
 in the reference.  With `replay_reference_rng=True` the stochastic tensors come from torch's CPU generator in the
@@ -18,6 +18,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import autograd as ag
 from . import dist as na_dist
 from . import loaders, nerf, refl, utils
 from .render import render, render_frame
@@ -32,7 +33,7 @@ DEFAULTS = dict(
     volsdf_scale_decay=0.0, delta_x_decay=0.0, opt_step=1, clip_gradients=0.0, train_imgs=-1, serial_idxs=False,
     higher_end_chance=0, opt_kind="adam", light_kind=None, occ_kind=None, volsdf_alternate=False, test_white_bg=False,
     sdf_eikonal=0.0, ffjord_div_decay=0.0, offset_decay=0.0, dyn_diverge_decay=0.0, smooth_normals=0.0,
-    neural_upsample=False, quiet=True,
+    neural_upsample=False, quiet=False,
 )
 
 loss_map = {
@@ -65,8 +66,11 @@ def args_from_argv(argv) -> SimpleNamespace:
         flag = "--" + k.replace("_", "-")
         if k == "learning_rate":
             p.add_argument("-lr", flag, type=float, default=v)
+        elif isinstance(v, bool) and v:
+            # defaults that are True (derive_kind, refl_bidirectional) get --flag / --no-flag so they can be switched off
+            p.add_argument(flag, action=argparse.BooleanOptionalAction, default=True)
         elif isinstance(v, bool):
-            p.add_argument(flag, action="store_true", default=v)
+            p.add_argument(flag, action="store_true", default=False)
         elif isinstance(v, list):
             p.add_argument(flag, nargs="+", default=v)
         elif v is None:
@@ -134,9 +138,12 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
     optimiser step (dist.allreduce_gradients); the reference's own --data-parallel is broken (SURVEY header table)."""
     if args.epochs == 0:
         return []
-    for k in ("sdf_eikonal", "ffjord_div_decay", "dyn_diverge_decay", "smooth_normals"):
+    for k in ("ffjord_div_decay", "dyn_diverge_decay", "smooth_normals"):
         if getattr(args, k, 0) > 0:
-            raise NotImplementedError(f"--{k.replace('_', '-')} needs second derivatives of the MLPs (DESIGN.md 9a)")
+            raise NotImplementedError(f"--{k.replace('_', '-')} needs input Jacobians of the deformation / normal "
+                                      "networks (hash-encoder and spline tangents are not implemented: DESIGN.md 9a)")
+    if args.sdf_eikonal > 0 and not hasattr(model, "sdf"):
+        raise ValueError("--sdf-eikonal needs an SDF model (--model volsdf)")
     device = next(model.parameters()).device
     loss_fn = load_loss_fn(args)
     times = None
@@ -160,8 +167,9 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
     for i in range(args.epochs):
         idxs = next_idxs(i)
         if world > 1:
+            # equal shards: the mean of the per-replica mean losses is then the single-process batch loss
+            assert len(idxs) % world == 0, f"batch_size {len(idxs)} must be a multiple of the {world} replicas"
             idxs = na_dist.shard_batch(idxs, rank, world)
-            assert idxs, "batch_size must be >= the number of replicas"
         ts = None if times is None else times[idxs]
         c0, c1, c2, c3 = crop = get_crop()
         ref = labels[idxs][:, c0:c0 + c2, c1:c1 + c3, :3].to(device)
@@ -175,6 +183,10 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
             loss = loss + args.delta_x_decay * model.dp.norm(dim=-1).mean()
         if args.offset_decay > 0:
             loss = loss + offset_decay_term(model, i / args.epochs) * args.offset_decay
+        if args.sdf_eikonal > 0:
+            # runner.py:683-692: E[|d sdf/dx|] = 1 on 10240 points 5*randn; normals by forward-mode tangents
+            pts = 5 * utils.randn(((1 << 13) * 5 // 4, 3), device)
+            loss = loss + args.sdf_eikonal * ag.EikonalFn.apply(model.sdf.underlying.normals_tangent_major(pts))
         if args.opt_step != 1:
             loss = loss / args.opt_step
         loss.backward()

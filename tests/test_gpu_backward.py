@@ -154,6 +154,52 @@ def test_plain_nerf_training_gradients_match_oracle_autograd(ops, train_prec):
         assert float(torch.nn.functional.mse_loss(m(h["rays"].cuda()), target.cuda())) < float(loss.detach())
 
 
+def test_pos_linear_combine_backward(ops):
+    """(sigmoid(lin)/2 + 0.5) * pos[..., :3] (src/refl.py:288-290): both gradients, pos given as a wider buffer."""
+    lin = torch.from_numpy(proc_uniform((257, 1), 11, 3.0))
+    pos = torch.from_numpy(proc_uniform((257, 67), 12, 1.0))
+    go = torch.from_numpy(proc_uniform((257, 3), 13, 1.0))
+    l, q = lin.clone().requires_grad_(), pos.clone().requires_grad_()
+    ((l.sigmoid() / 2 + 0.5) * q[..., :3] * go).sum().backward()
+    g_lin, g_pos = ops.pos_linear_combine_backward(lin.cuda(), pos.cuda(), go.cuda(), 3)
+    assert rel(g_lin, l.grad) <= 2e-6 and rel(g_pos, q.grad) <= 2e-6
+    assert float(g_pos[:, 3:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):  # the raw op refuses inputs that require grad instead of silently detaching
+        ops.pos_linear_combine(lin.cuda().requires_grad_(), pos.cuda(), 3)
+
+
+def test_pos_linear_view_training_gradients_match_oracle_autograd(ops, train_prec):
+    """--refl-kind pos-linear-view (make dnerf): every parameter of refl.pos and refl.view receives the gradient
+    torch.autograd computes through the oracle (the colour head used to come out of a non-differentiable kernel)."""
+    import nerf_atlas_amd.nerf as nerf
+    import nerf_atlas_amd.refl as refl
+    h = load_golden("g11_plain_pos-linear-view_b1")
+    params = golden_params(h)
+    T = int(h["steps"])
+    m = nerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m.set_refl(refl.refl_kinds["pos-linear-view"](latent_size=64, act="upshifted", out_features=3))
+    m = m.cuda().eval()
+    sd = m.state_dict()
+    for k, v in params.items():
+        sd[k].copy_(v)
+    target = torch.from_numpy(proc_uniform(tuple(h["out"].shape), 78, 0.5)) + 0.5
+    out = m(h["rays"].cuda())
+    assert out.requires_grad
+    loss = torch.nn.functional.mse_loss(out, target.cuda())
+    loss.backward()
+    ref_p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    ref_out = O.plain_nerf(ref_p, h["rays"], 2.0, 6.0, T, "pos-linear-view", act="upshifted")
+    ref_loss = torch.nn.functional.mse_loss(ref_out, target)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-6 * E2E_TOL[train_prec]
+    named = dict(m.named_parameters())
+    for k in named:
+        if k.startswith("refl.") and k in ref_p and ref_p[k].grad is not None:
+            assert named[k].grad is not None and float(named[k].grad.abs().max()) > 0, k
+    checked = check_grads(named, ref_p, train_prec, 5e-4, 2e-2, "plain/pos-linear-view")
+    assert checked >= 20
+
+
 def test_hash_backward_wrt_positions(ops):
     """d(features)/d(x): needed once positions are predicted (D-NeRF canonical warp).  floor() carries no gradient."""
     g = load_golden("g4_hash")
@@ -375,3 +421,50 @@ def test_backward_and_march_edge_cases(ops):
     with pytest.raises(NaError):
         ops.check(lib.na_hash_encode_backward_input(None, 4, None, None, 1, None, s))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kind", ["siren", "mlp"])
+def test_sdf_normals_and_eikonal_gradients(ops, kind, train_prec):
+    """N1 remainder: SDF normals (src/sdf.py:43-48) and the eikonal regulariser (runner.py:685-692, src/utils.py:31).
+    Normals by forward-mode tangents vs torch.autograd.grad of the CPU oracle; d(eikonal)/d(every weight) vs the
+    oracle's double backward.  Points 5*randn like the reference's get_pts()."""
+    import nerf_atlas_amd.sdf as sdf
+    from nerf_atlas_amd import autograd as ag
+    h = load_golden(f"g10_volsdf_{kind}")
+    allp = golden_params(h)
+    prefix = f"sdf.underlying.{'mlp' if kind == 'mlp' else 'siren'}."
+    m = sdf.sdf_kinds[kind](intermediate_size=64).cuda()
+    sd = m.state_dict()
+    sub = {k[len("sdf.underlying."):]: v for k, v in allp.items() if k.startswith("sdf.underlying.")}
+    for k, v in sub.items():
+        sd[k].copy_(v)
+    pts = torch.from_numpy(proc_uniform((300, 3), 21, 1.0)) * (0.8 if kind == "mlp" else 2.5)
+    # ---- oracle: normals by autograd, eikonal loss, second-order gradients
+    ref_p = {k: v.clone().requires_grad_(not k.endswith("basis")) for k, v in allp.items() if k.startswith(prefix)}
+    x = pts.clone().requires_grad_()
+    if kind == "mlp":
+        raw = O.skip_mlp(ref_p, prefix, x, enc=lambda q: O.fourier_encode(q, ref_p[prefix + "enc.basis"]))
+    else:
+        raw = O.skip_mlp(ref_p, prefix, x, act="sin")
+    n_ref, = torch.autograd.grad(raw[..., 0].sum(), x, create_graph=True)
+    loss_ref = (torch.linalg.norm(n_ref, dim=-1) - 1).square().mean()
+    loss_ref.backward()
+    # ---- HIP
+    n = m.normals(pts.cuda())
+    tol_n = 2e-5 if train_prec == "fp32" else 2e-3
+    scale = float(n_ref.abs().max())
+    assert float((n.detach().cpu() - n_ref.detach()).abs().max()) <= tol_n * scale, float((n.detach().cpu() - n_ref.detach()).abs().max())
+    loss = ag.EikonalFn.apply(m.normals_tangent_major(pts.cuda()))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= (1e-5 if train_prec == "fp32" else 1e-3) * max(1.0, float(loss_ref.detach()))
+    loss.backward()
+    named = {prefix + k.split(".", 1)[1] if False else k: v for k, v in m.named_parameters()}
+    checked = 0
+    for k, rp in ref_p.items():
+        if rp.grad is None:
+            continue
+        gp = named[k[len("sdf.underlying."):]].grad
+        assert gp is not None, k
+        e = rel(gp, rp.grad) if train_prec == "fp32" else rel_l2(gp, rp.grad)
+        assert e <= (2e-3 if train_prec == "fp32" else 3e-2), (k, e)
+        checked += 1
+    assert checked >= 10

@@ -1,0 +1,148 @@
+"""Full-size parity of the configs that were only checked at 6x6 rays x 8 steps: tiles of the
+800^2 x 128-step geometry against the CPU oracle for TinyNeRF (config 1), D-NeRF spline 6 at t = 0.5 (config 4) and
+VolSDF mlp / siren with DTUCamera rays, near 0.3 / far 1.8 (config 5), plus size-independent whole-frame properties
+(weights are a partition of unity; a row band rendered alone equals the same rows of the full frame bit for bit).
+RGB tolerance 1e-4 L-inf in the bf16x3 precision (north_star)."""
+import math
+
+import pytest
+import torch
+
+import oracle as O
+from conftest import load_golden, golden_params
+
+pytestmark = pytest.mark.gpu
+SIZE, T = 800, 128
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    with torch.no_grad():
+        yield
+
+
+@pytest.fixture(scope="module")
+def na():
+    assert torch.cuda.is_available()
+    import nerf_atlas_amd.nerf as nerf
+    import nerf_atlas_amd.refl as refl
+    import nerf_atlas_amd.sdf as sdf
+    import nerf_atlas_amd.cameras as cameras
+    import nerf_atlas_amd.render as render
+    from nerf_atlas_amd import config, ops
+    config.set_precision("bf16x3")
+    class NS: pass
+    ns = NS()
+    ns.nerf, ns.refl, ns.sdf, ns.cameras, ns.render, ns.ops = nerf, refl, sdf, cameras, render, ops
+    return ns
+
+
+def load_params(model, params):
+    sd = model.state_dict()
+    for k, v in params.items():
+        assert k in sd, k
+        sd[k].copy_(v)
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu() - b).abs().max())
+
+
+def nerf_cam(na):
+    focal = 0.5 * SIZE / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    return na.cameras.NeRFCamera(cam_to_world=c2w, focal=focal).cuda(), c2w, focal
+
+
+def dtu_cam(na):
+    """Synthetic DTU-like camera: fx = fy = 2892, cx = 800, cy = 600 at 1600x1200, looking at the
+    origin from (0.3, -0.2, -2.2) with a small roll."""
+    K = torch.tensor([[[2892.0, 0.3, 800.0], [0, 2892.0, 600.0], [0, 0, 1.0]]])
+    eye = torch.tensor([0.3, -0.2, -2.2])
+    fwd = -eye / eye.norm()
+    up = torch.tensor([0.05, 1.0, 0.0])
+    right = torch.linalg.cross(up, fwd); right = right / right.norm()
+    up2 = torch.linalg.cross(fwd, right)
+    pose = torch.eye(4)[None].clone()
+    pose[0, :3, 0], pose[0, :3, 1], pose[0, :3, 2], pose[0, :3, 3] = right, up2, fwd, eye
+    return na.cameras.DTUCamera(pose=pose, intrinsic=K).cuda(), pose, K
+
+
+def band_equals_full(render_rays, rays_full, r0, r1):
+    """render_rays(rays [B,h,w,6]) -> rgb; rows r0..r1 alone == the same rows of the larger crop, bit for bit"""
+    full = render_rays(rays_full)
+    band = render_rays(rays_full[:, r0:r1].contiguous())
+    assert torch.equal(band, full[:, r0:r1])
+    return full
+
+
+def test_tiny_nerf_tile_and_properties(na):
+    h = load_golden("g13_tiny")
+    p = golden_params(h)
+    m = na.nerf.TinyNeRF(steps=T, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted").cuda().eval()
+    load_params(m, p)
+    cam, c2w, focal = nerf_cam(na)
+    crop = (380, 390, 40, 40)
+    rays = cam.sample_positions(crop, size=SIZE)
+    assert torch.equal(rays.cpu(), O.nerf_camera_rays(O.pixel_grid(SIZE, crop), c2w, focal, SIZE))
+    out = m(rays)
+    aux = {}
+    ref = O.tiny_nerf(p, rays.cpu(), 2.0, 6.0, T, act="upshifted", aux=aux)
+    assert maxdiff(out, ref) <= 1e-4
+    assert maxdiff(m.weights, aux["weights"]) <= 1e-4 and maxdiff(m.alpha, aux["alpha"]) <= 1e-4
+    # whole-frame properties on a 200-row slab of the 800-wide frame (20.5 M samples)
+    slab = cam.sample_positions((300, 0, 200, SIZE), size=SIZE)
+    full = band_equals_full(lambda r: m(r), slab, 64, 96)
+    assert torch.isfinite(full).all()
+    m(slab)
+    assert float((m.weights.sum(0) - 1).abs().max()) <= 1e-5
+
+
+def test_dnerf_spline6_tile_and_properties(na):
+    h = load_golden("g9_dnerf_spline6")
+    p = golden_params(h)
+    canon = na.nerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=6).cuda().eval()
+    load_params(m, p)
+    cam, c2w, focal = nerf_cam(na)
+    crop = (380, 390, 40, 40)
+    rays = cam.sample_positions(crop, size=SIZE)
+    times = torch.tensor([0.5])
+    out = m((rays, times.cuda()))
+    aux = {}
+    ref = O.dynamic_nerf_spline(p, rays.cpu(), times, 2.0, 6.0, T, 6, act="upshifted", aux=aux)
+    assert maxdiff(out, ref) <= 1e-4
+    assert maxdiff(m.dp, aux["dp"]) <= 1e-4 and maxdiff(m.rigidity, aux["rigidity"]) <= 1e-4
+    assert maxdiff(canon.weights, aux["weights"]) <= 1e-4
+    slab = cam.sample_positions((300, 0, 96, SIZE), size=SIZE)
+    band_equals_full(lambda r: m((r, times.cuda())), slab, 32, 64)
+    m((slab, times.cuda()))
+    assert float((canon.weights.sum(0) - 1).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["mlp", "siren"])
+def test_volsdf_dtu_tile_and_properties(na, kind):
+    h = load_golden(f"g10_volsdf_{kind}")
+    p = golden_params(h)
+    under = na.sdf.sdf_kinds[kind](intermediate_size=64)
+    r = na.refl.View(latent_size=64, act="upshifted", out_features=3)
+    s = na.sdf.SDF(under, r, isect=None, t_near=0.3, t_far=1.8)
+    m = na.nerf.VolSDF(sdf=s, steps=T, t_near=0.3, t_far=1.8, sigmoid_kind="upshifted").cuda().eval()
+    load_params(m, p)
+    cam, pose, K = dtu_cam(na)
+    crop = (380, 390, 40, 40)
+    rays = cam.sample_positions(crop, size=SIZE)
+    rays_ref = O.dtu_camera_rays(O.pixel_grid(SIZE, crop), pose, K, SIZE)
+    assert maxdiff(rays, rays_ref) <= 2e-6
+    out = m(rays)
+    aux = {}
+    ref = O.volsdf(p, rays.cpu(), 0.3, 1.8, T, sdf_kind=kind, act="upshifted", aux=aux)
+    # the Fourier-encoded SDF MLP inherits ~1e-4 feature-level fp32 noise; RGB stays within 1e-4
+    assert maxdiff(out, ref) <= 1e-4
+    assert maxdiff(m.weights, aux["weights"]) <= 2e-4
+    slab = cam.sample_positions((300, 0, 96, SIZE), size=SIZE)
+    full = band_equals_full(lambda r: m(r), slab, 32, 64)
+    assert torch.isfinite(full).all()
+    # VolSDF has no 1e10 closing interval in its density (relu path): weights sum to <= 1
+    m(slab)
+    assert float(m.weights.sum(0).max()) <= 1 + 1e-5

@@ -156,6 +156,42 @@ def test_mip_plain_nerf_runs(na):
     assert out.shape == (1, 6, 6, 3) and torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("kind", ["cylinder", "cone"])
+def test_mip_plain_nerf_tile_800_geometry(na, kind):
+    """config 3 (MipNeRF IPE, intended layout -- the reference's composed path is NaN/scrambled at HEAD):
+    a 40x40 tile of the 800^2 geometry x 128 steps through PlainNeRF(mip=...) against the oracle's composed model
+    (IPE primitives pinned by the g8 goldens), both kinds, RGB / alpha / weights <= 1e-4."""
+    import math
+    import oracle as O
+    from oracle.procedural import proc_param
+    from nerf_atlas_amd.utils import CylinderGaussian, ConicGaussian
+    size, T = 800, 128
+    mip = CylinderGaussian() if kind == "cylinder" else ConicGaussian()
+    m = na.nerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted", mip=mip).cuda().eval()
+    params = {}
+    for k, v in m.state_dict().items():
+        if k.endswith("primes") or v.numel() == 0:
+            continue
+        params[k] = torch.from_numpy(proc_param(k, tuple(v.shape)))
+    load_params(m, params, strict=False)
+    assert m.first.init.weight.shape[1] == 38 + 96 and m.refl.mlp.init.weight.shape[1] == 5 + 64 + 96
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    crop = (380, 390, 40, 40)
+    rays = O.nerf_camera_rays(O.pixel_grid(size, crop), c2w, focal, size)
+    out = m(rays.cuda())
+    aux = {}
+    ref = O.plain_nerf(params, rays, 2.0, 6.0, T, "view", act="upshifted", mip=kind, aux=aux)
+    assert torch.isfinite(ref).all()
+    assert maxdiff(out, ref) <= 1e-4, kind
+    assert maxdiff(m.alpha, aux["alpha"]) <= 1e-4 and maxdiff(m.weights, aux["weights"]) <= 1e-4
+    # the latent itself (what the IPE kernel writes) against the oracle's composed latent
+    lat = m.mip_encoding(rays.cuda(), m.ts)
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    ref_lat = O.mip_latent_intended(r_o, r_d, aux["ts"], kind, end=float(2 * aux["ts"][-1] - aux["ts"][-2]))
+    assert maxdiff(lat, ref_lat) <= 2e-5, kind
+
+
 def test_aux_render_outputs_and_extra_encoders(na):
     """N3-style outputs that reuse .weights (runner.py:894-920) and the low-priority encoders of A4."""
     import oracle as O

@@ -84,3 +84,61 @@ def test_hip_marching_through_the_fused_siren_sdf():
     assert (tput.cpu() - g["nn_bi_tput"]).abs().squeeze(-1)[same].median() <= 1e-4
     ok = (pts.cpu() - g["nn_bi_pts"]).abs().amax(-1) <= 1e-3
     assert ok.float().mean() >= 0.9
+
+
+@pytest.mark.gpu
+def test_hip_marching_disagreements_are_threshold_grazing():
+    """Why the decisions through the fused MLP are not bit-identical to the golden, shown iteration by
+    iteration with the oracle teacher-forced onto the GPU's own march state: (a) the fused bf16x3 SDF is within 2e-5 of the
+    fp32 oracle SDF at the SAME points; (b) given the SDF values the update kernels take exactly the reference's
+    decisions; hence (c) every ray whose hit / stop decision differs from what fp32 arithmetic would decide at that
+    state has |sdf - eps| (or |dist + sdf - far|) <= 2e-5 at the deciding iteration -- a threshold-grazing ray, not a
+    logic error.  Rays are dropped from the audit after their first divergence (their states differ from then on)."""
+    from nerf_atlas_amd import config, ops
+    import nerf_atlas_amd.sdf as sdf
+    g = load_golden("g15_march")
+    config.set_precision("bf16x3")
+    m = sdf.SIREN(intermediate_size=0).cuda().eval()
+    sd = m.state_dict()
+    for k, v in golden_params(g).items():
+        sd[k].copy_(v)
+    fn = siren_fn(g)
+    r_o, r_d = g["r_o"].cuda().contiguous(), g["r_d"].cuda().contiguous()
+    near, far, eps, tol = float(g["nn_near"]), float(g["nn_far"]), 1e-3, 2e-5
+    batch = r_o.shape[:-1]
+    dist = torch.full(batch + (1,), near, device="cuda")
+    hits = torch.zeros(batch, device="cuda", dtype=torch.uint8)
+    rem = torch.ones(batch, device="cuda", dtype=torch.uint8)
+    audited = torch.ones(batch, dtype=torch.bool)
+    grazing = torch.zeros(batch, dtype=torch.bool)
+    worst_sdf_err = 0.0
+    with torch.no_grad():
+        for _ in range(24):
+            pts = ops.ray_points(r_o, r_d, dist)
+            s_gpu = m(pts).contiguous()
+            s_ref = fn(pts.cpu())[..., 0]                        # fp32 oracle at the GPU's points
+            worst_sdf_err = max(worst_sdf_err, float((s_gpu[..., 0].cpu() - s_ref).abs().max()))
+            d0, h0, r0 = dist.cpu()[..., 0], hits.cpu().bool(), rem.cpu().bool()
+            ops.sphere_march_update(s_gpu, eps, far, dist, hits, rem)
+            # (b) the kernel's decisions are the reference's (src/march.py:39-45) for the SDF values it was given
+            sg = s_gpu[..., 0].cpu()
+            h_exp = h0 | (r0 & (sg < eps) & (d0 <= far))
+            d_exp = torch.where(r0, d0 + sg, d0)
+            r_exp = r0 & ~(h_exp | (d_exp > far))
+            assert torch.equal(hits.cpu().bool(), h_exp) and torch.equal(rem.cpu().bool(), r_exp)
+            assert torch.equal(dist.cpu()[..., 0], d_exp)
+            # (c) what fp32 SDF values would have decided at the same state
+            h_ref = h0 | (r0 & (s_ref < eps) & (d0 <= far))
+            r_ref = r0 & ~(h_ref | (torch.where(r0, d0 + s_ref, d0) > far))
+            differ = audited & ((h_ref != h_exp) | (r_ref != r_exp))
+            margin = torch.minimum((s_ref - eps).abs(), (d0 + s_ref - far).abs())
+            assert bool((margin[differ] <= tol).all()), float(margin[differ].max())
+            grazing |= differ
+            audited &= ~differ
+    assert worst_sdf_err <= tol, worst_sdf_err
+    final_differs = hits.cpu().bool() != g["nn_sm_hits"]
+    # every ray whose final decision differs from the golden diverged at a grazing threshold (or never diverged from the
+    # teacher-forced fp32 decisions at all, in which case the golden's own trajectory drifted by the accumulated 1e-5s)
+    print(f"\n[march] fused-vs-fp32 SDF error {worst_sdf_err:.2e}; {int(grazing.sum())} grazing rays, "
+          f"{int(final_differs.sum())} of {final_differs.numel()} final decisions differ from the golden")
+    assert float(final_differs.float().mean()) <= 0.05
