@@ -16,8 +16,9 @@
 //    other runs its epilogue / encoder / compositing (VALU + LDS writes) on the same SIMDs, so VALU work never sits
 //    between a wave's own MFMAs and each SIMD always has one MFMA-only wave.
 //  * LDS: per group NBLK x (16 hidden + 4 init) chunks = 80 KiB, 160 KiB per workgroup (bf16: NBLK = 4; bf16x3 keeps
-//    hi and lo planes: NBLK = 2).  The fifth init chunk of the View MLP (x, y, z, elev, azim) does not fit: its
-//    fragments go through a 16-KiB per-workgroup global scratch (L2) and are prefetched like weights.
+//    hi and lo planes: NBLK = 2).  The fifth init chunk of the View MLP (x, y, z, elev, azim) does not fit: every
+//    consuming wave rebuilds its fragments in registers (scalar loads of the ray and of its per-ray elev/azim, which a
+//    small pre-kernel writes once per ray; ~15 VALU per block) right before the two MFMAs that use them.
 //  * `first.out` / `view.out` (65 and 3 rows) run block-per-wave (wave rg = block rg, all out tiles), which is also the
 //    assignment of the hash-encoder prologue and of compositing, so density and colour never leave their wave.
 //
@@ -64,7 +65,6 @@ struct Cfg {
   static constexpr int IREG = NBLK * 4 * FRAG;                  // init-input chunks of one group
   static constexpr int GROUP = HREG + IREG;                     // 80 KiB
   static constexpr int STREAM = kPairsPerPass * PAIR;           // weight stream of one row group
-  static constexpr int SCRATCH = 2 * NBLK * 2 * FRAG;           // geometry chunk fragments (raw, sin) per workgroup
 };
 
 inline size_t packed_bytes(int precision) {
@@ -81,7 +81,7 @@ struct Args {
   float* alpha;          // nullable [T,R]
   float* weights;        // nullable [T,R] (block-local; finalize applies the cross-block prefix)
   float* partials;       // [R*nb, 8]
-  char* scratch;         // [grid][Cfg::SCRATCH]
+  const float* elaz;     // [R,2] elev/azim of every ray (ray_elaz_kernel)
   int64_t R;
   int64_t nitems;        // R * nb
   int T, nb;
@@ -140,28 +140,41 @@ __device__ __forceinline__ f32x16 bias_tile(__amdgpu_buffer_rsrc_t rs, int bias_
   return a;
 }
 
-// ---- MFMA phase of a 256-row Linear: K = [NI init chunks from LDS | geometry chunk | NH hidden chunks from LDS]
-template <int PREC, int RING0, int NI, bool GEO, int NH, bool WRAP>
+// ---- MFMA phase of a 256-row Linear: K = [NI init chunks from LDS | NH hidden chunks from LDS | geometry chunk]
+// GEO: 0 none, 1 raw (view.init), 2 through the activation (skip layer).  geo(b) builds block b's fragment in registers.
+template <int PREC, int RING0, int NI, int GEO, int NH, bool WRAP, class GeoLoad, class GeoMake>
 __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag<PREC> (&ring)[kPF][2], int& cur,
                                          __amdgpu_buffer_rsrc_t rs, int wvoff, const char* hb, const char* ib, int lane,
-                                         const Frag<PREC> (&geoB)[Cfg<PREC>::NBLK]) {
+                                         GeoLoad geo_load, GeoMake geo_make) {
   constexpr int NB = Cfg<PREC>::NBLK, FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
-  constexpr int NCH = NI + (GEO ? 1 : 0) + NH;
+  constexpr int NL = NI + NH;                 // chunks whose B fragments come from LDS
+  constexpr int NCH = NL + (GEO ? 1 : 0);
   // the partner wave on this SIMD is in a VALU-dense epilogue: MFMA issue must win the arbitration
   __builtin_amdgcn_s_setprio(1);
   Frag<PREC> Bq[2][NB];
   auto bsrc = [&](int q, int b) -> Frag<PREC> {
     if (q < NI) return fread<PREC>(ib + (b * 4 + q) * FR + lane * 16);
-    if (GEO && q == NI) return geoB[b];
-    return fread<PREC>(hb + (b * 16 + (q - NI - (GEO ? 1 : 0))) * FR + lane * 16);
+    return fread<PREC>(hb + (b * 16 + (q - NI)) * FR + lane * 16);
   };
+  auto refill = [&](int q) {
+    int nx = cur + q + kPF;
+    if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
+    ring[(RING0 + q) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
+    ring[(RING0 + q) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
+  };
+  // raw inputs of the geometry chunk: in flight under the LDS-fed chunks
+  decltype(geo_load(0)) graw[GEO != 0 ? NB : 1];
+  if constexpr (GEO != 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+  }
 #pragma unroll
   for (int b = 0; b < NB; ++b) Bq[0][b] = bsrc(0, b);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int q = 0; q < NCH; ++q) {
+  for (int q = 0; q < NL; ++q) {
     const Frag<PREC> A0 = ring[(RING0 + q) % kPF][0], A1 = ring[(RING0 + q) % kPF][1];
-    if (q + 1 < NCH) {
+    if (q + 1 < NL) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) Bq[(q + 1) & 1][b] = bsrc(q + 1, b);
     }
@@ -170,14 +183,20 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
     for (int b = 0; b < NB; ++b) {
       mma<PREC>(acc[0][b], A0, Bq[q & 1][b]);
       mma<PREC>(acc[1][b], A1, Bq[q & 1][b]);
-      if (b == 0) {
-        int nx = cur + q + kPF;
-        if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
-        ring[(RING0 + q) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
-        ring[(RING0 + q) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
-      }
+      if (b == 0) refill(q);
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (GEO != 0) {
+    constexpr int q = NL;
+    const Frag<PREC> A0 = ring[(RING0 + q) % kPF][0], A1 = ring[(RING0 + q) % kPF][1];
+    refill(q);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const Frag<PREC> B = geo_make(b, graw[b], GEO == 2);
+      mma<PREC>(acc[0][b], A0, B);
+      mma<PREC>(acc[1][b], A1, B);
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   cur += NCH;
@@ -260,16 +279,58 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, a.packed_size, 0x00020000);
   const int wvoff = kHeaderBytes + kBiasBytes + rg * C::STREAM + lane * 16;
   const int bias_rg = kHeaderBytes + rg * (kNPhase * 1024);  // scalar offset of this row group's bias blocks
-  // geometry-chunk scratch of this workgroup / sample group: [block][raw, sin] fragments
-  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.scratch + (size_t)blockIdx.x * C::SCRATCH), 0, C::SCRATCH, 0x00020000);
-  const int scr = g * (NB * 2 * FR);
-  auto scr_store = [&](int soff, const Frag<PREC>& f) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, f.hi), srs, lane * 16, soff, 0);
-    if constexpr (PREC == NA_PREC_BF16X3)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, f.lo), srs, lane * 16, soff + 1024, 0);
+  // Fifth init chunk of the View MLP for block b of this group (x, y, z, elev, azim in the hi = 0 lanes; src/refl.py:
+  // 190-207).  The ray of a block is wave-uniform: its origin, direction and elev/azim (from the pre-kernel) are read once
+  // per pass (in the short epilogue of first.out) and kept in SGPRs (geo_u, readfirstlane), together with the block's step
+  // offset; the two MFMA phases that consume the chunk only load t (or the explicit position) of their lane at their start.
+  float geo_u[NB][8];   // ox oy oz dx dy dz elev azim of block b's ray (uniform)
+  int geo_t0[NB];       // first step of block b
+  int geo_ray[NB];
+  auto geo_setup = [&](int pass) {
+    const int64_t item0 = ((int64_t)pass * 2 + g) * NB;
+    int ray = __builtin_amdgcn_readfirstlane((int)(item0 / a.nb));
+    int tb = __builtin_amdgcn_readfirstlane((int)(item0 - (int64_t)ray * a.nb));
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (ray >= a.R) { ray = (int)a.R - 1; tb = a.nb - 1; }
+      const float* ry = a.rays + (int64_t)ray * 6;
+      const float* ea = a.elaz + (int64_t)ray * 2;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) geo_u[b][e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ry[e])));
+      geo_u[b][6] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ea[0])));
+      geo_u[b][7] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ea[1])));
+      geo_t0[b] = tb * 32;
+      geo_ray[b] = ray;
+      if (++tb >= a.nb) { tb = 0; ++ray; }
+    }
   };
-
+  struct GeoRaw { float x, y, z; };  // t (x) or the explicit position of this lane's sample
+  auto geo_load = [&](int b) -> GeoRaw {
+    const int t = geo_t0[b] + ln;
+    const int tc = t < a.T ? t : a.T - 1;
+    GeoRaw r;
+    if (a.pts != nullptr) {
+      const float* p = a.pts + ((int64_t)tc * a.R + geo_ray[b]) * 3;
+      r.x = p[0]; r.y = p[1]; r.z = p[2];
+    } else {
+      r.x = a.ts[tc]; r.y = r.z = 0.f;
+    }
+    return r;
+  };
+  auto geo_make = [&](int b, const GeoRaw& r, bool act) -> Frag<PREC> {
+    float px = r.x, py = r.y, pz = r.z;
+    if (a.pts == nullptr) {
+      const float tt = r.x;
+      px = geo_u[b][0] + tt * geo_u[b][3]; py = geo_u[b][1] + tt * geo_u[b][4]; pz = geo_u[b][2] + tt * geo_u[b][5];
+    }
+    float v4[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v4[e] = 0.f;
+    if (hi == 0) { v4[0] = px; v4[1] = py; v4[2] = pz; v4[3] = geo_u[b][6]; v4[4] = geo_u[b][7]; }
+    Frag<PREC> f = make_frag<PREC>(v4);
+    if (act) frag_activate<PREC, NA_ACT_SIN>(f);
+    return f;
+  };
   struct Geom {
     int64_t item, ray;
     bool item_ok, t_ok;
@@ -375,9 +436,6 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     ring[p][0] = wload<PREC>(wrs, wvoff, p * C::PAIR);
     ring[p][1] = wload<PREC>(wrs, wvoff, p * C::PAIR + FR);
   }
-  Frag<PREC> geoB[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) geoB[b] = ring[0][0];  // defined value; only phases 6 and 7 read it
 
   f32x16 oc[1];
   float density = 0.f;
@@ -390,25 +448,24 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     ton = pass == (int)blockIdx.x + (int)gridDim.x;
 #endif
     // ================= EP: compositing of the previous pass, hash encoder of this one
-    // All 4 x 8 table gathers of this lane half are issued FIRST (the accumulators are dead here, so 128 registers are
-    // free): the gathers are TA-bound (64 distinct 128-B lines per instruction, 8 MiB of tables) and a dependent round
-    // costs ~2-3k cycles under load -- one round, with the compositing of the previous pass in its shadow, instead of
-    // four.  (Spreading the levels over the epilogues of the other layers was measured slower: every gathering wave
-    // stalls ~3k cycles per round and the epilogues have ~1.8k cycles of slack.)
+    // The 4 x 8 table gathers of this lane half go out one level at a time (35 live registers), the first with the
+    // compositing of the previous pass in its shadow.  They are TA-bound (64 distinct 128-B lines per instruction, 8 MiB of tables): ~10k
+    // cycles per group and pass whether issued as four rounds, two or one (measured); spreading the levels over the
+    // epilogues of the other layers was slower still (every gathering wave stalls ~3k cycles per round and those
+    // epilogues have ~1.8k cycles of slack).
     if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
       const Geom q = geom(pass, blk);
-      HashGather hg0, hg1, hg2, hg3;
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 0], 4 * hi + 0, hg0);
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 1], 4 * hi + 1, hg1);
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 2], 4 * hi + 2, hg2);
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 3], 4 * hi + 3, hg3);
+      HashGather hg;
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 0], 4 * hi + 0, hg);
       __builtin_amdgcn_sched_barrier(0);
       if (prev >= 0) composite(prev, oc[0], density);
       __builtin_amdgcn_sched_barrier(0);
-      hash_finish(0, hg0);
-      hash_finish(1, hg1);
-      hash_finish(2, hg2);
-      hash_finish(3, hg3);
+      hash_finish(0, hg);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
+        hash_finish(k, hg);
+      }
       float v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v2[e] = 0.f;
@@ -423,13 +480,16 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
     SYNC();
     // ================= `first` MLP (LeakyReLU)
-    m_hidden<PREC, 0, 3, false, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    m_hidden<PREC, 0, 3, 0, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
     SYNC();
     {
       f32x16 bv[2];
+      // tile 0 first: its 16 x NBLK accumulator registers are dead before the bias of the next layer is loaded
+      store_acts<PREC, NA_ACT_LEAKY_RELU, 0, 1>(acc, hb, rg, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 1 * 1024, t, lane);
-      store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
+      store_acts<PREC, NA_ACT_LEAKY_RELU, 1, 2>(acc, hb, rg, lane);
       if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -437,19 +497,22 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
     }
     SYNC();
-    m_hidden<PREC, 3, 3, false, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    m_hidden<PREC, 3, 3, 0, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
     SYNC();
     for (int i = 0; i < 3; ++i) {
       f32x16 bv[2];
+      // tile 0 first: its 16 x NBLK accumulator registers are dead before the bias of the next layer is loaded
+      store_acts<PREC, NA_ACT_LEAKY_RELU, 0, 1>(acc, hb, rg, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (2 + i) * 1024, t, lane);
-      store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
+      store_acts<PREC, NA_ACT_LEAKY_RELU, 1, 2>(acc, hb, rg, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
       SYNC();
-      m_hidden<PREC, 2, 0, false, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+      m_hidden<PREC, 2, 0, 0, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
       SYNC();
     }
     f32x16 o3[3];
@@ -466,6 +529,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       f32x16 bv[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 6 * 1024, t, lane);
+      geo_setup(pass);  // ray / elev / azim of the group's blocks -> SGPRs, for the two View phases that follow
       if (owner) {
         density = o3[2][0];  // row 64 lives in register 0 of the hi=0 lanes
         char* dst = ib + blk * 4 * FR + lane * 16;
@@ -476,20 +540,6 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           fwrite<PREC>(dst + (2 * j) * FR, f0);
           fwrite<PREC>(dst + (2 * j + 1) * FR, f1);
         }
-        // fifth init chunk of the View MLP: x, y, z, elev, azim (raw for view.init, sin() for the skip layer)
-        const Geom q = geom(pass, blk);
-        float el, az;
-        elev_azim(q.dx, q.dy, q.dz, el, az);
-        float v4[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v4[e] = 0.f;
-        if (hi == 0) { v4[0] = q.px; v4[1] = q.py; v4[2] = q.pz; v4[3] = el; v4[4] = az; }
-        Frag<PREC> raw = make_frag<PREC>(v4);
-        Frag<PREC> act = raw;
-        frag_activate<PREC, NA_ACT_SIN>(act);
-        scr_store(scr + (blk * 2) * FR, raw);
-        scr_store(scr + (blk * 2 + 1) * FR, act);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the scratch stores are read by the other waves after the barrier
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -498,15 +548,16 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
     SYNC();
     // ================= View MLP (sin)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) geoB[b] = wload<PREC>(srs, lane * 16, scr + (b * 2) * FR);
-    m_hidden<PREC, 2, 4, true, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    m_hidden<PREC, 2, 4, 1, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);
     SYNC();
     {
       f32x16 bv[2];
+      // tile 0 first: its 16 x NBLK accumulator registers are dead before the bias of the next layer is loaded
+      store_acts<PREC, NA_ACT_SIN, 0, 1>(acc, hb, rg, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 7 * 1024, t, lane);
-      store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+      store_acts<PREC, NA_ACT_SIN, 1, 2>(acc, hb, rg, lane);
       if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -514,21 +565,22 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
     }
     SYNC();
-#pragma unroll
-    for (int b = 0; b < NB; ++b) geoB[b] = wload<PREC>(srs, lane * 16, scr + (b * 2 + 1) * FR);
-    m_hidden<PREC, 3, 4, true, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+    m_hidden<PREC, 3, 4, 2, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);
     SYNC();
     for (int i = 0; i < 3; ++i) {
       f32x16 bv[2];
+      // tile 0 first: its 16 x NBLK accumulator registers are dead before the bias of the next layer is loaded
+      store_acts<PREC, NA_ACT_SIN, 0, 1>(acc, hb, rg, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (8 + i) * 1024, t, lane);
-      store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+      store_acts<PREC, NA_ACT_SIN, 1, 2>(acc, hb, rg, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
       SYNC();
-      m_hidden<PREC, 0, 0, false, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geoB);
+      m_hidden<PREC, 0, 0, 0, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
       SYNC();
     }
     {
@@ -546,6 +598,16 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 
 // ================================================================================================ pack
 #if NA_PREC_INST == 0
+// dir_to_elev_azim of every ray, once (src/utils.py:247-254): the View MLP's geometry chunk reads it per block
+__global__ void ray_elaz_kernel(const float* __restrict__ rays, int64_t R, float* __restrict__ elaz) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    float el, az;
+    elev_azim(rays[r * 6 + 3], rays[r * 6 + 4], rays[r * 6 + 5], el, az);
+    elaz[r * 2] = el;
+    elaz[r * 2 + 1] = az;
+  }
+}
+
 struct PackArgs {
   const float* w_first[6];  // init, layers.0..3, out   (nn.Linear layout [out,in])
   const float* b_first[6];
@@ -595,8 +657,11 @@ __global__ void pack_ls_kernel(PackArgs w, int planes, char* __restrict__ dst) {
         out_dim = kHidden;
         if (lp == 0) { col = init_slot_feature(d, q, kappa); in_dim = dim_p; }
         else if (lp == 1) {
-          if (q < NIc) { col = init_slot_feature(d, q, kappa); if (col >= 0) col += kHidden; }
-          else col = 16 * (q - NIc) + pi_perm(kappa);
+          // chunk order of the skip layer: init chunks from LDS, the 16 hidden chunks, then (View) the geometry chunk
+          const int nlds = view ? 4 : 3;
+          if (q < nlds) { col = init_slot_feature(d, q, kappa); if (col >= 0) col += kHidden; }
+          else if (q < nlds + kHC) col = 16 * (q - nlds) + pi_perm(kappa);
+          else { col = init_slot_feature(d, 4, kappa); if (col >= 0) col += kHidden; }
           in_dim = kHidden + dim_p;
         } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
       }
@@ -699,7 +764,7 @@ extern "C" int na_render_ls_pack(int precision, const float* const* w_first, con
 extern "C" size_t na_render_ls_workspace_bytes(int T, int64_t R) {
   if (T < 1 || R < 0) return 0;
   const int64_t nb = (T + 31) / 32;
-  return (size_t)(R * nb * ls::kPartialFloats * sizeof(float)) + 256 + 256 * (size_t)ls::Cfg<NA_PREC_BF16>::SCRATCH + 256 +
+  return (size_t)(R * nb * ls::kPartialFloats * sizeof(float)) + 256 + (size_t)R * 2 * sizeof(float) + 256 +
          (NA_LS_TRACE ? 4096 : 0);
 }
 
@@ -724,10 +789,12 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   a.alpha = alpha; a.weights = weights;
   a.partials = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.R = R; a.T = T; a.nb = (T + 31) / 32; a.nitems = R * a.nb;
-  a.scratch = (char*)(((uintptr_t)(a.partials + a.nitems * ls::kPartialFloats) + 255) & ~(uintptr_t)255);
+  float* elaz = (float*)(((uintptr_t)(a.partials + a.nitems * ls::kPartialFloats) + 255) & ~(uintptr_t)255);
+  a.elaz = elaz;
+  hipLaunchKernelGGL(ls::ray_elaz_kernel, dim3(grid_for(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays, R, elaz);
   a.sigmoid_kind = sigmoid_kind;
   a.res = hash_resolutions();
-  a.trace = NA_LS_TRACE ? (unsigned long long*)(a.scratch + 256 * (size_t)ls::Cfg<NA_PREC_BF16>::SCRATCH) : nullptr;
+  a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
   int rc = precision == NA_PREC_BF16 ? render_ls_dispatch_bf16(a, (hipStream_t)stream)
                                      : render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
   if (rc != NA_OK) return rc;

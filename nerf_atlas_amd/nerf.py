@@ -310,6 +310,26 @@ class DynamicNeRF(nn.Module):
         return c.from_pts(warped, self.ts, r_o, r_d, rays=rays)
 
 
+    def render_keyframes(self, rays):
+        """src/nerf.py:1305-1319 (runner.py:1019-1039 writes them as keyframe_NN.png): the scene rendered at each Bezier
+        control point, canonical.from_pts(pts + p_k * rigidity).  The reference splits the 3*spline_n control
+        coordinates into spline_n - 1 chunks, which torch.split rejects (sizes must sum to the dimension); the intended
+        one frame per control point is produced here.  Keyframe k goes through the warp kernel with every control point
+        set to p_k (the Bernstein weights sum to one, so dp = p_k)."""
+        assert self.spline > 0
+        c = self.canonical
+        self.pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, c.t_near, c.t_far, c.steps, perturb=0)
+        c.ts = self.ts
+        est = self.delta_estim(self.pts)
+        tt = torch.zeros(self.pts.shape[:-1], device=rays.device)
+        frames = []
+        for k in range(self.spline_n):
+            est_k = torch.cat([est[..., :1]] + [est[..., 1 + 3 * k:4 + 3 * k]] * self.spline_n, dim=-1).contiguous()
+            warped, _, self.rigidity = ops.bezier_warp(est_k, self.pts, tt, self.spline_n)
+            frames.append(c.from_pts(warped, self.ts, r_o, r_d, rays=rays))
+        return frames
+
+
 # ------------------------------------------------------------------------------------------------- registries
 def _experimental(name):
     def cons(*a, **k):

@@ -77,6 +77,17 @@ class SDF(nn.Module):
 
     def normals(self, pts, values=None): return self.underlying.normals(pts, values)
 
+    def intersect_mask(self, r_o, r_d, near=None, far=None, eps=1e-3):
+        """src/sdf.py:123-135: rays whose closest uniform sample along [near, far] stays outside the surface
+        (throughput >= eps) are masked out; (~hits, throughput, None)."""
+        from . import march
+        with torch.no_grad():
+            throughput, _, _, _ = march.throughput_with_sign_change(
+                self.underlying, r_o, r_d, near=self.near if near is None else near, far=self.far if far is None else far,
+                batch_size=32 if self.training else 196)
+            hits = throughput < eps
+            return ~hits, throughput, None
+
 
 def _out_of_scope(name):
     def cons(*a, **k):

@@ -57,7 +57,8 @@ def nerf_cam(na):
 def dtu_cam(na):
     """Synthetic DTU-like camera: fx = fy = 2892, cx = 800, cy = 600 at 1600x1200, looking at the
     origin from (0.3, -0.2, -2.2) with a small roll."""
-    K = torch.tensor([[[2892.0, 0.3, 800.0], [0, 2892.0, 600.0], [0, 0, 1.0]]])
+    K = torch.eye(4)[None].clone()  # 4x4 like the reference's loader output (src/loaders.py:150-160)
+    K[0, :3, :3] = torch.tensor([[2892.0, 0.3, 800.0], [0, 2892.0, 600.0], [0, 0, 1.0]])
     eye = torch.tensor([0.3, -0.2, -2.2])
     fwd = -eye / eye.norm()
     up = torch.tensor([0.05, 1.0, 0.0])
@@ -136,7 +137,8 @@ def test_volsdf_dtu_tile_and_properties(na, kind):
     assert maxdiff(rays, rays_ref) <= 2e-6
     out = m(rays)
     aux = {}
-    ref = O.volsdf(p, rays.cpu(), 0.3, 1.8, T, sdf_kind=kind, act="upshifted", aux=aux)
+    p_ref = dict(p, scale=h["scale"])
+    ref = O.volsdf(p_ref, rays.cpu(), 0.3, 1.8, T, sdf_kind=kind, act="upshifted", aux=aux)
     # the Fourier-encoded SDF MLP inherits ~1e-4 feature-level fp32 noise; RGB stays within 1e-4
     assert maxdiff(out, ref) <= 1e-4
     assert maxdiff(m.weights, aux["weights"]) <= 2e-4

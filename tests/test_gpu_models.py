@@ -192,6 +192,58 @@ def test_mip_plain_nerf_tile_800_geometry(na, kind):
     assert maxdiff(lat, ref_lat) <= 2e-5, kind
 
 
+def test_bezier_keyframes_and_intersect_mask(na):
+    """N3 tail (runner.py:1019-1039, src/nerf.py:1305-1319): one frame per Bezier control point, against the oracle's
+    from_pts on pts + p_k * rigidity; N4 tail: SDF.intersect_mask (src/sdf.py:123-135) against the oracle's marching."""
+    import oracle as O
+    h = load_golden("g9_dnerf_spline6")
+    p = golden_params(h)
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=6).cuda().eval()
+    load_params(m, p)
+    frames = m.render_keyframes(h["rays"].cuda())
+    assert len(frames) == 6
+    rays = h["rays"]
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    ts, _ = O.compute_ts(2.0, 6.0, int(h["steps"]))
+    pts = O.compute_pts(r_o, r_d, ts)
+    est = O.skip_mlp(p, "delta_estim.", pts, enc=O.nerf_oracle._hash_enc_from(p, "delta_estim.enc."))
+    rig = (est[..., :1] / 2).sigmoid()
+    # the control points are raw MLP outputs (not the small blended dp of a render at time t), so the canonical hash grid
+    # is evaluated far from the rays and its fine levels amplify the 1e-5-level difference of the two delta_estim
+    # evaluations; the chain is therefore checked link by link: delta_estim against the oracle, then the canonical render
+    # of the GPU's own control points against the oracle at 1e-4, and the end-to-end frames at 3e-4.
+    est_gpu = m.delta_estim(m.pts).cpu()
+    assert maxdiff(est_gpu, est) <= 2e-5
+    rig_gpu = (est_gpu[..., :1] / 2).sigmoid()
+    for k, f in enumerate(frames):
+        ref_own = O.plain_nerf_from_pts(p, pts + est_gpu[..., 1 + 3 * k:4 + 3 * k] * rig_gpu, ts, r_o, r_d, "view",
+                                        act="upshifted", prefix="canonical.")
+        assert maxdiff(f, ref_own) <= 1e-4, k
+        ref = O.plain_nerf_from_pts(p, pts + est[..., 1 + 3 * k:4 + 3 * k] * rig, ts, r_o, r_d, "view", act="upshifted",
+                                    prefix="canonical.")
+        assert maxdiff(f, ref) <= 3e-4, k
+    assert maxdiff(frames[0], frames[5]) > 1e-5  # the control points differ
+    # intersect_mask
+    g = load_golden("g15_march")
+    under = na.sdf.SIREN(intermediate_size=0)
+    s = na.sdf.SDF(under, na.refl.View(latent_size=0, act="upshifted", out_features=3), t_near=float(g["nn_near"]),
+                   t_far=float(g["nn_far"])).cuda().eval()
+    sd = under.state_dict()
+    for k, v in golden_params(g).items():
+        sd[k].copy_(v)
+    import random
+    random.seed(0)
+    mask, tput, _ = s.intersect_mask(g["r_o"].cuda(), g["r_d"].cuda())
+    fn = lambda x: O.skip_mlp(golden_params(g), "siren.", x, act="sin")
+    random.seed(0)
+    tref, _, _, _ = O.throughput_with_sign_change(fn, g["r_o"], g["r_d"], float(g["nn_near"]), float(g["nn_far"]), 196,
+                                                  jitter=random.random())
+    assert maxdiff(tput, tref) <= 2e-4
+    decided = (tref - 1e-3).abs() > 2e-4  # away from the threshold the masks agree exactly
+    assert torch.equal(mask.cpu()[decided], ~(tref < 1e-3)[decided])
+
+
 def test_aux_render_outputs_and_extra_encoders(na):
     """N3-style outputs that reuse .weights (runner.py:894-920) and the low-priority encoders of A4."""
     import oracle as O
