@@ -324,6 +324,19 @@ int na_sign_change_update(const float* sdf, int stride, int64_t R, int step, flo
 int na_bisection_update(const float* sdf_mid, int stride, int64_t R, float eps, float* low, float* high, float* sdf_low,
                         float* sdf_high, float* z, uint8_t* todo, void* stream);
 
+/* ---- N4: lights and occlusion (src/lights.py:69-132 Point; src/renderers.py:29-163 occlusion kinds) ----------------
+ * na_point_light      Point.forward for N points: dir[N,3] = normalize(center - x) (eps 1e-6), dist[N] = |center - x|,
+ *                     spectrum[N,3] = intensity / (4 pi dist^2) (or intensity when distance_decay == 0).  center and
+ *                     intensity are one vector (stride 0) or one per point (stride 3: `loc.expand(mask.shape)[mask]`).
+ * na_occlusion_apply  out = spectrum * a * v:  att_mode 0 a = 1; 1 a = sigmoid(raw_att) on hidden points only
+ *                     (LearnedLighting :65-67); 2 a = sigmoid(raw_att) + 1e-2 (AllLearnedOcc :111-121);  v = 1 where
+ *                     visible (or visible == NULL), hidden_value elsewhere (0: LightingWIsect :40-45; sigmoid(alpha):
+ *                     LearnedConstantSoftLighting :82-83, JointLearnedConstOcc :143-146).                           */
+int na_point_light(const float* x, const float* center, int center_stride, const float* intensity, int intensity_stride,
+                   int distance_decay, int64_t N, float* dir, float* dist, float* spectrum, void* stream);
+int na_occlusion_apply(const float* spectrum, const uint8_t* visible, const float* raw_att, int att_mode,
+                       float hidden_value, int64_t N, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

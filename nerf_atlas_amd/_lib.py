@@ -61,6 +61,9 @@ SIGNATURES = {
                                         C.c_void_p]),
     "na_bisection_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                       C.c_void_p, C.c_void_p]),
+    "na_point_light": (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, c_i64, c_f32p, c_f32p, c_f32p,
+                                 C.c_void_p]),
+    "na_occlusion_apply": (C.c_int, [c_f32p, C.c_void_p, c_f32p, C.c_int, C.c_float, c_i64, c_f32p, C.c_void_p]),
     "na_set_deterministic": (C.c_int, [C.c_void_p, C.c_size_t]),
     "na_act_deriv": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "na_mul_bcast": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),

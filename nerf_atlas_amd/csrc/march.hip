@@ -75,6 +75,47 @@ __global__ void bisection_update_kernel(const float* __restrict__ sdf_mid, int s
   }
 }
 
+// src/lights.py:118-132 Point.forward for N points: direction to the light (F.normalize, eps 1e-6), distance and
+// inverse-square spectrum.  center / intensity: one [3] vector (stride 0) or one per point (stride 3).
+__global__ void point_light_kernel(const float* __restrict__ x, const float* __restrict__ center, int c_stride,
+                                   const float* __restrict__ intensity, int i_stride, int decay, int64_t N,
+                                   float* __restrict__ dir, float* __restrict__ dist, float* __restrict__ spectrum) {
+#pragma clang fp contract(off)
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    const float* c = center + n * c_stride;
+    const float* in = intensity + n * i_stride;
+    const float dx = c[0] - x[3 * n], dy = c[1] - x[3 * n + 1], dz = c[2] - x[3 * n + 2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float den = fmaxf(len, 1e-6f);
+    dir[3 * n] = dx / den; dir[3 * n + 1] = dy / den; dir[3 * n + 2] = dz / den;
+    dist[n] = len;
+    const float att = (len * len) * 12.566370614359172f;  // 4 * pi * dist^2 in the reference's order
+    for (int k = 0; k < 3; ++k) spectrum[3 * n + k] = decay ? in[k] / att : in[k];
+  }
+}
+
+// src/renderers.py:40-45, :65-67, :82-83, :118-121, :143-146: spectrum * a(raw_att) * v(visible)
+//   att_mode 0: a = 1;  1: a = sigmoid(raw) only where hidden (learned);  2: a = sigmoid(raw) + 1e-2 everywhere
+//   visible == nullptr: v = 1; else v = visible ? 1 : hidden_value (0 hard, sigmoid(alpha) learned-const; mode 1: 1)
+__global__ void occlusion_apply_kernel(const float* __restrict__ spectrum, const uint8_t* __restrict__ visible,
+                                       const float* __restrict__ raw_att, int att_mode, float hidden_value, int64_t N,
+                                       float* __restrict__ out) {
+#pragma clang fp contract(off)
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    const bool vis = visible == nullptr || visible[n] != 0;
+    float s0 = spectrum[3 * n], s1 = spectrum[3 * n + 1], s2 = spectrum[3 * n + 2];
+    if (att_mode == 2) {
+      const float a = sigmoidf_(raw_att[n]) + 1e-2f;
+      s0 *= a; s1 *= a; s2 *= a;
+    }
+    if (!vis) {
+      const float h = att_mode == 1 ? sigmoidf_(raw_att[n]) : hidden_value;
+      s0 *= h; s1 *= h; s2 *= h;
+    }
+    out[3 * n] = s0; out[3 * n + 1] = s1; out[3 * n + 2] = s2;
+  }
+}
+
 }  // namespace na
 
 using namespace na;
@@ -122,6 +163,31 @@ int na_bisection_update(const float* sdf_mid, int stride, int64_t R, float eps, 
   hipLaunchKernelGGL(bisection_update_kernel, dim3(grid_for(R, 256, 8192)), dim3(256), 0, (hipStream_t)stream, sdf_mid,
                      stride, R, eps, low, high, sdf_low, sdf_high, z, todo);
   return check_launch("na_bisection_update");
+}
+
+int na_point_light(const float* x, const float* center, int center_stride, const float* intensity, int intensity_stride,
+                   int distance_decay, int64_t N, float* dir, float* dist, float* spectrum, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_point_light: N %lld", (long long)N);
+  NA_REQUIRE(x && center && intensity && dir && dist && spectrum, NA_ENULL, "na_point_light: null pointer");
+  NA_REQUIRE((center_stride == 0 || center_stride == 3) && (intensity_stride == 0 || intensity_stride == 3), NA_EINVAL,
+             "na_point_light: strides must be 0 (one light) or 3 (one per point)");
+  hipLaunchKernelGGL(point_light_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, center,
+                     center_stride, intensity, intensity_stride, distance_decay, N, dir, dist, spectrum);
+  return check_launch("na_point_light");
+}
+
+int na_occlusion_apply(const float* spectrum, const uint8_t* visible, const float* raw_att, int att_mode,
+                       float hidden_value, int64_t N, float* out, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_occlusion_apply: N %lld", (long long)N);
+  NA_REQUIRE(spectrum && out, NA_ENULL, "na_occlusion_apply: null pointer");
+  NA_REQUIRE(att_mode >= 0 && att_mode <= 2, NA_EINVAL, "na_occlusion_apply: att_mode %d", att_mode);
+  NA_REQUIRE(att_mode == 0 || raw_att, NA_ENULL, "na_occlusion_apply: att_mode %d needs raw_att", att_mode);
+  NA_REQUIRE(att_mode != 1 || visible, NA_ENULL, "na_occlusion_apply: att_mode 1 needs the visibility mask");
+  hipLaunchKernelGGL(occlusion_apply_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, spectrum,
+                     visible, raw_att, att_mode, hidden_value, N, out);
+  return check_launch("na_occlusion_apply");
 }
 
 }  // extern "C"

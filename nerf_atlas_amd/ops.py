@@ -294,6 +294,46 @@ def bisection_update(sdf_mid, eps: float, low, high, sdf_low, sdf_high, z, todo)
 
 
 # ------------------------------------------------------------------------------------------------- MLP
+
+
+# ---------------------------------------------------------------------------------------- N4 lights / occlusion
+def point_light(x: torch.Tensor, center: torch.Tensor, intensity: torch.Tensor, distance_decay: bool = True):
+    """src/lights.py:118-132: (unit direction to the light, distance [..., 1], spectrum [..., 3]) for points x [..., 3];
+    center / intensity hold one light ([3]) or one per point (x.shape)."""
+    lib = _lib.load()
+    x, center, intensity = _f32(x, "x"), _f32(center, "center"), _f32(intensity, "intensity")
+    N = x.numel() // 3
+    strides = []
+    for t, name in ((center, "center"), (intensity, "intensity")):
+        assert t.numel() in (3, 3 * N), f"{name}: one light or one per point"
+        strides.append(3 if (t.numel() == 3 * N and N > 1) else 0)
+    d = torch.empty_like(x)
+    dist = torch.empty(tuple(x.shape[:-1]) + (1,), device=x.device, dtype=torch.float32)
+    spectrum = torch.empty_like(x)
+    check(lib.na_point_light(_ptr(x), _ptr(center), strides[0], _ptr(intensity), strides[1], int(bool(distance_decay)), N,
+                             _ptr(d), _ptr(dist), _ptr(spectrum), _stream()))
+    return d, dist, spectrum
+
+
+def occlusion_apply(spectrum: torch.Tensor, visible: Optional[torch.Tensor] = None, raw_att: Optional[torch.Tensor] = None,
+                    att_mode: int = 0, hidden_value: float = 0.0) -> torch.Tensor:
+    """spectrum * a(raw_att) * v(visible): see include/nerf_atlas_amd.h (src/renderers.py:40-45,65-67,82-83,118-121)."""
+    lib = _lib.load()
+    spectrum = _f32(spectrum, "spectrum")
+    N = spectrum.numel() // 3
+    vis = None
+    if visible is not None:
+        assert visible.dtype == torch.bool and visible.numel() == N and visible.is_cuda
+        vis = visible.contiguous().view(torch.uint8)
+    if raw_att is not None:
+        raw_att = _f32(raw_att, "raw_att")
+        assert raw_att.numel() == N
+    out = torch.empty_like(spectrum)
+    check(lib.na_occlusion_apply(_ptr(spectrum), _ptr(vis), _ptr(raw_att), int(att_mode), float(hidden_value), N, _ptr(out),
+                                 _stream()))
+    return out
+
+
 def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre_act: str = "none",
                x1: Optional[torch.Tensor] = None, split_bf16: bool = False) -> torch.Tensor:
     """y = W . act([x0 | x1]) + b: exact fp32 (f32 MFMA), or with split_bf16 the 3-product bf16 split used by the

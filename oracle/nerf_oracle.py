@@ -24,6 +24,7 @@ __all__ = [
     "cubic_bezier", "laplace_cdf", "tiny_nerf", "plain_nerf", "plain_nerf_from_pts", "volsdf", "dynamic_nerf_spline",
     "view_refl", "positional_refl", "pos_linear_view_refl", "mse2psnr", "render_tiled",
     "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
+    "point_light", "intersect_mask", "occlusion",
 ]
 
 # ----------------------------------------------------------------------------- A1 pixels
@@ -633,3 +634,71 @@ def bisect(sdf_fn, r_o, r_d, iters: int = 128, near: float = 0, far: float = 1, 
     tput, best_pos, last_pos, first_neg = throughput_with_sign_change(sdf_fn, r_o, r_d, near, far, iters, jitter)
     pts = bisection(sdf_fn, r_o, r_d, last_pos, first_neg, iters=min(32, iters))
     return pts, tput < 0, best_pos, tput.unsqueeze(-1)
+
+
+# ----------------------------------------------------------------------------- N4 lights + occlusion
+
+
+def point_light(x, center, intensity, distance_decay: bool = True):
+    """src/lights.py:118-132 Point.forward for one light: center/intensity [3] (what `Point.iter()` hands out, curr_idx 0);
+    x [...,3] (already masked by the caller) -> (unit direction to the light, distance [...,1], spectrum [...,3])."""
+    d = center - x
+    dist = torch.linalg.norm(d, ord=2, dim=-1, keepdim=True)
+    d = F.normalize(d, eps=1e-6, dim=-1)
+    spectrum = (intensity / (4 * math.pi * dist.square())) if distance_decay else intensity.expand_as(x)
+    return d, dist, spectrum
+
+
+def intersect_mask(sdf_fn, r_o, r_d, near: float, far: float, eps: float = 1e-3, batch_size: int = 196, jitter: float = 0.0):
+    """src/sdf.py:123-135 (eval mode: 196 uniform probes): (visible = ~(throughput < eps), throughput)."""
+    tput, _, _, _ = throughput_with_sign_change(sdf_fn, r_o, r_d, near, far, batch_size, jitter=jitter)
+    return ~(tput < eps), tput
+
+
+def occlusion(kind, params, pts, center, intensity, sdf_fn, jitter: float = 0.0, mask=None, alpha=None,
+              component: str = "pos-elaz", aux=None):
+    """src/renderers.py:29-163: (direction to the light, attenuated spectrum) for one point light.
+    kind: None | hard | learned | learned-const | all-learned | joint-all-const.  params: the occlusion module's
+    state dict ("attenuation." / "alo.attenuation." SkipConnMLP with a FourierEncoder, "alpha" / "lcsl.alpha")."""
+    x = pts if mask is None else pts[mask]
+    d, dist, spectrum = point_light(x, center, intensity)
+    aux = {} if aux is None else aux
+
+    def visible(near, far, eps=1e-3):
+        vis, tput = intersect_mask(sdf_fn, x, d, near, far, eps, jitter=jitter)
+        aux["tput"], aux["far"] = tput, far
+        return vis
+
+    def att_mlp(prefix, inp):
+        basis = params[prefix + "enc.basis"]
+        return skip_mlp(params, prefix, inp, enc=lambda v: fourier_encode(v, basis))
+
+    def far_of(default=6):  # :37,62 / :81 (no mask -> 6) / :140
+        return float(dist.max())
+
+    if kind is None:                                   # :29-31
+        return d, spectrum
+    if kind == "hard":                                 # :34-46
+        vis = visible(0.1, far_of())
+        return d, torch.where(vis[..., None], spectrum, torch.zeros_like(spectrum))
+    if kind == "learned":                              # :48-68
+        vis = visible(2e-3, far_of())
+        att = att_mlp("attenuation.", torch.cat([x, dir_to_elev_azim(d)], dim=-1)).sigmoid()
+        return d, torch.where(vis.reshape_as(att), spectrum, spectrum * att)
+    if kind == "learned-const":                        # :70-84 (`mask and mask.any()` -> far 6 without a mask)
+        vis = visible(1e-2, far_of() if mask is not None else 6)
+        hit_att = vis + (~vis) * torch.as_tensor(alpha).sigmoid()
+        return d, spectrum * hit_att.unsqueeze(-1)
+    comp = (lambda a, b: a) if component == "pos" else (lambda a, b: torch.cat([a, dir_to_elev_azim(b)], dim=-1))
+    if kind == "all-learned":                          # :96-121
+        raw = att_mlp("attenuation.", comp(x, d))
+        aux["raw_att"] = raw
+        return d, spectrum * (raw.sigmoid() + 1e-2)
+    if kind == "joint-all-const":                      # :123-147
+        assert mask is None, "src/renderers.py:138"
+        raw = att_mlp("alo.attenuation.", comp(x, d))
+        aux["raw_att"] = raw
+        vis = visible(1e-1, far_of())
+        hit_att = vis + (~vis) * torch.as_tensor(alpha).sigmoid()
+        return d, spectrum * (raw.sigmoid() + 1e-2) * hit_att.unsqueeze(-1)
+    raise NotImplementedError(kind)

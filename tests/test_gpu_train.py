@@ -63,20 +63,23 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     print(f"\n[{name}/{train_prec}] |loss - ref| first 10: {np.abs(got[:10] - ref[:10]).max():.2e}, first 5: "
           f"{np.abs(got[:5] - ref[:5]).max():.2e}; test PSNR build {np.round(res['test_psnr'], 4).tolist()} vs reference "
           f"{np.round(fx['test_psnr'], 4).tolist()} (max diff {d.max():.4f} dB)")
-    # same trajectory while rounding noise has not been amplified yet.  D-NeRF: predicted positions cross hash-cell faces
-    # and the fp32 atomics of the scatter kernels reorder from run to run, so its trajectory decorrelates after ~5
-    # iterations even in exact fp32 (run-to-run: first-10 deviation 7e-5..3.4e-4, per-view PSNR 0.03..0.85 dB)
+    # same trajectory while rounding noise has not been amplified yet.  D-NeRF: predicted positions cross hash-cell faces,
+    # so the rounding-order difference between the reference's CPU kernels and these ones is amplified after ~5
+    # iterations.  With config.set_deterministic the build's own trajectory is bit-reproducible (test below), so the
+    # numbers are fixed: first-10 deviation 2.3e-4 (bf16x3) / 3.0e-4 (fp32), per-view PSNR 0.08 / 0.35 dB.
     assert np.abs(got[:5] - ref[:5]).max() <= 2e-4, (got[:5], ref[:5])
-    assert np.abs(got[:10] - ref[:10]).max() <= (5e-3 if name == "dnerf" else 2e-4), (got[:10], ref[:10])
+    assert np.abs(got[:10] - ref[:10]).max() <= (1e-3 if name == "dnerf" else 2e-4), (got[:10], ref[:10])
     # the whole curve stays on the reference's (smoothed: single iterations are noisy by design)
     k = 20
     sm = lambda v: np.convolve(v, np.ones(k) / k, mode="valid")
-    assert np.abs(sm(got) - sm(ref)).max() <= (0.35 if name == "dnerf" else 0.1) * sm(ref).max(), np.abs(sm(got) - sm(ref)).max()
+    dev = np.abs(sm(got) - sm(ref)).max() / sm(ref).max()
+    print(f"[{name}/{train_prec}] smoothed-curve deviation {dev:.4f} of the curve's maximum")
+    assert dev <= (0.35 if name == "dnerf" else 0.1), dev
     assert ref[-k:].mean() < 0.5 * ref[:k].mean(), "the recipe must actually learn"
     if name == "dnerf":
-        # chaotic trajectory (see above): a statistical bar -- per view 2.5 dB, mean 1.2 dB (observed over ~40 runs:
-        # <= 0.85 / 0.49, with one unexplained suite failure in between; an untrained model is > 8 dB away)
-        assert d.max() <= 2.5 and abs(res["test_psnr_mean"] - fx["test_psnr_mean"]) <= 1.2, (res["test_psnr"], fx["test_psnr"])
+        # chaotic but deterministic trajectory (see above): measured 0.08 dB per view / 0.04 dB mean in bf16x3 and
+        # 0.35 / 0.20 dB in fp32 (an untrained model is > 8 dB away); the bars leave ~1.5x for a different toolchain
+        assert d.max() <= 0.5 and abs(res["test_psnr_mean"] - fx["test_psnr_mean"]) <= 0.3, (res["test_psnr"], fx["test_psnr"])
     else:
         assert d.max() <= (0.01 if train_prec == "fp32" else 0.1), (res["test_psnr"], fx["test_psnr"])
     # the fast renderer on the trained model

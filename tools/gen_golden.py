@@ -539,9 +539,66 @@ def g15():
     save("g15_march", **kw)
 
 
+# ------------------------------------------------------------------ G16 occlusion models (N4)
+def g16():
+    """Reference src/renderers.py:29-163 occlusion kinds over a src/lights.py Point light and the reference SIREN SDF's
+    intersect_mask (src/sdf.py:123-135), all with procedural weights; points on a [2,6,8] grid, some masked out."""
+    import random
+    import src.renderers as rrend
+    import src.lights as rlights
+    siren = rsdf.SIREN(intermediate_size=0)
+    names, shapes = fill_procedural(siren)
+    sdf = rsdf.SDF(siren, rrefl.View(latent_size=0), None, t_near=0.5, t_far=5.0)
+    sdf.eval()
+    # the procedural SIREN is negative somewhere along every ray: lift its output bias so about half the points see the light
+    shift = 0.9
+    siren.siren.out.bias.data += shift
+    light0 = rlights.Point(center=[1.5, 2.0, -1.0], intensity=[30.0])
+    light = next(iter(light0.iter()))  # how src/renderers.py:198 hands lights to the occlusion model
+    gen = torch.Generator().manual_seed(16)
+    pts = torch.rand(2, 6, 8, 3, generator=gen) * 2.4 - 1.2
+    mask = torch.rand(2, 6, 8, generator=gen) > 0.25
+    kw = dict(pts=pts, mask=mask, sdf_out_bias_shift=np.float64(shift), center=light.center.detach(), intensity=light.intensity.detach(),
+              sdf_param_names=np.array(names), sdf_param_shapes=np.array([",".join(map(str, sh)) for sh in shapes]))
+    seen = {}
+
+    def isect(r_o, r_d, near=None, far=None, eps=1e-3):
+        vis, tput, _ = sdf.intersect_mask(r_o, r_d, near=near, far=far, eps=eps)
+        seen["tput"], seen["far"] = tput, far
+        return vis, tput, None
+    cases = [("hard", True, {}), ("learned", True, {}), ("learned-const", False, {}),
+             ("all-learned", True, {"all_learned_occ_kind": "pos-elaz"}), ("all-learned-pos", False, {"all_learned_occ_kind": "pos"}),
+             ("joint-all-const", False, {})]
+    for tag, use_mask, extra in cases:
+        kind = "all-learned" if tag.startswith("all-learned") else tag
+        args = types.SimpleNamespace(occ_kind=kind, **extra)
+        occ = rrend.load_occlusion_kind(args, kind, 0)
+        occ.eval()
+        onames, oshapes = fill_procedural(occ, sigma_by_suffix=4.0)
+        for n_, p_ in occ.named_parameters():
+            if n_.endswith("alpha"):
+                p_.data.fill_(0.3)
+        seen.clear()
+        random.seed(16)
+        d, s = occ(pts, light, isect, mask=mask if use_mask else None, latent=None)
+        t = tag.replace("-", "_")
+        kw.update({f"{t}_dir": d, f"{t}_spectrum": s, f"{t}_param_names": np.array(onames),
+                   f"{t}_param_shapes": np.array([",".join(map(str, sh)) for sh in oshapes])})
+        if "tput" in seen:
+            kw[f"{t}_tput"], kw[f"{t}_far"] = seen["tput"], np.float64(seen["far"])
+        if hasattr(occ, "all_learned_occ"):
+            kw[f"{t}_raw_att"] = occ.all_learned_occ.raw_att
+    random.seed(16)
+    kw["jitter"] = np.float64(random.random())
+    # no-shadow lighting (src/renderers.py:29-31)
+    d, s = rrend.lighting_wo_isect(pts, light, None, mask=mask)
+    kw["none_dir"], kw["none_spectrum"] = d, s
+    save("g16_occlusion", **kw)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for g in which:
         globals()[g]()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
