@@ -275,6 +275,20 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
                             float* tables_grad, void* stream);
 int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,
                                   int include_input, float* g_x, void* stream);
+/* Forward-mode derivative of the hash features along a per-point direction e (the deformation network's input
+ * Jacobian-vector product that the FFJORD divergence estimate needs: runner.py:697-700, src/utils.py:467-478;
+ * src/neural_blocks.py:166-190 is what is differentiated).
+ * na_hash_encode_jvp           t_out[N, 32 (+3)] = d hash_encode(x)/dx . e   (rows [e | per-level features])
+ * na_hash_encode_jvp_backward  tables_grad += d <g_t, J(x).e> / d tables (the adjoint of the above in the tables)
+ * na_ffjord_div                div[N] = <e, d(rigid_dp)/dx . e> from the deformation MLP's outputs est[N, stride] =
+ *                              [rigidity | n_ctrl control points | ...] and their directional derivatives est_tangent:
+ *                              rigid_dp = bezier(P, t) * sigmoid(est0 / 2)  (src/nerf.py:1267-1278).               */
+int na_hash_encode_jvp(const float* x, int64_t N, const float* tables, const float* tangent, int include_input,
+                       float* t_out, void* stream);
+int na_hash_encode_jvp_backward(const float* x, const float* tangent, int64_t N, const float* g_t, int include_input,
+                                float* tables_grad, void* stream);
+int na_ffjord_div(const float* est, const float* est_tangent, int est_stride, const float* t, const float* e, int64_t N,
+                  int n_ctrl, float* div, void* stream);
 int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, const float* g, float* g_sdf,
                                 float* g_beta, void* stream);
 int na_bezier_warp_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl,

@@ -84,6 +84,9 @@ SIGNATURES = {
                                          c_f32p, C.c_void_p]),
     "na_hash_encode_backward": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_hash_encode_backward_input": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_hash_encode_jvp": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_hash_encode_jvp_backward": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "na_ffjord_div": (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_laplace_density_backward": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_bezier_warp_backward": (C.c_int, [c_f32p, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.c_void_p]),

@@ -188,7 +188,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restrict__ x, int64_t N,
                                                             const float* __restrict__ g_out, int include_input,
                                                             HashRes res, float* __restrict__ tables_grad,
-                                                            long long* __restrict__ fix) {
+                                                            long long* __restrict__ fix,
+                                                            const float* __restrict__ tangent) {
+  // tangent != nullptr: g_out is the gradient of the directional derivative J(x).e of hash_jvp_kernel, whose corner
+  // weights are N_l * <grad w_corner, e> instead of w_corner
   const int odim = 32 + 3 * include_input;
   const int lvl = blockIdx.y;
   const float Nl = res.n[lvl];
@@ -200,7 +203,11 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
     const int64_t n = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const bool live = n < N;
     float wx = 0.f, wy = 0.f, wz = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    float ex = 0.f, ey = 0.f, ez = 0.f;
     int lx = 0, ly = 0, lz = 0;
+    if (live && tangent != nullptr) {
+      ex = tangent[n * 3] * Nl; ey = tangent[n * 3 + 1] * Nl; ez = tangent[n * 3 + 2] * Nl;
+    }
     if (live) {
       const float vx = x[n * 3] * Nl, vy = x[n * 3 + 1] * Nl, vz = x[n * 3 + 2] * Nl;
       const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
@@ -213,7 +220,12 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t id = hash_index(lx + ((c >> 2) & 1), ly + ((c >> 1) & 1), lz + (c & 1));
-      const float w = (((c >> 2) & 1) ? wx : iwx) * (((c >> 1) & 1) ? wy : iwy) * ((c & 1) ? wz : iwz);
+      const float ux = ((c >> 2) & 1) ? wx : iwx, uy = ((c >> 1) & 1) ? wy : iwy, uz = (c & 1) ? wz : iwz;
+      float w = ux * uy * uz;
+      if (tangent != nullptr) {
+        const float sx = ((c >> 2) & 1) ? ex : -ex, sy = ((c >> 1) & 1) ? ey : -ey, sz = (c & 1) ? ez : -ez;
+        w = (sx * (uy * uz) + sy * (ux * uz)) + sz * (ux * uy);
+      }
       const float a0 = w * g0, a1 = w * g1, a2 = w * g2, a3 = w * g3;
       bool todo = live;
       // at most 4 leader rounds (covers the common case of a wave straddling a cell face), then per-lane atomics
@@ -292,6 +304,75 @@ __global__ void hash_backward_input_kernel(const float* __restrict__ x, int64_t 
       }
       g_x[n * 3] = gx; g_x[n * 3 + 1] = gy; g_x[n * 3 + 2] = gz;
     }
+  }
+}
+
+// Directional derivative of the hash features along e (forward mode; the reference's FFJORD estimate
+// src/utils.py:467-478 obtains e^T J e with a vector-Jacobian product, which is the same number):
+//   t[n, 0:3] = e (include_input),   t[n, lvl, :] = N_lvl * sum_corner <grad w_corner, e> * emb_corner.
+// One thread per (sample, level), like hash_backward_input_kernel.
+__global__ void hash_jvp_kernel(const float* __restrict__ x, int64_t N, const float* __restrict__ tables,
+                                const float* __restrict__ tangent, int include_input, HashRes res,
+                                float* __restrict__ t_out) {
+  const int odim = 32 + 3 * include_input;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N * 8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lvl = (int)(i & 7);
+    const int64_t n = i >> 3;
+    const float Nl = res.n[lvl];
+    const float vx = x[n * 3] * Nl, vy = x[n * 3 + 1] * Nl, vz = x[n * 3 + 2] * Nl;
+    const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
+    const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
+    const float wx = vx - fx, wy = vy - fy, wz = vz - fz;
+    const float iwx = 1.f - wx, iwy = 1.f - wy, iwz = 1.f - wz;
+    const float e0 = tangent[n * 3], e1 = tangent[n * 3 + 1], e2 = tangent[n * 3 + 2];
+    const float ex = e0 * Nl, ey = e1 * Nl, ez = e2 * Nl;
+    const float* tab = tables + (int64_t)lvl * 65536 * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+      const uint32_t id = hash_index(lx + bx, ly + by, lz + bz);
+      const float4 emb = *(const float4*)(tab + (int64_t)id * 4);
+      const float ux = bx ? wx : iwx, uy = by ? wy : iwy, uz = bz ? wz : iwz;
+      const float sx = bx ? ex : -ex, sy = by ? ey : -ey, sz = bz ? ez : -ez;
+      const float w = (sx * (uy * uz) + sy * (ux * uz)) + sz * (ux * uy);
+      a0 += w * emb.x; a1 += w * emb.y; a2 += w * emb.z; a3 += w * emb.w;
+    }
+    float* o = t_out + n * odim + 3 * include_input + lvl * 4;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    if (lvl == 0 && include_input) {
+      t_out[n * odim] = e0; t_out[n * odim + 1] = e1; t_out[n * odim + 2] = e2;
+    }
+  }
+}
+
+// FFJORD divergence estimate of the rigid deformation field (runner.py:697-700, src/utils.py:467-478) from the
+// deformation network's outputs `est` = [rigidity | control points] and their directional derivatives `tan` along e:
+//   rig = sigmoid(z0/2), d rig = rig (1-rig)/2 * t0, dp = sum_k B_k(t) P_k, d dp = sum_k B_k(t) tP_k,
+//   div = <e, d dp * rig + dp * d rig>  (= e^T J e),   out[n] = div.
+__global__ void ffjord_div_kernel(const float* __restrict__ est, const float* __restrict__ tan, int stride,
+                                  const float* __restrict__ tt, const float* __restrict__ e, int64_t N, int n,
+                                  float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* z = est + i * stride;
+    const float* dz = tan + i * stride;
+    const float rig = sigmoidf_(z[0] / 2.f);
+    const float drig = rig * (1.f - rig) * 0.5f * dz[0];
+    const float t = tt[i], m1t = 1.f - t;
+    float B[8];
+    B[0] = 1.f;
+    for (int it = 1; it < n; ++it) {
+      B[it] = B[it - 1] * t;
+      for (int k = it - 1; k >= 1; --k) B[k] = B[k] * m1t + B[k - 1] * t;
+      B[0] *= m1t;
+    }
+    float div = 0.f;
+    for (int a = 0; a < 3; ++a) {
+      float dp = 0.f, ddp = 0.f;
+      for (int k = 0; k < n; ++k) { dp += B[k] * z[1 + 3 * k + a]; ddp += B[k] * dz[1 + 3 * k + a]; }
+      div += e[i * 3 + a] * (ddp * rig + dp * drig);
+    }
+    out[i] = div;
   }
 }
 
@@ -557,7 +638,7 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
   long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_backward", &rc);
   if (rc != NA_OK) return rc;
   hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
-                     g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix);
+                     g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, (const float*)nullptr);
   if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_backward");
   return check_launch("na_hash_encode_backward");
 }
@@ -570,6 +651,43 @@ int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables
   hipLaunchKernelGGL(hash_backward_input_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
                      x, N, tables, g_out, include_input ? 1 : 0, hash_resolutions(), g_x);
   return check_launch("na_hash_encode_backward_input");
+}
+
+int na_hash_encode_jvp(const float* x, int64_t N, const float* tables, const float* tangent, int include_input,
+                       float* t_out, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_hash_encode_jvp: N %lld", (long long)N);
+  NA_REQUIRE(x && tables && tangent && t_out, NA_ENULL, "na_hash_encode_jvp: null pointer");
+  hipLaunchKernelGGL(hash_jvp_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, tables,
+                     tangent, include_input ? 1 : 0, hash_resolutions(), t_out);
+  return check_launch("na_hash_encode_jvp");
+}
+
+int na_hash_encode_jvp_backward(const float* x, const float* tangent, int64_t N, const float* g_t, int include_input,
+                                float* tables_grad, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_hash_encode_jvp_backward: N %lld", (long long)N);
+  NA_REQUIRE(x && tangent && g_t && tables_grad, NA_ENULL, "na_hash_encode_jvp_backward: null pointer");
+  const int64_t ntab = 8LL * 65536 * 4;
+  int rc;
+  long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_jvp_backward", &rc);
+  if (rc != NA_OK) return rc;
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
+                     g_t, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, tangent);
+  if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_jvp_backward");
+  return check_launch("na_hash_encode_jvp_backward");
+}
+
+int na_ffjord_div(const float* est, const float* est_tangent, int est_stride, const float* t, const float* e, int64_t N,
+                  int n_ctrl, float* div, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(N > 0, NA_EINVAL, "na_ffjord_div: N %lld", (long long)N);
+  NA_REQUIRE(est && est_tangent && t && e && div, NA_ENULL, "na_ffjord_div: null pointer");
+  NA_REQUIRE(n_ctrl >= 2 && n_ctrl <= 8 && est_stride >= 1 + 3 * n_ctrl, NA_EINVAL,
+             "na_ffjord_div: n_ctrl=%d (2..8) stride=%d", n_ctrl, est_stride);
+  hipLaunchKernelGGL(ffjord_div_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est, est_tangent,
+                     est_stride, t, e, N, n_ctrl, div);
+  return check_launch("na_ffjord_div");
 }
 
 int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, const float* g, float* g_sdf,

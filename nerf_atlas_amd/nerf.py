@@ -295,13 +295,21 @@ class DynamicNeRF(nn.Module):
         the render path carries no extra elementwise pass over the samples."""
         return self.dp * self.rigidity
 
+    def ffjord_div(self, e):
+        """utils.div_approx(model.pts, model.rigid_dp) of runner.py:697-699 (src/utils.py:467-478) at the samples of the
+        last forward: <e, d(rigid_dp)/d(pts) . e> per sample, e [T,B,H,W,3] the caller's randn draw.  The reference
+        contracts a vector-Jacobian product with e; here the same number comes from one forward-mode sweep (hash_jvp ->
+        tangent MLP -> ffjord_div kernels).  Like the reference's, the estimate has no graph."""
+        est, dest = self.delta_estim.forward_with_direction_tangent(self.pts, e)
+        return ops.ffjord_div(est, dest, self._tt, e.contiguous(), self.spline_n).reshape(self.pts.shape[:-1])
+
     def forward(self, rays_t):
         rays, t = rays_t
         c = self.canonical
         self.pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, c.t_near, c.t_far, c.steps,
                                                         perturb=1 if self.training else 0)
         c.ts = self.ts
-        tt = t[None, :, None, None].expand(*self.pts.shape[:-1]).contiguous()
+        tt = self._tt = t[None, :, None, None].expand(*self.pts.shape[:-1]).contiguous()
         est = self.delta_estim(self.pts)
         if ag.needs_grad(est):
             warped, self.dp, self.rigidity = ag.BezierWarpFn.apply(est.contiguous(), self.pts, tt, self.spline_n)

@@ -326,6 +326,42 @@ class SkipConnMLP(nn.Module):
             t = ag.LinearFn.apply(mt.reshape(3 * N, -1), None, lin.weight, None, "none").reshape(3, N, -1)
         return z, t
 
+    @torch.no_grad()
+    def forward_with_direction_tangent(self, p, e):
+        """(y [N,out], dy [N,out]) with dy = (d y / d p) . e for one direction e per point -- the Jacobian-vector product
+        the FFJORD divergence estimate contracts with e (runner.py:697-700, src/utils.py:467-478).  Values and tangent go
+        through the network side by side in exact fp32 (the tangent sees no biases and act'(.) instead of act(.)).  No
+        graph: the reference's estimate is a constant for the optimiser (torch.autograd.grad without create_graph).
+        Encoders: none, HashEncoder (hash_jvp kernel), FourierEncoder."""
+        assert self.latent_size == 0 and p.shape[-1] == self.in_size == 3 and e.shape == p.shape
+        p, e = p.reshape(-1, 3).contiguous(), e.reshape(-1, 3).contiguous()
+        init, dinit = p, e
+        if isinstance(self.enc, HashEncoder):
+            tables = self.enc.tables()
+            init = torch.cat([p, ops.hash_encode(p, tables, self.enc.include_input)], dim=-1)
+            dinit = torch.cat([e, ops.hash_encode_jvp(p, tables, e, self.enc.include_input)], dim=-1)
+        elif isinstance(self.enc, FourierEncoder):
+            enc = ops.fourier_encode(p, self.enc.basis.data, float(self.enc.extra_scale))
+            F_ = self.enc.freqs
+            proj = ops.linear_f32(e, (self.enc.basis.data * float(self.enc.extra_scale)).T.contiguous(), None)  # e . B
+            swapped = torch.cat([enc[:, F_:], -enc[:, :F_]], dim=-1).contiguous()                              # cos | -sin
+            denc = ops.mul_bcast(swapped, torch.cat([proj, proj], dim=-1)[None].contiguous())[0]
+            init, dinit = torch.cat([p, enc], dim=-1), torch.cat([e, denc], dim=-1)
+        elif self.enc is not None:
+            raise NotImplementedError("direction tangents through " + type(self.enc).__name__)
+        init, dinit = init.contiguous(), dinit.contiguous()
+        z = ops.linear_f32(init, self.init.weight.data, self.init.bias.data)
+        t = ops.linear_f32(dinit, self.init.weight.data, None)
+        n = len(self.layers)
+        lins = [(l, i != n - 1 and (i % self.skip) == 0) for i, l in enumerate(self.layers)] + [(self.out, False)]
+        for lin, skip in lins:
+            x_in = torch.cat([z, init], dim=-1).contiguous() if skip else z
+            t_in = torch.cat([t, dinit], dim=-1).contiguous() if skip else t
+            mt = ops.mul_bcast(ops.act_deriv(x_in, self.act_name), t_in[None])[0]
+            z = ops.linear_f32(z, lin.weight.data, lin.bias.data, pre_act=self.act_name, x1=init if skip else None)
+            t = ops.linear_f32(mt, lin.weight.data, None)
+        return z, t
+
     def zero_last_layer(self):
         nn.init.zeros_(self.out.weight)
         nn.init.zeros_(self.out.bias)

@@ -433,6 +433,40 @@ def hash_encode_backward_input(x: torch.Tensor, tables: torch.Tensor, g_out: tor
     return gx
 
 
+def hash_encode_jvp(x: torch.Tensor, tables: torch.Tensor, tangent: torch.Tensor, include_input: bool = True) -> torch.Tensor:
+    """d hash_encode(x)/dx . tangent, rows [tangent | per-level features] like hash_encode's output."""
+    lib = _lib.load()
+    x, tables, tangent = _f32(x, "x"), _f32(tables, "tables"), _f32(tangent, "tangent")
+    assert tangent.shape == x.shape and x.shape[-1] == 3 and tuple(tables.shape) == (8, 65536, 4)
+    N = x.numel() // 3
+    out = torch.empty(tuple(x.shape[:-1]) + (32 + 3 * int(include_input),), device=x.device, dtype=torch.float32)
+    check(lib.na_hash_encode_jvp(_ptr(x), N, _ptr(tables), _ptr(tangent), int(include_input), _ptr(out), _stream()))
+    return out
+
+
+def hash_encode_jvp_backward(x: torch.Tensor, tangent: torch.Tensor, g_t: torch.Tensor, include_input: bool = True) -> torch.Tensor:
+    """d <g_t, J(x).tangent> / d tables -> [8, 65536, 4]."""
+    lib = _lib.load()
+    x, tangent, g_t = _f32(x, "x"), _f32(tangent, "tangent"), _f32(g_t, "g_t")
+    N = x.numel() // 3
+    assert g_t.numel() == N * (32 + 3 * int(include_input))
+    grad = torch.zeros(8, 65536, 4, device=x.device, dtype=torch.float32)
+    check(lib.na_hash_encode_jvp_backward(_ptr(x), _ptr(tangent), N, _ptr(g_t), int(include_input), _ptr(grad), _stream()))
+    return grad
+
+
+def ffjord_div(est: torch.Tensor, est_tangent: torch.Tensor, t: torch.Tensor, e: torch.Tensor, n_ctrl: int) -> torch.Tensor:
+    """<e, d(rigid_dp)/dx . e> per point (runner.py:697-700): est / est_tangent [..., S], t [...], e [..., 3]."""
+    lib = _lib.load()
+    est, est_tangent, t, e = _f32(est, "est"), _f32(est_tangent, "est_tangent"), _f32(t, "t"), _f32(e, "e")
+    S = est.shape[-1]
+    N = est.numel() // S
+    assert est_tangent.shape == est.shape and t.numel() == N and e.numel() == 3 * N
+    out = torch.empty(est.shape[:-1], device=est.device, dtype=torch.float32)
+    check(lib.na_ffjord_div(_ptr(est), _ptr(est_tangent), S, _ptr(t), _ptr(e), N, int(n_ctrl), _ptr(out), _stream()))
+    return out
+
+
 def laplace_density_backward(sdf: torch.Tensor, beta: torch.Tensor, g: torch.Tensor, want_beta: bool = True):
     """-> (g_sdf, g_beta [1] or None)."""
     lib = _lib.load()

@@ -2,7 +2,8 @@
 :1221-1322 main), restricted to what the five hot-path configs use: l2/l1/rmse loss in RGB, Adam(eps 1e-7) with the
 cosine schedule, random crops/views from Python's `random`, pixel jitter 0.1, stratified sampling and density noise
 in training mode, `--volsdf-scale-decay`, `--delta-x-decay`, `--offset-decay`, `--sdf-eikonal` (SDF normals by forward-mode
-tangents through the MLP); the FFJORD divergence and smooth-normals terms raise.
+tangents through the MLP), `--ffjord-div-decay` (forward-mode divergence estimate); the smooth-normals and
+`--dyn-diverge-decay` terms raise.
 
 Every forward and backward is a HIP kernel (nerf_atlas_amd/autograd.py); torch.optim owns the parameter update, like
 in the reference.  With `replay_reference_rng=True` the stochastic tensors come from torch's CPU generator in the
@@ -138,7 +139,7 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
     optimiser step (dist.allreduce_gradients); the reference's own --data-parallel is broken (SURVEY header table)."""
     if args.epochs == 0:
         return []
-    for k in ("ffjord_div_decay", "dyn_diverge_decay", "smooth_normals"):
+    for k in ("dyn_diverge_decay", "smooth_normals"):
         if getattr(args, k, 0) > 0:
             raise NotImplementedError(f"--{k.replace('_', '-')} needs input Jacobians of the deformation / normal "
                                       "networks (hash-encoder and spline tangents are not implemented: DESIGN.md 9a)")
@@ -187,6 +188,14 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
             # runner.py:683-692: E[|d sdf/dx|] = 1 on 10240 points 5*randn; normals by forward-mode tangents
             pts = 5 * utils.randn(((1 << 13) * 5 // 4, 3), device)
             loss = loss + args.sdf_eikonal * ag.EikonalFn.apply(model.sdf.underlying.normals_tangent_major(pts))
+        if args.ffjord_div_decay:
+            # runner.py:697-700: FFJORD divergence estimate of the rigid deformation, e = randn_like(rigid_dp).  The
+            # reference's div_approx builds no graph (src/utils.py:471-477: autograd.grad without create_graph), so the
+            # term shifts the loss value and advances the RNG stream but contributes no gradient -- same here.
+            e = utils.randn(tuple(model.pts.shape), device)
+            exp_ratio = (1 / 100) ** (1 - i / args.epochs)
+            div = model.ffjord_div(e).abs().square()
+            loss = loss + exp_ratio * args.ffjord_div_decay * (model.canonical.alpha.detach() * div).mean()
         if args.opt_step != 1:
             loss = loss / args.opt_step
         loss.backward()

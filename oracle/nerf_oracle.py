@@ -24,7 +24,7 @@ __all__ = [
     "cubic_bezier", "laplace_cdf", "tiny_nerf", "plain_nerf", "plain_nerf_from_pts", "volsdf", "dynamic_nerf_spline",
     "view_refl", "positional_refl", "pos_linear_view_refl", "mse2psnr", "render_tiled",
     "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
-    "point_light", "intersect_mask", "occlusion",
+    "point_light", "intersect_mask", "occlusion", "div_approx", "dnerf_rigid_dp", "ffjord_div",
 ]
 
 # ----------------------------------------------------------------------------- A1 pixels
@@ -544,6 +544,30 @@ def dynamic_nerf_spline(params, rays, times, near, far, steps, spline: int, refl
         aux.update(dp=dp, rigidity=rigidity, rigid_dp=rigid_dp, pts=pts)
     return plain_nerf_from_pts(params, pts + rigid_dp, ts, r_o, r_d, refl_kind, act, bg, aux=aux,
                                prefix="canonical.")
+
+
+def dnerf_rigid_dp(params, pts, t, spline: int):
+    """src/nerf.py:1267-1278 spline_interpolate: dp * rigidity at points pts [...,3] and times t [...,1]."""
+    est = skip_mlp(params, "delta_estim.", pts, enc=_hash_enc_from(params, "delta_estim.enc."))
+    rigidity = (est[..., :1] / 2).sigmoid()
+    ps = torch.stack(est[..., 1:1 + 3 * spline].split([3] * spline, dim=-1), dim=0)
+    dp = (cubic_bezier if spline == 4 else de_casteljau)(ps, t, spline)
+    return dp * rigidity
+
+
+def div_approx(x, fn_x, e):
+    """src/utils.py:467-478 with the reference's randn_like draw passed in as `e`: <e, (d fn_x / d x)^T e>.  Like the
+    reference it builds no graph for the result (no create_graph): the estimate is a constant for the optimiser."""
+    e_dydx, = torch.autograd.grad(inputs=x, outputs=fn_x, grad_outputs=e, retain_graph=True, only_inputs=True)
+    return (e_dydx * e).sum(dim=-1)
+
+
+def ffjord_div(params, pts, times, spline: int, e):
+    """runner.py:697-699 for a DynamicNeRF: div_approx(model.pts, model.rigid_dp); pts [T,B,H,W,3], times [B]."""
+    with torch.enable_grad():
+        x = pts.detach().clone().requires_grad_()
+        t = times[None, :, None, None, None].expand(*x.shape[:-1], 1)
+        return div_approx(x, dnerf_rigid_dp(params, x, t, spline), e).detach()
 
 
 # ----------------------------------------------------------------------------- test()-style frame

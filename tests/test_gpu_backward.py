@@ -468,3 +468,43 @@ def test_sdf_normals_and_eikonal_gradients(ops, kind, train_prec):
         assert e <= (2e-3 if train_prec == "fp32" else 3e-2), (k, e)
         checked += 1
     assert checked >= 10
+
+
+def test_hash_jvp_ffjord_divergence_and_adjoint():
+    """N1: the FFJORD divergence estimate (runner.py:697-700, src/utils.py:467-478).  (a) hash_encode_jvp against
+    torch.autograd's JVP of the oracle's hash encoder; (b) its adjoint in the tables by linearity: <tables_grad, T'> ==
+    <g, J(x; T').e> for fresh tables T'; (c) DynamicNeRF.ffjord_div against the reference's own numbers (g17)."""
+    import oracle as O
+    from conftest import load_golden, golden_params
+    from nerf_atlas_amd import ops, nerf
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(300, 3, generator=gen) * 3 - 1.5
+    e = torch.randn(300, 3, generator=gen)
+    tables = torch.randn(8, 65536, 4, generator=gen) * 0.1
+    t_gpu = ops.hash_encode_jvp(x.cuda(), tables.cuda(), e.cuda(), True).cpu()
+    _, t_ref = torch.autograd.functional.jvp(lambda v: O.hash_encode(v, list(tables), True), (x,), (e,))
+    scale = float(t_ref.abs().max())
+    assert (t_gpu - t_ref).abs().max() <= 2e-5 * scale, float((t_gpu - t_ref).abs().max())
+    g_t = torch.randn(300, 35, generator=gen)
+    grad = ops.hash_encode_jvp_backward(x.cuda(), e.cuda(), g_t.cuda(), True)
+    tables2 = torch.randn(8, 65536, 4, generator=gen)
+    lhs = float((grad.double() * tables2.cuda().double()).sum())
+    t2 = ops.hash_encode_jvp(x.cuda(), tables2.cuda(), e.cuda(), True)
+    rhs = float((g_t.cuda()[:, 3:].double() * t2[:, 3:].double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs)), (lhs, rhs)
+    # (c)
+    g = load_golden("g17_ffjord")
+    p = golden_params(g)
+    canon = nerf.PlainNeRF(steps=int(g["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = nerf.DynamicNeRF(canonical=canon, spline=6).cuda().eval()
+    sd = m.state_dict()
+    for k, v in p.items():
+        sd[k].copy_(v)
+    m.pts = g["pts"].cuda()
+    m._tt = g["times"].cuda()[None, :, None, None].expand(*m.pts.shape[:-1]).contiguous()
+    div = m.ffjord_div(g["e"].cuda()).cpu()
+    scale = float(g["div"].abs().max())
+    assert div.shape == g["div"].shape and (div - g["div"]).abs().max() <= 5e-5 * scale, float((div - g["div"]).abs().max())
+    term = float((g["alpha"] * div.abs().square()).mean())
+    assert abs(term - float(g["term"])) <= 2e-4 * float(g["term"])
+    assert not div.requires_grad

@@ -221,3 +221,17 @@ def test_g13_tiny():
     out = O.tiny_nerf(golden_params(h), h["rays"], float(h["near"]), float(h["far"]), int(h["steps"]), aux=aux)
     close(out, h["out"], 2e-6, 1e-5)
     close(aux["weights"], h["weights"], 2e-6, 1e-5)
+
+
+def test_ffjord_divergence_estimate_matches_reference():
+    """g17: utils.div_approx on DynamicNeRF.rigid_dp as runner.py:697-700 calls it (training-mode points, e recorded)."""
+    g = load_golden("g17_ffjord")
+    p = golden_params(g)
+    div = O.ffjord_div(p, g["pts"], g["times"], 6, g["e"])
+    scale = float(g["div"].abs().max())
+    assert (div - g["div"]).abs().max() <= 2e-5 * scale
+    t = g["times"][None, :, None, None, None].expand(*g["pts"].shape[:-1], 1)
+    assert (O.dnerf_rigid_dp(p, g["pts"], t, 6) - g["rigid_dp"]).abs().max() <= 1e-6
+    term = (g["alpha"] * div.abs().square()).mean()
+    assert abs(float(term) - float(g["term"])) <= 1e-4 * float(g["term"])
+    assert not bool(g["term_requires_grad"])  # the reference's term is a constant for the optimiser (no create_graph)

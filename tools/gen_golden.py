@@ -596,9 +596,34 @@ def g16():
     save("g16_occlusion", **kw)
 
 
+# ------------------------------------------------------------------ G17 FFJORD divergence estimate (N1)
+def g17():
+    """Reference utils.div_approx (src/utils.py:467-478) on DynamicNeRF.rigid_dp exactly as runner.py:697-700 calls it:
+    training-mode forward (perturbed samples, pts.requires_grad_()), e = randn_like(rigid_dp).  The estimate carries no
+    graph (torch.autograd.grad without create_graph): `term_requires_grad` records that the loss term is a constant."""
+    size, T, spline = 6, 8, 6
+    canon = rnerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = rnerf.DynamicNeRF(canonical=canon, spline=spline)
+    m.train()
+    names, shapes = fill_procedural(m)
+    c, focal = cam(POSES[:2], size)
+    rays = c.sample_positions(ref_pixel_grid(size, (0, 0, size, size)), size=size)
+    times = torch.tensor([0.25, 0.8])
+    with torch.enable_grad():
+        torch.manual_seed(17)
+        out = m((rays, times))
+        torch.manual_seed(18)
+        div = rutils.div_approx(m.pts, m.rigid_dp)
+        torch.manual_seed(18)
+        e = torch.randn_like(m.rigid_dp)
+        term = (m.canonical.alpha.detach() * div.abs().square()).mean()
+    save("g17_ffjord", rays=rays, times=times, pts=m.pts, e=e, div=div, rigid_dp=m.rigid_dp, alpha=m.canonical.alpha,
+         term=term, term_requires_grad=np.bool_(term.requires_grad), steps=T, near=2.0, far=6.0, **spec(names, shapes))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for g in which:
         globals()[g]()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:

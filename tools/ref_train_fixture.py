@@ -40,6 +40,11 @@ RECIPES = {
     "plain": (False, ["--model", "plain", "--refl-kind", "view"]),
     "dnerf": (True, ["--model", "plain", "--refl-kind", "view", "--data-kind", "dnerf", "--dyn-model", "plain",
                      "--spline", "4"]),
+    # `make dnerf`'s regularisers (reference makefile:106-114) on the small scene: NR-NeRF offset decay + the FFJORD
+    # divergence estimate (whose randn_like draw advances the RNG stream every iteration), opt-step 3, upshifted sigmoid
+    "dnerf_make": (True, ["--model", "plain", "--refl-kind", "pos-linear-view", "--data-kind", "dnerf", "--dyn-model",
+                          "plain", "--spline", "6", "--higher-end-chance", "1", "--offset-decay", "60",
+                          "--ffjord-div-decay", "0.5", "--sigmoid-kind", "upshifted", "--opt-step", "3"]),
     "volsdf": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6"]),
 }
 
