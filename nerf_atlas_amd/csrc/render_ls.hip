@@ -37,9 +37,6 @@
 #endif
 namespace na {
 
-int launch_render_finalize(const float* partials, int64_t R, int nb, int T, int bg_kind, float* weights, float* out,
-                           hipStream_t stream);  // render_fused.hip
-
 namespace ls {
 
 constexpr int kPF = 4;       // weight prefetch depth, in fragment pairs
@@ -79,14 +76,16 @@ struct Args {
   const float4* tables;  // [8,65536]
   const char* packed;    // LS stream (na_render_ls_pack)
   float* alpha;          // nullable [T,R]
-  float* weights;        // nullable [T,R] (block-local; finalize applies the cross-block prefix)
-  float* partials;       // [R*nb, 8]
+  float* weights;        // nullable [T,R]
+  float* out;            // [R,3]
   const float* elaz;     // [R,2] elev/azim of every ray (ray_elaz_kernel)
   int64_t R;
-  int64_t nitems;        // R * nb
   int T, nb;
-  int npass;             // ceil(nitems / (2*NBLK))
+  int nG;                // sample groups of the launch (2 per workgroup): group G renders rays G, G + nG, G + 2 nG, ...
+  int npg;               // passes per group: ceil(ceil(R / nG) * nb / NBLK)
+  uint64_t nb_magic;     // 2^32 / nb + 1: block index / nb by multiplication
   int sigmoid_kind;
+  int bg_kind;
   uint32_t packed_size;
   HashRes res;
   unsigned long long* trace;  // NA_LS_TRACE builds only: [2 groups][128] s_memtime stamps of workgroup 0, second pass
@@ -151,7 +150,6 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
   constexpr int NCH = NL + (GEO ? 1 : 0);
   // the partner wave on this SIMD is in a VALU-dense epilogue: MFMA issue must win the arbitration
   __builtin_amdgcn_s_setprio(1);
-  Frag<PREC> Bq[2][NB];
   auto bsrc = [&](int q, int b) -> Frag<PREC> {
     if (q < NI) return fread<PREC>(ib + (b * 4 + q) * FR + lane * 16);
     return fread<PREC>(hb + (b * 16 + (q - NI)) * FR + lane * 16);
@@ -162,30 +160,53 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
     ring[(RING0 + q) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
     ring[(RING0 + q) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
   };
-  // raw inputs of the geometry chunk: in flight under the LDS-fed chunks
+  // raw inputs of the geometry chunk: requested under the last LDS-fed chunk
   decltype(geo_load(0)) graw[GEO != 0 ? NB : 1];
-  if constexpr (GEO != 0) {
+  if constexpr (NB == 4) {
+    // bf16 (4 blocks): ONE set of B fragments, refilled in place -- block b's fragment of chunk q+1 is requested right
+    // after its two MFMAs of chunk q have issued and has the other three blocks' MFMAs (192 cycles) to arrive.  Halves
+    // the fragment registers (16 instead of 32), which is what keeps this kernel inside 256 VGPRs without scratch.
+    Frag<PREC> Bs[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) Bq[0][b] = bsrc(0, b);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < NL; ++q) {
-    const Frag<PREC> A0 = ring[(RING0 + q) % kPF][0], A1 = ring[(RING0 + q) % kPF][1];
-    if (q + 1 < NL) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) Bq[(q + 1) & 1][b] = bsrc(q + 1, b);
-    }
+    for (int b = 0; b < NB; ++b) Bs[b] = bsrc(0, b);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      mma<PREC>(acc[0][b], A0, Bq[q & 1][b]);
-      mma<PREC>(acc[1][b], A1, Bq[q & 1][b]);
-      if (b == 0) refill(q);
+    for (int q = 0; q < NL; ++q) {
+      const Frag<PREC> A0 = ring[(RING0 + q) % kPF][0], A1 = ring[(RING0 + q) % kPF][1];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        mma<PREC>(acc[0][b], A0, Bs[b]);
+        mma<PREC>(acc[1][b], A1, Bs[b]);
+        if (q + 1 < NL) Bs[b] = bsrc(q + 1, b);
+        else if constexpr (GEO != 0) graw[b] = geo_load(b);
+        if (b == 0) refill(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+  } else {
+    Frag<PREC> Bq[2][NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) Bq[0][b] = bsrc(0, b);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const Frag<PREC> A0 = ring[(RING0 + q) % kPF][0], A1 = ring[(RING0 + q) % kPF][1];
+      if (q + 1 < NL) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) Bq[(q + 1) & 1][b] = bsrc(q + 1, b);
+      } else if constexpr (GEO != 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        mma<PREC>(acc[0][b], A0, Bq[q & 1][b]);
+        mma<PREC>(acc[1][b], A1, Bq[q & 1][b]);
+        if (b == 0) refill(q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   if constexpr (GEO != 0) {
     constexpr int q = NL;
@@ -286,22 +307,65 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   float geo_u[NB][8];   // ox oy oz dx dy dz elev azim of block b's ray (uniform)
   int geo_t0[NB];       // first step of block b
   int geo_ray[NB];
-  auto geo_setup = [&](int pass) {
-    const int64_t item0 = ((int64_t)pass * 2 + g) * NB;
-    int ray = __builtin_amdgcn_readfirstlane((int)(item0 / a.nb));
-    int tb = __builtin_amdgcn_readfirstlane((int)(item0 - (int64_t)ray * a.nb));
+  // Work distribution: sample group G = 2 * workgroup + g renders the rays G, G + nG, G + 2 nG, ... one after the other,
+  // each as its nb 32-step blocks in step order, NB blocks per pass.  At any moment the launch works on ~nG consecutive
+  // rays (hash-table locality in L2 as before), and the blocks of one ray pass through one group in order, so the
+  // transmittance is carried from block to block inside the kernel (no per-block partials, no second launch).
+  const int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 2 + g);
+  struct Loc { int ray, tb; bool ok; };
+  auto locate = [&](int pl, int b) {
+    const int sidx = pl * NB + b;
+    const int k = (int)(((uint64_t)(uint32_t)sidx * a.nb_magic) >> 32);  // sidx / nb (exact: sidx * nb < 2^32), scalar ALU
+    Loc L;
+    L.tb = sidx - k * a.nb;
+    const int64_t r = G + (int64_t)k * a.nG;
+    L.ok = r < a.R;
+    L.ray = L.ok ? (int)r : (int)a.R - 1;
+    if (!L.ok) L.tb = a.nb - 1;
+    return L;
+  };
+  auto geo_setup = [&](int pl) {
+    // scalar (SMEM) loads: the addresses are wave-uniform and rays / elaz are read-only for the whole launch.  All loads
+    // and their wait sit in ONE asm statement, so the compiler can neither read nor spill a destination in flight.
+    // (ox oy) (oz dx) (dy dz) (elev azim): 8-byte loads (a ray is 24 bytes), each into a 64-bit scalar -- vector-typed
+    // SGPR asm outputs are mis-split by the compiler (element 1 read from element 0's register)
+    uint64_t ra[NB], rb[NB], rc[NB], e2[NB];
+    const float* ry[NB];
+    const float* ea[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (ray >= a.R) { ray = (int)a.R - 1; tb = a.nb - 1; }
-      const float* ry = a.rays + (int64_t)ray * 6;
-      const float* ea = a.elaz + (int64_t)ray * 2;
-#pragma unroll
-      for (int e = 0; e < 6; ++e) geo_u[b][e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ry[e])));
-      geo_u[b][6] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ea[0])));
-      geo_u[b][7] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ea[1])));
-      geo_t0[b] = tb * 32;
+      const Loc L = locate(pl, b);
+      const int ray = __builtin_amdgcn_readfirstlane(L.ray);
+      ry[b] = a.rays + (int64_t)ray * 6;
+      ea[b] = a.elaz + (int64_t)ray * 2;
+      geo_t0[b] = __builtin_amdgcn_readfirstlane(L.tb) * 32;
       geo_ray[b] = ray;
-      if (++tb >= a.nb) { tb = 0; ++ray; }
+    }
+#define NA_LS_GEO_LOAD(oa, ob, oc, oe, pr, pe)                                                              \
+  "s_load_dwordx2 " oa ", " pr ", 0x0\n\ts_load_dwordx2 " ob ", " pr ", 0x8\n\ts_load_dwordx2 " oc ", " pr ", 0x10\n\t" \
+  "s_load_dwordx2 " oe ", " pe ", 0x0\n\t"
+    if constexpr (NB == 4)
+      asm volatile(NA_LS_GEO_LOAD("%0", "%1", "%2", "%3", "%16", "%17") NA_LS_GEO_LOAD("%4", "%5", "%6", "%7", "%18", "%19")
+                   NA_LS_GEO_LOAD("%8", "%9", "%10", "%11", "%20", "%21") NA_LS_GEO_LOAD("%12", "%13", "%14", "%15", "%22", "%23")
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&s"(ra[0]), "=&s"(rb[0]), "=&s"(rc[0]), "=&s"(e2[0]), "=&s"(ra[1]), "=&s"(rb[1]), "=&s"(rc[1]), "=&s"(e2[1]),
+                     "=&s"(ra[2]), "=&s"(rb[2]), "=&s"(rc[2]), "=&s"(e2[2]), "=&s"(ra[3]), "=&s"(rb[3]), "=&s"(rc[3]), "=&s"(e2[3])
+                   : "s"(ry[0]), "s"(ea[0]), "s"(ry[1]), "s"(ea[1]), "s"(ry[2]), "s"(ea[2]), "s"(ry[3]), "s"(ea[3]));
+    else
+      asm volatile(NA_LS_GEO_LOAD("%0", "%1", "%2", "%3", "%8", "%9") NA_LS_GEO_LOAD("%4", "%5", "%6", "%7", "%10", "%11")
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&s"(ra[0]), "=&s"(rb[0]), "=&s"(rc[0]), "=&s"(e2[0]), "=&s"(ra[1 % NB]), "=&s"(rb[1 % NB]), "=&s"(rc[1 % NB]),
+                     "=&s"(e2[1 % NB])
+                   : "s"(ry[0]), "s"(ea[0]), "s"(ry[1 % NB]), "s"(ea[1 % NB]));
+#undef NA_LS_GEO_LOAD
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      auto lo = [](uint64_t v) { return __builtin_bit_cast(float, (uint32_t)v); };
+      auto hi32 = [](uint64_t v) { return __builtin_bit_cast(float, (uint32_t)(v >> 32)); };
+      geo_u[b][0] = lo(ra[b]); geo_u[b][1] = hi32(ra[b]);
+      geo_u[b][2] = lo(rb[b]); geo_u[b][3] = hi32(rb[b]);
+      geo_u[b][4] = lo(rc[b]); geo_u[b][5] = hi32(rc[b]);
+      geo_u[b][6] = lo(e2[b]); geo_u[b][7] = hi32(e2[b]);
     }
   };
   struct GeoRaw { float x, y, z; };  // t (x) or the explicit position of this lane's sample
@@ -332,18 +396,17 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     return f;
   };
   struct Geom {
-    int64_t item, ray;
+    int64_t ray;
     bool item_ok, t_ok;
     int t;
     float px, py, pz, dist, dx, dy, dz;
   };
   auto geom = [&](int pass, int b) {
     Geom q;
-    const int64_t item_raw = ((int64_t)pass * 2 + g) * NB + b;
-    q.item_ok = item_raw < a.nitems;
-    q.item = q.item_ok ? item_raw : a.nitems - 1;
-    q.ray = q.item / a.nb;
-    const int tb = (int)(q.item - q.ray * a.nb);
+    const Loc L = locate(pass, b);
+    q.item_ok = L.ok;
+    q.ray = L.ray;
+    const int tb = L.tb;
     q.t = tb * 32 + ln;
     q.t_ok = q.t < a.T;
     const int tc = q.t_ok ? q.t : a.T - 1;
@@ -361,6 +424,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     return q;
   };
 
+  float w_local = 0.f;  // block-local weight of this lane's sample, until `combine` knows the transmittance in front
   // compositing of block rg of pass `pass` (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
   auto composite = [&](int pass, const f32x16& oc, float density) {
     const Geom q = geom(pass, blk);
@@ -389,15 +453,52 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       wh += __shfl_xor(wh, d, 32);
     }
     const float P = __shfl(incl, 31, 32);
-    if (owner && q.item_ok && hi == 0) {
+    if (owner && hi == 0) {
       if (ln == 0) {
-        float* o = a.partials + q.item * kPartialFloats;
+        // block product and block-local sums -> the group's (idle) hidden region; combined by `combine` after the barrier
+        float* o = (float*)hb + blk * kPartialFloats;
         o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
       }
-      if (q.t_ok) {
-        if (a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
-        if (a.weights != nullptr) a.weights[(int64_t)q.t * a.R + q.ray] = w;
+      if (q.item_ok && q.t_ok && a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
+    }
+    w_local = w;
+  };
+  // Cross-block step of the compositing (the reference's cumprod runs over all T steps: src/nerf.py:22-27): every wave of
+  // the group walks the NB blocks of pass `pl` in step order with the running transmittance / colour of the current ray
+  // (uniform values, carried from pass to pass), scales its own block's weights by the transmittance in front of it and
+  // wave 0 stores a ray's colour + background (src/nerf.py:96-98) after its last block.
+  float cT = 1.f, cr0 = 0.f, cr1 = 0.f, cr2 = 0.f, cwh = 0.f;
+  auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  auto combine = [&](int pl) {
+    float mine = 1.f;
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    f4 pv[NB];
+    float pw[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {  // all the group's partials in one batch of LDS reads (uniform addresses)
+      pv[b] = *(const f4*)((const float*)hb + b * kPartialFloats);
+      pw[b] = ((const float*)hb)[b * kPartialFloats + 4];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const Loc L = locate(pl, b);
+      if (!L.ok) continue;
+      const float P = pv[b][0], s0 = pv[b][1], s1 = pv[b][2], s2 = pv[b][3], swh = pw[b];
+      if (L.tb == 0) { cT = 1.f; cr0 = cr1 = cr2 = cwh = 0.f; }
+      if (b == blk) mine = cT;
+      cr0 = cr0 + cT * s0; cr1 = cr1 + cT * s1; cr2 = cr2 + cT * s2; cwh = cwh + cT * swh;
+      cT = cT * P;
+      if (L.tb == a.nb - 1 && rg == 0 && lane == 0) {
+        const float sky = a.bg_kind == NA_BG_WHITE ? 1.0f - cwh : 0.f;
+        float* o = a.out + (int64_t)L.ray * 3;
+        o[0] = cr0 + sky; o[1] = cr1 + sky; o[2] = cr2 + sky;
       }
+    }
+    cT = uni(cT); cr0 = uni(cr0); cr1 = uni(cr1); cr2 = uni(cr2); cwh = uni(cwh);
+    if (a.weights != nullptr && owner && hi == 0) {
+      const Loc L = locate(pl, blk);
+      const int t = L.tb * 32 + ln;
+      if (L.ok && t < a.T) a.weights[(int64_t)t * a.R + L.ray] = w_local * mine;
     }
   };
 
@@ -442,10 +543,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   int prev = -1;
   if (g == 1) __syncthreads();  // group 1 runs one phase behind group 0
 
-  for (int pass = blockIdx.x; pass < a.npass; pass += gridDim.x) {
+  for (int pass = 0; pass < a.npg; ++pass) {
     int cur = 0;
 #if NA_LS_TRACE
-    ton = pass == (int)blockIdx.x + (int)gridDim.x;
+    ton = pass == 1;
 #endif
     // ================= EP: compositing of the previous pass, hash encoder of this one
     // The 4 x 8 table gathers of this lane half go out one level at a time (35 live registers), the first with the
@@ -472,13 +573,17 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; v2[3] = q.px; v2[4] = q.py; v2[5] = q.pz; }
       fwrite<PREC>(ib + blk * 4 * FR + lane * 16 + 2 * FR, make_frag<PREC>(v2));
     }
+    {
+      f32x16 bv[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const f32x16 bv = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+      for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+      SYNC();
+      if (prev >= 0) combine(prev);  // the accumulators are not live yet: 32 bias registers instead of 32 x NB
 #pragma unroll
-      for (int b = 0; b < NB; ++b) acc[t][b] = bv;
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
     }
-    SYNC();
     // ================= `first` MLP (LeakyReLU)
     m_hidden<PREC, 0, 3, 0, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
     SYNC();
@@ -593,6 +698,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     prev = pass;
   }
   if (prev >= 0 && (NB == 4 || owner)) composite(prev, oc[0], density);
+  __syncthreads();
+  if (prev >= 0) combine(prev);
   if (g == 0) __syncthreads();  // group 0 takes its extra barrier at the end
 }
 
@@ -715,8 +822,13 @@ static int launch(Args& a, hipStream_t stream) {
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-  a.npass = (int)((a.nitems + 2 * C::NBLK - 1) / (2 * C::NBLK));
-  const int grid = a.npass < 256 ? a.npass : 256;
+  const int64_t wgs = (a.R + 1) / 2;  // at least one ray per sample group
+  const int grid = wgs < 256 ? (int)wgs : 256;
+  a.nG = 2 * grid;
+  const int64_t rays_per_group = (a.R + a.nG - 1) / a.nG;
+  a.npg = (int)((rays_per_group * a.nb + C::NBLK - 1) / C::NBLK);
+  a.nb_magic = (1ull << 32) / (uint64_t)a.nb + 1;
+  if ((int64_t)(a.npg + 1) * C::NBLK * a.nb >= (1ll << 32)) { set_error("na_render_plain_view_ls: batch too large"); return NA_EINVAL; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * C::GROUP, stream, a);
   return check_launch("na_render_plain_view_ls");
 }
@@ -764,8 +876,8 @@ extern "C" int na_render_ls_pack(int precision, const float* const* w_first, con
 extern "C" size_t na_render_ls_workspace_bytes(int T, int64_t R) {
   if (T < 1 || R < 0) return 0;
   const int64_t nb = (T + 31) / 32;
-  return (size_t)(R * nb * ls::kPartialFloats * sizeof(float)) + 256 + (size_t)R * 2 * sizeof(float) + 256 +
-         (NA_LS_TRACE ? 4096 : 0);
+  (void)nb;
+  return (size_t)R * 2 * sizeof(float) + 256 + (NA_LS_TRACE ? 4096 + 256 : 0);
 }
 
 extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T,
@@ -786,18 +898,15 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   ls::Args a;
   a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
   a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision);
-  a.alpha = alpha; a.weights = weights;
-  a.partials = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  a.R = R; a.T = T; a.nb = (T + 31) / 32; a.nitems = R * a.nb;
-  float* elaz = (float*)(((uintptr_t)(a.partials + a.nitems * ls::kPartialFloats) + 255) & ~(uintptr_t)255);
+  a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  float* elaz = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.elaz = elaz;
   hipLaunchKernelGGL(ls::ray_elaz_kernel, dim3(grid_for(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays, R, elaz);
   a.sigmoid_kind = sigmoid_kind;
   a.res = hash_resolutions();
   a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
-  int rc = precision == NA_PREC_BF16 ? render_ls_dispatch_bf16(a, (hipStream_t)stream)
-                                     : render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
-  if (rc != NA_OK) return rc;
-  return launch_render_finalize(a.partials, R, a.nb, T, bg_kind, weights, out, (hipStream_t)stream);
+  return precision == NA_PREC_BF16 ? render_ls_dispatch_bf16(a, (hipStream_t)stream)
+                                   : render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
 }
 #endif

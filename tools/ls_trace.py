@@ -69,8 +69,8 @@ def run(prec="bf16"):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1])
     nb = (T + 31) // 32
-    base = ((ws.data_ptr() + 255) & ~255) - ws.data_ptr() + R * nb * 8 * 4
-    base = ((ws.data_ptr() + base + 255) & ~255) - ws.data_ptr() + R * 8
+    base = ((ws.data_ptr() + 255) & ~255) - ws.data_ptr() + R * 8
+    base = ((ws.data_ptr() + base + 255) & ~255) - ws.data_ptr()
     raw = ws[base: base + 2 * 128 * 8].cpu().view(torch.int64).reshape(2, 128)
     print(f"{prec}: {ms:.2f} ms/frame = {R * T / ms / 1e3:.0f} Msamples/s (traced build)")
     for g in range(2):
