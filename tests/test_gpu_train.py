@@ -37,7 +37,8 @@ def procedural_init(model):
 
 
 @pytest.mark.parametrize("name,train_prec", [("plain", "fp32"), ("plain", "bf16x3"), ("dnerf", "bf16x3"),
-                                             ("volsdf", "bf16x3"), ("dnerf", "fp32"), ("volsdf", "fp32")])
+                                             ("volsdf", "bf16x3"), ("dnerf", "fp32"), ("volsdf", "fp32"),
+                                             ("dnerf_make", "bf16x3"), ("dnerf_make", "fp32")])
 def test_training_tracks_the_reference(name, train_prec, tmp_path):
     path = os.path.join(GOLDEN, f"train_parity_{name}.json")
     if not os.path.exists(path):
@@ -68,15 +69,20 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     # iterations.  With config.set_deterministic the build's own trajectory is bit-reproducible (test below), so the
     # numbers are fixed: first-10 deviation 2.3e-4 (bf16x3) / 3.0e-4 (fp32), per-view PSNR 0.08 / 0.35 dB.
     assert np.abs(got[:5] - ref[:5]).max() <= 2e-4, (got[:5], ref[:5])
-    assert np.abs(got[:10] - ref[:10]).max() <= (1e-3 if name == "dnerf" else 2e-4), (got[:10], ref[:10])
+    # dnerf_make = `make dnerf`'s regularisers (offset decay 60, the FFJORD estimate whose randn draw advances the RNG
+    # stream, opt-step 3, pos-linear-view): not chaotic -- it tracks the reference to 2e-6 in the loss and 0.0007 dB, so it
+    # gets the strict bars; only the plain `dnerf` recipe needs the chaotic ones
+    dyn = name == "dnerf"
+    assert np.abs(got[:10] - ref[:10]).max() <= (1e-3 if dyn else 2e-4), (got[:10], ref[:10])
     # the whole curve stays on the reference's (smoothed: single iterations are noisy by design)
     k = 20
     sm = lambda v: np.convolve(v, np.ones(k) / k, mode="valid")
     dev = np.abs(sm(got) - sm(ref)).max() / sm(ref).max()
     print(f"[{name}/{train_prec}] smoothed-curve deviation {dev:.4f} of the curve's maximum")
-    assert dev <= (0.35 if name == "dnerf" else 0.1), dev
-    assert ref[-k:].mean() < 0.5 * ref[:k].mean(), "the recipe must actually learn"
-    if name == "dnerf":
+    assert dev <= (0.35 if dyn else 0.1), dev
+    # (dnerf_make steps the optimiser every third iteration: 67 updates in the 200 iterations)
+    assert ref[-k:].mean() < (0.7 if name == "dnerf_make" else 0.5) * ref[:k].mean(), "the recipe must actually learn"
+    if dyn:
         # chaotic but deterministic trajectory (see above): measured 0.08 dB per view / 0.04 dB mean in bf16x3 and
         # 0.35 / 0.20 dB in fp32 (an untrained model is > 8 dB away); the bars leave ~1.5x for a different toolchain
         assert d.max() <= 0.5 and abs(res["test_psnr_mean"] - fx["test_psnr_mean"]) <= 0.3, (res["test_psnr"], fx["test_psnr"])
