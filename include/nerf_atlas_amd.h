@@ -184,6 +184,22 @@ int na_mlp_forward(const NaMlpDesc* desc, int precision, const void* packed,
 int na_mlp_forward_ld(const NaMlpDesc* desc, int precision, const void* packed,
                       const float* p, int64_t p_ld, const float* latent, int64_t latent_ld,
                       const float* enc_params, int64_t N, float* y, void* stream);
+/* IPE latent generated in the MLP prologue (config 3: src/utils.py:83-140 cylinder / conic Gaussians, hook
+ * src/nerf.py:256-261).  `mip` describes the crop the N = T*B*H*W samples come from (sample n = t*B*H*W + ray); the
+ * leading 6*(max_deg-min_deg) latent columns are computed from it inside the kernel (same arithmetic as na_mip_encode,
+ * intended layout), the remaining latent_size - 6 nd columns are read from `latent` (pitch latent_ld) as usual.
+ * mip == NULL is na_mlp_forward_ld.                                                                               */
+typedef struct NaMipDesc {
+  const float* rays;   /* [B,H,W,6] rays of ONE crop (pixel radii difference neighbouring rows)   */
+  const float* ts;     /* [T]                                                                     */
+  int32_t B, H, W, T;
+  int32_t kind;        /* 0 cylinder, 1 cone                                                      */
+  int32_t min_deg, max_deg;
+  float t_end;         /* closes the last interval (see na_mip_encode)                            */
+} NaMipDesc;
+int na_mlp_forward_mip(const NaMlpDesc* desc, int precision, const void* packed, const float* p, int64_t p_ld,
+                       const float* latent, int64_t latent_ld, const float* enc_params, const NaMipDesc* mip, int64_t N,
+                       float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A10 PlainNeRF.forward with the View head (src/nerf.py:326-361, src/refl.py:190-207), fully

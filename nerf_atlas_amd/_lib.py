@@ -13,6 +13,13 @@ c_f32p = C.c_void_p  # device pointers travel as integers
 c_i64 = C.c_int64
 
 
+class NaMipDesc(C.Structure):
+    """include/nerf_atlas_amd.h NaMipDesc: the crop an IPE latent is generated from inside the MLP prologue."""
+    _fields_ = [("rays", C.c_void_p), ("ts", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("T", C.c_int32), ("kind", C.c_int32), ("min_deg", C.c_int32), ("max_deg", C.c_int32),
+                ("t_end", C.c_float)]
+
+
 class NaMlpDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "in_size", "enc_kind", "enc_dims", "latent_size", "num_layers", "hidden", "out_size", "skip",
@@ -54,6 +61,8 @@ SIGNATURES = {
                                  C.c_void_p]),
     "na_mlp_forward_ld": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64, c_f32p,
                                     c_i64, c_f32p, C.c_void_p]),
+    "na_mlp_forward_mip": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64, c_f32p,
+                                     C.c_void_p, c_i64, c_f32p, C.c_void_p]),
     "na_ray_points": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_float, c_i64, c_f32p, C.c_void_p]),
     "na_sphere_march_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, C.c_float, c_f32p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),

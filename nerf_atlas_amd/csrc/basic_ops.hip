@@ -276,10 +276,6 @@ __global__ void sigmoid_kernel(const float* __restrict__ x, int64_t N, int kind,
 // One thread per (sample, 4 consecutive features): the [.., 6*nd] rows leave as coalesced float4 stores (a thread per
 // sample wrote 96 floats 384 bytes apart from its neighbour: 0.45 TB/s); the few dozen flops of cone/cylinder geometry
 // are recomputed per thread.
-__device__ __forceinline__ float mip_sin(float y) {
-  return fabsf(y) <= 3.0e3f ? sin_cw(y) : sinf(y);  // sin_cw: 1.6e-7 inside its range; 2^15 * x needs libm's reduction
-}
-
 template <int VEC>
 __global__ void mip_kernel(const float* __restrict__ rays, int B, int H, int W, const float* __restrict__ ts, int T,
                            int kind, float t_end, int min_deg, int max_deg, float* __restrict__ out) {
@@ -296,52 +292,12 @@ __global__ void mip_kernel(const float* __restrict__ rays, int B, int H, int W, 
     int wq = (int)(r % W);
     int hq = (int)((r / W) % H);
     int b = (int)(r / ((int64_t)W * H));
-    // radii_x: rows hq and hq+1 (last row: rows H-2... the reference appends dx[:, -2:-1], i.e. the
-    // difference of rows H-3 and H-2 when H>=3)
-    int h0 = hq < H - 1 ? hq : H - 3;
-    if (h0 < 0) h0 = 0;
-    const float* ra = rays + (((int64_t)b * H + h0) * W + wq) * 6 + 3;
-    const float* rb = rays + (((int64_t)b * H + h0 + 1) * W + wq) * 6 + 3;
-    float e0 = ra[0] - rb[0], e1 = ra[1] - rb[1], e2 = ra[2] - rb[2];
-    float rad = sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * 2.0f / 3.4641016151377544f;
-    const float* ry = rays + r * 6;
-    float t0 = ts[t], t1 = t < T - 1 ? ts[t + 1] : t_end;
-    float t_mean, t_var, r_var;
-    if (kind == 0) {
-      t_mean = (t1 + t0) / 2.f;
-      r_var = rad * rad / 4.f;
-      float dt = t1 - t0;
-      t_var = dt * dt / 12.f;
-    } else {
-      float mu = (t1 + t0) / 2.f, hw = (t1 - t0) / 2.f;
-      float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
-      float den = 3.f * mu2 + hw2;
-      t_mean = mu + (2.f * mu * hw2) / den;
-      t_var = hw / 3.f - (4.f / 15.f) * ((hw4 * (12.f * mu2 - hw2)) / (den * den));
-      r_var = rad * rad * (mu2 / 4.f + (5.f / 12.f) * hw2 - 4.f / 15.f * hw4 / den);
-    }
-    float dsq[3] = {ry[3] * ry[3], ry[4] * ry[4], ry[5] * ry[5]};
-    float magn = fmaxf((dsq[0] + dsq[1]) + dsq[2], 1e-10f);
-    float mean[3], cov[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      mean[a] = ry[3 + a] * t_mean + ry[a];
-      cov[a] = t_var * dsq[a] + r_var * (1.f - dsq[a] / magn);
-    }
+    const float rad = mip_radius(rays, H, W, b, hq, wq);
+    const float t0 = ts[t], t1 = t < T - 1 ? ts[t + 1] : t_end;
+    const MipGauss gs = mip_gaussian(rays + r * 6, rad, t0, t1, kind);
     float v[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const int f = f0 + e;
-      const int part = f >= 3 * nd;            // 0: sin(y), 1: sin(y + pi/2)
-      const int rem = f - part * 3 * nd;
-      const int k = rem / 3, a = rem - 3 * k;
-      const float m = a == 0 ? mean[0] : (a == 1 ? mean[1] : mean[2]);
-      const float c = a == 0 ? cov[0] : (a == 1 ? cov[1] : cov[2]);
-      const float sc = exp2f((float)(min_deg + k));
-      const float y = m * sc;
-      const float damp = expf(-0.5f * (c * (sc * sc)));
-      v[e] = damp * mip_sin(part ? y + 0.5f * 3.14159265358979323846f : y);
-    }
+    for (int e = 0; e < VEC; ++e) v[e] = mip_feature(gs.m0, gs.m1, gs.m2, gs.c0, gs.c1, gs.c2, f0 + e, nd, min_deg);
     float* o = out + i * F + f0;
     if (VEC == 4) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
     else o[0] = v[0];

@@ -95,6 +95,77 @@ __device__ __forceinline__ float sin_cw(float x) {
   return (qi & 1) ? -s : s;
 }
 
+// Gaussian of one conical-frustum / cylinder sample (src/utils.py:39-48 lift, :60-101 cylinder / cone moments, cov laid
+// out like mean): mean[3], diagonal cov[3] from the ray, its pixel radius and the interval [t0, t1].  kind 0 = cylinder.
+// (scalar members: arrays in this struct are indexed through scratch memory by the per-axis selects of mip_feature)
+struct MipGauss { float m0, m1, m2, c0, c1, c2; };
+__device__ __forceinline__ MipGauss mip_gaussian(const float* ry, float rad, float t0, float t1, int kind) {
+  float t_mean, t_var, r_var;
+  if (kind == 0) {
+    t_mean = (t1 + t0) / 2.f;
+    r_var = rad * rad / 4.f;
+    float dt = t1 - t0;
+    t_var = dt * dt / 12.f;
+  } else {
+    float mu = (t1 + t0) / 2.f, hw = (t1 - t0) / 2.f;
+    float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+    float den = 3.f * mu2 + hw2;
+    t_mean = mu + (2.f * mu * hw2) / den;
+    t_var = hw / 3.f - (4.f / 15.f) * ((hw4 * (12.f * mu2 - hw2)) / (den * den));
+    r_var = rad * rad * (mu2 / 4.f + (5.f / 12.f) * hw2 - 4.f / 15.f * hw4 / den);
+  }
+  const float dsq[3] = {ry[3] * ry[3], ry[4] * ry[4], ry[5] * ry[5]};
+  const float magn = fmaxf((dsq[0] + dsq[1]) + dsq[2], 1e-10f);
+  MipGauss g;
+  g.m0 = ry[3] * t_mean + ry[0]; g.m1 = ry[4] * t_mean + ry[1]; g.m2 = ry[5] * t_mean + ry[2];
+  g.c0 = t_var * dsq[0] + r_var * (1.f - dsq[0] / magn);
+  g.c1 = t_var * dsq[1] + r_var * (1.f - dsq[1] / magn);
+  g.c2 = t_var * dsq[2] + r_var * (1.f - dsq[2] / magn);
+  return g;
+}
+
+// pixel radius of ray (b, hq, wq) of a [B,H,W,6] crop (src/utils.py:77-81: difference of neighbouring rows' directions;
+// the appended last row repeats the second-to-last difference)
+__device__ __forceinline__ float mip_radius(const float* rays, int H, int W, int b, int hq, int wq) {
+  int h0 = hq < H - 1 ? hq : H - 3;
+  if (h0 < 0) h0 = 0;
+  const float* ra = rays + (((int64_t)b * H + h0) * W + wq) * 6 + 3;
+  const float* rb = rays + (((int64_t)b * H + h0 + 1) * W + wq) * 6 + 3;
+  float e0 = ra[0] - rb[0], e1 = ra[1] - rb[1], e2 = ra[2] - rb[2];
+  return sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * 2.0f / 3.4641016151377544f;
+}
+
+// feature f of the 6*nd-wide IPE row [sin(mean 2^k) damped | sin(mean 2^k + pi/2) damped], k-major, axis-minor
+// (src/utils.py:23-27).  Branch-free and libm-free: y = mean * 2^k is an exact scaling, so its revolution count is
+// p = mean * (2^k / 2pi) with the product's rounding error recovered by an fma (two-term constant), the integer part
+// drops out exactly and the sine sees an angle in [-pi, pi] for every degree (the reference's fp32 sin(y) reduces
+// y = 2^15 mean the same way inside libm).  The cosine half is sin(fl(y + pi/2)) like the reference: the rounded sum
+// differs from y by an exactly representable delta, which is added to the reduced angle.  damp = exp(-cov 4^k / 2)
+// through v_exp_f32.  Max deviation from libm's sinf / expf: 6e-7 (angle) and 2 ulp (damp).  FAST (bf16 operands
+// downstream): hardware v_sin_f32 on the revolution count instead of the polynomial.
+template <bool FAST = false>
+__device__ __forceinline__ float mip_feature(float m0, float m1, float m2, float c0, float c1, float c2, int f, int nd,
+                                             int min_deg) {
+  const int part = f >= 3 * nd;            // 0: sin(y), 1: sin(y + pi/2)
+  const int rem = f - part * 3 * nd;
+  const int k = (rem * 43) >> 7;           // rem / 3 for rem < 128
+  const int a = rem - 3 * k;
+  // (the six moments arrive as scalars: selects over members of a struct in memory become an indexed scratch load)
+  const float m = a == 0 ? m0 : (a == 1 ? m1 : m2);
+  const float c = a == 0 ? c0 : (a == 1 ? c1 : c2);
+  const int deg = min_deg + k;
+  const float chi = ldexpf(0.15915494309189535f, deg), clo = ldexpf(6.4206383e-9f, deg);  // 1/2pi = chi + clo
+  const float p = m * chi;
+  const float e = fmaf(m, chi, -p) + m * clo;
+  const float rev = (p - rintf(p)) + e;
+  const float y = ldexpf(m, deg);
+  const float yc = y + 1.5707963267948966f;
+  const float delta = part ? yc - y : 0.f;    // exact: yc ~ y
+  const float damp = __builtin_amdgcn_exp2f(c * ldexpf(-0.7213475204444817f, 2 * deg));  // exp(-0.5 c 4^deg)
+  if constexpr (FAST) return damp * __builtin_amdgcn_sinf(rev + delta * 0.15915494309189535f);
+  return damp * sin_cw(6.283185307179586f * rev + delta);
+}
+
 // cos on the same reduction: even Taylor polynomial to r^10 on [-pi/2,pi/2] (max |err| 5e-7), sign by parity.
 __device__ __forceinline__ float cos_cw(float x) {
   float q = rintf(x * 0.318309886183790672f);

@@ -6,8 +6,19 @@
 namespace na {
 
 // ================================================================================================ forward
+// IPE latent generated in the prologue (SURVEY config 3; src/utils.py:83-140, hook src/nerf.py:256-261): the leading
+// 6*nd latent columns of sample n = t * (B*H*W) + ray are the integrated positional encoding of that conical-frustum /
+// cylinder sample, computed from the rays of the crop instead of being read from a [N, 6 nd] tensor in HBM
+struct MipGen {
+  const float* rays;  // [B,H,W,6]
+  const float* ts;    // [T]
+  int B, H, W, T, kind, min_deg, nd;
+  float t_end;
+};
+
 struct MlpArgs {
   NaMlpDesc d;
+  MipGen mip;
   const char* packed;
   const float* p;
   const float* latent;
@@ -21,7 +32,7 @@ struct MlpArgs {
   HashRes res;
 };
 
-template <int PREC, int ACT, int ENC, int NI, int NWAVES>
+template <int PREC, int ACT, int ENC, int NI, int NWAVES, int GEN = 0>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, TileTab tab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -47,7 +58,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
       if constexpr (ENC == NA_ENC_HASH) {
         px = a.p[n * a.p_ld]; py = a.p[n * a.p_ld + 1]; pz = a.p[n * a.p_ld + 2];
         float f[16];
-        hash_levels4(px, py, pz, (const float4*)a.enc, a.res, 4 * hi, f);
+        if constexpr (GEN != 0) {
+          // two levels in flight (64 result + 16 offset registers instead of 128 + 64 address registers): with the IPE
+          // state live next to it, the all-at-once gather of hash_levels4 spilled its results to scratch one by one
+#pragma unroll
+          for (int k2 = 0; k2 < 4; k2 += 2) {
+            HashGather h0, h1;
+            hash_level_issue(px, py, pz, (const float4*)a.enc, hi ? a.res.n[4 + k2] : a.res.n[k2], 4 * hi + k2, h0);
+            hash_level_issue(px, py, pz, (const float4*)a.enc, hi ? a.res.n[5 + k2] : a.res.n[1 + k2], 4 * hi + k2 + 1, h1);
+            float f0[4], f1[4];
+            hash_level_finish(h0, f0);
+            hash_level_finish(h1, f1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { f[4 * k2 + q] = f0[q]; f[4 * k2 + 4 + q] = f1[q]; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          hash_levels4(px, py, pz, (const float4*)a.enc, a.res, 4 * hi, f);
+        }
         float v0[8], v1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v0[e] = f[e]; v1[e] = f[8 + e]; }
@@ -90,12 +118,26 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
       // per element compiled to ~900 branches in this prologue.
       const int dim_rest = ENC == NA_ENC_HASH ? 6 + d.latent_size : d.in_size + d.latent_size;
       const float* prow = a.p + n * a.p_ld;
-      const float* lrow = d.latent_size > 0 ? a.latent + n * a.latent_ld : prow;
+      const int gen = GEN ? 6 * a.mip.nd : 0;  // latent columns produced here instead of being loaded
+      const float* lrow = d.latent_size > gen ? a.latent + n * a.latent_ld : prow;
+      float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
+      if constexpr (GEN != 0) {
+        const MipGen& m = a.mip;
+        const int64_t R = (int64_t)m.B * m.H * m.W;
+        const int t = (int)(n / R);
+        const int64_t r = n - (int64_t)t * R;
+        const int wq = (int)(r % m.W), hq = (int)((r / m.W) % m.H), b = (int)(r / ((int64_t)m.W * m.H));
+        const float rad = mip_radius(m.rays, m.H, m.W, b, hq, wq);
+        const MipGauss gs = mip_gaussian(m.rays + r * 6, rad, m.ts[t], t < m.T - 1 ? m.ts[t + 1] : m.t_end, m.kind);
+        gm0 = gs.m0; gm1 = gs.m1; gm2 = gs.m2; gc0 = gs.c0; gc1 = gs.c1; gc2 = gs.c2;
+      }
       const int npos = ENC == NA_ENC_HASH ? 6 : d.in_size;  // leading position slots (hash: p then x, both = p)
 #pragma unroll
       for (int c = 0; c < NI; ++c) {
         if (c >= c0) {
           float v[8];
+          // (uniform) does this chunk hold any generated column?  The View MLP's trailing chunks carry only loaded ones.
+          const bool chunk_gen = GEN != 0 && 16 * (c - c0) < npos + gen && 16 * (c - c0) + 16 > npos;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int rho = 16 * (c - c0) + 8 * hi + e;  // index into the virtual row
@@ -106,10 +148,21 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
             int li = rho - npos;
             li = (!is_pos && ok) ? li : 0;
             const float xp = prow[pi];
-            const float xl = lrow[li];
+            float xl;
+            if constexpr (GEN != 0) {
+              const bool is_gen = li < gen;
+              const float xg = chunk_gen ? mip_feature<PREC == NA_PREC_BF16>(gm0, gm1, gm2, gc0, gc1, gc2, is_gen ? li : 0,
+                                                                             a.mip.nd, a.mip.min_deg) : 0.f;
+              xl = is_gen ? xg : lrow[is_gen ? 0 : li - gen];
+            } else {
+              xl = lrow[li];
+            }
             v[e] = ok ? (is_pos ? xp : xl) : 0.f;
           }
           I[c] = make_frag<PREC>(v);
+          // one chunk at a time: interleaving the transcendental chains of several chunks costs more registers than the
+          // 44 the finished fragments already hold
+          if constexpr (GEN != 0) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }

@@ -123,8 +123,24 @@ int na_mlp_forward(const NaMlpDesc* desc, int precision, const void* packed, con
 int na_mlp_forward_ld(const NaMlpDesc* desc, int precision, const void* packed, const float* p, int64_t p_ld,
                       const float* latent, int64_t latent_ld, const float* enc_params, int64_t N, float* y,
                       void* stream) {
+  return na_mlp_forward_mip(desc, precision, packed, p, p_ld, latent, latent_ld, enc_params, nullptr, N, y, stream);
+}
+
+int na_mlp_forward_mip(const NaMlpDesc* desc, int precision, const void* packed, const float* p, int64_t p_ld,
+                       const float* latent, int64_t latent_ld, const float* enc_params, const NaMipDesc* mip, int64_t N,
+                       float* y, void* stream) {
   NA_REQUIRE(desc && packed && p && y, NA_ENULL, "na_mlp_forward: null pointer");
-  NA_REQUIRE(p_ld >= desc->in_size && (desc->latent_size == 0 || latent_ld >= desc->latent_size), NA_EINVAL,
+  int gen = 0;
+  if (mip != nullptr) {
+    NA_REQUIRE(mip->rays && mip->ts, NA_ENULL, "na_mlp_forward_mip: null rays / ts");
+    NA_REQUIRE(mip->kind == 0 || mip->kind == 1, NA_EUNSUPPORTED, "na_mlp_forward_mip: kind %d", mip->kind);
+    gen = 6 * (mip->max_deg - mip->min_deg);
+    NA_REQUIRE(mip->max_deg > mip->min_deg && mip->max_deg - mip->min_deg <= 42 && gen <= desc->latent_size, NA_EINVAL,
+               "na_mlp_forward_mip: %d IPE columns do not fit latent_size %d", gen, desc->latent_size);
+    NA_REQUIRE(mip->B >= 1 && mip->H >= 2 && mip->W >= 1 && mip->T >= 1 && N == (int64_t)mip->T * mip->B * mip->H * mip->W,
+               NA_EINVAL, "na_mlp_forward_mip: N must be T*B*H*W (radii need H >= 2 rows)");
+  }
+  NA_REQUIRE(p_ld >= desc->in_size && (desc->latent_size == gen || latent_ld >= desc->latent_size - gen), NA_EINVAL,
              "na_mlp_forward: row pitch smaller than the row (p_ld=%lld, latent_ld=%lld)", (long long)p_ld,
              (long long)latent_ld);
   NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_mlp_forward: precision %d",
@@ -133,13 +149,17 @@ int na_mlp_forward_ld(const NaMlpDesc* desc, int precision, const void* packed, 
   NA_REQUIRE(why == nullptr, NA_EUNSUPPORTED, "na_mlp_forward: %s", why);
   NA_REQUIRE(desc->layout == NA_LAYOUT_GENERIC, NA_EUNSUPPORTED,
              "na_mlp_forward: PLAIN_* layouts are only consumed by na_render_plain_view");
-  NA_REQUIRE(desc->latent_size == 0 || latent != nullptr, NA_ENULL, "na_mlp_forward: latent_size>0 needs latent");
+  NA_REQUIRE(desc->latent_size == gen || latent != nullptr, NA_ENULL, "na_mlp_forward: latent_size>0 needs latent");
   NA_REQUIRE(desc->enc_kind == NA_ENC_NONE || enc_params != nullptr, NA_ENULL, "na_mlp_forward: encoder needs enc_params");
   NA_REQUIRE(N >= 0, NA_EINVAL, "na_mlp_forward: N=%lld", (long long)N);
   if (N == 0) return NA_OK;
   MlpArgs a;
   a.d = *desc; a.packed = (const char*)packed; a.p = p; a.latent = latent; a.enc = enc_params; a.y = y; a.N = N;
   a.p_ld = p_ld; a.latent_ld = latent_ld;
+  a.mip = MipGen{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0.f};
+  if (mip != nullptr)
+    a.mip = MipGen{mip->rays, mip->ts, mip->B, mip->H, mip->W, mip->T, mip->kind, mip->min_deg, mip->max_deg - mip->min_deg,
+                   mip->t_end};
   a.out_tiles = out_tiles(*desc);
   a.res = hash_resolutions();
   TileTab tab;

@@ -9,9 +9,9 @@
 
 namespace na {
 
-template <int PREC, int ACT, int ENC, int NI, int NWAVES>
+template <int PREC, int ACT, int ENC, int NI, int NWAVES, int GEN = 0>
 static int launch_forward(const MlpArgs& a, const TileTab& tab, hipStream_t stream) {
-  auto kern = mlp_forward_kernel<PREC, ACT, ENC, NI, NWAVES>;
+  auto kern = mlp_forward_kernel<PREC, ACT, ENC, NI, NWAVES, GEN>;
   // the attribute is per DEVICE (not per thread): one bit per device ordinal
   static std::atomic<uint64_t> attr_done{0};
   {
@@ -34,6 +34,19 @@ static int dispatch_forward(MlpArgs& a, const TileTab& tab, int NI, hipStream_t 
   const int act = a.d.activation;
   // 8 waves (2 per SIMD, <=256 VGPR) when the fragments fit, else 4 waves with the whole register file
   constexpr int NWS = PREC == NA_PREC_BF16X3 ? 4 : 8;
+  // IPE latent generated in the prologue: the two MLPs of PlainNeRF(view) + mip (config 3)
+#define NA_CASE_GEN(ACTV, ENCV, NIV, NW)                                                          \
+  if (a.mip.rays != nullptr && act == ACTV && a.d.enc_kind == ENCV && NI == NIV) {                \
+    a.ngroups = (int)((a.N + 32 * NW - 1) / (32 * NW));                                           \
+    return launch_forward<PREC, ACTV, ENCV, NIV, NW, 1>(a, tab, s);                               \
+  }
+  NA_CASE_GEN(NA_ACT_LEAKY_RELU, NA_ENC_HASH, 9, NWS)
+  NA_CASE_GEN(NA_ACT_SIN, NA_ENC_NONE, 11, NWS)
+#undef NA_CASE_GEN
+  if (a.mip.rays != nullptr) {
+    set_error("na_mlp_forward_mip: no IPE-prologue kernel for activation %d, encoder %d, NI %d", act, a.d.enc_kind, NI);
+    return NA_EUNSUPPORTED;
+  }
 #define NA_CASE(ACTV, ENCV, NIV, NW)                                                              \
   if (act == ACTV && a.d.enc_kind == ENCV && NI == NIV) {                                         \
     a.ngroups = (int)((a.N + 32 * NW - 1) / (32 * NW));                                           \

@@ -55,7 +55,10 @@ def white(_, weights): return 1 - weights[:-1].sum(dim=0).unsqueeze(-1)
 sky_kinds = {"black": black, "white": white, "mlp": "MLP_MARKER", "random": None}
 
 
-def cat_not_none(a, b, dim=-1): return a if b is None else (b if a is None else torch.cat([a, b], dim=dim))
+def cat_not_none(a, b, dim=-1):
+    if isinstance(a, utils.MipLatent):  # lazy IPE latent: stays lazy, the other columns ride along
+        return a if b is None else a.with_rest(b)
+    return a if b is None else (b if a is None else torch.cat([a, b], dim=dim))
 
 
 # ------------------------------------------------------------------------------------------------- CommonNeRF
@@ -102,6 +105,10 @@ class CommonNeRF(nn.Module):
     def nerf(self): return self
 
     def mip_size(self): return 0 if self.mip is None else self.mip.size() * 6
+
+    def mip_latent(self, rays, ts):
+        """the IPE latent as a lazy handle (utils.MipLatent): generated inside the fused MLP kernels"""
+        return None if self.mip is None else self.mip.lazy(rays, ts)
 
     def mip_encoding(self, rays, ts):
         """src/nerf.py:256-261, intended layout; rays [B,H,W,6] of one crop."""
@@ -197,7 +204,7 @@ class PlainNeRF(CommonNeRF):
             # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
             out, self.alpha, self.weights = self._render_fused(rays, ts, True, pts=pts.contiguous())
             return out
-        latent = self.mip_encoding(rays, ts)
+        latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
         first_out = self.first(pts, latent)
         density = first_out[..., 0].contiguous()
         if self.training and self.noise_std > 0:

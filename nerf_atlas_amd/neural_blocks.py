@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import autograd as ag
-from . import config, ops
+from . import config, ops, utils
 
 
 class PositionalEncoder(nn.Module):
@@ -226,6 +226,15 @@ class SkipConnMLP(nn.Module):
             self._packed[key] = (stamp, buf)
         return desc, self._packed[key][1]
 
+    def _mip_prologue_shape(self):
+        """the shapes csrc/mlp_fwd_inst.hip instantiates with the IPE prologue: PlainNeRF.first (hash, 38 + 96 inputs)
+        and View.mlp (sin, 5 + 96 + 64 inputs)"""
+        if self.init.out_features != 256 or self.packed(config.precision)[1] is None:
+            return False
+        if isinstance(self.enc, HashEncoder):
+            return self.act_name == "leaky_relu" and self.dim_p == 38 + 96
+        return self.enc is None and self.act_name == "sin" and self.dim_p == 5 + 96 + 64
+
     def enc_params(self):
         if isinstance(self.enc, HashEncoder):
             return self.enc.tables()
@@ -236,12 +245,29 @@ class SkipConnMLP(nn.Module):
 
     def forward(self, p, latent: Optional[torch.Tensor] = None):
         batches = p.shape[:-1]
+        mip = None
+        if isinstance(latent, utils.MipLatent):
+            # lazy IPE latent (config 3): the two MLP shapes of PlainNeRF(view) generate it in their prologue; every other
+            # consumer (training, other shapes) sees the materialised tensor
+            rest = latent.rest
+            if (not self.last_layer_act and latent.width == 96 and self._mip_prologue_shape()
+                    and not ag.needs_grad(p, rest, *self.parameters())):
+                mip, latent = latent, rest
+            else:
+                latent = latent.tensor()
         if self.latent_size != 0:
-            assert latent is not None, "Did not pass latent vector when some was expected"
+            assert latent is not None or mip is not None, "Did not pass latent vector when some was expected"
         else:
             assert (latent is None) or (latent.shape[-1] == 0), "Passed latent vector when none was expected"
             latent = None
         out_size = self.out.out_features
+        if mip is not None:
+            desc, packed = self.packed(config.precision)
+            assert packed is not None and self.latent_size == mip.width + (0 if latent is None else latent.shape[-1])
+            y = ops.mlp_forward(desc, config.precision, packed, p.reshape(-1, p.shape[-1]),
+                                None if latent is None else latent.reshape(-1, latent.shape[-1]), self.enc_params(),
+                                mip=mip.args())
+            return y.reshape(batches + (out_size,))
         if not ag.needs_grad(p, latent, *self.parameters()):
             desc, packed = (None, None) if self.last_layer_act else self.packed(config.precision)
             if packed is not None:

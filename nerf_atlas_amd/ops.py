@@ -146,6 +146,9 @@ def sigmoid(x: torch.Tensor, kind: str) -> torch.Tensor:
     return out
 
 
+MIP_KIND = {"cylinder": 0, "cone": 1}
+
+
 def mip_encode(rays: torch.Tensor, ts: torch.Tensor, kind: str, t_end: float, min_deg: int = 0, max_deg: int = 16):
     """rays [B,H,W,6] of ONE crop -> [T,B,H,W,6*(max_deg-min_deg)] (intended layout)."""
     lib = _lib.load()
@@ -153,7 +156,7 @@ def mip_encode(rays: torch.Tensor, ts: torch.Tensor, kind: str, t_end: float, mi
     B, H, W, _ = rays.shape
     T = ts.shape[0]
     out = torch.empty(T, B, H, W, 6 * (max_deg - min_deg), device=rays.device, dtype=torch.float32)
-    check(lib.na_mip_encode(_ptr(rays), B, H, W, _ptr(ts), T, {"cylinder": 0, "cone": 1}[kind], float(t_end), min_deg,
+    check(lib.na_mip_encode(_ptr(rays), B, H, W, _ptr(ts), T, MIP_KIND[kind], float(t_end), min_deg,
                             max_deg, _ptr(out), _stream()))
     return out
 
@@ -550,21 +553,34 @@ def _rows(t: torch.Tensor, width: int, name: str):
 
 
 def mlp_forward(desc: NaMlpDesc, precision: str, packed: torch.Tensor, p: torch.Tensor,
-                latent: Optional[torch.Tensor] = None, enc_params: Optional[torch.Tensor] = None) -> torch.Tensor:
+                latent: Optional[torch.Tensor] = None, enc_params: Optional[torch.Tensor] = None, mip=None) -> torch.Tensor:
     """Fused SkipConnMLP forward.  p [..., in_size] and latent [..., latent_size] may be column slices of wider
-    buffers (e.g. `first_out[..., 1:]`): their row pitch is passed down instead of making them contiguous."""
+    buffers (e.g. `first_out[..., 1:]`): their row pitch is passed down instead of making them contiguous.
+    mip = (rays [B,H,W,6], ts [T], kind, t_end, min_deg, max_deg): the leading 6*(max_deg-min_deg) latent columns are the
+    IPE of the samples, generated in the kernel's prologue; `latent` then holds only the remaining columns (or is None)."""
     lib = _lib.load()
     p2, p_ld = _rows(p, desc.in_size, "p")
     N = p2.shape[0]
+    gen = 0
+    mdesc = None
+    if mip is not None:
+        rays, ts, kind, t_end, min_deg, max_deg = mip
+        rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+        assert rays.dim() == 4 and rays.shape[-1] == 6
+        B, H, W = rays.shape[:3]
+        gen = 6 * (max_deg - min_deg)
+        mdesc = _lib.NaMipDesc(rays.data_ptr(), ts.data_ptr(), B, H, W, ts.shape[0], MIP_KIND[kind], min_deg, max_deg,
+                               float(t_end))
     lat2, lat_ld = (None, 0)
     if latent is not None:
-        lat2, lat_ld = _rows(latent, desc.latent_size, "latent")
+        lat2, lat_ld = _rows(latent, desc.latent_size - gen, "latent")
         assert lat2.shape[0] == N
     if enc_params is not None:
         enc_params = _f32(enc_params, "enc_params")
     y = torch.empty(tuple(p.shape[:-1]) + (desc.out_size,), device=p.device, dtype=torch.float32)
-    check(lib.na_mlp_forward_ld(C.byref(desc), PREC[precision], _ptr(packed), _ptr(p2), p_ld, _ptr(lat2), lat_ld,
-                                _ptr(enc_params), N, _ptr(y), _stream()))
+    check(lib.na_mlp_forward_mip(C.byref(desc), PREC[precision], _ptr(packed), _ptr(p2), p_ld, _ptr(lat2), lat_ld,
+                                 _ptr(enc_params), None if mdesc is None else C.cast(C.byref(mdesc), C.c_void_p), N, _ptr(y),
+                                 _stream()))
     return y
 
 

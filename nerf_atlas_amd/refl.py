@@ -90,6 +90,8 @@ class PosLinearView(Reflectance):
                                 hidden_size=128, init="siren", activation=torch.sin)
 
     def forward(self, x, view, normal=None, light=None, latent=None):
+        if hasattr(latent, "tensor") and not torch.is_tensor(latent):
+            latent = latent.tensor()  # lazy IPE latent (utils.MipLatent): this head concatenates it, so materialise
         pos_all = self.act(self.pos(x, latent))  # [..., out_features + im]
         intermediate = pos_all[..., self.out_features:]
         view_latent = intermediate if latent is None else torch.cat([latent, intermediate], dim=-1)

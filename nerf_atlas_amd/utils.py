@@ -45,6 +45,36 @@ def dir_to_elev_azim(direc):
     return ops.view_elaz(direc)
 
 
+class MipLatent:
+    """The IPE latent of one crop, not materialised: the fused MLP kernels generate its 6*nd columns in their prologue
+    (ops.mlp_forward(..., mip=...)), every other consumer gets the [T,B,H,W,6 nd] tensor from .tensor() (na_mip_encode).
+    `rest` is an optional tensor of further latent columns that follow it (cat_not_none(mip, intermediate))."""
+
+    def __init__(self, rays, ts, kind, t_end, min_deg, max_deg, rest=None):
+        self.rays, self.ts, self.kind, self.t_end, self.min_deg, self.max_deg, self.rest = rays, ts, kind, t_end, min_deg, max_deg, rest
+        self._t = None
+
+    @property
+    def width(self): return 6 * (self.max_deg - self.min_deg)
+
+    def args(self): return (self.rays, self.ts, self.kind, self.t_end, self.min_deg, self.max_deg)
+
+    def with_rest(self, rest):
+        assert self.rest is None
+        m = MipLatent(self.rays, self.ts, self.kind, self.t_end, self.min_deg, self.max_deg, rest)
+        m._t = self._t
+        return m
+
+    def mip_tensor(self):
+        if self._t is None:
+            self._t = ops.mip_encode(self.rays, self.ts, self.kind, self.t_end, self.min_deg, self.max_deg)
+        return self._t
+
+    def tensor(self):
+        t = self.mip_tensor()
+        return t if self.rest is None else torch.cat([t, self.rest], dim=-1)
+
+
 class _Mip:
     def __init__(self, kind, min_deg=0, max_deg=16):
         self.kind, self.min_deg, self.max_deg = kind, min_deg, max_deg
@@ -55,8 +85,11 @@ class _Mip:
     def __call__(self, rays, ts):
         """rays [B,H,W,6] of one crop, ts [T] -> [T,B,H,W,96] (intended layout; the last interval is closed
         at ts[-1] + (ts[-1]-ts[-2]) instead of 1e10)."""
+        return self.lazy(rays, ts).tensor()
+
+    def lazy(self, rays, ts) -> MipLatent:
         t_end = float(2 * ts[-1] - ts[-2]) if ts.shape[0] > 1 else float(ts[-1]) + 1.0
-        return ops.mip_encode(rays, ts, self.kind, t_end, self.min_deg, self.max_deg)
+        return MipLatent(rays.contiguous(), ts, self.kind, t_end, self.min_deg, self.max_deg)
 
 
 def CylinderGaussian(min_deg=0, max_deg=16):
