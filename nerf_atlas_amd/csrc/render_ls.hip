@@ -289,6 +289,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
+  // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
+  // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
+  __builtin_amdgcn_s_dcache_inv();
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rg = wv & 3, g = wv >> 2;

@@ -143,6 +143,9 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
         if getattr(args, k, 0) > 0:
             raise NotImplementedError(f"--{k.replace('_', '-')} needs input Jacobians of the deformation / normal "
                                       "networks (hash-encoder and spline tangents are not implemented: DESIGN.md 9a)")
+    if args.ffjord_div_decay and not hasattr(model, "ffjord_div"):
+        raise ValueError("--ffjord-div-decay needs a dynamic model (--data-kind dnerf --dyn-model plain --spline N): the "
+                         "reference reads model.pts / model.rigid_dp (runner.py:698-699)")
     if args.sdf_eikonal > 0 and not hasattr(model, "sdf"):
         raise ValueError("--sdf-eikonal needs an SDF model (--model volsdf)")
     device = next(model.parameters()).device

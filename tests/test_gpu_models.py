@@ -223,7 +223,7 @@ def test_bezier_keyframes_and_intersect_mask(na):
         ref = O.plain_nerf_from_pts(p, pts + est[..., 1 + 3 * k:4 + 3 * k] * rig, ts, r_o, r_d, "view", act="upshifted",
                                     prefix="canonical.")
         assert maxdiff(f, ref) <= 3e-4, k
-    assert maxdiff(frames[0], frames[5]) > 1e-5  # the control points differ
+    assert maxdiff(frames[0], frames[5].cpu()) > 1e-5  # the control points differ
     # intersect_mask
     g = load_golden("g15_march")
     under = na.sdf.SIREN(intermediate_size=0)

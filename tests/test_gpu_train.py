@@ -131,9 +131,11 @@ def _test_set(T, args):
 def test_unsupported_regularisers_raise_and_eikonal_trains(tmp_path):
     import nerf_atlas_amd.train as T
     data = make_scene(str(tmp_path / "s"), size=16, n_train=2, n_test=1) + "/"
-    args = T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, ffjord_div_decay=0.1)
+    args = T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, dyn_diverge_decay=0.1)
     with pytest.raises(NotImplementedError):
         T.fit(args)
+    with pytest.raises(ValueError):  # the FFJORD estimate reads the deformation field of a dynamic model
+        T.fit(T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, ffjord_div_decay=0.1))
     with pytest.raises(ValueError):  # the eikonal term needs an SDF model
         T.fit(T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, sdf_eikonal=0.1))
     # `make dtu`-style recipe: VolSDF + --sdf-eikonal runs and lowers E[(|n|-1)^2] of the SDF
