@@ -12,3 +12,8 @@ python tools/pmc_collect.py --kernel "render_ls_kernel<0>" --out $O/pmc_render_l
 rm -rf $O/prof_bench
 ls -la $O
 cat $O/bench_default.json
+python tools/ls_bench.py 3 > $O/ls_bench.log 2>&1
+python tools/ls_trace.py run bf16 > $O/ls_trace_bf16.log 2>&1
+python tools/ls_trace.py run bf16x3 > $O/ls_trace_bf16x3.log 2>&1
+python tools/kernel_bench.py --json $O/kernel_bench.json > $O/kernel_bench.log 2>&1
+python tools/train_bench.py > $O/train_bench.log 2>&1
