@@ -321,8 +321,10 @@ int na_composite_backward(const float* density, const float* feat, const float* 
  *   w_first / b_first = {init, layers.0..3, out} of PlainNeRF.first  (hash encoder, 4x256, out 65; src/nerf.py:320-324)
  *   w_view  / b_view  = {init, layers.0..3, out} of View.mlp         (5 + 64 latent -> 4x256 -> 3; src/refl.py:201-204)
  * in nn.Linear layout (fp32, device pointers; biases may be NULL).  `pts` ([T,R,3], nullable) replaces o + t d by
- * explicit sample positions (PlainNeRF.from_pts with deformed points, src/nerf.py:337-361).  Workspace: partials of
- * the per-block compositing + a 16-KiB-per-workgroup scratch.                                                    */
+ * explicit sample positions (PlainNeRF.from_pts with deformed points, src/nerf.py:337-361).  A ray's 32-step blocks
+ * pass through one sample group in step order, so the transmittance product of src/nerf.py:22-27 is carried inside the
+ * kernel: `out`, `alpha`, `weights` are final when it returns (no second launch).  Workspace: 8 B per ray (elev / azim
+ * of the ray, written by a pre-kernel and read with scalar loads).                                                  */
 size_t na_render_ls_packed_bytes(int precision);
 int na_render_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
                       const float* const* w_view, const float* const* b_view, void* packed, void* stream);

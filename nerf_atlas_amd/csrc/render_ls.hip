@@ -21,6 +21,9 @@
 //    small pre-kernel writes once per ray; ~15 VALU per block) right before the two MFMAs that use them.
 //  * `first.out` / `view.out` (65 and 3 rows) run block-per-wave (wave rg = block rg, all out tiles), which is also the
 //    assignment of the hash-encoder prologue and of compositing, so density and colour never leave their wave.
+//  * Sample group G = 2 * workgroup + g renders the rays G, G + nG, ... one after the other, block by block in step
+//    order: the transmittance is carried across blocks (and passes) inside the group -- block partials meet in the
+//    group's idle hidden region of LDS -- so there are no per-block partials in HBM and no finalize launch.
 //
 // Compiled once per precision (-DNA_PREC_INST=0|1).
 #include <atomic>
