@@ -287,6 +287,57 @@ __device__ __forceinline__ void activate_init(char* ib, int blk, int lane) {
   }
 }
 
+// ---- compositing arithmetic on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each).  The
+// libm calls they replace made the compositing of a block the longest piece of the exposed EP phase (~5 k cycles).
+// exp(x): x log2(e) with the product's rounding error recovered by an fma (2e-7 relative for |x| <= 88)
+__device__ __forceinline__ float fast_exp(float x) {
+  x = fminf(x, 88.f);
+  const float t = x * 1.4426950408889634f;
+  const float r = fmaf(x, 1.4426950408889634f, -t) + x * 1.925963033500235e-8f;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-v)); }
+// log1p(exp(v)) with the RELATIVE accuracy the 1e10-long last interval needs (src/nerf.py:60-68: sigma * 1e10): series
+// below 2^-6, log(u) * e / (u - 1) above (u = fl(1 + e); the quotient undoes the rounding of the sum)
+__device__ __forceinline__ float fast_softplus(float v) {
+  if (v > 20.f) return v;
+  const float e = fast_exp(v);
+  const float series = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.0f);
+  const float u = 1.0f + e;
+  const float lg = __builtin_amdgcn_logf(u) * 0.6931471805599453f * (e * __builtin_amdgcn_rcpf(u - 1.0f));
+  return e < 0.015625f ? series : lg;
+}
+__device__ __forceinline__ float fast_sigmoid_kind(float v, int kind) {
+  switch (kind) {  // the sigmoid family on the fast path, everything else as in apply_sigmoid_kind
+    case NA_SIG_NORMAL: return fast_sigmoid(v);
+    case NA_SIG_THIN: return (fast_sigmoid(v) * (1.f + 2.f * -1e-2f) - -1e-2f) + 1e-2f;
+    case NA_SIG_FAT: return fast_sigmoid(v) * (1.f + 2.f * 1e-2f) - 1e-2f;
+    case NA_SIG_UPSHIFTED: return fast_sigmoid(v) + 1e-2f;
+    default: return apply_sigmoid_kind(v, kind);
+  }
+}
+// 32-lane scans on DPP (row shifts inside rows of 16 + row_bcast:15 into the odd rows): 5 VALU instructions instead of
+// 5 dependent ds_bpermute round trips.  The two 32-lane halves of the wave scan independently.
+#define NA_DPP(OLD, SRC, CTRL, ROWS) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, OLD), __builtin_bit_cast(int, SRC), CTRL, ROWS, 0xF, false))
+__device__ __forceinline__ float scan32_mul(float x) {
+  x *= NA_DPP(1.0f, x, 0x111, 0xF);
+  x *= NA_DPP(1.0f, x, 0x112, 0xF);
+  x *= NA_DPP(1.0f, x, 0x114, 0xF);
+  x *= NA_DPP(1.0f, x, 0x118, 0xF);
+  x *= NA_DPP(1.0f, x, 0x142, 0xA);
+  return x;
+}
+__device__ __forceinline__ float scan32_add(float x) {
+  x += NA_DPP(0.0f, x, 0x111, 0xF);
+  x += NA_DPP(0.0f, x, 0x112, 0xF);
+  x += NA_DPP(0.0f, x, 0x114, 0xF);
+  x += NA_DPP(0.0f, x, 0x118, 0xF);
+  x += NA_DPP(0.0f, x, 0x142, 0xA);
+  return x;
+}
+
 template <int PREC>
 __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -313,6 +364,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   float geo_u[NB][8];   // ox oy oz dx dy dz elev azim of block b's ray (uniform)
   int geo_t0[NB];       // first step of block b
   int geo_ray[NB];
+  float own_u[6];       // origin | direction of the ray of this wave's OWN block (encoder + compositing), per pass
+  float own_dn = 0.f;   // |direction| of that ray
+  float prev_dn = 0.f;  // the same for the wave's block of the previous pass (its compositing runs one pass later)
   // Work distribution: sample group G = 2 * workgroup + g renders the rays G, G + nG, G + 2 nG, ... one after the other,
   // each as its nb 32-step blocks in step order, NB blocks per pass.  At any moment the launch works on ~nG consecutive
   // rays (hash-table locality in L2 as before), and the blocks of one ray pass through one group in order, so the
@@ -374,6 +428,21 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       geo_u[b][6] = lo(e2[b]); geo_u[b][7] = hi32(e2[b]);
     }
   };
+  // the ray of this wave's own block of pass `pl`: three scalar loads at the top of EP (short-lived SGPRs; the group-wide
+  // table above is filled later, in the epilogue of first.out, for the two View phases -- holding it for the whole pass
+  // made the compiler park it in scratch memory and re-store it every pass)
+  auto own_setup = [&](int pl) {
+    const Loc L = locate(pl, blk);
+    const float* ry = a.rays + (int64_t)__builtin_amdgcn_readfirstlane(L.ray) * 6;
+    uint64_t ra, rb, rc;
+    asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dwordx2 %2, %3, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(ra), "=&s"(rb), "=&s"(rc) : "s"(ry));
+    auto lo = [](uint64_t v) { return __builtin_bit_cast(float, (uint32_t)v); };
+    auto hi32 = [](uint64_t v) { return __builtin_bit_cast(float, (uint32_t)(v >> 32)); };
+    own_u[0] = lo(ra); own_u[1] = hi32(ra); own_u[2] = lo(rb); own_u[3] = hi32(rb); own_u[4] = lo(rc); own_u[5] = hi32(rc);
+    const float dx = own_u[3], dy = own_u[4], dz = own_u[5];
+    own_dn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sqrtf((dx * dx + dy * dy) + dz * dz))));
+  };
   struct GeoRaw { float x, y, z; };  // t (x) or the explicit position of this lane's sample
   auto geo_load = [&](int b) -> GeoRaw {
     const int t = geo_t0[b] + ln;
@@ -407,6 +476,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     int t;
     float px, py, pz, dist, dx, dy, dz;
   };
+  // geometry of this lane's sample of the wave's own block of the CURRENT pass (own_setup(pass) has run)
   auto geom = [&](int pass, int b) {
     Geom q;
     const Loc L = locate(pass, b);
@@ -416,56 +486,59 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     q.t = tb * 32 + ln;
     q.t_ok = q.t < a.T;
     const int tc = q.t_ok ? q.t : a.T - 1;
-    const float* ry = a.rays + q.ray * 6;
-    q.dx = ry[3]; q.dy = ry[4]; q.dz = ry[5];
+    const float (&u)[6] = own_u;
+    q.dx = u[3]; q.dy = u[4]; q.dz = u[5];
     const float tt = a.ts[tc];
     if (a.pts != nullptr) {
       const float* p = a.pts + ((int64_t)tc * a.R + q.ray) * 3;
       q.px = p[0]; q.py = p[1]; q.pz = p[2];
     } else {
-      q.px = ry[0] + tt * q.dx; q.py = ry[1] + tt * q.dy; q.pz = ry[2] + tt * q.dz;
+      q.px = u[0] + tt * q.dx; q.py = u[1] + tt * q.dy; q.pz = u[2] + tt * q.dz;
     }
     const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
-    q.dist = d * sqrtf((q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz);
+    q.dist = d * own_dn;
+    return q;
+  };
+  // what the compositing of block `blk` of the PREVIOUS pass needs: issued at the top of EP next to the loads above
+  struct Prev { int64_t ray; int t; bool ok, t_ok; float dist; };
+  auto prev_geom = [&](int pl) {
+    Prev q;
+    const Loc L = locate(pl, blk);
+    q.ok = L.ok;
+    q.ray = L.ray;
+    q.t = L.tb * 32 + ln;
+    q.t_ok = q.t < a.T;
+    const int tc = q.t_ok ? q.t : a.T - 1;
+    const float tt = a.ts[tc];
+    const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+    q.dist = d * prev_dn;
     return q;
   };
 
   float w_local = 0.f;  // block-local weight of this lane's sample, until `combine` knows the transmittance in front
   // compositing of block rg of pass `pass` (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
-  auto composite = [&](int pass, const f32x16& oc, float density) {
-    const Geom q = geom(pass, blk);
-    const float cr = apply_sigmoid_kind(oc[0], a.sigmoid_kind);
-    const float cg = apply_sigmoid_kind(oc[1], a.sigmoid_kind);
-    const float cb = apply_sigmoid_kind(oc[2], a.sigmoid_kind);
-    const float sigma = softplusf_(density - 1.0f);
-    float alpha = q.t_ok ? 1.0f - expf(-sigma * q.dist) : 0.f;
-    float f = (1.0f - alpha) + 1e-10f;
-    float incl = f;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      float up = __shfl_up(incl, d, 32);
-      if (ln >= d) incl = incl * up;
-    }
-    float excl = __shfl_up(incl, 1, 32);
-    if (ln == 0) excl = 1.0f;
+  auto composite = [&](const Prev& q, const f32x16& oc, float density) {
+    const float cr = fast_sigmoid_kind(oc[0], a.sigmoid_kind);
+    const float cg = fast_sigmoid_kind(oc[1], a.sigmoid_kind);
+    const float cb = fast_sigmoid_kind(oc[2], a.sigmoid_kind);
+    const float sigma = fast_softplus(density - 1.0f);
+    const float alpha = q.t_ok ? 1.0f - fast_exp(-sigma * q.dist) : 0.f;
+    const float f = (1.0f - alpha) + 1e-10f;
+    // exclusive product scan over the 32 steps of the block: shift by one lane (lane 0 of each half: 1), then scan
+    float fs = NA_DPP(1.0f, f, 0x138, 0xF);  // wave_shr:1
+    if (ln == 0) fs = 1.0f;
+    const float excl = scan32_mul(fs);
     const float w = alpha * excl;
-    float sr = w * cr, sg = w * cg, sb = w * cb;
-    float wh = (q.t < a.T - 1) ? w : 0.f;
-#pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) {
-      sr += __shfl_xor(sr, d, 32);
-      sg += __shfl_xor(sg, d, 32);
-      sb += __shfl_xor(sb, d, 32);
-      wh += __shfl_xor(wh, d, 32);
-    }
-    const float P = __shfl(incl, 31, 32);
+    const float P = excl * f;                 // lane 31: product of the whole block
+    const float sr = scan32_add(w * cr), sg = scan32_add(w * cg), sb = scan32_add(w * cb);
+    const float wh = scan32_add((q.t < a.T - 1) ? w : 0.f);
     if (owner && hi == 0) {
-      if (ln == 0) {
+      if (ln == 31) {
         // block product and block-local sums -> the group's (idle) hidden region; combined by `combine` after the barrier
         float* o = (float*)hb + blk * kPartialFloats;
         o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
       }
-      if (q.item_ok && q.t_ok && a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
+      if (q.ok && q.t_ok && a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
     }
     w_local = w;
   };
@@ -518,8 +591,15 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     __syncthreads();                                                                        \
     if (tlog != nullptr && ton && tpos < 126) tlog[tpos++] = __builtin_amdgcn_s_memtime();  \
   } while (0)
+#define STAMP(i)                                                                              \
+  do {                                                                                         \
+    if (tlog != nullptr && ton) a.trace[256 + g * 16 + (i)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
 #else
 #define SYNC() __syncthreads()
+#define STAMP(i) \
+  do {           \
+  } while (0)
 #endif
   f32x16 acc[2][NB];
   // One hash level (4*hi + k) of a sample -> bytes 8*(k&1)..+7 of this lane's 16 B of init chunk k>>1 (LDS).
@@ -560,24 +640,42 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     // cycles per group and pass whether issued as four rounds, two or one (measured); spreading the levels over the
     // epilogues of the other layers was slower still (every gathering wave stalls ~3k cycles per round and those
     // epilogues have ~1.8k cycles of slack).
+    STAMP(0);
     if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
+      prev_dn = own_dn;
+      own_setup(pass);
       const Geom q = geom(pass, blk);
-      HashGather hg;
+      Prev qp;
+      if (prev >= 0) qp = prev_geom(prev);
+      // two levels in flight at a time (2 x 32 registers; the accumulators are dead here): levels 0,1 with the compositing
+      // of the previous pass in their shadow, then levels 2,3 -- two gather round trips per pass instead of four
+      HashGather hg, hg2;
       hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 0], 4 * hi + 0, hg);
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 1], 4 * hi + 1, hg2);
       __builtin_amdgcn_sched_barrier(0);
-      if (prev >= 0) composite(prev, oc[0], density);
+      STAMP(1);
+      if (prev >= 0) composite(qp, oc[0], density);
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(2);
       hash_finish(0, hg);
-#pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
-        hash_finish(k, hg);
-      }
+      hash_finish(1, hg2);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(3);
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 2], 4 * hi + 2, hg);
+      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 3], 4 * hi + 3, hg2);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(4);
+      hash_finish(2, hg);
+      STAMP(5);
+      hash_finish(3, hg2);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(6);
       float v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v2[e] = 0.f;
       if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; v2[3] = q.px; v2[4] = q.py; v2[5] = q.pz; }
       fwrite<PREC>(ib + blk * 4 * FR + lane * 16 + 2 * FR, make_frag<PREC>(v2));
+      STAMP(7);
     }
     {
       f32x16 bv[2];
@@ -703,7 +801,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     SYNC();
     prev = pass;
   }
-  if (prev >= 0 && (NB == 4 || owner)) composite(prev, oc[0], density);
+  if (prev >= 0 && (NB == 4 || owner)) {
+    prev_dn = own_dn;
+    composite(prev_geom(prev), oc[0], density);
+  }
   __syncthreads();
   if (prev >= 0) combine(prev);
   if (g == 0) __syncthreads();  // group 0 takes its extra barrier at the end

@@ -73,6 +73,12 @@ def run(prec="bf16"):
     base = ((ws.data_ptr() + base + 255) & ~255) - ws.data_ptr()
     raw = ws[base: base + 2 * 128 * 8].cpu().view(torch.int64).reshape(2, 128)
     print(f"{prec}: {ms:.2f} ms/frame = {R * T / ms / 1e3:.0f} Msamples/s (traced build)")
+    ep = ws[base + 256 * 8: base + 256 * 8 + 2 * 16 * 8].cpu().view(torch.int64).reshape(2, 16)
+    for g in range(2):
+        st = [int(v) for v in ep[g][:8]]
+        if st[0]:
+            names = ["geom + issue levels 0,1", "composite(prev)", "finish 0,1", "issue 2,3", "finish 2", "finish 3", "pos chunk"]
+            print(f"   EP of group {g}: " + ", ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(names)) + f" (total {st[7] - st[0]})")
     for g in range(2):
         t = [int(v) for v in raw[g][:48]]
         if t[0] == 0:
