@@ -163,8 +163,11 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
     ring[(RING0 + q) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
     ring[(RING0 + q) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
   };
-  // raw inputs of the geometry chunk: requested under the last LDS-fed chunk
+  // raw inputs of the geometry chunk (t or the explicit position of the lane's sample): requested two (bf16) or five (bf16x3)
+  // chunks before the chunk that uses them; under the last LDS-fed chunk their latency was exposed (view.L0 7.3 k cycles)
   decltype(geo_load(0)) graw[GEO != 0 ? NB : 1];
+  constexpr int LEAD = NB == 4 ? 2 : 5;  // (bf16 has no registers to hold them longer without spilling)
+  constexpr int GQ = NL > LEAD ? NL - LEAD : 0;
   if constexpr (NB == 4) {
     // bf16 (4 blocks): ONE set of B fragments, refilled in place -- block b's fragment of chunk q+1 is requested right
     // after its two MFMAs of chunk q have issued and has the other three blocks' MFMAs (192 cycles) to arrive.  Halves
@@ -181,7 +184,9 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
         mma<PREC>(acc[0][b], A0, Bs[b]);
         mma<PREC>(acc[1][b], A1, Bs[b]);
         if (q + 1 < NL) Bs[b] = bsrc(q + 1, b);
-        else if constexpr (GEO != 0) graw[b] = geo_load(b);
+        if constexpr (GEO != 0) {
+          if (q == GQ) graw[b] = geo_load(b);
+        }
         if (b == 0) refill(q);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -197,9 +202,12 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
       if (q + 1 < NL) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) Bq[(q + 1) & 1][b] = bsrc(q + 1, b);
-      } else if constexpr (GEO != 0) {
+      }
+      if constexpr (GEO != 0) {
+        if (q == GQ) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+          for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -647,29 +655,27 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const Geom q = geom(pass, blk);
       Prev qp;
       if (prev >= 0) qp = prev_geom(prev);
-      // two levels in flight at a time (2 x 32 registers; the accumulators are dead here): levels 0,1 with the compositing
-      // of the previous pass in their shadow, then levels 2,3 -- two gather round trips per pass instead of four
-      HashGather hg, hg2;
+      // one level (8 gathers, 32 registers) at a time, the first with the compositing of the previous pass in its shadow.
+      // Two levels in flight were no faster (the gathers are bound by their issue rate, ~90 cycles each) and made the
+      // kernel's output irreproducible run to run (tools/ls_determinism.py: 16 samples of one ray off by ~1e-5 in a third
+      // of the runs; cause not found in the ISA -- the waits are in order and conservative -- so the variant is not used).
+      HashGather hg;
       hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 0], 4 * hi + 0, hg);
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 1], 4 * hi + 1, hg2);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(1);
       if (prev >= 0) composite(qp, oc[0], density);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(2);
       hash_finish(0, hg);
-      hash_finish(1, hg2);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(3);
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 2], 4 * hi + 2, hg);
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 3], 4 * hi + 3, hg2);
-      __builtin_amdgcn_sched_barrier(0);
-      STAMP(4);
-      hash_finish(2, hg);
-      STAMP(5);
-      hash_finish(3, hg2);
-      __builtin_amdgcn_sched_barrier(0);
-      STAMP(6);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
+        hash_finish(k, hg);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(3 + k);
+      }
       float v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v2[e] = 0.f;

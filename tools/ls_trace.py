@@ -77,7 +77,7 @@ def run(prec="bf16"):
     for g in range(2):
         st = [int(v) for v in ep[g][:8]]
         if st[0]:
-            names = ["geom + issue levels 0,1", "composite(prev)", "finish 0,1", "issue 2,3", "finish 2", "finish 3", "pos chunk"]
+            names = ["geom + issue level 0", "composite(prev)", "finish level 0", "level 1", "level 2", "level 3", "pos chunk"]
             print(f"   EP of group {g}: " + ", ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(names)) + f" (total {st[7] - st[0]})")
     for g in range(2):
         t = [int(v) for v in raw[g][:48]]
