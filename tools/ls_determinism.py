@@ -34,5 +34,37 @@ for prec in ("bf16x3", "bf16"):
                     d = [float((a - b).abs().max()) for a, b in zip(cur, ref)]
                     nz = [int(((a - b) != 0).sum()) for a, b in zip(cur, ref)]
                     print(prec, mode, crop, "run", i, "differs: max", d, "count", nz)
+# whole models through the generic fused MLP kernels (register engine), the warp and the standalone compositing
+from nerf_atlas_amd import refl, sdf as nsdf
+from nerf_atlas_amd.utils import load_mip
+import types
+rays = cam.sample_positions((380, 390, 40, 40), size=800)
+times = torch.tensor([0.5], device="cuda")
+for prec in ("bf16x3", "bf16"):
+    config.set_precision(prec)
+    canon = nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    models = {
+        "dnerf": (nerf.DynamicNeRF(canonical=canon, spline=6), lambda m: m((rays, times))),
+        "tiny": (nerf.TinyNeRF(steps=128, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted"), lambda m: m(rays)),
+        "volsdf": (nerf.VolSDF(sdf=nsdf.SDF(nsdf.MLP(intermediate_size=64), refl.View(latent_size=64, act="upshifted", out_features=3),
+                                            t_near=2.0, t_far=6.0), steps=128, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted"),
+                   lambda m: m(rays)),
+        "mip": (nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted",
+                               mip=load_mip(types.SimpleNamespace(mip="cone"))), lambda m: m(rays)),
+    }
+    with torch.no_grad():
+        for name, (m, run) in models.items():
+            m = m.cuda().eval()
+            if name == "dnerf":
+                torch.nn.init.normal_(m.delta_estim.out.weight, std=0.05)
+            ref = None
+            for i in range(n):
+                torch.empty(1 + (i * 7919) % 100000, device="cuda")
+                out = run(m).clone()
+                if ref is None:
+                    ref = out
+                elif not torch.equal(out, ref):
+                    bad += 1
+                    print(prec, name, "run", i, "differs: max", float((out - ref).abs().max()), "count", int((out != ref).sum()))
 print(f"{bad} nondeterministic runs")
 sys.exit(1 if bad else 0)
