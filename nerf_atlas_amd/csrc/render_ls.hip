@@ -38,6 +38,9 @@
 #ifndef NA_LS_TRACE
 #define NA_LS_TRACE 0
 #endif
+#ifndef NA_LS_LAG_OVERRIDE
+#define NA_LS_LAG_OVERRIDE 0  // experiments: -DNA_LS_LAG_OVERRIDE=n (odd)
+#endif
 namespace na {
 
 namespace ls {
@@ -635,7 +638,16 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   f32x16 oc[1];
   float density = 0.f;
   int prev = -1;
-  if (g == 1) __syncthreads();  // group 1 runs one phase behind group 0
+  // Group 1 runs ONE phase behind group 0.  (A larger odd lag would put the ~9 k-cycle EP of either group opposite a full
+  // hidden-layer MFMA phase of the other instead of its 1-k / 2.4-k-cycle view.out / first.init: a slot model over the traced
+  // phase lengths predicts -3 % (bf16, lag 9) / -6 % (bf16x3, lag 7).  Measured with -DNA_LS_LAG_OVERRIDE: no gain (957 vs
+  // 947 Msamples/s at lag 1 vs 3), and lags 3 and 9 make the output irreproducible run to run -- tools/ls_determinism.py --
+  // although the groups share nothing but the workgroup barrier; not understood, not used.)
+  constexpr int LAG = NA_LS_LAG_OVERRIDE > 0 ? NA_LS_LAG_OVERRIDE : 1;
+  if (g == 1) {
+#pragma unroll 1
+    for (int i = 0; i < LAG; ++i) __syncthreads();
+  }
 
   for (int pass = 0; pass < a.npg; ++pass) {
     int cur = 0;
@@ -813,7 +825,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   }
   __syncthreads();
   if (prev >= 0) combine(prev);
-  if (g == 0) __syncthreads();  // group 0 takes its extra barrier at the end
+  if (g == 0) {  // group 0 takes its extra barriers at the end
+#pragma unroll 1
+    for (int i = 0; i < LAG; ++i) __syncthreads();
+  }
 }
 
 // ================================================================================================ pack
