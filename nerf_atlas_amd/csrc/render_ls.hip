@@ -47,15 +47,15 @@ namespace ls {
 
 constexpr int kPF = 4;       // weight prefetch depth, in fragment pairs
 constexpr int kNPhase = 12;  // MFMA phases per pass
-// fragment pairs a wave consumes per phase: first.init, first.L0 (3 skip + 16), L1..L3, first.out (16 x 3 tiles / 2),
-// view.init (4 latent + geometry), view.L0 (5 skip + 16), L1..L3, view.out (16 / 2)
+// fragment pairs a wave consumes per phase: first.init, first.L0 (3 skip + 16), L1..L3, first.out (ONE 32-row tile per
+// row group: 16 fragments), view.init (4 latent + geometry), view.L0 (5 skip + 16), L1..L3, view.out (16 / 2)
 __host__ __device__ constexpr int phase_pairs(int p) {
-  return p == 0 ? 3 : p == 1 ? 19 : p == 5 ? 24 : p == 6 ? 5 : p == 7 ? 21 : p == 11 ? 8 : 16;
+  return p == 0 ? 3 : p == 1 ? 19 : p == 5 ? 8 : p == 6 ? 5 : p == 7 ? 21 : p == 11 ? 8 : 16;
 }
-constexpr int kPairsPerPass = 176;
+constexpr int kPairsPerPass = 160;
 constexpr int kHeaderBytes = 1024;
 constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB blocks: floats [slot][hi(2)][16]
-constexpr uint32_t kMagic = 0x4C533031u;        // "LS01"
+constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"
 constexpr int kPartialFloats = 8;
 
 template <int PREC>
@@ -266,6 +266,43 @@ __device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2
   }
   __builtin_amdgcn_s_setprio(0);
   cur += NT * 8;
+}
+
+// ---- MFMA phase of `first.out` (65 rows = 3 tiles), ROW-major like the hidden layers: row group rg computes tile
+// min(rg, 2) for all NBLK blocks of its sample group (16 chunks x NBLK MFMAs, one A fragment feeds NBLK MFMAs; row group 3
+// repeats tile 2 to keep the four weight rings in step, its result is dropped).  Block-per-wave (every wave streaming all
+// three tiles for its own block: 48 KiB of fragments) was bound by weight delivery: 3.9 k cycles for 1.5 k of MFMA work in
+// bf16, 7.2 k for 4.6 k in bf16x3, where two of the four waves did redundant work on top.
+template <int PREC, int RING0, bool WRAP>
+__device__ __forceinline__ void m_out_rows(f32x16 (&o)[Cfg<PREC>::NBLK], Frag<PREC> (&ring)[kPF][2], int& cur,
+                                           __amdgpu_buffer_rsrc_t rs, int wvoff, const char* hb, int lane) {
+  constexpr int NB = Cfg<PREC>::NBLK, FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
+  __builtin_amdgcn_s_setprio(1);
+  Frag<PREC> Bq[2][NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) Bq[0][b] = fread<PREC>(hb + (b * 16) * FR + lane * 16);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int p = c >> 1, t = c & 1;
+    const Frag<PREC> A = ring[(RING0 + p) % kPF][t];
+    if (c + 1 < 16) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) Bq[(c + 1) & 1][b] = fread<PREC>(hb + (b * 16 + c + 1) * FR + lane * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mma<PREC>(o[b], A, Bq[c & 1][b]);
+    if (t == 1) {
+      int nx = cur + p + kPF;
+      if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
+      ring[(RING0 + p) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
+      ring[(RING0 + p) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  cur += 8;
 }
 
 // ---- epilogue of a 256-row Linear: act(acc) -> the group's hidden fragments in LDS (in place)
@@ -742,31 +779,37 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       m_hidden<PREC, 2, 0, 0, 16, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
       SYNC();
     }
-    f32x16 o3[3];
+    f32x16 oq[NB];  // first.out: this row group's tile (0, 1: latent rows 0..63; 2: density row 64) for the NB blocks
     {
+      const f32x16 bo = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? rg : 2, lane);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) o3[j] = bias_tile(wrs, bias_rg + 5 * 1024, j, lane);
+      for (int b = 0; b < NB; ++b) oq[b] = bo;
       store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
     }
     SYNC();
     // first.out: rows 0..63 = intermediate (-> View latent), row 64 = density
-    m_out<PREC, 2, 3, false>(o3, ring, cur, wrs, wvoff, hb, lane, blk);
+    m_out_rows<PREC, 2, false>(oq, ring, cur, wrs, wvoff, hb, lane);
     SYNC();
     {
       f32x16 bv[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 6 * 1024, t, lane);
       geo_setup(pass);  // ray / elev / azim of the group's blocks -> SGPRs, for the two View phases that follow
-      if (owner) {
-        density = o3[2][0];  // row 64 lives in register 0 of the hi=0 lanes
-        char* dst = ib + blk * 4 * FR + lane * 16;
+      if (rg < 2) {
+        // latent rows 32 rg .. 32 rg + 31 -> init chunks 2 rg, 2 rg + 1 of every block (the View MLP's B fragments)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int b = 0; b < NB; ++b) {
           Frag<PREC> f0, f1;
-          acc_to_frags<PREC, NA_ACT_NONE>(o3[j], f0, f1);
-          fwrite<PREC>(dst + (2 * j) * FR, f0);
-          fwrite<PREC>(dst + (2 * j + 1) * FR, f1);
+          acc_to_frags<PREC, NA_ACT_NONE>(oq[b], f0, f1);
+          char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
+          fwrite<PREC>(dst, f0);
+          fwrite<PREC>(dst + FR, f1);
         }
+      } else if (rg == 2 && hi == 0) {
+        // density (row 64 = register 0 of the hi = 0 lanes) of block b's 32 samples -> the idle hidden region; block b's
+        // owner picks it up after the barrier (it composites the block one pass later)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[b][0];
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -774,6 +817,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
     }
     SYNC();
+    if (owner) density = ((const float*)hb)[blk * 32 + ln];
     // ================= View MLP (sin)
     m_hidden<PREC, 2, 4, 1, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);
     SYNC();
@@ -880,9 +924,8 @@ __global__ void pack_ls_kernel(PackArgs w, int planes, char* __restrict__ dst) {
       const int NIc = view ? 5 : 3;     // init chunks
       const int dim_p = d.in_size + d.enc_dims + d.latent_size;
       int row, col, in_dim, out_dim;
-      if (lp == 5) {  // out layer: fragment f = c*NT + j
-        const int NT = view ? 1 : 3;
-        const int c = f / NT, j = f % NT;
+      if (lp == 5) {  // out layers.  view.out: fragment f = chunk c (one tile); first.out: row group rg holds tile min(rg, 2)
+        const int c = f, j = view ? 0 : (rg < 2 ? rg : 2);
         row = out_row_map(d, 32 * j + (l & 31));
         col = 16 * c + pi_perm(kappa);
         in_dim = kHidden; out_dim = d.out_size;
