@@ -718,8 +718,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       hash_finish(0, hg);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(3);
+      // bf16x3: levels 2,3 of this lane half are gathered by the partner row group rg + 2 (below), which owns no block
+      constexpr int KEND = NB == 4 ? 4 : 2;
 #pragma unroll
-      for (int k = 1; k < 4; ++k) {
+      for (int k = 1; k < KEND; ++k) {
         hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
         hash_finish(k, hg);
         __builtin_amdgcn_sched_barrier(0);
@@ -731,6 +733,18 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; v2[3] = q.px; v2[4] = q.py; v2[5] = q.pz; }
       fwrite<PREC>(ib + blk * 4 * FR + lane * 16 + 2 * FR, make_frag<PREC>(v2));
       STAMP(7);
+    } else {
+      // bf16x3, row groups 2 and 3: half of the hash encoder of block rg - 2 (levels 2,3 of each lane half), so that the
+      // exposed phase is two gather rounds long instead of four
+      own_setup(pass);
+      const Geom q = geom(pass, blk);
+      HashGather hg;
+#pragma unroll
+      for (int k = 2; k < 4; ++k) {
+        hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
+        hash_finish(k, hg);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     {
       f32x16 bv[2];

@@ -78,7 +78,13 @@ def run(prec="bf16"):
         st = [int(v) for v in ep[g][:8]]
         if st[0]:
             names = ["geom + issue level 0", "composite(prev)", "finish level 0", "level 1", "level 2", "level 3", "pos chunk"]
-            print(f"   EP of group {g}: " + ", ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(names)) + f" (total {st[7] - st[0]})")
+            # (bf16x3: levels 2,3 are gathered by the helper row groups; their stamps are not written)
+            last, parts = st[0], []
+            for i, n in enumerate(names):
+                if st[i + 1]:
+                    parts.append(f"{n} {st[i + 1] - last}")
+                    last = st[i + 1]
+            print(f"   EP of group {g}: " + ", ".join(parts) + f" (total {st[7] - st[0]})")
     for g in range(2):
         t = [int(v) for v in raw[g][:48]]
         if t[0] == 0:
