@@ -525,7 +525,19 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     float px, py, pz, dist, dx, dy, dz;
   };
   // geometry of this lane's sample of the wave's own block of the CURRENT pass (own_setup(pass) has run)
-  auto geom = [&](int pass, int b) {
+  // ts[t] and ts[t + 1] of this lane's step of block `blk` of pass pl: requested first thing in EP, before the scalar loads
+  // of the ray (whose wait would otherwise sit in front of them)
+  struct TsPair { float t0, t1; };
+  auto ts_load = [&](int pl) {
+    const Loc L = locate(pl, blk);
+    const int t = L.tb * 32 + ln;
+    const int tc = t < a.T ? t : a.T - 1;
+    TsPair r;
+    r.t0 = a.ts[tc];
+    r.t1 = a.ts[tc < a.T - 1 ? tc + 1 : tc];
+    return r;
+  };
+  auto geom = [&](int pass, int b, const TsPair& tp) {
     Geom q;
     const Loc L = locate(pass, b);
     q.item_ok = L.ok;
@@ -536,20 +548,20 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     const int tc = q.t_ok ? q.t : a.T - 1;
     const float (&u)[6] = own_u;
     q.dx = u[3]; q.dy = u[4]; q.dz = u[5];
-    const float tt = a.ts[tc];
+    const float tt = tp.t0;
     if (a.pts != nullptr) {
       const float* p = a.pts + ((int64_t)tc * a.R + q.ray) * 3;
       q.px = p[0]; q.py = p[1]; q.pz = p[2];
     } else {
       q.px = u[0] + tt * q.dx; q.py = u[1] + tt * q.dy; q.pz = u[2] + tt * q.dz;
     }
-    const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+    const float d = tc < a.T - 1 ? fmaxf(tp.t1 - tt, 1e-5f) : 1e10f;
     q.dist = d * own_dn;
     return q;
   };
   // what the compositing of block `blk` of the PREVIOUS pass needs: issued at the top of EP next to the loads above
   struct Prev { int64_t ray; int t; bool ok, t_ok; float dist; };
-  auto prev_geom = [&](int pl) {
+  auto prev_geom = [&](int pl, const TsPair& tp) {
     Prev q;
     const Loc L = locate(pl, blk);
     q.ok = L.ok;
@@ -557,8 +569,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     q.t = L.tb * 32 + ln;
     q.t_ok = q.t < a.T;
     const int tc = q.t_ok ? q.t : a.T - 1;
-    const float tt = a.ts[tc];
-    const float d = tc < a.T - 1 ? fmaxf(a.ts[tc + 1] - tt, 1e-5f) : 1e10f;
+    const float tt = tp.t0;
+    const float d = tc < a.T - 1 ? fmaxf(tp.t1 - tt, 1e-5f) : 1e10f;
     q.dist = d * prev_dn;
     return q;
   };
@@ -700,10 +712,13 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     STAMP(0);
     if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
       prev_dn = own_dn;
+      const TsPair tcur = ts_load(pass);
+      TsPair tprev = tcur;
+      if (prev >= 0) tprev = ts_load(prev);
       own_setup(pass);
-      const Geom q = geom(pass, blk);
+      const Geom q = geom(pass, blk, tcur);
       Prev qp;
-      if (prev >= 0) qp = prev_geom(prev);
+      if (prev >= 0) qp = prev_geom(prev, tprev);
       // one level (8 gathers, 32 registers) at a time, the first with the compositing of the previous pass in its shadow.
       // Two levels in flight were no faster (the gathers are bound by their issue rate, ~90 cycles each) and made the
       // kernel's output irreproducible run to run (tools/ls_determinism.py: 16 samples of one ray off by ~1e-5 in a third
@@ -736,8 +751,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     } else {
       // bf16x3, row groups 2 and 3: half of the hash encoder of block rg - 2 (levels 2,3 of each lane half), so that the
       // exposed phase is two gather rounds long instead of four
+      const TsPair tcur = ts_load(pass);
       own_setup(pass);
-      const Geom q = geom(pass, blk);
+      const Geom q = geom(pass, blk, tcur);
       HashGather hg;
 #pragma unroll
       for (int k = 2; k < 4; ++k) {
@@ -879,7 +895,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   }
   if (prev >= 0 && (NB == 4 || owner)) {
     prev_dn = own_dn;
-    composite(prev_geom(prev), oc[0], density);
+    composite(prev_geom(prev, ts_load(prev)), oc[0], density);
   }
   __syncthreads();
   if (prev >= 0) combine(prev);
