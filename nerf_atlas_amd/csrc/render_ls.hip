@@ -715,10 +715,13 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const TsPair tcur = ts_load(pass);
       TsPair tprev = tcur;
       if (prev >= 0) tprev = ts_load(prev);
+      STAMP(8);
       own_setup(pass);
+      STAMP(9);
       const Geom q = geom(pass, blk, tcur);
       Prev qp;
       if (prev >= 0) qp = prev_geom(prev, tprev);
+      STAMP(10);
       // one level (8 gathers, 32 registers) at a time, the first with the compositing of the previous pass in its shadow.
       // Two levels in flight were no faster (the gathers are bound by their issue rate, ~90 cycles each) and made the
       // kernel's output irreproducible run to run (tools/ls_determinism.py: 16 samples of one ray off by ~1e-5 in a third

@@ -85,6 +85,10 @@ def run(prec="bf16"):
                     parts.append(f"{n} {st[i + 1] - last}")
                     last = st[i + 1]
             print(f"   EP of group {g}: " + ", ".join(parts) + f" (total {st[7] - st[0]})")
+            fine = [int(v) for v in ep[g][8:11]]
+            if all(fine):
+                print(f"      within the first piece: locate + ts loads issued {fine[0] - st[0]}, scalar ray loads {fine[1] - fine[0]}, "
+                      f"positions (waits for ts) {fine[2] - fine[1]}, hash indices + 8 gathers issued {st[1] - fine[2]}")
     for g in range(2):
         t = [int(v) for v in raw[g][:48]]
         if t[0] == 0:
