@@ -134,3 +134,33 @@ def test_ls_matches_register_engine_and_bands(ops):
         band = ops.raygen(c2w, focal, size, (316, 200, 16, 200))
         c, _, _ = ops.render_plain_view_ls(band, ts, tables, packed, prec, "upshifted", "black")
         assert torch.equal(c, a[:, 16:32]), prec
+
+
+@pytest.mark.parametrize("T", [72, 160])
+def test_ls_rays_straddle_passes_in_both_precisions(ops, T):
+    """nb = ceil(T/32) = 3 or 5 blocks per ray against 4 (bf16) / 2 (bf16x3) blocks per pass: the blocks of a ray are
+    spread over consecutive passes and share passes with the next ray of the group, so the in-kernel transmittance carry
+    (reset at a ray's first block, colour stored after its last) is exercised off its aligned case; the last block is
+    ragged (T % 32 = 8 / 0).  Both precisions against the register engine (out, alpha, weights) and the partition of unity;
+    bf16x3 also against the CPU oracle."""
+    from test_gpu_render import pack_plain
+    h = load_golden("g11_plain_view_b1")
+    p = golden_params(h)
+    size = 800
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]).cuda()
+    ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+    rays = ops.raygen(c2w, focal, size, (380, 390, 37, 41))  # 1517 rays: not a multiple of the 512 sample groups
+    for prec, tol in (("bf16x3", 2e-5), ("bf16", 2e-2)):
+        packed, tables = pack_ls(ops, p, prec)
+        a, aa, aw = ops.render_plain_view_ls(rays, ts, tables, packed, prec, "upshifted", "white", want_weights=True)
+        pf, pv, _ = pack_plain(ops, p, prec)
+        b, ba, bw = ops.render_plain_view(rays, ts, tables, pf, pv, prec, "upshifted", "white", want_weights=True)
+        assert float((a - b).abs().max()) <= tol, prec
+        assert float((aa - ba).abs().max()) <= tol and float((aw - bw).abs().max()) <= tol, prec
+        assert float((aw.sum(0) - 1).abs().max()) <= 1e-5, prec
+        if prec == "bf16x3":
+            aux = {}
+            ref = O.plain_nerf(p, rays.cpu(), 2.0, 6.0, T, "view", act="upshifted", bg="white", aux=aux)
+            assert float((a.cpu() - ref).abs().max()) <= 1e-4
+            assert float((aw.cpu() - aux["weights"]).abs().max()) <= 1e-4
