@@ -335,27 +335,7 @@ __device__ __forceinline__ void activate_init(char* ib, int blk, int lane) {
   }
 }
 
-// ---- compositing arithmetic on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each).  The
-// libm calls they replace made the compositing of a block the longest piece of the exposed EP phase (~5 k cycles).
-// exp(x): x log2(e) with the product's rounding error recovered by an fma (2e-7 relative for |x| <= 88)
-__device__ __forceinline__ float fast_exp(float x) {
-  x = fminf(x, 88.f);
-  const float t = x * 1.4426950408889634f;
-  const float r = fmaf(x, 1.4426950408889634f, -t) + x * 1.925963033500235e-8f;
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.6931471805599453f, e);
-}
-__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-v)); }
-// log1p(exp(v)) with the RELATIVE accuracy the 1e10-long last interval needs (src/nerf.py:60-68: sigma * 1e10): series
-// below 2^-6, log(u) * e / (u - 1) above (u = fl(1 + e); the quotient undoes the rounding of the sum)
-__device__ __forceinline__ float fast_softplus(float v) {
-  if (v > 20.f) return v;
-  const float e = fast_exp(v);
-  const float series = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.33333334f), -0.5f), 1.0f);
-  const float u = 1.0f + e;
-  const float lg = __builtin_amdgcn_logf(u) * 0.6931471805599453f * (e * __builtin_amdgcn_rcpf(u - 1.0f));
-  return e < 0.015625f ? series : lg;
-}
+// ---- compositing arithmetic: fast_exp / fast_sigmoid / fast_softplus live in common.h (hardware transcendentals).
 __device__ __forceinline__ float fast_sigmoid_kind(float v, int kind) {
   switch (kind) {  // the sigmoid family on the fast path, everything else as in apply_sigmoid_kind
     case NA_SIG_NORMAL: return fast_sigmoid(v);
