@@ -110,7 +110,8 @@ int na_sigmoid(const float* x, int64_t N, int kind, float* out, void* stream);
 
 /* A6 mip integrated positional encoding, intended layout: rays [B*H*W,6] of an
  * H x W crop (radii_x differences rows), ts [T]; kind 0 = cylinder, 1 = cone; t_end = upper
- * bound of the last interval; out [T, B*H*W, 6*(max_deg-min_deg)].                            */
+ * bound of the last interval (NaN: the kernel uses 2 ts[T-1] - ts[T-2], the intended closing, so
+ * the host need not read ts back); out [T, B*H*W, 6*(max_deg-min_deg)].                      */
 int na_mip_encode(const float* rays, int B, int H, int W, const float* ts, int T, int kind,
                   float t_end, int min_deg, int max_deg, float* out, void* stream);
 
@@ -195,7 +196,7 @@ typedef struct NaMipDesc {
   int32_t B, H, W, T;
   int32_t kind;        /* 0 cylinder, 1 cone                                                      */
   int32_t min_deg, max_deg;
-  float t_end;         /* closes the last interval (see na_mip_encode)                            */
+  float t_end;         /* closes the last interval (see na_mip_encode); NaN = 2 ts[T-1] - ts[T-2] */
 } NaMipDesc;
 int na_mlp_forward_mip(const NaMlpDesc* desc, int precision, const void* packed, const float* p, int64_t p_ld,
                        const float* latent, int64_t latent_ld, const float* enc_params, const NaMipDesc* mip, int64_t N,

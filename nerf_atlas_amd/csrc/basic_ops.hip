@@ -293,7 +293,7 @@ __global__ void mip_kernel(const float* __restrict__ rays, int B, int H, int W, 
     int hq = (int)((r / W) % H);
     int b = (int)(r / ((int64_t)W * H));
     const float rad = mip_radius(rays, H, W, b, hq, wq);
-    const float t0 = ts[t], t1 = t < T - 1 ? ts[t + 1] : t_end;
+    const float t0 = ts[t], t1 = t < T - 1 ? ts[t + 1] : mip_last_edge(ts, T, t_end);
     const MipGauss gs = mip_gaussian(rays + r * 6, rad, t0, t1, kind);
     float v[VEC];
 #pragma unroll

@@ -145,6 +145,14 @@ __device__ __forceinline__ MipGauss mip_gaussian(const float* ry, float rad, flo
   return g;
 }
 
+// upper edge of the last sample interval: the caller's t_end, or -- t_end = NaN -- the intended closing 2 ts[T-1] - ts[T-2]
+// (ts[T-1] + 1 for a single step) evaluated here in fp32 exactly like torch evaluates `2 * ts[-1] - ts[-2]`, so that the
+// host does not have to read ts back (a device synchronisation per forward)
+__device__ __forceinline__ float mip_last_edge(const float* ts, int T, float t_end) {
+  if (t_end == t_end) return t_end;
+  return T > 1 ? 2.0f * ts[T - 1] - ts[T - 2] : ts[T - 1] + 1.0f;
+}
+
 // pixel radius of ray (b, hq, wq) of a [B,H,W,6] crop (src/utils.py:77-81: difference of neighbouring rows' directions;
 // the appended last row repeats the second-to-last difference)
 __device__ __forceinline__ float mip_radius(const float* rays, int H, int W, int b, int hq, int wq) {

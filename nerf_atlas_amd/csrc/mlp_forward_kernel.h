@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
         const int64_t r = n - (int64_t)t * R;
         const int wq = (int)(r % m.W), hq = (int)((r / m.W) % m.H), b = (int)(r / ((int64_t)m.W * m.H));
         const float rad = mip_radius(m.rays, m.H, m.W, b, hq, wq);
-        const MipGauss gs = mip_gaussian(m.rays + r * 6, rad, m.ts[t], t < m.T - 1 ? m.ts[t + 1] : m.t_end, m.kind);
+        const MipGauss gs = mip_gaussian(m.rays + r * 6, rad, m.ts[t], t < m.T - 1 ? m.ts[t + 1] : mip_last_edge(m.ts, m.T, m.t_end), m.kind);
         gm0 = gs.m0; gm1 = gs.m1; gm2 = gs.m2; gc0 = gs.c0; gc1 = gs.c1; gc2 = gs.c2;
       }
       const int npos = ENC == NA_ENC_HASH ? 6 : d.in_size;  // leading position slots (hash: p then x, both = p)

@@ -88,8 +88,9 @@ class _Mip:
         return self.lazy(rays, ts).tensor()
 
     def lazy(self, rays, ts) -> MipLatent:
-        t_end = float(2 * ts[-1] - ts[-2]) if ts.shape[0] > 1 else float(ts[-1]) + 1.0
-        return MipLatent(rays.contiguous(), ts, self.kind, t_end, self.min_deg, self.max_deg)
+        # t_end = NaN: the kernels close the last interval at 2 ts[-1] - ts[-2] themselves (reading it here would be a
+        # device synchronisation per forward)
+        return MipLatent(rays.contiguous(), ts, self.kind, float("nan"), self.min_deg, self.max_deg)
 
 
 def CylinderGaussian(min_deg=0, max_deg=16):
