@@ -399,7 +399,17 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   // each as its nb 32-step blocks in step order, NB blocks per pass.  At any moment the launch works on ~nG consecutive
   // rays (hash-table locality in L2 as before), and the blocks of one ray pass through one group in order, so the
   // transmittance is carried from block to block inside the kernel (no per-block partials, no second launch).
-  const int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 2 + g);
+  // XCD-aware order: hardware workgroup w runs on XCD w % 8 (round-robin dispatch, each XCD has its own L2), so logical
+  // workgroup lw = (w % 8) * (n / 8) + w / 8 puts CONSECUTIVE sample groups -- neighbouring rays, the same hash-table
+  // lines and weight fragments -- on one XCD instead of on all eight: HBM traffic per launch 173 -> 93 MB (bf16),
+  // 210 -> 150 MB (bf16x3) at equal speed (profiles/r02).  Grids that are not a multiple of 8 keep the identity.
+#ifndef NA_LS_NO_XCD_MAP
+  const int nwg = (int)gridDim.x;
+  const int lw = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+#else
+  const int lw = (int)blockIdx.x;
+#endif
+  const int G = __builtin_amdgcn_readfirstlane(lw * 2 + g);
   struct Loc { int ray, tb; bool ok; };
   auto locate = [&](int pl, int b) {
     const int sidx = pl * NB + b;
@@ -684,8 +694,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     ton = pass == 1;
 #endif
     // ================= EP: compositing of the previous pass, hash encoder of this one
-    // The 4 x 8 table gathers of this lane half go out one level at a time (35 live registers), the first with the
-    // compositing of the previous pass in its shadow.  They are TA-bound (64 distinct 128-B lines per instruction, 8 MiB of tables): ~10k
+    // The 4 x 8 table gathers of this lane half go out one level at a time (35 live registers), after the compositing of
+    // the previous pass.  They are TA-bound (64 distinct 128-B lines per instruction, 8 MiB of tables): ~10k
     // cycles per group and pass whether issued as four rounds, two or one (measured); spreading the levels over the
     // epilogues of the other layers was slower still (every gathering wave stalls ~3k cycles per round and those
     // epilogues have ~1.8k cycles of slack).
@@ -702,24 +712,22 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       Prev qp;
       if (prev >= 0) qp = prev_geom(prev, tprev);
       STAMP(10);
-      // one level (8 gathers, 32 registers) at a time, the first with the compositing of the previous pass in its shadow.
-      // Two levels in flight were no faster (the gathers are bound by their issue rate, ~90 cycles each) and made the
-      // kernel's output irreproducible run to run (tools/ls_determinism.py: 16 samples of one ray off by ~1e-5 in a third
-      // of the runs; cause not found in the ISA -- the waits are in order and conservative -- so the variant is not used).
-      HashGather hg;
-      hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + 0], 4 * hi + 0, hg);
-      __builtin_amdgcn_sched_barrier(0);
-      STAMP(1);
+      // The compositing of the previous pass FIRST, then one level (8 gathers, 32 registers) at a time.  (Until r02 the
+      // level-0 gathers were issued before the compositing and combined after it.  That variant is not reproducible run
+      // to run under changed timing -- lag 3, XCD-aware order, two levels in flight: the level-4 feature of lanes 48..63
+      // of ONE block comes out different although every gathered corner and the lerp weights dumped from the same
+      // registers are identical; not a missing wait (forcing vmcnt(0) + 24 wait states in front of the combine, or in
+      // front of the compositing, changes nothing), not the alpha / weight stores.  With the compositing out of the
+      // gather's shadow -- or with -fno-slp-vectorize -- 0 events in 400 stress runs against 10^3..10^4; the speed is
+      // the same within noise, the exposed phase is hidden behind the other group.  DESIGN 3b, "reproducibility".)
       if (prev >= 0) composite(qp, oc[0], density);
       __builtin_amdgcn_sched_barrier(0);
-      STAMP(2);
-      hash_finish(0, hg);
-      __builtin_amdgcn_sched_barrier(0);
-      STAMP(3);
+      STAMP(1);
       // bf16x3: levels 2,3 of this lane half are gathered by the partner row group rg + 2 (below), which owns no block
       constexpr int KEND = NB == 4 ? 4 : 2;
+      HashGather hg;
 #pragma unroll
-      for (int k = 1; k < KEND; ++k) {
+      for (int k = 0; k < KEND; ++k) {
         hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
         hash_finish(k, hg);
         __builtin_amdgcn_sched_barrier(0);

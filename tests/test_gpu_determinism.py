@@ -17,3 +17,11 @@ def test_repeated_calls_are_bit_identical():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 nondeterministic runs" in r.stdout
+
+
+def test_full_grid_slab_is_reproducible_over_many_runs():
+    """The slab that fills all 256 workgroups, 150 runs per precision, every output element against the per-element
+    median (tools/ls_repeat.py; DESIGN 3b "reproducibility": before the fix a few hundred elements per ~20..1000 runs)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "ls_repeat.py"), "150"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "\n0 irreproducible runs" in r.stdout

@@ -77,7 +77,7 @@ def run(prec="bf16"):
     for g in range(2):
         st = [int(v) for v in ep[g][:8]]
         if st[0]:
-            names = ["geom + issue level 0", "composite(prev)", "finish level 0", "level 1", "level 2", "level 3", "pos chunk"]
+            names = ["geom + composite(prev)", "", "level 0", "level 1", "level 2", "level 3", "pos chunk"]
             # (bf16x3: levels 2,3 are gathered by the helper row groups; their stamps are not written)
             last, parts = st[0], []
             for i, n in enumerate(names):
@@ -88,7 +88,7 @@ def run(prec="bf16"):
             fine = [int(v) for v in ep[g][8:11]]
             if all(fine):
                 print(f"      within the first piece: locate + ts loads issued {fine[0] - st[0]}, scalar ray loads {fine[1] - fine[0]}, "
-                      f"positions (waits for ts) {fine[2] - fine[1]}, hash indices + 8 gathers issued {st[1] - fine[2]}")
+                      f"positions (waits for ts) {fine[2] - fine[1]}, compositing of the previous pass {st[1] - fine[2]}")
     for g in range(2):
         t = [int(v) for v in raw[g][:48]]
         if t[0] == 0:
