@@ -12,8 +12,9 @@ Synthetic data: camera c2w=[I|(0,0,4)], fov 0.6911, near 2, far 6; random-init w
 architecture (default nn.Linear init / siren init / N(0,1) hash tables, seed 2).
 
 Prints ONE JSON line (rank 0).  `value` is Msamples/s over all ranks with everything already in HBM.  The line carries
-both precision modes on the same frame and `--steps` (the primary one in the top-level fields, the other under
-`other_precision`), each with its own roofline object and its L-inf against the CPU oracle on the CPU-baseline tile.
+the precision modes on the same frame and `--steps` (the primary one in the top-level fields, BASELINE's named bf16
+under `other_precision`, the layer-synchronous engine's f16-operand mode under `f16_precision`), each with its own
+roofline object and its L-inf against the CPU oracle on the CPU-baseline tile.
 """
 import argparse
 import json
@@ -41,7 +42,8 @@ try:
             HBM_TRAFFIC_FULL_FRAME[tuple(_k.split("/"))] = int(_v)
 except (OSError, ValueError):
     pass
-DTYPE_NAME = {"bf16": "bf16", "bf16x3": "bf16x3 (2-way split bf16, 3 MFMA products, fp32 accumulate)"}
+DTYPE_NAME = {"bf16": "bf16", "bf16x3": "bf16x3 (2-way split bf16, 3 MFMA products, fp32 accumulate)",
+              "f16": "f16 (IEEE half operands, 1 MFMA product, fp32 accumulate)"}
 
 
 def build_model(device, seed=2):
@@ -99,7 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     # primary = the mode that meets north_star's 1e-4 L-inf bar (split bf16, fp32-class); plain bf16 (BASELINE's named
     # dtype, ~3e-3 L-inf) is timed on the same frame and reported under `other_precision`
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3", "f16"])
     ap.add_argument("--engine", default=None, choices=["ls", "reg"], help="fused renderer engine (default: config.engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -197,6 +199,10 @@ def main():
     dt, kern_ms, gath_ms, per_rank, frame = timed(prec, args.steps, args.warmup)
     other = "bf16x3" if prec == "bf16" else "bf16"
     dt2, kern2_ms, _, _, _ = timed(other, args.steps, 1)
+    # third line: the f16-operand mode of the layer-synchronous engine (the fast mode's speed class, 11-bit operands)
+    third = "f16" if (engine == "ls" and "f16" not in (prec, other)) else None
+    if third is not None:
+        dt3, kern3_ms, _, _, _ = timed(third, args.steps, 1)
 
     if rank == 0:
         samples = SIZE * SIZE * STEPS_PER_RAY
@@ -218,6 +224,10 @@ def main():
         res["other_precision"] = {"precision": other, "dtype": DTYPE_NAME[other], "value": round(samples * args.steps / dt2 / 1e6, 2),
                                   "unit": "Msamples/s", "steps": args.steps, "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                                   "roofline": roofline(other, kern2_ms)}
+        if third is not None:
+            res["f16_precision"] = {"precision": third, "dtype": DTYPE_NAME[third], "value": round(samples * args.steps / dt3 / 1e6, 2),
+                                    "unit": "Msamples/s", "steps": args.steps, "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                                    "roofline": roofline(third, kern3_ms)}
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, rays_cpu = cpu_baseline(model)
             res["cpu_baseline"] = cb
@@ -225,6 +235,8 @@ def main():
             rd = rays_cpu.to(dev)
             res["parity_sample_linf_vs_cpu_oracle"] = float((renderer(prec)(rd).cpu() - ref).abs().max())
             res["other_precision"]["linf_vs_cpu_oracle"] = float((renderer(other)(rd).cpu() - ref).abs().max())
+            if third is not None:
+                res["f16_precision"]["linf_vs_cpu_oracle"] = float((renderer(third)(rd).cpu() - ref).abs().max())
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -35,6 +35,7 @@ UNITS = [
     # is the same.
     ("render_ls.hip", ["-DNA_PREC_INST=0", "-fno-slp-vectorize"], "_bf16"),
     ("render_ls.hip", ["-DNA_PREC_INST=1", "-fno-slp-vectorize"], "_bf16x3"),
+    ("render_ls.hip", ["-DNA_PREC_INST=2", "-fno-slp-vectorize"], "_f16"),
 ]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("NA_EXTRA_HIPCC_FLAGS", "").split()
 

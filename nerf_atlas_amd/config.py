@@ -1,13 +1,15 @@
 """Process-wide knobs of the HIP path."""
 
 # MLP arithmetic: "bf16x3" = 2-way split bf16 with 3 MFMA products (fp32-class accuracy, meets the
-# 1e-4 RGB parity bound); "bf16" = plain bf16 operands with fp32 accumulation (fast mode).
+# 1e-4 RGB parity bound); "bf16" = plain bf16 operands with fp32 accumulation (fast mode); "f16" = IEEE half operands
+# with fp32 accumulation: the fast mode's speed with 11-bit instead of 8-bit operands (L-inf 3e-4 instead of 3e-3 on the
+# bench frame) -- implemented by the layer-synchronous fused renderer only, every other kernel rejects it.
 precision = "bf16x3"
 
 
 def set_precision(p: str):
     global precision
-    if p not in ("bf16", "bf16x3"):
+    if p not in ("bf16", "bf16x3", "f16"):
         raise ValueError(p)
     precision = p
 

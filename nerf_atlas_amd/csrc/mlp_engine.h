@@ -80,17 +80,30 @@ __device__ __forceinline__ float act_apply(float v) {
   // leaky_relu(v) = max(v, 0.01 v) = median(v, 0.01 v, +big): v_med3_f32 needs no canonicalising v_max
   if constexpr ((NA_ABLATE & 2) != 0) return v;
   if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, 3.0e38f);
-  else if constexpr (ACT == NA_ACT_SIN) return PREC == NA_PREC_BF16 ? sin_hw(v) : sin_hw2(v);
+  else if constexpr (ACT == NA_ACT_SIN) return PREC == NA_PREC_BF16X3 ? sin_hw2(v) : sin_hw(v);
   else return v;
 }
 
 // ------------------------------------------------------------------------------------------------ fragments
+// One 16-bit operand element.  NA_PREC_F16 keeps IEEE half values in the same 16-byte containers (bit patterns in
+// bf16x8); only these two conversions, the element pair packing of the epilogue and the MFMA builtin differ.
+template <int PREC>
+__device__ __forceinline__ __bf16 to_elem(float v) {
+  if constexpr (PREC == NA_PREC_F16) return __builtin_bit_cast(__bf16, (_Float16)v);
+  else return (__bf16)v;
+}
+template <int PREC>
+__device__ __forceinline__ float from_elem(__bf16 h) {
+  if constexpr (PREC == NA_PREC_F16) return (float)__builtin_bit_cast(_Float16, h);
+  else return (float)h;
+}
+
 template <int PREC>
 __device__ __forceinline__ Frag<PREC> make_frag(const float (&v)[8]) {
   Frag<PREC> f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    __bf16 h = (__bf16)v[e];
+    __bf16 h = to_elem<PREC>(v[e]);
     f.hi[e] = h;
     if constexpr (PREC == NA_PREC_BF16X3) f.lo[e] = (__bf16)(v[e] - (float)h);
   }
@@ -99,7 +112,7 @@ __device__ __forceinline__ Frag<PREC> make_frag(const float (&v)[8]) {
 
 template <int PREC>
 __device__ __forceinline__ float frag_value(const Frag<PREC>& f, int e) {
-  float v = (float)f.hi[e];
+  float v = from_elem<PREC>(f.hi[e]);
   if constexpr (PREC == NA_PREC_BF16X3) v = v + (float)f.lo[e];
   return v;
 }
@@ -268,10 +281,11 @@ template <int PREC> constexpr int stage_depth() { return PREC == NA_PREC_BF16 ? 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+template <int PREC = NA_PREC_BF16>
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   bf16x2 v;
-  v[0] = (__bf16)a;
-  v[1] = (__bf16)b;
+  v[0] = to_elem<PREC>(a);
+  v[1] = to_elem<PREC>(b);
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
@@ -290,7 +304,7 @@ struct Epilogue {
     const int b = u >> 3, d = u & 7;
     const float x = act_apply<ACT, PREC>(acc[b][2 * d]);
     const float y = act_apply<ACT, PREC>(acc[b][2 * d + 1]);
-    hi[b][d] = pack_bf16x2(x, y);
+    hi[b][d] = pack_bf16x2<PREC>(x, y);
     // the volatile asm orders this dword with the surrounding scheduling fences, i.e. keeps its VALU work
     // between the two MFMAs it was written between (pure VALU would otherwise sink to the end of the tile)
     asm volatile("" : "+v"(hi[b][d]));

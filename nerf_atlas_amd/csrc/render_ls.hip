@@ -25,13 +25,13 @@
 //    order: the transmittance is carried across blocks (and passes) inside the group -- block partials meet in the
 //    group's idle hidden region of LDS -- so there are no per-block partials in HBM and no finalize launch.
 //
-// Compiled once per precision (-DNA_PREC_INST=0|1).
+// Compiled once per precision (-DNA_PREC_INST=0|1|2).
 #include <atomic>
 #include "mlp_layout.h"
 #include "encoders.h"
 
 #ifndef NA_PREC_INST
-#error "compile with -DNA_PREC_INST=0 (bf16) or 1 (bf16x3)"
+#error "compile with -DNA_PREC_INST=0 (bf16), 1 (bf16x3) or 2 (f16)"
 #endif
 // NA_LS_TRACE: waves 0 and 4 of workgroup 0 stamp s_memtime before and after every barrier of their second pass
 // (tools/ls_trace.py).  Timing experiments only.
@@ -129,7 +129,12 @@ __device__ __forceinline__ void mma(f32x16& acc, const Frag<PREC>& A, const Frag
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc, 0, 0, 0);
   }
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
+  if constexpr (PREC == NA_PREC_F16) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.hi), __builtin_bit_cast(f16x8, B.hi), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
+  }
 }
 
 // floats [slot][hi(2)][16] of one phase's bias block -> accumulator init of tile `slot`.  Buffer loads with the
@@ -660,8 +665,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     bf16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      h[e] = (__bf16)f[e];
-      l[e] = (__bf16)(f[e] - (float)h[e]);
+      h[e] = to_elem<PREC>(f[e]);
+      l[e] = (__bf16)(f[e] - (float)h[e]);  // (bf16x3 only)
     }
     char* dst = ib + (blk * 4 + (k >> 1)) * FR + lane * 16 + (k & 1) * 8;
     *(bf16x4*)dst = h;
@@ -922,7 +927,7 @@ __host__ __device__ inline int phase_first_frag(int p) {
 }
 
 // One thread per bf16 element of the hi plane of every fragment, plus the bias blocks.
-__global__ void pack_ls_kernel(PackArgs w, int planes, char* __restrict__ dst) {
+__global__ void pack_ls_kernel(PackArgs w, int planes, int f16, char* __restrict__ dst) {
   const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
   const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
   const int frag_bytes = 1024 * planes;
@@ -967,7 +972,7 @@ __global__ void pack_ls_kernel(PackArgs w, int planes, char* __restrict__ dst) {
       float v = 0.f;
       if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
       char* o = dst + kHeaderBytes + kBiasBytes + ((int64_t)rg * nfrag_rg + (fg % nfrag_rg)) * frag_bytes + l * 16 + e * 2;
-      const __bf16 h = (__bf16)v;
+      const __bf16 h = f16 ? to_elem<NA_PREC_F16>(v) : (__bf16)v;
       *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
       if (planes == 2) {
         const __bf16 lo = (__bf16)(v - (float)h);
@@ -1029,11 +1034,14 @@ static int launch(Args& a, hipStream_t stream) {
 
 #if NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_BF16>(a, s); }
-#else
+#elif NA_PREC_INST == 1
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_BF16X3>(a, s); }
+#else
+int render_ls_dispatch_f16(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_F16>(a, s); }
 #endif
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s);
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s);
+int render_ls_dispatch_f16(ls::Args& a, hipStream_t s);
 
 }  // namespace na
 
@@ -1041,15 +1049,15 @@ int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s);
 using namespace na;
 
 extern "C" size_t na_render_ls_packed_bytes(int precision) {
-  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3) return 0;
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
   return ls::packed_bytes(precision);
 }
 
 extern "C" int na_render_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
                                  const float* const* w_view, const float* const* b_view, void* packed, void* stream) {
   NA_REQUIRE(w_first && b_first && w_view && b_view && packed, NA_ENULL, "na_render_ls_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_render_ls_pack: precision %d",
-             precision);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_ls_pack: precision %d", precision);
   ls::PackArgs w;
   for (int i = 0; i < 6; ++i) {
     NA_REQUIRE(w_first[i] && w_view[i], NA_ENULL, "na_render_ls_pack: weights[%d] is null", i);
@@ -1061,7 +1069,7 @@ extern "C" int na_render_ls_pack(int precision, const float* const* w_first, con
                      (uint32_t*)packed);
   const int64_t total = 4 * 2 * (int64_t)ls::kPairsPerPass * 512 + 4 * ls::kNPhase * 256;
   hipLaunchKernelGGL(ls::pack_ls_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, planes,
-                     (char*)packed);
+                     precision == NA_PREC_F16 ? 1 : 0, (char*)packed);
   return check_launch("na_render_ls_pack");
 }
 
@@ -1079,7 +1087,7 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;  // empty batch: a no-op before any pointer check (zero-size tensors carry null pointers)
   NA_REQUIRE(rays && ts && hash_tables && packed && out && workspace, NA_ENULL, "na_render_plain_view_ls: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
              "na_render_plain_view_ls: precision %d", precision);
   NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_plain_view_ls: sigmoid %d",
              sigmoid_kind);
@@ -1098,7 +1106,8 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   a.sigmoid_kind = sigmoid_kind;
   a.res = hash_resolutions();
   a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
-  return precision == NA_PREC_BF16 ? render_ls_dispatch_bf16(a, (hipStream_t)stream)
-                                   : render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
+  if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream);
+  if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream);
+  return render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
 }
 #endif

@@ -48,6 +48,13 @@ def test_ls_render_vs_reference_golden(ops, B):
     mse = float(((fast - out) ** 2).mean())
     assert -10 * math.log10(max(mse, 1e-20)) >= 40.0
     assert float((fast - out).abs().max()) <= 2e-2
+    # f16 operands: the same speed class with 11-bit operands (5e-4 on these weights, 3e-4 on the bench's)
+    packed, tables = pack_ls(ops, p, "f16")
+    half, ha, hw = ops.render_plain_view_ls(h["rays"].cuda(), ts, tables, packed, "f16", "upshifted", str(h["bg"]), want_weights=True)
+    assert float((half - out).abs().max()) <= 2e-3 and float((ha - alpha).abs().max()) <= 2e-3
+    assert float((half - out).abs().max()) <= 0.34 * float((fast - out).abs().max())
+    assert -10 * math.log10(max(float(((half - out) ** 2).mean()), 1e-20)) >= 58.0
+    assert float((hw.sum(0) - 1).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize("T", [128, 192])
@@ -74,6 +81,9 @@ def test_ls_render_tile_800_geometry(ops, T):
     packed16, _ = pack_ls(ops, p, "bf16")
     fast, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed16, "bf16", "upshifted", "black")
     assert float((fast - out).abs().max()) <= 2e-2
+    packedh, _ = pack_ls(ops, p, "f16")
+    half, _, _ = ops.render_plain_view_ls(rays, ts, tables, packedh, "f16", "upshifted", "black")
+    assert float((half.cpu() - ref).abs().max()) <= 2e-3
 
 
 def test_ls_render_ragged_steps_white_bg_and_errors(ops):
@@ -164,3 +174,18 @@ def test_ls_rays_straddle_passes_in_both_precisions(ops, T):
             ref = O.plain_nerf(p, rays.cpu(), 2.0, 6.0, T, "view", act="upshifted", bg="white", aux=aux)
             assert float((a.cpu() - ref).abs().max()) <= 1e-4
             assert float((aw.cpu() - aux["weights"]).abs().max()) <= 1e-4
+            # f16 (layer-synchronous engine only: 4 blocks per pass like bf16) against the parity outputs
+            packed, tables = pack_ls(ops, p, "f16")
+            c, ca, cw = ops.render_plain_view_ls(rays, ts, tables, packed, "f16", "upshifted", "white", want_weights=True)
+            assert float((c - a).abs().max()) <= 2e-3 and float((ca - aa).abs().max()) <= 2e-3
+            assert float((cw - aw).abs().max()) <= 2e-3 and float((cw.sum(0) - 1).abs().max()) <= 1e-5
+
+
+def test_f16_is_rejected_outside_the_ls_renderer(ops):
+    """NA_PREC_F16 exists for na_render_ls_pack / na_render_plain_view_ls only: the generic packers and the register
+    engine fail loudly instead of running another precision."""
+    from test_gpu_render import pack_plain
+    h = load_golden("g11_plain_view_b1")
+    p = golden_params(h)
+    with pytest.raises(Exception, match="precision"):
+        pack_plain(ops, p, "f16")

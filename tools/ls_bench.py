@@ -29,12 +29,16 @@ def main(rounds=3):
         pl = model.packed_ls(prec)
         runs[("reg", prec)] = lambda pf=pf, pv=pv, prec=prec: ops.render_plain_view(rays, ts, tables, pf, pv, prec, "upshifted", "black")
         runs[("ls", prec)] = lambda pl=pl, prec=prec: ops.render_plain_view_ls(rays, ts, tables, pl, prec, "upshifted", "black")
+    plh = model.packed_ls("f16")  # f16 operands: layer-synchronous engine only
+    runs[("ls", "f16")] = lambda: ops.render_plain_view_ls(rays, ts, tables, plh, "f16", "upshifted", "black")
     outs = {}
     for k, f in runs.items():
         outs[k] = f()[0]
     torch.cuda.synchronize()
     for prec in ("bf16", "bf16x3"):
         print(f"{prec}: max |ls - reg| = {float((outs[('ls', prec)] - outs[('reg', prec)]).abs().max()):.3e}")
+    for prec in ("bf16", "f16"):
+        print(f"{prec}: max |ls {prec} - ls bf16x3| = {float((outs[('ls', prec)] - outs[('ls', 'bf16x3')]).abs().max()):.3e}")
     res = {k: [] for k in runs}
     for _ in range(rounds):
         for k, f in runs.items():
