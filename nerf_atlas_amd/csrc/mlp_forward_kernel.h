@@ -174,10 +174,22 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
       mlp_out_tile<PREC, 1>(ws, H, lane, accs);
       const f32x16 acc = accs[0];
       if (n_raw < a.N) {
+        // registers 4q..4q+3 of a lane are 4 CONSECUTIVE output features of its sample (acc_row): one 16-byte store per
+        // q instead of four 4-byte stores one row pitch apart across the lanes (rows are only 4-byte aligned when
+        // out_size is odd, e.g. VolSDF's 257: dword-aligned vector stores)
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        float* yrow = a.y + n_raw * a.d.out_size;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int f = 32 * j + acc_row(r, lane);
-          if (f < a.d.out_size) a.y[n_raw * a.d.out_size + f] = acc[r];
+        for (int q = 0; q < 4; ++q) {
+          const int f0 = 32 * j + acc_row(4 * q, lane);
+          if (f0 + 4 <= a.d.out_size) {
+            const f32x4u v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4u*)(yrow + f0) = v;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (f0 + i < a.d.out_size) yrow[f0 + i] = acc[4 * q + i];
+          }
         }
       }
     }
