@@ -68,6 +68,29 @@ def test_plain_nerf(na, kind, B):
     assert m.nerf is m and m.intermediate_size == 64 and m.total_latent_size() == 0
 
 
+def test_plain_nerf_f16_mode_and_its_scope(na):
+    """config.set_precision("f16"): the fused PlainNeRF(view) renderer runs with IEEE-half operands (fast-mode speed, ~7x
+    less error than bf16); models whose kernels have no f16 instantiation fail loudly instead of switching precision."""
+    h = load_golden("g11_plain_view_b1")
+    m = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=float(h["near"]), t_far=float(h["far"]), intermediate_size=64,
+                          sigmoid_kind="upshifted", bg=str(h["bg"])).cuda().eval()
+    load_params(m, golden_params(h))
+    rays = h["rays"].cuda()
+    from nerf_atlas_amd import config
+    try:
+        config.set_precision("bf16")
+        e_bf16 = maxdiff(m(rays), h["out"])
+        config.set_precision("f16")
+        out = m(rays)
+        assert maxdiff(out, h["out"]) <= 2e-3 and maxdiff(out, h["out"]) <= 0.34 * e_bf16
+        assert maxdiff(m.weights, h["weights"]) <= 2e-3
+        tiny = na.nerf.TinyNeRF(steps=8, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted").cuda().eval()
+        with pytest.raises(Exception, match="f16"):
+            tiny(rays)
+    finally:
+        config.set_precision("bf16x3")
+
+
 def test_plain_nerf_unfused_path_equals_fused(na):
     h = load_golden("g11_plain_view_b1")
     m = na.nerf.PlainNeRF(steps=16, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").cuda().eval()
