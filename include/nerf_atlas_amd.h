@@ -337,6 +337,18 @@ int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, cons
                             float* alpha, float* weights, float* out, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* TinyNeRF (/root/reference/src/nerf.py:278-305 with the intended density = estim[..., 0]) on the same
+ * layer-synchronous engine, one kernel per call: sample -> SkipConnMLP(3 -> 6 x 256 -> 4, skip 3, LeakyReLU; src/
+ * neural_blocks.py:279-296) -> density | sigmoid_kind(colour) -> alpha compositing (src/nerf.py:22-27,60-80,96-98).
+ * na_render_tiny_ls_pack takes the 8 Linears {init, layers.0..5, out} (nn.Linear layout, fp32 device pointers, biases may
+ * be NULL).  Same ray / sample indexing, `pts`, alpha / weights outputs and precisions as na_render_plain_view_ls; no
+ * workspace.                                                                                                         */
+size_t na_render_tiny_ls_packed_bytes(int precision);
+int na_render_tiny_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream);
+int na_render_tiny_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const void* packed,
+                      int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
+                      void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SDF ray marching (src/march.py).  Per-ray state lives in caller-owned device arrays; the SDF network
  * is evaluated for ALL rays by na_mlp_forward between the updates (no mask compaction, no host sync) and the updates

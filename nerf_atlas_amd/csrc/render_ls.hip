@@ -53,6 +53,12 @@ __host__ __device__ constexpr int phase_pairs(int p) {
   return p == 0 ? 3 : p == 1 ? 19 : p == 5 ? 8 : p == 6 ? 5 : p == 7 ? 21 : p == 11 ? 8 : 16;
 }
 constexpr int kPairsPerPass = 160;
+// TinyNeRF (src/nerf.py:278-305: one SkipConnMLP 3 -> 256 x 6 -> 4, skip 3, no encoder) on the same engine, MODEL = 1: phases
+// init (x,y,z chunk + one zero chunk: 108 pairs per pass keep the 4-deep ring phase static), L0 (1 skip + 16), L1, L2,
+// L3 (1 skip + 16), L4, L5, out (16 / 2: one 32-row tile, block per wave)
+constexpr int kTinyPhases = 8;
+__host__ __device__ constexpr int tiny_phase_pairs(int p) { return p == 0 ? 2 : (p == 1 || p == 4) ? 17 : p == 7 ? 8 : 16; }
+constexpr int kTinyPairs = 108;
 constexpr int kHeaderBytes = 1024;
 constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB blocks: floats [slot][hi(2)][16]
 constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"
@@ -70,9 +76,9 @@ struct Cfg {
   static constexpr int STREAM = kPairsPerPass * PAIR;           // weight stream of one row group
 };
 
-inline size_t packed_bytes(int precision) {
+inline size_t packed_bytes(int precision, int pairs = kPairsPerPass) {
   const int pair = 2048 * (precision == NA_PREC_BF16X3 ? 2 : 1);
-  return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)kPairsPerPass * pair;
+  return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)pairs * pair;
 }
 
 struct Args {
@@ -152,7 +158,7 @@ __device__ __forceinline__ f32x16 bias_tile(__amdgpu_buffer_rsrc_t rs, int bias_
 
 // ---- MFMA phase of a 256-row Linear: K = [NI init chunks from LDS | NH hidden chunks from LDS | geometry chunk]
 // GEO: 0 none, 1 raw (view.init), 2 through the activation (skip layer).  geo(b) builds block b's fragment in registers.
-template <int PREC, int RING0, int NI, int GEO, int NH, bool WRAP, class GeoLoad, class GeoMake>
+template <int PREC, int RING0, int NI, int GEO, int NH, bool WRAP, int PPP = kPairsPerPass, class GeoLoad, class GeoMake>
 __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag<PREC> (&ring)[kPF][2], int& cur,
                                          __amdgpu_buffer_rsrc_t rs, int wvoff, const char* hb, const char* ib, int lane,
                                          GeoLoad geo_load, GeoMake geo_make) {
@@ -167,7 +173,7 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
   };
   auto refill = [&](int q) {
     int nx = cur + q + kPF;
-    if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
+    if (WRAP) nx = nx >= PPP ? nx - PPP : nx;
     ring[(RING0 + q) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
     ring[(RING0 + q) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
   };
@@ -243,7 +249,7 @@ __device__ __forceinline__ void m_hidden(f32x16 (&acc)[2][Cfg<PREC>::NBLK], Frag
 }
 
 // ---- MFMA phase of an out Linear, block-per-wave: NT 32-row tiles x 16 chunks for block `blk`; fragment f = c*NT + j
-template <int PREC, int RING0, int NT, bool WRAP>
+template <int PREC, int RING0, int NT, bool WRAP, int PPP = kPairsPerPass>
 __device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2], int& cur, __amdgpu_buffer_rsrc_t rs,
                                       int wvoff, const char* hb, int lane, int blk) {
   constexpr int FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
@@ -262,7 +268,7 @@ __device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2
       mma<PREC>(o[j], ring[(RING0 + p) % kPF][t], Bq[c & 1]);
       if (t == 1) {
         int nx = cur + p + kPF;
-        if (WRAP) nx = nx >= kPairsPerPass ? nx - kPairsPerPass : nx;
+        if (WRAP) nx = nx >= PPP ? nx - PPP : nx;
         ring[(RING0 + p) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
         ring[(RING0 + p) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
       }
@@ -371,11 +377,12 @@ __device__ __forceinline__ float scan32_add(float x) {
   return x;
 }
 
-template <int PREC>
+template <int PREC, int MODEL = 0>
 __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
+  constexpr int PPP = MODEL == 1 ? kTinyPairs : kPairsPerPass;  // fragment pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
   __builtin_amdgcn_s_dcache_inv();
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   const bool owner = rg < NB;           // this wave owns block rg of its group (encoder, out layers, compositing)
   const int blk = owner ? rg : rg - NB;  // non-owners (bf16x3: rg 2,3) shadow a block to keep their weight ring in step
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, a.packed_size, 0x00020000);
-  const int wvoff = kHeaderBytes + kBiasBytes + rg * C::STREAM + lane * 16;
+  const int wvoff = kHeaderBytes + kBiasBytes + rg * (PPP * C::PAIR) + lane * 16;
   const int bias_rg = kHeaderBytes + rg * (kNPhase * 1024);  // scalar offset of this row group's bias blocks
   // Fifth init chunk of the View MLP for block b of this group (x, y, z, elev, azim in the hi = 0 lanes; src/refl.py:
   // 190-207).  The ray of a block is wave-uniform: its origin, direction and elev/azim (from the pre-kernel) are read once
@@ -682,15 +689,23 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   f32x16 oc[1];
   float density = 0.f;
   int prev = -1;
-  // Group 1 runs ONE phase behind group 0.  (A larger odd lag would put the ~9 k-cycle EP of either group opposite a full
-  // hidden-layer MFMA phase of the other instead of its 1-k / 2.4-k-cycle view.out / first.init: a slot model over the traced
-  // phase lengths predicts -3 % (bf16, lag 9) / -6 % (bf16x3, lag 7).  Measured with -DNA_LS_LAG_OVERRIDE: no gain (957 vs
-  // 947 Msamples/s at lag 1 vs 3), and lags 3 and 9 make the output irreproducible run to run -- tools/ls_determinism.py --
-  // although the groups share nothing but the workgroup barrier; not understood, not used.)
+  // Group 1 runs ONE phase behind group 0.  (A larger odd lag would put the ~10 k-cycle EP of either group opposite a full
+  // hidden-layer MFMA phase of the other instead of its 1-k / 2.4-k-cycle view.out / first.init; measured with
+  // -DNA_LS_LAG_OVERRIDE = 3 ... 11: the frame time is the same to 0.2 %.)
   constexpr int LAG = NA_LS_LAG_OVERRIDE > 0 ? NA_LS_LAG_OVERRIDE : 1;
   if (g == 1) {
 #pragma unroll 1
     for (int i = 0; i < LAG; ++i) __syncthreads();
+  }
+
+  if constexpr (MODEL == 1) {
+    // the zero chunk behind (x, y, z): its weights are zero, its LDS words only have to be finite
+    if (owner) {
+      float z8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z8[e] = 0.f;
+      fwrite<PREC>(ib + (blk * 4 + 1) * FR + lane * 16, make_frag<PREC>(z8));
+    }
   }
 
   for (int pass = 0; pass < a.npg; ++pass) {
@@ -698,6 +713,84 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #if NA_LS_TRACE
     ton = pass == 1;
 #endif
+    if constexpr (MODEL == 1) {
+      // ================= TinyNeRF: EP = sample position of this pass + compositing of the previous one
+      auto none_l = [](int) { return 0; };
+      auto none_m = [](int, int, bool) { return 0; };
+      if (NB == 4 || owner) {
+        prev_dn = own_dn;
+        const TsPair tcur = ts_load(pass);
+        TsPair tprev = tcur;
+        if (prev >= 0) tprev = ts_load(prev);
+        own_setup(pass);
+        const Geom q = geom(pass, blk, tcur);
+        if (prev >= 0) {
+          // out tile of the previous pass: row 0 = density, rows 1..3 = colour (src/nerf.py:296-300, intended semantics)
+          f32x16 rgbv = oc[0];
+          rgbv[0] = oc[0][1]; rgbv[1] = oc[0][2]; rgbv[2] = oc[0][3];
+          composite(prev_geom(prev, tprev), rgbv, oc[0][0]);
+        }
+        float v2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v2[e] = 0.f;
+        if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; }
+        fwrite<PREC>(ib + blk * 4 * FR + lane * 16, make_frag<PREC>(v2));
+      }
+      {
+        f32x16 bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+        SYNC();
+        if (prev >= 0) combine(prev);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      }
+      m_hidden<PREC, 0, 2, 0, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // init
+      SYNC();
+      // six hidden layers; the input re-enters through the activation at layers 0 and 3 (src/neural_blocks.py:290-296)
+#define NA_TINY_EPILOGUE(PH, FIRST)                                                              \
+      {                                                                                            \
+        f32x16 bv[2];                                                                              \
+        store_acts<PREC, NA_ACT_LEAKY_RELU, 0, 1>(acc, hb, rg, lane);                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (PH) * 1024, t, lane); \
+        store_acts<PREC, NA_ACT_LEAKY_RELU, 1, 2>(acc, hb, rg, lane);                              \
+        if ((FIRST) && owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 1>(ib, blk, lane);            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                              \
+          _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];                        \
+      }                                                                                            \
+      SYNC();
+      NA_TINY_EPILOGUE(1, true)
+      m_hidden<PREC, 2, 1, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L0 (skip)
+      SYNC();
+      NA_TINY_EPILOGUE(2, false)
+      m_hidden<PREC, 3, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L1
+      SYNC();
+      NA_TINY_EPILOGUE(3, false)
+      m_hidden<PREC, 3, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L2
+      SYNC();
+      NA_TINY_EPILOGUE(4, false)
+      m_hidden<PREC, 3, 1, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L3 (skip)
+      SYNC();
+      NA_TINY_EPILOGUE(5, false)
+      m_hidden<PREC, 0, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L4
+      SYNC();
+      NA_TINY_EPILOGUE(6, false)
+      m_hidden<PREC, 0, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L5
+      SYNC();
+#undef NA_TINY_EPILOGUE
+      {
+        oc[0] = bias_tile(wrs, bias_rg + 7 * 1024, 0, lane);
+        store_acts<PREC, NA_ACT_LEAKY_RELU>(acc, hb, rg, lane);
+      }
+      SYNC();
+      m_out<PREC, 0, 1, true, PPP>(oc, ring, cur, wrs, wvoff, hb, lane, blk);
+      SYNC();
+      prev = pass;
+      continue;
+    }
     // ================= EP: compositing of the previous pass, hash encoder of this one
     // The 4 x 8 table gathers of this lane half go out one level at a time (35 live registers), after the compositing of
     // the previous pass.  They are TA-bound (64 distinct 128-B lines per instruction, 8 MiB of tables): ~10k
@@ -891,7 +984,13 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   }
   if (prev >= 0 && (NB == 4 || owner)) {
     prev_dn = own_dn;
-    composite(prev_geom(prev, ts_load(prev)), oc[0], density);
+    if constexpr (MODEL == 1) {
+      f32x16 rgbv = oc[0];
+      rgbv[0] = oc[0][1]; rgbv[1] = oc[0][2]; rgbv[2] = oc[0][3];
+      composite(prev_geom(prev, ts_load(prev)), rgbv, oc[0][0]);
+    } else {
+      composite(prev_geom(prev, ts_load(prev)), oc[0], density);
+    }
   }
   __syncthreads();
   if (prev >= 0) combine(prev);
@@ -999,17 +1098,82 @@ __global__ void pack_ls_kernel(PackArgs w, int planes, int f16, char* __restrict
   }
 }
 
-__global__ void pack_ls_header_kernel(uint32_t magic, uint32_t precision, uint32_t* __restrict__ dst) {
-  if (threadIdx.x == 0) { dst[0] = magic; dst[1] = precision; dst[2] = kPairsPerPass; dst[3] = kNPhase; }
+__global__ void pack_ls_header_kernel(uint32_t magic, uint32_t precision, uint32_t* __restrict__ dst, uint32_t pairs) {
+  if (threadIdx.x == 0) { dst[0] = magic; dst[1] = precision; dst[2] = pairs; dst[3] = kNPhase; }
+}
+
+// TinyNeRF stream (MODEL 1): same element order as pack_ls_kernel, phases per tiny_phase_pairs
+struct TinyPackArgs {
+  const float* w[8];  // init, layers.0..5, out   (nn.Linear layout [out,in])
+  const float* b[8];
+};
+__global__ void pack_ls_tiny_kernel(TinyPackArgs w, int planes, int f16, char* __restrict__ dst) {
+  const NaMlpDesc d = {3, NA_ENC_NONE, 0, 0, 6, 256, 4, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
+  const int frag_bytes = 1024 * planes;
+  const int64_t nfrag_rg = 2 * kTinyPairs;
+  const int64_t nelem = 4 * nfrag_rg * 512;
+  const int64_t nbias = 4 * kNPhase * 256;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nelem + nbias; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nelem) {
+      const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+      const int64_t fg = i >> 9;
+      const int rg = (int)(fg / nfrag_rg);
+      int f = (int)(fg % nfrag_rg);
+      int p = 0;
+      while (f >= 2 * tiny_phase_pairs(p)) { f -= 2 * tiny_phase_pairs(p); ++p; }
+      const int kappa = 8 * (l >> 5) + e;
+      const float* W = w.w[p];  // p: 0 init, 1..6 layers.0..5, 7 out
+      int row, col, in_dim, out_dim;
+      if (p == 7) {  // fragment f = chunk c of the single out tile
+        row = out_row_map(d, l & 31);
+        col = 16 * f + pi_perm(kappa);
+        in_dim = kHidden; out_dim = d.out_size;
+      } else {
+        const int q = f >> 1, t = f & 1;
+        row = 32 * (2 * rg + t) + (l & 31);
+        out_dim = kHidden;
+        if (p == 0) { col = q == 0 ? init_slot_feature(d, 0, kappa) : -1; in_dim = d.in_size; }
+        else if (p == 1 || p == 4) {  // [hidden | init] in the reference's column order, init chunk first in the stream
+          if (q == 0) { col = init_slot_feature(d, 0, kappa); if (col >= 0) col += kHidden; }
+          else col = 16 * (q - 1) + pi_perm(kappa);
+          in_dim = kHidden + d.in_size;
+        } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
+      }
+      float v = 0.f;
+      if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + ((int64_t)rg * nfrag_rg + (fg % nfrag_rg)) * frag_bytes + l * 16 + e * 2;
+      const __bf16 h = f16 ? to_elem<NA_PREC_F16>(v) : (__bf16)v;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
+      if (planes == 2) {
+        const __bf16 lo = (__bf16)(v - (float)h);
+        *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
+      }
+    } else {
+      const int64_t q = i - nelem;
+      const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
+      const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
+      const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v = 0.f;
+      if (p < kTinyPhases && w.b[p] != nullptr) {
+        if (p == 7) {
+          const int row = slot < 1 ? out_row_map(d, rin) : -1;
+          if (row >= 0 && row < d.out_size) v = w.b[p][row];
+        } else if (slot < 2) {
+          v = w.b[p][32 * (2 * rg + slot) + rin];
+        }
+      }
+      *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
+    }
+  }
 }
 
 #endif  // NA_PREC_INST == 0
 
 // per-device hipFuncSetAttribute bookkeeping (the attribute is per device, not per thread)
-template <int PREC>
+template <int PREC, int MODEL = 0>
 static int launch(Args& a, hipStream_t stream) {
   using C = Cfg<PREC>;
-  auto kern = render_ls_kernel<PREC>;
+  auto kern = render_ls_kernel<PREC, MODEL>;
   static std::atomic<uint64_t> attr_done{0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return NA_EHIP; }
@@ -1033,15 +1197,21 @@ static int launch(Args& a, hipStream_t stream) {
 }  // namespace ls
 
 #if NA_PREC_INST == 0
-int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_BF16>(a, s); }
+int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
+  return model == 1 ? ls::launch<NA_PREC_BF16, 1>(a, s) : ls::launch<NA_PREC_BF16>(a, s);
+}
 #elif NA_PREC_INST == 1
-int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_BF16X3>(a, s); }
+int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model) {
+  return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
+}
 #else
-int render_ls_dispatch_f16(ls::Args& a, hipStream_t s) { return ls::launch<NA_PREC_F16>(a, s); }
+int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
+  return model == 1 ? ls::launch<NA_PREC_F16, 1>(a, s) : ls::launch<NA_PREC_F16>(a, s);
+}
 #endif
-int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s);
-int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s);
-int render_ls_dispatch_f16(ls::Args& a, hipStream_t s);
+int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model);
+int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model);
+int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model);
 
 }  // namespace na
 
@@ -1066,7 +1236,7 @@ extern "C" int na_render_ls_pack(int precision, const float* const* w_first, con
   }
   const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
   hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
-                     (uint32_t*)packed);
+                     (uint32_t*)packed, (uint32_t)ls::kPairsPerPass);
   const int64_t total = 4 * 2 * (int64_t)ls::kPairsPerPass * 512 + 4 * ls::kNPhase * 256;
   hipLaunchKernelGGL(ls::pack_ls_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, planes,
                      precision == NA_PREC_F16 ? 1 : 0, (char*)packed);
@@ -1106,8 +1276,56 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   a.sigmoid_kind = sigmoid_kind;
   a.res = hash_resolutions();
   a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
-  if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream);
-  if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream);
-  return render_ls_dispatch_bf16x3(a, (hipStream_t)stream);
+  if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 0);
+  if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 0);
+  return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 0);
+}
+
+// ---- TinyNeRF on the same engine (src/nerf.py:278-305)
+extern "C" size_t na_render_tiny_ls_packed_bytes(int precision) {
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  return ls::packed_bytes(precision, ls::kTinyPairs);
+}
+
+extern "C" int na_render_tiny_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream) {
+  NA_REQUIRE(w && b && packed, NA_ENULL, "na_render_tiny_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_tiny_ls_pack: precision %d", precision);
+  ls::TinyPackArgs pa;
+  for (int i = 0; i < 8; ++i) {
+    NA_REQUIRE(w[i], NA_ENULL, "na_render_tiny_ls_pack: weights[%d] is null", i);
+    pa.w[i] = w[i]; pa.b[i] = b[i];
+  }
+  const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
+  hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
+                     (uint32_t*)packed, (uint32_t)ls::kTinyPairs);
+  const int64_t total = 4 * 2 * (int64_t)ls::kTinyPairs * 512 + 4 * ls::kNPhase * 256;
+  hipLaunchKernelGGL(ls::pack_ls_tiny_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, pa, planes,
+                     precision == NA_PREC_F16 ? 1 : 0, (char*)packed);
+  return check_launch("na_render_tiny_ls_pack");
+}
+
+extern "C" int na_render_tiny_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const void* packed,
+                                 int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
+                                 void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_tiny_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && packed && out, NA_ENULL, "na_render_tiny_ls: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_tiny_ls: precision %d", precision);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_tiny_ls: sigmoid %d", sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_tiny_ls: bg %d", bg_kind);
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = nullptr;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision, ls::kTinyPairs);
+  a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.elaz = nullptr;
+  a.sigmoid_kind = sigmoid_kind;
+  a.res = hash_resolutions();
+  a.trace = nullptr;
+  if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 1);
+  if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 1);
+  return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 1);
 }
 #endif

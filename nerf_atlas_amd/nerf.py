@@ -136,7 +136,29 @@ class TinyNeRF(CommonNeRF):
         self.estim = SkipConnMLP(in_size=3, out=1 + out_features, latent_size=self.total_latent_size(), num_layers=6,
                                  hidden_size=256, init="xavier")
 
-    def forward(self, rays):
+    def _fusable(self):
+        """one-kernel inference on the layer-synchronous engine (csrc/render_ls.hip, MODEL 1)"""
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return (config.engine == "ls" and self.mip is None and self.total_latent_size() == 0
+                and self.estim.out.out_features == 4 and not self.training and not wants_grad)
+
+    def packed_ls(self, precision: str):
+        """Weight stream of the layer-synchronous renderer (cached, re-packed when any parameter changed)."""
+        lin = self.estim._linears()
+        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        cache = self.__dict__.setdefault("_packed_ls", {})
+        hit = cache.get(precision)
+        if hit is None or hit[0] != stamp:
+            cache[precision] = (stamp, ops.render_tiny_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
+        return cache[precision][1]
+
+    def forward(self, rays, want_weights: bool = True):
+        if self._fusable():
+            _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
+            prec = config.precision
+            out, self.alpha, self.weights = ops.render_tiny_ls(rays, self.ts, self.packed_ls(prec), prec, self.sigmoid_kind,
+                                                                self.bg, want_weights)
+            return out
         pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb())
         return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
 

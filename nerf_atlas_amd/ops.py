@@ -665,6 +665,44 @@ def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torc
     return out, alpha, weights
 
 
+def render_tiny_ls_pack(precision: str, weights, biases) -> torch.Tensor:
+    """Pack TinyNeRF.estim ({init, layers.0..5, out}) into the weight stream of the layer-synchronous renderer."""
+    lib = _lib.load()
+    assert len(weights) == 8 and len(biases) == 8, "TinyNeRF.estim has 6 hidden layers"
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [None if b is None else _f32(b.detach(), "bias") for b in biases]
+    shapes = [(256, 3), (256, 259), (256, 256), (256, 256), (256, 259), (256, 256), (256, 256), (4, 256)]
+    for w, shp in zip(ws, shapes):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS TinyNeRF renderer: weight shape {tuple(w.shape)} != {shp}")
+    wp = (C.c_void_p * 8)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * 8)(*[0 if b is None else b.data_ptr() for b in bs])
+    packed = torch.empty(int(lib.na_render_tiny_ls_packed_bytes(PREC[precision])), device=ws[0].device, dtype=torch.uint8)
+    check(lib.na_render_tiny_ls_pack(PREC[precision], wp, bp, _ptr(packed), _stream()))
+    return packed
+
+
+def render_tiny_ls(rays: torch.Tensor, ts: torch.Tensor, packed: torch.Tensor, precision: str, sigmoid_kind: str = "thin",
+                   bg: str = "black", want_weights: bool = False, pts: Optional[torch.Tensor] = None):
+    """TinyNeRF forward in one kernel (layer-synchronous engine): rays [..., 6], ts [T] -> (rgb [..., 3], alpha, weights)."""
+    lib = _lib.load()
+    rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3, (pts.shape, T, R)
+    check(lib.na_render_tiny_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(packed), PREC[precision], SIGMOID[sigmoid_kind],
+                                BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _stream()))
+    return out, alpha, weights
+
+
 # ------------------------------------------------------------------------------------------------- forward-mode tangents
 def act_deriv(x: torch.Tensor, act: str, order: int = 1) -> torch.Tensor:
     lib = _lib.load()

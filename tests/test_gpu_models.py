@@ -84,9 +84,10 @@ def test_plain_nerf_f16_mode_and_its_scope(na):
         out = m(rays)
         assert maxdiff(out, h["out"]) <= 2e-3 and maxdiff(out, h["out"]) <= 0.34 * e_bf16
         assert maxdiff(m.weights, h["weights"]) <= 2e-3
-        tiny = na.nerf.TinyNeRF(steps=8, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted").cuda().eval()
+        from nerf_atlas_amd.neural_blocks import SkipConnMLP
+        generic = SkipConnMLP(in_size=3, out=4, num_layers=5, hidden_size=256).cuda().eval()
         with pytest.raises(Exception, match="f16"):
-            tiny(rays)
+            generic(rays[..., :3])
     finally:
         config.set_precision("bf16x3")
 
@@ -109,6 +110,36 @@ def test_tiny_nerf(na):
     load_params(m, golden_params(h))
     out = m(h["rays"].cuda())
     assert maxdiff(out, h["out"]) <= 1e-4 and maxdiff(m.weights, h["weights"]) <= 1e-4
+
+
+def test_tiny_nerf_fused_kernel_vs_operator_chain(na):
+    """TinyNeRF on the layer-synchronous engine (one kernel) against the chain generic fused MLP -> sigmoid -> composite
+    (engine "reg"), the golden of the reference's primitives and the partition of unity, in the three precisions; T = 72
+    straddles the 4-block (2-block) passes and ends in a ragged block; white background."""
+    import math
+    from nerf_atlas_amd import config
+    h = load_golden("g13_tiny")
+    cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]),
+                                focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
+    rays = cam.sample_positions((380, 390, 37, 41), size=800)
+    try:
+        for T, bg in ((int(h["steps"]), "black"), (72, "white"), (128, "black")):
+            m = na.nerf.TinyNeRF(steps=T, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted", bg=bg).cuda().eval()
+            load_params(m, golden_params(h))
+            config.set_precision("bf16x3")
+            config.set_engine("reg")
+            chain = m(rays)
+            cw, ca = m.weights.clone(), m.alpha.clone()
+            config.set_engine("ls")
+            for prec, tol in (("bf16x3", 2e-5), ("f16", 2e-3), ("bf16", 2e-2)):
+                config.set_precision(prec)
+                out = m(rays)
+                assert float((out - chain).abs().max()) <= tol, (T, prec)
+                assert float((m.weights - cw).abs().max()) <= tol and float((m.alpha - ca).abs().max()) <= tol, (T, prec)
+                assert float((m.weights.sum(0) - 1).abs().max()) <= 1e-5
+    finally:
+        config.set_precision("bf16x3")
+        config.set_engine("ls")
 
 
 @pytest.mark.parametrize("kind", ["mlp", "siren"])
