@@ -7,8 +7,8 @@ python bench.py --steps 5 --warmup 2 > $O/bench_default.json 2> $O/bench_default
 python bench.py --steps 5 --warmup 2 --engine reg --no-cpu-baseline > $O/bench_engine_reg.json 2> $O/bench_reg.err
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$O/bench_under_rocprof.json 2> $OLDPWD/$O/rocprof.err)
 find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bench.csv
-python tools/pmc_collect.py --kernel "render_ls_kernel<1>" --out $O/pmc_render_ls_bf16x3.json -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_x3.log 2>&1
-python tools/pmc_collect.py --kernel "render_ls_kernel<0>" --out $O/pmc_render_ls_bf16.json -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_bf16.log 2>&1
+python tools/pmc_collect.py --kernel "render_ls_kernel<1, 0>" --out $O/pmc_render_ls_bf16x3.json -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_x3.log 2>&1
+python tools/pmc_collect.py --kernel "render_ls_kernel<0, 0>" --out $O/pmc_render_ls_bf16.json -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_bf16.log 2>&1
 rm -rf $O/prof_bench
 ls -la $O
 cat $O/bench_default.json
