@@ -189,3 +189,46 @@ def test_f16_is_rejected_outside_the_ls_renderer(ops):
     p = golden_params(h)
     with pytest.raises(Exception, match="precision"):
         pack_plain(ops, p, "f16")
+
+
+def test_tiny_ls_edge_shapes_pts_mode_and_repeatability(ops):
+    """na_render_tiny_ls against the oracle on awkward shapes: a single ray, fewer rays than sample groups, T = 1 / 5 / 33 /
+    130 (one step, a ragged single block, one step into the second block, 5 blocks), explicit sample positions, no
+    alpha / weights outputs, the empty batch; and bit-identical results over repeated calls on a slab that fills the
+    grid."""
+    from conftest import load_golden, golden_params
+    h = load_golden("g13_tiny")
+    p = golden_params(h)
+    names = ["estim.init"] + [f"estim.layers.{i}" for i in range(6)] + ["estim.out"]
+    wb = ([p[n + ".weight"].cuda() for n in names], [p[n + ".bias"].cuda() for n in names])
+    packed = {prec: ops.render_tiny_ls_pack(prec, *wb) for prec in ("bf16x3", "f16", "bf16")}
+    size = 800
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]).cuda()
+    for crop, T in (((400, 400, 1, 1), 130), ((10, 20, 3, 5), 33), ((380, 390, 9, 7), 5), ((0, 0, 2, 2), 1), ((700, 100, 16, 40), 64)):
+        rays = ops.raygen(c2w, focal, size, crop)
+        ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+        aux = {}
+        ref = O.tiny_nerf(p, rays.cpu(), 2.0, 6.0, T, act="upshifted", bg="white", aux=aux)
+        out, alpha, weights = ops.render_tiny_ls(rays, ts, packed["bf16x3"], "bf16x3", "upshifted", "white", want_weights=True)
+        assert float((out.cpu() - ref).abs().max()) <= 1e-4, (crop, T)
+        assert float((alpha.cpu() - aux["alpha"]).abs().max()) <= 1e-4 and float((weights.cpu() - aux["weights"]).abs().max()) <= 1e-4
+        bare, a0, w0 = ops.render_tiny_ls(rays, ts, packed["bf16x3"], "bf16x3", "upshifted", "white")
+        assert a0 is None and w0 is None and torch.equal(bare, out)
+        # explicit positions = the same positions: same result up to the rounding of o + t d done on the host side here
+        pts = ops.compute_pts(rays, ts)
+        viap, _, _ = ops.render_tiny_ls(rays, ts, packed["bf16x3"], "bf16x3", "upshifted", "white", pts=pts)
+        assert float((viap - out).abs().max()) <= 1e-5
+        for prec, tol in (("f16", 3e-3), ("bf16", 3e-2)):
+            fast, _, _ = ops.render_tiny_ls(rays, ts, packed[prec], prec, "upshifted", "white")
+            assert float((fast - out).abs().max()) <= tol, (prec, crop, T)
+    empty, _, _ = ops.render_tiny_ls(rays[:0], ts, packed["bf16x3"], "bf16x3")
+    assert empty.shape == (0,) + tuple(rays.shape[1:-1]) + (3,)
+    slab = ops.raygen(c2w, focal, size, (300, 0, 24, 800))
+    ts, _ = ops.compute_ts(2.0, 6.0, 128, "cuda")
+    for prec in ("bf16x3", "f16", "bf16"):
+        first = [t.clone() for t in ops.render_tiny_ls(slab, ts, packed[prec], prec, "upshifted", "black", want_weights=True)]
+        for i in range(40):
+            torch.empty(1 + (i * 7919) % 100000, device="cuda")
+            again = ops.render_tiny_ls(slab, ts, packed[prec], prec, "upshifted", "black", want_weights=True)
+            assert all(torch.equal(x, y) for x, y in zip(first, again)), (prec, i)
