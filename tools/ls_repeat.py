@@ -4,7 +4,7 @@ sample groups, ~37 rays each): the same call N times, colour / alpha / weights c
 per-element median over the runs.  This is the test that exposed the timing-dependent differences of DESIGN 3b
 "reproducibility" (16 samples of one block, lanes 16..31, off by ~1e-3 relative in one run of ~20..10^4).
 
-    python tools/ls_repeat.py [bf16x3|bf16|f16] [N]
+    python tools/ls_repeat.py [bf16x3|bf16|f16] [--tiny] [N]
     python tools/ls_repeat.py variants        # here: timing-stress builds (group lag 3 / 5 / 9, no XCD-aware order) under
                                               # gpurun_ablate/repeat_<name>/; run each with  --lib <dir>
 """
@@ -41,7 +41,7 @@ def main(argv):
     import torch
     from nerf_atlas_amd import nerf, config, cameras, ops
     precs = [argv[0]] if argv and argv[0] in ("bf16", "bf16x3", "f16") else ["bf16x3", "bf16", "f16"]
-    n = int(argv[-1]) if argv and argv[-1].isdigit() else 200
+    n = int([x for x in argv if x.isdigit()][-1]) if any(x.isdigit() for x in argv) else 200
     torch.manual_seed(0)
     c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
     cam = cameras.NeRFCamera(cam_to_world=c2w, focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
@@ -49,14 +49,20 @@ def main(argv):
     R = rays.numel() // 6
     ts, _ = ops.compute_ts(2.0, 6.0, 128, "cuda")
     total_bad = 0
+    tiny = "--tiny" in argv  # the TinyNeRF schedule of the same engine
     for prec in precs:
         config.set_precision(prec)
-        m = nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").cuda().eval()
+        if tiny:
+            m = nerf.TinyNeRF(steps=128, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted").cuda().eval()
+            call = lambda: ops.render_tiny_ls(rays, ts, m.packed_ls(prec), prec, "upshifted", "black", True)
+        else:
+            m = nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").cuda().eval()
+            call = lambda: m._render_fused(rays, ts, True)
         with torch.no_grad():
             outs = []
             for i in range(n):
                 torch.empty(1 + (i * 7919) % 100000, device="cuda")  # perturb the allocator
-                outs.append([t.clone() for t in m._render_fused(rays, ts, True)])
+                outs.append([t.clone() for t in call()])
         bad_runs = set()
         for j, name in enumerate(("colour", "alpha", "weights")):
             x = torch.stack([o[j] for o in outs]).reshape(n, -1)
