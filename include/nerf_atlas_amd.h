@@ -327,7 +327,8 @@ int na_composite_backward(const float* density, const float* feat, const float* 
  * explicit sample positions (PlainNeRF.from_pts with deformed points, src/nerf.py:337-361).  A ray's 32-step blocks
  * pass through one sample group in step order, so the transmittance product of src/nerf.py:22-27 is carried inside the
  * kernel: `out`, `alpha`, `weights` are final when it returns (no second launch).  Workspace: 8 B per ray (elev / azim
- * of the ray, written by a pre-kernel and read with scalar loads).                                                  */
+ * of the ray, written by a pre-kernel and read with scalar loads).  The stream's header names its precision and
+ * schedule; a kernel handed a stream packed for anything else writes NaN colours instead of consuming it.          */
 size_t na_render_ls_packed_bytes(int precision);
 int na_render_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
                       const float* const* w_view, const float* const* b_view, void* packed, void* stream);

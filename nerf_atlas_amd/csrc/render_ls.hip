@@ -386,6 +386,16 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
   __builtin_amdgcn_s_dcache_inv();
+  {
+    // a stream packed for another precision or schedule (or not a stream at all) would be consumed without any fault:
+    // refuse it -- NaN colour for every ray -- instead of rendering garbage (header: na_render_*_ls_pack)
+    const uint32_t* hdr = (const uint32_t*)a.packed;
+    if (hdr[0] != kMagic || hdr[1] != (uint32_t)PREC || hdr[2] != (uint32_t)PPP) {
+      const float nan = __builtin_nanf("");
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.R * 3; i += (int64_t)gridDim.x * blockDim.x) a.out[i] = nan;
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rg = wv & 3, g = wv >> 2;

@@ -232,3 +232,25 @@ def test_tiny_ls_edge_shapes_pts_mode_and_repeatability(ops):
             torch.empty(1 + (i * 7919) % 100000, device="cuda")
             again = ops.render_tiny_ls(slab, ts, packed[prec], prec, "upshifted", "black", want_weights=True)
             assert all(torch.equal(x, y) for x, y in zip(first, again)), (prec, i)
+
+
+def test_ls_kernels_refuse_a_stream_packed_for_something_else(ops):
+    """The packed stream carries (magic, precision, pairs per pass) in its header; a kernel handed another precision's or
+    another schedule's stream returns NaN colours instead of consuming it."""
+    from conftest import load_golden, golden_params
+    h = load_golden("g11_plain_view_b1")
+    p = golden_params(h)
+    ts, _ = ops.compute_ts(2.0, 6.0, 16, "cuda")
+    rays = h["rays"].cuda()
+    packed_x3, tables = pack_ls(ops, p, "bf16x3")
+    packed_16, _ = pack_ls(ops, p, "bf16")
+    good, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed_x3, "bf16x3", "upshifted", "black")
+    assert torch.isfinite(good).all()
+    bad, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed_x3[: packed_16.numel()].clone(), "bf16", "upshifted", "black")
+    assert torch.isnan(bad).all()
+    t = load_golden("g13_tiny")
+    tp = golden_params(t)
+    names = ["estim.init"] + [f"estim.layers.{i}" for i in range(6)] + ["estim.out"]
+    tiny = ops.render_tiny_ls_pack("bf16", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])
+    assert torch.isfinite(ops.render_tiny_ls(rays, ts, tiny, "bf16", "upshifted", "black")[0]).all()
+    assert torch.isnan(ops.render_tiny_ls(rays, ts, packed_16, "bf16", "upshifted", "black")[0]).all()  # PlainNeRF stream
