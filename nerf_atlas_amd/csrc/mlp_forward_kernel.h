@@ -131,7 +131,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
         const MipGauss gs = mip_gaussian(m.rays + r * 6, rad, m.ts[t], t < m.T - 1 ? m.ts[t + 1] : mip_last_edge(m.ts, m.T, m.t_end), m.kind);
         gm0 = gs.m0; gm1 = gs.m1; gm2 = gs.m2; gc0 = gs.c0; gc1 = gs.c1; gc2 = gs.c2;
       }
-      const int npos = ENC == NA_ENC_HASH ? 6 : d.in_size;  // leading position slots (hash: p then x, both = p)
+      // leading position slots (hash: p then x, both = p).  The IPE-prologue instantiation without an encoder is the View
+      // head (x, y, z, elev, azim): a compile-time 5 lets every chunk behind the first drop its position loads
+      const int npos = ENC == NA_ENC_HASH ? 6 : (GEN != 0 ? 5 : d.in_size);
 #pragma unroll
       for (int c = 0; c < NI; ++c) {
         if (c >= c0) {

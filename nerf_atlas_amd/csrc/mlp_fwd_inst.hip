@@ -36,7 +36,8 @@ static int dispatch_forward(MlpArgs& a, const TileTab& tab, int NI, hipStream_t 
   constexpr int NWS = PREC == NA_PREC_BF16X3 ? 4 : 8;
   // IPE latent generated in the prologue: the two MLPs of PlainNeRF(view) + mip (config 3)
 #define NA_CASE_GEN(ACTV, ENCV, NIV, NW)                                                          \
-  if (a.mip.rays != nullptr && act == ACTV && a.d.enc_kind == ENCV && NI == NIV) {                \
+  if (a.mip.rays != nullptr && act == ACTV && a.d.enc_kind == ENCV && NI == NIV &&                \
+      (ENCV != NA_ENC_NONE || a.d.in_size == 5)) { /* (the encoder-less instantiation hard-wires the View head's 5 inputs) */ \
     a.ngroups = (int)((a.N + 32 * NW - 1) / (32 * NW));                                           \
     return launch_forward<PREC, ACTV, ENCV, NIV, NW, 1>(a, tab, s);                               \
   }
