@@ -116,7 +116,7 @@ def main():
                              frac_of_mfma_peak=round(fl / peak, 3)))
             print(f"mlp {name:30s} [{prec:6s}] {dt * 1e6:9.1f} us  {M / dt / 1e6:8.1f} Msamples/s  {fl / 1e12:7.1f} TFLOP/s "
                   f"({fl / peak:5.1%} of {'bf16' if prec == 'bf16' else 'bf16/3'} peak)")
-    # whole models of the other BASELINE configs on one tile (unfused operator chains except PlainNeRF)
+    # whole models of the other BASELINE configs on one tile (operator chains except PlainNeRF(view) and TinyNeRF)
     import nerf_atlas_amd.nerf as nerf
     import nerf_atlas_amd.refl as refl
     import nerf_atlas_amd.sdf as sdf
@@ -132,8 +132,13 @@ def main():
         return nerf.VolSDF(sdf=sdf.SDF(under, r, isect=None, t_near=0.3, t_far=1.8), steps=T, t_near=0.3, t_far=1.8,
                            sigmoid_kind="upshifted")
     common = dict(steps=T, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted")
+    def tiny_chain():
+        m = nerf.TinyNeRF(**common)
+        m._fusable = lambda: False  # the operator chain (generic fused MLP -> sigmoid -> composite) instead of the one kernel
+        return m
     models = {
-        "1 TinyNeRF": (lambda: nerf.TinyNeRF(**common), 793088, False),
+        "1 TinyNeRF (one kernel)": (lambda: nerf.TinyNeRF(**common), 793088, False),
+        "1 TinyNeRF (operator chain)": (tiny_chain, 793088, False),
         "2 PlainNeRF(view) fused": (lambda: nerf.PlainNeRF(intermediate_size=64, **common), 1192960, False),
         "3 PlainNeRF + mip cylinder": (lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False),
         "4 D-NeRF spline 6": (lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True),
