@@ -1056,7 +1056,6 @@ __global__ void pack_ls_kernel(PackArgs w, int planes, int f16, char* __restrict
       const NaMlpDesc& d = view ? d2 : d1;
       const int lp = view ? p - 6 : p;  // 0 init, 1 skip layer, 2..4 hidden, 5 out
       const float* W = view ? w.w_view[lp] : w.w_first[lp];
-      const int NIc = view ? 5 : 3;     // init chunks
       const int dim_p = d.in_size + d.enc_dims + d.latent_size;
       int row, col, in_dim, out_dim;
       if (lp == 5) {  // out layers.  view.out: fragment f = chunk c (one tile); first.out: row group rg holds tile min(rg, 2)
