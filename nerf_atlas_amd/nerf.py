@@ -164,6 +164,12 @@ class TinyNeRF(CommonNeRF):
 
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1)
+        if self._fusable() and refl_latent is None and not ag.needs_grad(pts):
+            # explicit sample positions (a deformation field in front of TinyNeRF) through the same kernel
+            prec = config.precision
+            out, self.alpha, self.weights = ops.render_tiny_ls(rays.contiguous(), ts, self.packed_ls(prec), prec, self.sigmoid_kind,
+                                                                self.bg, True, pts=pts.contiguous())
+            return out
         latent = self.mip_encoding(rays, ts)
         o = self.estim(pts, latent)
         density, feats = o[..., 0].contiguous(), o[..., 1:].contiguous()

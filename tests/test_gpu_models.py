@@ -131,6 +131,9 @@ def test_tiny_nerf_fused_kernel_vs_operator_chain(na):
             chain = m(rays)
             cw, ca = m.weights.clone(), m.alpha.clone()
             config.set_engine("ls")
+            pts, ts_, r_o, r_d, _ = na.nerf.compute_pts_ts(rays, 2.0, 6.0, T)
+            viap = m.from_pts(pts, ts_, r_o, r_d, rays=rays)  # explicit positions through the same kernel
+            assert float((viap - chain).abs().max()) <= 2e-5 and float((m.weights - cw).abs().max()) <= 2e-5
             for prec, tol in (("bf16x3", 2e-5), ("f16", 2e-3), ("bf16", 2e-2)):
                 config.set_precision(prec)
                 out = m(rays)
