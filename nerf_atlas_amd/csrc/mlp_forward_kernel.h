@@ -90,11 +90,23 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
         for (int c = 0; c < NI; ++c) {
           if ((c & 1) == 0 && c + 1 < F / 8) {
             float sv[8], cv[8];
+            // this lane's 8 frequencies are consecutive columns of the basis: two 16-byte loads per input dimension
+            // instead of eight 4-byte ones (same products and the same summation order per frequency)
+            float mv[8];
+            {
+              const int freq0 = 16 * (c >> 1) + 8 * hi;
+              for (int q = 0; q < D; ++q) {
+                const f32x4 b0 = *(const f32x4*)(a.enc + q * F + freq0), b1 = *(const f32x4*)(a.enc + q * F + freq0 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float be = e < 4 ? b0[e & 3] : b1[e & 3];
+                  mv[e] = q == 0 ? xv[0] * be : fmaf(xv[q], be, mv[e]);
+                }
+              }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              int freq = 16 * (c >> 1) + 8 * hi + e;
-              float m = 0.f;
-              for (int q = 0; q < D; ++q) m = q == 0 ? xv[0] * a.enc[freq] : fmaf(xv[q], a.enc[q * F + freq], m);
+              const float m = mv[e];
               // Cody-Waite + polynomial (1.6e-7 / 5e-7 for |m| <= 3e3; the fp32 argument itself carries 6e-5 at
               // |m| = 1e3) -- libm's sinf/cosf with their large-argument path cost 30-40 % of this kernel;
               // fast mode: hardware v_sin / v_cos on the fractional revolution
@@ -140,6 +152,17 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
           float v[8];
           // (uniform) does this chunk hold any generated column?  The View MLP's trailing chunks carry only loaded ones.
           const bool chunk_gen = GEN != 0 && 16 * (c - c0) < npos + gen && 16 * (c - c0) + 16 > npos;
+          // this lane's 8 slots are 8 consecutive columns of the virtual row: when all of them are STORED latent columns
+          // they come in as two 16-byte loads (rows are only dword-aligned in general) instead of 8 + 8 four-byte loads a
+          // row pitch apart across the lanes -- measured on the mip `first` shape with the latent in HBM: prologue 1.6 -> ... ms
+          const int rho0 = 16 * (c - c0) + 8 * hi;
+          if (rho0 >= npos + gen && rho0 + 8 <= dim_rest) {
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const float* src = lrow + (rho0 - npos - gen);
+            const f32x4u lo4 = *(const f32x4u*)src, hi4 = *(const f32x4u*)(src + 4);
+            v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+            v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+          } else
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int rho = 16 * (c - c0) + 8 * hi + e;  // index into the virtual row
@@ -155,7 +178,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
               const bool is_gen = li < gen;
               const float xg = chunk_gen ? mip_feature<PREC == NA_PREC_BF16>(gm0, gm1, gm2, gc0, gc1, gc2, is_gen ? li : 0,
                                                                              a.mip.nd, a.mip.min_deg) : 0.f;
-              xl = is_gen ? xg : lrow[is_gen ? 0 : li - gen];
+              // (the hash instantiation is PlainNeRF.first: its whole latent is generated, there is no stored column to load)
+              if constexpr (ENC == NA_ENC_HASH) xl = xg;
+              else xl = is_gen ? xg : lrow[is_gen ? 0 : li - gen];
             } else {
               xl = lrow[li];
             }
