@@ -836,7 +836,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       HashGather hg;
 #pragma unroll
       for (int k = 0; k < KEND; ++k) {
-        hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
+        hash_level_issue(q.px, q.py, q.pz, a.tables, (hi ? a.res.n[4 + k] : a.res.n[k]), 4 * hi + k, hg);
         hash_finish(k, hg);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(3 + k);
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       HashGather hg;
 #pragma unroll
       for (int k = 2; k < 4; ++k) {
-        hash_level_issue(q.px, q.py, q.pz, a.tables, a.res.n[4 * hi + k], 4 * hi + k, hg);
+        hash_level_issue(q.px, q.py, q.pz, a.tables, (hi ? a.res.n[4 + k] : a.res.n[k]), 4 * hi + k, hg);
         hash_finish(k, hg);
         __builtin_amdgcn_sched_barrier(0);
       }
