@@ -162,6 +162,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
             const f32x4u lo4 = *(const f32x4u*)src, hi4 = *(const f32x4u*)(src + 4);
             v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
             v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+          } else if (rho0 >= dim_rest) {  // padding behind the row: nothing to load
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
           } else
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
