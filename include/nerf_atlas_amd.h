@@ -350,6 +350,19 @@ int na_render_tiny_ls(const float* rays, const float* pts, int64_t R, const floa
                       int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
                       void* stream);
 
+/* The View head + alpha compositing alone on the same engine: VolSDF's second half (/root/reference/
+ * src/nerf.py:981-1013 with src/refl.py:190-207 and src/utils.py:50-58).  `feat` holds one row per sample (sample n =
+ * t * R + ray, row pitch feat_ld >= 65 floats): column 0 the signed distance, columns 1..64 the latent the SDF network
+ * produced; the kernel turns the distance into the Laplace density with scale beta[0] (device pointer), evaluates
+ * refl.View (x, elev / azim of the ray, latent -> sigmoid_kind(rgb)) and composites with the density used as it is (no
+ * softplus).  na_render_view_ls_pack takes View.mlp's 6 Linears {init, layers.0..3, out}.  Workspace and `pts` as for
+ * na_render_plain_view_ls.                                                                                          */
+size_t na_render_view_ls_packed_bytes(int precision);
+int na_render_view_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream);
+int na_render_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* feat, int feat_ld,
+                      const float* beta, const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
+                      float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SDF ray marching (src/march.py).  Per-ray state lives in caller-owned device arrays; the SDF network
  * is evaluated for ALL rays by na_mlp_forward between the updates (no mask compaction, no host sync) and the updates

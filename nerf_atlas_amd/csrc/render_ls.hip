@@ -59,6 +59,12 @@ constexpr int kPairsPerPass = 160;
 constexpr int kTinyPhases = 8;
 __host__ __device__ constexpr int tiny_phase_pairs(int p) { return p == 0 ? 2 : (p == 1 || p == 4) ? 17 : p == 7 ? 8 : 16; }
 constexpr int kTinyPairs = 108;
+// The View head + compositing alone (MODEL 2; VolSDF's second half, src/nerf.py:981-1013): density and the 64-wide latent
+// of every sample come from HBM (the SDF network's output rows), phases view.init (4 latent + geometry), L0 (5 skip + 16),
+// L1..L3, out (16 / 2) + 2 zero pairs that keep a pass a multiple of the ring depth
+constexpr int kViewPhases = 6;
+__host__ __device__ constexpr int view_phase_pairs(int p) { return p == 0 ? 5 : p == 1 ? 21 : p == 5 ? 10 : 16; }
+constexpr int kViewPairs = 84;
 constexpr int kHeaderBytes = 1024;
 constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB blocks: floats [slot][hi(2)][16]
 constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"
@@ -91,6 +97,9 @@ struct Args {
   float* weights;        // nullable [T,R]
   float* out;            // [R,3]
   const float* elaz;     // [R,2] elev/azim of every ray (ray_elaz_kernel)
+  const float* feat;     // MODEL 2: [T*R, feat_ld] rows of the SDF network: column 0 = signed distance, 1..64 = latent
+  const float* beta;     // MODEL 2: Laplace scale (one float)
+  int feat_ld;
   int64_t R;
   int T, nb;
   int nG;                // sample groups of the launch (2 per workgroup): group G renders rays G, G + nG, G + 2 nG, ...
@@ -279,6 +288,20 @@ __device__ __forceinline__ void m_out(f32x16 (&o)[NT], Frag<PREC> (&ring)[kPF][2
   cur += NT * 8;
 }
 
+// N fragment pairs of the stream that carry no work (padding): keep the ring and `cur` in step
+template <int PREC, int RING0, int N, bool WRAP, int PPP>
+__device__ __forceinline__ void ring_skip(Frag<PREC> (&ring)[kPF][2], int& cur, __amdgpu_buffer_rsrc_t rs, int wvoff) {
+  constexpr int FR = Cfg<PREC>::FRAG, PAIR = Cfg<PREC>::PAIR;
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    int nx = cur + p + kPF;
+    if (WRAP) nx = nx >= PPP ? nx - PPP : nx;
+    ring[(RING0 + p) % kPF][0] = wload<PREC>(rs, wvoff, nx * PAIR);
+    ring[(RING0 + p) % kPF][1] = wload<PREC>(rs, wvoff, nx * PAIR + FR);
+  }
+  cur += N;
+}
+
 // ---- MFMA phase of `first.out` (65 rows = 3 tiles), ROW-major like the hidden layers: row group rg computes tile
 // min(rg, 2) for all NBLK blocks of its sample group (16 chunks x NBLK MFMAs, one A fragment feeds NBLK MFMAs; row group 3
 // repeats tile 2 to keep the four weight rings in step, its result is dropped).  Block-per-wave (every wave streaming all
@@ -382,7 +405,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
-  constexpr int PPP = MODEL == 1 ? kTinyPairs : kPairsPerPass;  // fragment pairs per pass and row group
+  constexpr int PPP = MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : kPairsPerPass;  // fragment pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
   __builtin_amdgcn_s_dcache_inv();
@@ -593,7 +616,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     const float cr = fast_sigmoid_kind(oc[0], a.sigmoid_kind);
     const float cg = fast_sigmoid_kind(oc[1], a.sigmoid_kind);
     const float cb = fast_sigmoid_kind(oc[2], a.sigmoid_kind);
-    const float sigma = fast_softplus(density - 1.0f);
+    // (MODEL 2: `density` is VolSDF's Laplace density, used as it is: src/nerf.py:1004-1006, softplus = False)
+    const float sigma = MODEL == 2 ? fmaxf(density, 0.f) : fast_softplus(density - 1.0f);
     const float alpha = q.t_ok ? 1.0f - fast_exp(-sigma * q.dist) : 0.f;
     const float f = (1.0f - alpha) + 1e-10f;
     // exclusive product scan over the 32 steps of the block: shift by one lane (lane 0 of each half: 1), then scan
@@ -723,6 +747,91 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #if NA_LS_TRACE
     ton = pass == 1;
 #endif
+    if constexpr (MODEL == 2) {
+      // ================= View head + compositing: EP = compositing of the previous pass + this pass's density / latent rows
+      auto none_l = [](int) { return 0; };
+      auto none_m = [](int, int, bool) { return 0; };
+      if (NB == 4 || owner) {
+        prev_dn = own_dn;
+        TsPair tprev = {0.f, 0.f};
+        if (prev >= 0) tprev = ts_load(prev);
+        const Loc L = locate(pass, blk);
+        const int t = L.tb * 32 + ln;
+        const float* row = a.feat + ((int64_t)(t < a.T ? t : a.T - 1) * a.R + L.ray) * a.feat_ld;
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const float sdfv = row[0];
+        f32x4u lat[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // chunk c, slot 8 hi + e <-> latent 16 c + pi_perm(8 hi + e): two runs of four columns
+          lat[c][0] = *(const f32x4u*)(row + 1 + 16 * c + 4 * hi);
+          lat[c][1] = *(const f32x4u*)(row + 1 + 16 * c + 8 + 4 * hi);
+        }
+        own_setup(pass);
+        if (prev >= 0) composite(prev_geom(prev, tprev), oc[0], density);
+        {  // Laplace density of this pass's sample (src/utils.py:50-58, src/nerf.py:1000-1003), composited one pass later
+          const float sc = a.beta[0];
+          const float scaled = (-sdfv) / sc;
+          const float cdf = scaled <= 0.f ? fast_exp(fminf(scaled, 0.f)) * 0.5f : 1.f - fast_exp(-fmaxf(scaled, 0.f)) * 0.5f;
+          density = (1.0f / sc) * cdf;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v8[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v8[e] = lat[c][0][e]; v8[4 + e] = lat[c][1][e]; }
+          fwrite<PREC>(ib + (blk * 4 + c) * FR + lane * 16, make_frag<PREC>(v8));
+        }
+      }
+      geo_setup(pass);
+      {
+        f32x16 bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+        SYNC();
+        if (prev >= 0) combine(prev);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      }
+      m_hidden<PREC, 0, 4, 1, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);  // view.init
+      SYNC();
+#define NA_VIEW_EPILOGUE(PH, FIRST)                                                              \
+      {                                                                                            \
+        f32x16 bv[2];                                                                              \
+        store_acts<PREC, NA_ACT_SIN, 0, 1>(acc, hb, rg, lane);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (PH) * 1024, t, lane); \
+        store_acts<PREC, NA_ACT_SIN, 1, 2>(acc, hb, rg, lane);                                     \
+        if ((FIRST) && owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);                   \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                              \
+          _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];                        \
+      }                                                                                            \
+      SYNC();
+      NA_VIEW_EPILOGUE(1, true)
+      m_hidden<PREC, 1, 4, 2, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);  // L0 (skip)
+      SYNC();
+      NA_VIEW_EPILOGUE(2, false)
+      m_hidden<PREC, 2, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L1
+      SYNC();
+      NA_VIEW_EPILOGUE(3, false)
+      m_hidden<PREC, 2, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L2
+      SYNC();
+      NA_VIEW_EPILOGUE(4, false)
+      m_hidden<PREC, 2, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L3
+      SYNC();
+#undef NA_VIEW_EPILOGUE
+      {
+        oc[0] = bias_tile(wrs, bias_rg + 5 * 1024, 0, lane);
+        store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+      }
+      SYNC();
+      m_out<PREC, 2, 1, true, PPP>(oc, ring, cur, wrs, wvoff, hb, lane, blk);
+      ring_skip<PREC, 2, 2, true, PPP>(ring, cur, wrs, wvoff);
+      SYNC();
+      prev = pass;
+      continue;
+    }
     if constexpr (MODEL == 1) {
       // ================= TinyNeRF: EP = sample position of this pass + compositing of the previous one
       auto none_l = [](int) { return 0; };
@@ -1176,6 +1285,75 @@ __global__ void pack_ls_tiny_kernel(TinyPackArgs w, int planes, int f16, char* _
   }
 }
 
+// View head stream (MODEL 2): same element order, phases per view_phase_pairs; the last two pairs of the out phase are zero
+struct ViewPackArgs {
+  const float* w[6];  // init, layers.0..3, out
+  const float* b[6];
+};
+__global__ void pack_ls_view_kernel(ViewPackArgs w, int planes, int f16, char* __restrict__ dst) {
+  const NaMlpDesc d = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  const int frag_bytes = 1024 * planes;
+  const int64_t nfrag_rg = 2 * kViewPairs;
+  const int64_t nelem = 4 * nfrag_rg * 512;
+  const int64_t nbias = 4 * kNPhase * 256;
+  const int dim_p = d.in_size + d.latent_size;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nelem + nbias; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nelem) {
+      const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+      const int64_t fg = i >> 9;
+      const int rg = (int)(fg / nfrag_rg);
+      int f = (int)(fg % nfrag_rg);
+      int p = 0;
+      while (f >= 2 * view_phase_pairs(p)) { f -= 2 * view_phase_pairs(p); ++p; }
+      const int kappa = 8 * (l >> 5) + e;
+      const float* W = w.w[p];  // p: 0 init, 1..4 layers.0..3, 5 out
+      int row = -1, col = -1, in_dim = 1, out_dim = 0;
+      if (p == 5) {
+        if (f < 16) {  // fragment f = chunk f of the single out tile; fragments 16..19 are padding
+          row = out_row_map(d, l & 31);
+          col = 16 * f + pi_perm(kappa);
+          in_dim = kHidden; out_dim = d.out_size;
+        }
+      } else {
+        const int q = f >> 1, t = f & 1;
+        row = 32 * (2 * rg + t) + (l & 31);
+        out_dim = kHidden;
+        if (p == 0) { col = init_slot_feature(d, q, kappa); in_dim = dim_p; }  // q = 0..3 latent chunks, 4 = geometry chunk
+        else if (p == 1) {  // init chunks from LDS, the 16 hidden chunks, then the geometry chunk
+          if (q < 4) { col = init_slot_feature(d, q, kappa); if (col >= 0) col += kHidden; }
+          else if (q < 4 + kHC) col = 16 * (q - 4) + pi_perm(kappa);
+          else { col = init_slot_feature(d, 4, kappa); if (col >= 0) col += kHidden; }
+          in_dim = kHidden + dim_p;
+        } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
+      }
+      float v = 0.f;
+      if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + ((int64_t)rg * nfrag_rg + (fg % nfrag_rg)) * frag_bytes + l * 16 + e * 2;
+      const __bf16 h = f16 ? to_elem<NA_PREC_F16>(v) : (__bf16)v;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
+      if (planes == 2) {
+        const __bf16 lo = (__bf16)(v - (float)h);
+        *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
+      }
+    } else {
+      const int64_t q = i - nelem;
+      const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
+      const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
+      const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v = 0.f;
+      if (p < kViewPhases && w.b[p] != nullptr) {
+        if (p == 5) {
+          const int row = slot < 1 ? out_row_map(d, rin) : -1;
+          if (row >= 0 && row < d.out_size) v = w.b[p][row];
+        } else if (slot < 2) {
+          v = w.b[p][32 * (2 * rg + slot) + rin];
+        }
+      }
+      *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
+    }
+  }
+}
+
 #endif  // NA_PREC_INST == 0
 
 // per-device hipFuncSetAttribute bookkeeping (the attribute is per device, not per thread)
@@ -1207,15 +1385,15 @@ static int launch(Args& a, hipStream_t stream) {
 
 #if NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
-  return model == 1 ? ls::launch<NA_PREC_BF16, 1>(a, s) : ls::launch<NA_PREC_BF16>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_BF16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16, 2>(a, s) : ls::launch<NA_PREC_BF16>(a, s);
 }
 #elif NA_PREC_INST == 1
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model) {
-  return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16X3, 2>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
 }
 #else
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
-  return model == 1 ? ls::launch<NA_PREC_F16, 1>(a, s) : ls::launch<NA_PREC_F16>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_F16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16, 2>(a, s) : ls::launch<NA_PREC_F16>(a, s);
 }
 #endif
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model);
@@ -1276,6 +1454,7 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   if (R == 0) return NA_OK;
   ls::Args a;
   a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
+  a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
   a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision);
   a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
   a.R = R; a.T = T; a.nb = (T + 31) / 32;
@@ -1326,6 +1505,7 @@ extern "C" int na_render_tiny_ls(const float* rays, const float* pts, int64_t R,
   NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_tiny_ls: bg %d", bg_kind);
   ls::Args a;
   a.rays = rays; a.ts = ts; a.pts = pts; a.tables = nullptr;
+  a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
   a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision, ls::kTinyPairs);
   a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
   a.R = R; a.T = T; a.nb = (T + 31) / 32;
@@ -1336,5 +1516,60 @@ extern "C" int na_render_tiny_ls(const float* rays, const float* pts, int64_t R,
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 1);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 1);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 1);
+}
+
+// ---- View head + compositing on per-sample (density source, latent) rows: VolSDF's second half (src/nerf.py:981-1013)
+extern "C" size_t na_render_view_ls_packed_bytes(int precision) {
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  return ls::packed_bytes(precision, ls::kViewPairs);
+}
+
+extern "C" int na_render_view_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream) {
+  NA_REQUIRE(w && b && packed, NA_ENULL, "na_render_view_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_view_ls_pack: precision %d", precision);
+  ls::ViewPackArgs pa;
+  for (int i = 0; i < 6; ++i) {
+    NA_REQUIRE(w[i], NA_ENULL, "na_render_view_ls_pack: weights[%d] is null", i);
+    pa.w[i] = w[i]; pa.b[i] = b[i];
+  }
+  const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
+  hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
+                     (uint32_t*)packed, (uint32_t)ls::kViewPairs);
+  const int64_t total = 4 * 2 * (int64_t)ls::kViewPairs * 512 + 4 * ls::kNPhase * 256;
+  hipLaunchKernelGGL(ls::pack_ls_view_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, pa, planes,
+                     precision == NA_PREC_F16 ? 1 : 0, (char*)packed);
+  return check_launch("na_render_view_ls_pack");
+}
+
+extern "C" int na_render_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* feat,
+                                 int feat_ld, const float* beta, const void* packed, int precision, int sigmoid_kind,
+                                 int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_view_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && feat && beta && packed && out && workspace, NA_ENULL, "na_render_view_ls: null pointer");
+  NA_REQUIRE(feat_ld >= 65, NA_EINVAL, "na_render_view_ls: feat_ld %d < 65 (signed distance + 64 latent columns)", feat_ld);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_view_ls: precision %d", precision);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_view_ls: sigmoid %d", sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_view_ls: bg %d", bg_kind);
+  NA_REQUIRE(workspace_bytes >= na_render_ls_workspace_bytes(T, R), NA_EWORKSPACE, "na_render_view_ls: workspace %zu < %zu bytes",
+             workspace_bytes, na_render_ls_workspace_bytes(T, R));
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = nullptr;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision, ls::kViewPairs);
+  a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.feat = feat; a.feat_ld = feat_ld; a.beta = beta;
+  float* elaz = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.elaz = elaz;
+  hipLaunchKernelGGL(ls::ray_elaz_kernel, dim3(grid_for(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays, R, elaz);
+  a.sigmoid_kind = sigmoid_kind;
+  a.res = hash_resolutions();
+  a.trace = nullptr;
+  if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 2);
+  if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 2);
+  return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 2);
 }
 #endif

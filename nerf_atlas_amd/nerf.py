@@ -270,8 +270,35 @@ class VolSDF(CommonNeRF):
     @property
     def refl(self): return self.sdf.refl
 
+    def _fusable_view(self, refl_latent=None):
+        """View head + compositing as one kernel on the layer-synchronous engine (csrc/render_ls.hip, MODEL 2)"""
+        r = self.sdf.refl
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return (config.engine == "ls" and type(r) is refl.View and r.latent_size == 64 and r.out_features == 3
+                and self.sdf.intermediate_size == 64 and getattr(r, "act_kind", None) in ops.SIGMOID and refl_latent is None
+                and not self.training and not wants_grad)
+
+    def packed_view_ls(self, precision: str):
+        lin = self.sdf.refl.mlp._linears()
+        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        cache = self.__dict__.setdefault("_packed_view_ls", {})
+        hit = cache.get(precision)
+        if hit is None or hit[0] != stamp:
+            cache[precision] = (stamp, ops.render_view_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
+        return cache[precision][1]
+
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
+        if self._fusable_view(refl_latent) and not ag.needs_grad(pts):
+            # SDF network (fused MLP kernel) -> one kernel for Laplace density, View head and compositing: the colour,
+            # density and [x | elev azim] tensors of the operator chain are never materialised
+            raw = self.sdf.underlying(pts)
+            scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
+            object.__setattr__(self, "scale_post_act", scale)
+            prec = config.precision
+            out, self.alpha, self.weights = ops.render_view_ls(rays.contiguous(), ts, raw, scale, self.packed_view_ls(prec), prec,
+                                                                self.sdf.refl.act_kind, "black", True, pts=pts.contiguous())
+            return out
         sdf_vals, latent = self.sdf.from_pts(pts)
         if ag.needs_grad(sdf_vals, self.scale):
             scale = torch.nn.functional.softplus(self.scale) if self.scale_softplus else self.scale
@@ -290,6 +317,7 @@ class VolSDF(CommonNeRF):
         if not hasattr(self, "sdf"): return
         self.sigmoid_kind = kind
         self.refl.act = load_sigmoid(kind)
+        self.refl.act_kind = kind
 
 
 # ------------------------------------------------------------------------------------------------- DynamicNeRF

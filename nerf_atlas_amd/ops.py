@@ -703,6 +703,51 @@ def render_tiny_ls(rays: torch.Tensor, ts: torch.Tensor, packed: torch.Tensor, p
     return out, alpha, weights
 
 
+def render_view_ls_pack(precision: str, weights, biases) -> torch.Tensor:
+    """Pack refl.View's MLP ({init, layers.0..3, out}; 5 + 64 inputs) into the weight stream of na_render_view_ls."""
+    lib = _lib.load()
+    assert len(weights) == 6 and len(biases) == 6
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [None if b is None else _f32(b.detach(), "bias") for b in biases]
+    shapes = [(256, 69), (256, 325), (256, 256), (256, 256), (256, 256), (3, 256)]
+    for w, shp in zip(ws, shapes):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS View renderer: weight shape {tuple(w.shape)} != {shp}")
+    wp = (C.c_void_p * 6)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * 6)(*[0 if b is None else b.data_ptr() for b in bs])
+    packed = torch.empty(int(lib.na_render_view_ls_packed_bytes(PREC[precision])), device=ws[0].device, dtype=torch.uint8)
+    check(lib.na_render_view_ls_pack(PREC[precision], wp, bp, _ptr(packed), _stream()))
+    return packed
+
+
+def render_view_ls(rays: torch.Tensor, ts: torch.Tensor, feat: torch.Tensor, beta: torch.Tensor, packed: torch.Tensor,
+                   precision: str, sigmoid_kind: str = "thin", bg: str = "black", want_weights: bool = False,
+                   pts: Optional[torch.Tensor] = None):
+    """View head + compositing in one kernel.  feat [T, *rays.shape[:-1], >= 65]: column 0 signed distance, 1..64 latent
+    (the SDF network's output, rows may be wider); beta: the Laplace scale (0-dim or 1-element device tensor)."""
+    lib = _lib.load()
+    rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    feat, ld = _rows(feat, feat.shape[-1], "feat")
+    assert feat.shape[0] == T * R and ld >= 65, (feat.shape, T, R, ld)
+    beta = _f32(beta.reshape(1), "beta")
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    workspace = torch.empty(int(lib.na_render_ls_workspace_bytes(T, R)), device=rays.device, dtype=torch.uint8)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3, (pts.shape, T, R)
+    check(lib.na_render_view_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(feat), ld, _ptr(beta), _ptr(packed), PREC[precision],
+                                SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace),
+                                workspace.numel(), _stream()))
+    return out, alpha, weights
+
+
 # ------------------------------------------------------------------------------------------------- forward-mode tangents
 def act_deriv(x: torch.Tensor, act: str, order: int = 1) -> torch.Tensor:
     lib = _lib.load()

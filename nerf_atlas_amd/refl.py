@@ -31,6 +31,7 @@ class Reflectance(nn.Module):
         self.out_features = out_features
         self.bidirectional = bidirectional
         self.act = load_sigmoid(act)
+        self.act_kind = act if isinstance(act, str) else None  # (the fused renderers apply it in-kernel by name)
 
     @property
     def can_use_normal(self): return False

@@ -160,6 +160,56 @@ def test_volsdf(na, kind):
     assert float(m.scale_post_act) == pytest.approx(0.1)
 
 
+@pytest.mark.parametrize("kind", ["mlp", "siren"])
+def test_volsdf_fused_view_half_vs_operator_chain(na, kind):
+    """VolSDF with Laplace density + View head + compositing as ONE kernel (layer-synchronous engine, MODEL 2) against the
+    operator chain (engine "reg": laplace_density -> generic View MLP -> sigmoid -> composite): colour, alpha, weights,
+    partition of unity; the three precisions; T = 72 straddles the passes and ends in a ragged block."""
+    import math
+    from nerf_atlas_amd import config
+    h = load_golden(f"g10_volsdf_{kind}")
+    cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1.0]]]),
+                                focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
+    rays = cam.sample_positions((380, 390, 37, 41), size=800)
+    try:
+        for T in (int(h["steps"]), 72, 128):
+            under = na.sdf.sdf_kinds[kind](intermediate_size=64)
+            r = na.refl.View(latent_size=64, act="upshifted", out_features=3)
+            m = na.nerf.VolSDF(sdf=na.sdf.SDF(under, r, isect=None, t_near=0.3, t_far=1.8), steps=T, t_near=0.3, t_far=1.8,
+                               sigmoid_kind="upshifted").cuda().eval()
+            load_params(m, golden_params(h))
+            config.set_precision("bf16x3")
+            config.set_engine("reg")
+            chain = m(rays)
+            cw, ca = m.weights.clone(), m.alpha.clone()
+            config.set_engine("ls")
+            for prec, tol in (("bf16x3", 3e-5), ("f16", 3e-3), ("bf16", 3e-2)):
+                config.set_precision(prec)
+                ref, rw, ra = (chain, cw, ca)
+                if prec != "bf16x3":  # the SDF network runs in the mode's own precision too: compare like with like
+                    config.set_engine("reg")
+                    if prec == "f16":
+                        config.set_precision("bf16x3")
+                    ref = m(rays); rw, ra = m.weights.clone(), m.alpha.clone()
+                    config.set_engine("ls"); config.set_precision(prec)
+                if prec == "f16":
+                    continue  # (f16 exists for the layer-synchronous kernels only: the SDF network rejects it)
+                out = m(rays)
+                assert float((out - ref).abs().max()) <= tol, (T, prec)
+                assert float((m.weights - rw).abs().max()) <= tol and float((m.alpha - ra).abs().max()) <= tol, (T, prec)
+                assert float((m.weights.sum(0) - 1).abs().max()) <= 1e-5 or prec == "bf16"
+                if T == 128:  # repeated calls are bit-identical (a slab that fills every workgroup)
+                    slab = cam.sample_positions((300, 0, 24, 800), size=800)
+                    first = m(slab).clone()
+                    fw = m.weights.clone()
+                    for i in range(15):
+                        torch.empty(1 + (i * 7919) % 100000, device="cuda")
+                        assert torch.equal(m(slab), first) and torch.equal(m.weights, fw), (prec, i)
+    finally:
+        config.set_precision("bf16x3")
+        config.set_engine("ls")
+
+
 @pytest.mark.parametrize("spline", [6, 4])
 def test_dynamic_nerf_spline(na, spline):
     h = load_golden(f"g9_dnerf_spline{spline}")
