@@ -363,6 +363,17 @@ int na_render_view_ls(const float* rays, const float* pts, int64_t R, const floa
                       const float* beta, const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
                       float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* VolSDF with the SIREN SDF network (/root/reference/src/sdf.py:278-287: SkipConnMLP 3 -> 5 x 256 -> 1 + 64, sin, skip 3)
+ * as ONE kernel: sample -> SIREN -> Laplace density | latent -> refl.View -> compositing (src/nerf.py:981-1013).  The pack
+ * call takes the SIREN's 7 Linears {init, layers.0..4, out} and View.mlp's 6; `beta` is the Laplace scale on the device.
+ * Workspace, `pts`, precisions and outputs as for na_render_plain_view_ls.                                          */
+size_t na_render_volsdf_siren_ls_packed_bytes(int precision);
+int na_render_volsdf_siren_ls_pack(int precision, const float* const* w_sdf, const float* const* b_sdf,
+                                   const float* const* w_view, const float* const* b_view, void* packed, void* stream);
+int na_render_volsdf_siren_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* beta,
+                              const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights,
+                              float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SDF ray marching (src/march.py).  Per-ray state lives in caller-owned device arrays; the SDF network
  * is evaluated for ALL rays by na_mlp_forward between the updates (no mask compaction, no host sync) and the updates

@@ -116,6 +116,11 @@ SIGNATURES = {
     "na_render_view_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     "na_render_view_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "na_render_volsdf_siren_ls_packed_bytes": (C.c_size_t, [C.c_int]),
+    "na_render_volsdf_siren_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "na_render_volsdf_siren_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "na_render_ls_packed_bytes": (C.c_size_t, [C.c_int]),
     "na_render_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),

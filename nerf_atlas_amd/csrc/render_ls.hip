@@ -46,7 +46,7 @@ namespace na {
 namespace ls {
 
 constexpr int kPF = 4;       // weight prefetch depth, in fragment pairs
-constexpr int kNPhase = 12;  // MFMA phases per pass
+constexpr int kNPhase = 16;  // bias blocks per row group (MFMA phases per pass: 12 PlainNeRF, 8 TinyNeRF, 6 View, 13 SIREN-VolSDF)
 // fragment pairs a wave consumes per phase: first.init, first.L0 (3 skip + 16), L1..L3, first.out (ONE 32-row tile per
 // row group: 16 fragments), view.init (4 latent + geometry), view.L0 (5 skip + 16), L1..L3, view.out (16 / 2)
 __host__ __device__ constexpr int phase_pairs(int p) {
@@ -65,6 +65,14 @@ constexpr int kTinyPairs = 108;
 constexpr int kViewPhases = 6;
 __host__ __device__ constexpr int view_phase_pairs(int p) { return p == 0 ? 5 : p == 1 ? 21 : p == 5 ? 10 : 16; }
 constexpr int kViewPairs = 84;
+// VolSDF with the SIREN SDF network (src/sdf.py:278-287: 3 -> 5 x 256 sin, skip 3 -> 1 + 64) as ONE kernel (MODEL 3): the
+// PlainNeRF schedule with `first` replaced by the SIREN -- sdf.init (x,y,z chunk + one zero chunk), L0 (1 skip + 16), L1, L2,
+// L3 (1 + 16), L4, sdf.out (65 rows row-major: 16 / 2), then the View half of MODEL 2 (5, 21, 16, 16, 16, 8 + 2 zero pairs)
+constexpr int kSirenPhases = 13;
+__host__ __device__ constexpr int siren_phase_pairs(int p) {
+  return p == 0 ? 2 : (p == 1 || p == 4) ? 17 : p == 6 ? 8 : p == 7 ? 5 : p == 8 ? 21 : p == 12 ? 10 : 16;
+}
+constexpr int kSirenPairs = 176;
 constexpr int kHeaderBytes = 1024;
 constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB blocks: floats [slot][hi(2)][16]
 constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
-  constexpr int PPP = MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : kPairsPerPass;  // fragment pairs per pass and row group
+  constexpr int PPP = MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
   __builtin_amdgcn_s_dcache_inv();
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     const float cg = fast_sigmoid_kind(oc[1], a.sigmoid_kind);
     const float cb = fast_sigmoid_kind(oc[2], a.sigmoid_kind);
     // (MODEL 2: `density` is VolSDF's Laplace density, used as it is: src/nerf.py:1004-1006, softplus = False)
-    const float sigma = MODEL == 2 ? fmaxf(density, 0.f) : fast_softplus(density - 1.0f);
+    const float sigma = MODEL >= 2 ? fmaxf(density, 0.f) : fast_softplus(density - 1.0f);
     const float alpha = q.t_ok ? 1.0f - fast_exp(-sigma * q.dist) : 0.f;
     const float f = (1.0f - alpha) + 1e-10f;
     // exclusive product scan over the 32 steps of the block: shift by one lane (lane 0 of each half: 1), then scan
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     for (int i = 0; i < LAG; ++i) __syncthreads();
   }
 
-  if constexpr (MODEL == 1) {
+  if constexpr (MODEL == 1 || MODEL == 3) {
     // the zero chunk behind (x, y, z): its weights are zero, its LDS words only have to be finite
     if (owner) {
       float z8[8];
@@ -747,6 +755,132 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #if NA_LS_TRACE
     ton = pass == 1;
 #endif
+    if constexpr (MODEL == 3) {
+      // ================= VolSDF, SIREN SDF network + View head: EP = sample position + compositing of the previous pass
+      auto none_l = [](int) { return 0; };
+      auto none_m = [](int, int, bool) { return 0; };
+      if (NB == 4 || owner) {
+        prev_dn = own_dn;
+        const TsPair tcur = ts_load(pass);
+        TsPair tprev = tcur;
+        if (prev >= 0) tprev = ts_load(prev);
+        own_setup(pass);
+        const Geom q = geom(pass, blk, tcur);
+        if (prev >= 0) composite(prev_geom(prev, tprev), oc[0], density);
+        float v2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v2[e] = 0.f;
+        fwrite<PREC>(ib + (blk * 4 + 1) * FR + lane * 16, make_frag<PREC>(v2));  // (the latent of the last pass sat here)
+        if (hi == 0) { v2[0] = q.px; v2[1] = q.py; v2[2] = q.pz; }
+        fwrite<PREC>(ib + blk * 4 * FR + lane * 16, make_frag<PREC>(v2));
+      }
+      {
+        f32x16 bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+        SYNC();
+        if (prev >= 0) combine(prev);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      }
+      m_hidden<PREC, 0, 2, 0, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // sdf.init
+      SYNC();
+#define NA_SIN_EPILOGUE(PH, NCHUNK)                                                              \
+      {                                                                                            \
+        f32x16 bv[2];                                                                              \
+        store_acts<PREC, NA_ACT_SIN, 0, 1>(acc, hb, rg, lane);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + (PH) * 1024, t, lane); \
+        store_acts<PREC, NA_ACT_SIN, 1, 2>(acc, hb, rg, lane);                                     \
+        if ((NCHUNK) > 0 && owner) activate_init<PREC, NA_ACT_SIN, ((NCHUNK) > 0 ? (NCHUNK) : 1)>(ib, blk, lane); \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                              \
+          _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];                        \
+      }                                                                                            \
+      SYNC();
+      NA_SIN_EPILOGUE(1, 1)
+      m_hidden<PREC, 2, 1, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L0 (skip)
+      SYNC();
+      NA_SIN_EPILOGUE(2, 0)
+      m_hidden<PREC, 3, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L1
+      SYNC();
+      NA_SIN_EPILOGUE(3, 0)
+      m_hidden<PREC, 3, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L2
+      SYNC();
+      NA_SIN_EPILOGUE(4, 0)
+      m_hidden<PREC, 3, 1, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L3 (skip)
+      SYNC();
+      NA_SIN_EPILOGUE(5, 0)
+      m_hidden<PREC, 0, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // L4
+      SYNC();
+      f32x16 oq[NB];  // sdf.out: this row group's tile (0, 1: latent rows 0..63; 2: the signed distance, row 64) for the NB blocks
+      {
+        const f32x16 bo = bias_tile(wrs, bias_rg + 6 * 1024, rg < 2 ? rg : 2, lane);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) oq[b] = bo;
+        store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+      }
+      SYNC();
+      m_out_rows<PREC, 0, false>(oq, ring, cur, wrs, wvoff, hb, lane);
+      SYNC();
+      {
+        f32x16 bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 7 * 1024, t, lane);
+        geo_setup(pass);
+        if (rg < 2) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            Frag<PREC> f0, f1;
+            acc_to_frags<PREC, NA_ACT_NONE>(oq[b], f0, f1);
+            char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
+            fwrite<PREC>(dst, f0);
+            fwrite<PREC>(dst + FR, f1);
+          }
+        } else if (rg == 2 && hi == 0) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[b][0];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      }
+      SYNC();
+      if (owner) {  // signed distance -> Laplace density (src/utils.py:50-58, src/nerf.py:1000-1003), composited one pass later
+        const float sdfv = ((const float*)hb)[blk * 32 + ln];
+        const float sc = a.beta[0];
+        const float scaled = (-sdfv) / sc;
+        const float cdf = scaled <= 0.f ? fast_exp(fminf(scaled, 0.f)) * 0.5f : 1.f - fast_exp(-fmaxf(scaled, 0.f)) * 0.5f;
+        density = (1.0f / sc) * cdf;
+      }
+      m_hidden<PREC, 0, 4, 1, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);  // view.init
+      SYNC();
+      NA_SIN_EPILOGUE(8, 4)
+      m_hidden<PREC, 1, 4, 2, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);  // view.L0 (skip)
+      SYNC();
+      NA_SIN_EPILOGUE(9, 0)
+      m_hidden<PREC, 2, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);
+      SYNC();
+      NA_SIN_EPILOGUE(10, 0)
+      m_hidden<PREC, 2, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);
+      SYNC();
+      NA_SIN_EPILOGUE(11, 0)
+      m_hidden<PREC, 2, 0, 0, 16, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);
+      SYNC();
+#undef NA_SIN_EPILOGUE
+      {
+        oc[0] = bias_tile(wrs, bias_rg + 12 * 1024, 0, lane);
+        store_acts<PREC, NA_ACT_SIN>(acc, hb, rg, lane);
+      }
+      SYNC();
+      m_out<PREC, 2, 1, true, PPP>(oc, ring, cur, wrs, wvoff, hb, lane, blk);
+      ring_skip<PREC, 2, 2, true, PPP>(ring, cur, wrs, wvoff);
+      SYNC();
+      prev = pass;
+      continue;
+    }
     if constexpr (MODEL == 2) {
       // ================= View head + compositing: EP = compositing of the previous pass + this pass's density / latent rows
       auto none_l = [](int) { return 0; };
@@ -1201,7 +1335,7 @@ __global__ void pack_ls_kernel(PackArgs w, int planes, int f16, char* __restrict
       const bool view = p >= 6;
       const NaMlpDesc& d = view ? d2 : d1;
       const int lp = view ? p - 6 : p;
-      const float* B = view ? w.b_view[lp] : w.b_first[lp];
+      const float* B = p >= 12 ? nullptr : view ? w.b_view[lp] : w.b_first[lp];  // (bias blocks 12..kNPhase-1: other schedules)
       const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
       const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
       float v = 0.f;
@@ -1354,6 +1488,106 @@ __global__ void pack_ls_view_kernel(ViewPackArgs w, int planes, int f16, char* _
   }
 }
 
+// SIREN-VolSDF stream (MODEL 3): the SIREN SDF network (7 Linears) followed by the View head (6 Linears)
+struct SirenPackArgs {
+  const float* ws[7];  // sdf: init, layers.0..4, out
+  const float* bs[7];
+  const float* wv[6];  // view: init, layers.0..3, out
+  const float* bv[6];
+};
+__global__ void pack_ls_siren_kernel(SirenPackArgs w, int planes, int f16, char* __restrict__ dst) {
+  const NaMlpDesc d1 = {3, NA_ENC_NONE, 0, 0, 5, 256, 65, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_FIRST};
+  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  const int frag_bytes = 1024 * planes;
+  const int64_t nfrag_rg = 2 * kSirenPairs;
+  const int64_t nelem = 4 * nfrag_rg * 512;
+  const int64_t nbias = 4 * kNPhase * 256;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nelem + nbias; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nelem) {
+      const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+      const int64_t fg = i >> 9;
+      const int rg = (int)(fg / nfrag_rg);
+      int f = (int)(fg % nfrag_rg);
+      int p = 0;
+      while (f >= 2 * siren_phase_pairs(p)) { f -= 2 * siren_phase_pairs(p); ++p; }
+      const int kappa = 8 * (l >> 5) + e;
+      const bool view = p >= 7;
+      const int lp = view ? p - 7 : p;  // sdf: 0 init, 1..5 layers.0..4, 6 out;  view: 0 init, 1..4 layers.0..3, 5 out
+      const float* W = view ? w.wv[lp] : w.ws[lp];
+      int row = -1, col = -1, in_dim = 1, out_dim = 0;
+      if (!view) {
+        if (lp == 6) {  // row group rg holds tile min(rg, 2) of the 65 rows; fragment f = chunk f
+          row = out_row_map(d1, 32 * (rg < 2 ? rg : 2) + (l & 31));
+          col = 16 * f + pi_perm(kappa);
+          in_dim = kHidden; out_dim = d1.out_size;
+        } else {
+          const int q = f >> 1, t = f & 1;
+          row = 32 * (2 * rg + t) + (l & 31);
+          out_dim = kHidden;
+          if (lp == 0) { col = q == 0 ? init_slot_feature(d1, 0, kappa) : -1; in_dim = d1.in_size; }
+          else if (lp == 1 || lp == 4) {
+            if (q == 0) { col = init_slot_feature(d1, 0, kappa); if (col >= 0) col += kHidden; }
+            else col = 16 * (q - 1) + pi_perm(kappa);
+            in_dim = kHidden + d1.in_size;
+          } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
+        }
+      } else {
+        const int dim_p = d2.in_size + d2.latent_size;
+        if (lp == 5) {
+          if (f < 16) {
+            row = out_row_map(d2, l & 31);
+            col = 16 * f + pi_perm(kappa);
+            in_dim = kHidden; out_dim = d2.out_size;
+          }
+        } else {
+          const int q = f >> 1, t = f & 1;
+          row = 32 * (2 * rg + t) + (l & 31);
+          out_dim = kHidden;
+          if (lp == 0) { col = init_slot_feature(d2, q, kappa); in_dim = dim_p; }
+          else if (lp == 1) {
+            if (q < 4) { col = init_slot_feature(d2, q, kappa); if (col >= 0) col += kHidden; }
+            else if (q < 4 + kHC) col = 16 * (q - 4) + pi_perm(kappa);
+            else { col = init_slot_feature(d2, 4, kappa); if (col >= 0) col += kHidden; }
+            in_dim = kHidden + dim_p;
+          } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
+        }
+      }
+      float v = 0.f;
+      if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + ((int64_t)rg * nfrag_rg + (fg % nfrag_rg)) * frag_bytes + l * 16 + e * 2;
+      const __bf16 h = f16 ? to_elem<NA_PREC_F16>(v) : (__bf16)v;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
+      if (planes == 2) {
+        const __bf16 lo = (__bf16)(v - (float)h);
+        *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
+      }
+    } else {
+      const int64_t q = i - nelem;
+      const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
+      const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
+      const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v = 0.f;
+      if (p < kSirenPhases) {
+        const bool view = p >= 7;
+        const int lp = view ? p - 7 : p;
+        const float* B = view ? w.bv[lp] : w.bs[lp];
+        if (B != nullptr) {
+          if (!view && lp == 6) {
+            const int row = slot < 3 ? out_row_map(d1, 32 * slot + rin) : -1;
+            if (row >= 0 && row < d1.out_size) v = B[row];
+          } else if (view && lp == 5) {
+            const int row = slot < 1 ? out_row_map(d2, rin) : -1;
+            if (row >= 0 && row < d2.out_size) v = B[row];
+          } else if (slot < 2) {
+            v = B[32 * (2 * rg + slot) + rin];
+          }
+        }
+      }
+      *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
+    }
+  }
+}
+
 #endif  // NA_PREC_INST == 0
 
 // per-device hipFuncSetAttribute bookkeeping (the attribute is per device, not per thread)
@@ -1385,15 +1619,18 @@ static int launch(Args& a, hipStream_t stream) {
 
 #if NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
-  return model == 1 ? ls::launch<NA_PREC_BF16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16, 2>(a, s) : ls::launch<NA_PREC_BF16>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_BF16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16, 2>(a, s)
+         : model == 3 ? ls::launch<NA_PREC_BF16, 3>(a, s) : ls::launch<NA_PREC_BF16>(a, s);
 }
 #elif NA_PREC_INST == 1
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model) {
-  return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16X3, 2>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16X3, 2>(a, s)
+         : model == 3 ? ls::launch<NA_PREC_BF16X3, 3>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
 }
 #else
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
-  return model == 1 ? ls::launch<NA_PREC_F16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16, 2>(a, s) : ls::launch<NA_PREC_F16>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_F16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16, 2>(a, s)
+         : model == 3 ? ls::launch<NA_PREC_F16, 3>(a, s) : ls::launch<NA_PREC_F16>(a, s);
 }
 #endif
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model);
@@ -1571,5 +1808,63 @@ extern "C" int na_render_view_ls(const float* rays, const float* pts, int64_t R,
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 2);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 2);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 2);
+}
+
+// ---- VolSDF with the SIREN SDF network as one kernel (src/sdf.py:278-287 + src/nerf.py:981-1013)
+extern "C" size_t na_render_volsdf_siren_ls_packed_bytes(int precision) {
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  return ls::packed_bytes(precision, ls::kSirenPairs);
+}
+
+extern "C" int na_render_volsdf_siren_ls_pack(int precision, const float* const* w_sdf, const float* const* b_sdf,
+                                              const float* const* w_view, const float* const* b_view, void* packed, void* stream) {
+  NA_REQUIRE(w_sdf && b_sdf && w_view && b_view && packed, NA_ENULL, "na_render_volsdf_siren_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_volsdf_siren_ls_pack: precision %d", precision);
+  ls::SirenPackArgs pa;
+  for (int i = 0; i < 7; ++i) {
+    NA_REQUIRE(w_sdf[i], NA_ENULL, "na_render_volsdf_siren_ls_pack: sdf weights[%d] is null", i);
+    pa.ws[i] = w_sdf[i]; pa.bs[i] = b_sdf[i];
+  }
+  for (int i = 0; i < 6; ++i) {
+    NA_REQUIRE(w_view[i], NA_ENULL, "na_render_volsdf_siren_ls_pack: view weights[%d] is null", i);
+    pa.wv[i] = w_view[i]; pa.bv[i] = b_view[i];
+  }
+  const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
+  hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
+                     (uint32_t*)packed, (uint32_t)ls::kSirenPairs);
+  const int64_t total = 4 * 2 * (int64_t)ls::kSirenPairs * 512 + 4 * ls::kNPhase * 256;
+  hipLaunchKernelGGL(ls::pack_ls_siren_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, pa, planes,
+                     precision == NA_PREC_F16 ? 1 : 0, (char*)packed);
+  return check_launch("na_render_volsdf_siren_ls_pack");
+}
+
+extern "C" int na_render_volsdf_siren_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* beta,
+                                         const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
+                                         float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_volsdf_siren_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && beta && packed && out && workspace, NA_ENULL, "na_render_volsdf_siren_ls: null pointer");
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_render_volsdf_siren_ls: precision %d", precision);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_volsdf_siren_ls: sigmoid %d", sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_volsdf_siren_ls: bg %d", bg_kind);
+  NA_REQUIRE(workspace_bytes >= na_render_ls_workspace_bytes(T, R), NA_EWORKSPACE,
+             "na_render_volsdf_siren_ls: workspace %zu < %zu bytes", workspace_bytes, na_render_ls_workspace_bytes(T, R));
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = nullptr;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision, ls::kSirenPairs);
+  a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.feat = nullptr; a.feat_ld = 0; a.beta = beta;
+  float* elaz = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.elaz = elaz;
+  hipLaunchKernelGGL(ls::ray_elaz_kernel, dim3(grid_for(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays, R, elaz);
+  a.sigmoid_kind = sigmoid_kind;
+  a.res = hash_resolutions();
+  a.trace = nullptr;
+  if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 3);
+  if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 3);
+  return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 3);
 }
 #endif

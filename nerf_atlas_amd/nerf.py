@@ -287,8 +287,27 @@ class VolSDF(CommonNeRF):
             cache[precision] = (stamp, ops.render_view_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
         return cache[precision][1]
 
+    def packed_siren_ls(self, precision: str):
+        lin = self.sdf.underlying.siren._linears() + self.sdf.refl.mlp._linears()
+        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        cache = self.__dict__.setdefault("_packed_siren_ls", {})
+        hit = cache.get(precision)
+        if hit is None or hit[0] != stamp:
+            wb = lambda m: ([l.weight.data for l in m._linears()], [l.bias.data for l in m._linears()])
+            cache[precision] = (stamp, ops.render_volsdf_siren_ls_pack(precision, wb(self.sdf.underlying.siren), wb(self.sdf.refl.mlp)))
+        return cache[precision][1]
+
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
+        from . import sdf as _sdf
+        if (self._fusable_view(refl_latent) and not ag.needs_grad(pts) and type(self.sdf.underlying) is _sdf.SIREN):
+            # the SIREN SDF network fits the layer-synchronous engine too: the whole model is ONE kernel (MODEL 3)
+            scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
+            object.__setattr__(self, "scale_post_act", scale)
+            prec = config.precision
+            out, self.alpha, self.weights = ops.render_volsdf_siren_ls(rays.contiguous(), ts, scale, self.packed_siren_ls(prec), prec,
+                                                                        self.sdf.refl.act_kind, "black", True, pts=pts.contiguous())
+            return out
         if self._fusable_view(refl_latent) and not ag.needs_grad(pts):
             # SDF network (fused MLP kernel) -> one kernel for Laplace density, View head and compositing: the colour,
             # density and [x | elev azim] tensors of the operator chain are never materialised

@@ -748,6 +748,49 @@ def render_view_ls(rays: torch.Tensor, ts: torch.Tensor, feat: torch.Tensor, bet
     return out, alpha, weights
 
 
+def render_volsdf_siren_ls_pack(precision: str, sdf_wb, view_wb) -> torch.Tensor:
+    """Pack the SIREN SDF network (7 Linears) and refl.View's MLP (6) into the stream of na_render_volsdf_siren_ls."""
+    lib = _lib.load()
+    (w1, b1), (w2, b2) = sdf_wb, view_wb
+    assert len(w1) == 7 and len(w2) == 6
+    keep = [[_f32(w.detach(), "weight") for w in w1], [None if b is None else _f32(b.detach(), "bias") for b in b1],
+            [_f32(w.detach(), "weight") for w in w2], [None if b is None else _f32(b.detach(), "bias") for b in b2]]
+    shapes = [(256, 3), (256, 259), (256, 256), (256, 256), (256, 259), (256, 256), (65, 256),
+              (256, 69), (256, 325), (256, 256), (256, 256), (256, 256), (3, 256)]
+    for w, shp in zip(keep[0] + keep[2], shapes):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS SIREN-VolSDF renderer: weight shape {tuple(w.shape)} != {shp}")
+    arrs = [(C.c_void_p * len(lst))(*[0 if t is None else t.data_ptr() for t in lst]) for lst in keep]
+    packed = torch.empty(int(lib.na_render_volsdf_siren_ls_packed_bytes(PREC[precision])), device=keep[0][0].device, dtype=torch.uint8)
+    check(lib.na_render_volsdf_siren_ls_pack(PREC[precision], arrs[0], arrs[1], arrs[2], arrs[3], _ptr(packed), _stream()))
+    return packed
+
+
+def render_volsdf_siren_ls(rays: torch.Tensor, ts: torch.Tensor, beta: torch.Tensor, packed: torch.Tensor, precision: str,
+                           sigmoid_kind: str = "thin", bg: str = "black", want_weights: bool = False,
+                           pts: Optional[torch.Tensor] = None):
+    """VolSDF (SIREN SDF network + View head) forward in one kernel: rays [..., 6], ts [T] -> (rgb, alpha, weights)."""
+    lib = _lib.load()
+    rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    beta = _f32(beta.reshape(1), "beta")
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    workspace = torch.empty(int(lib.na_render_ls_workspace_bytes(T, R)), device=rays.device, dtype=torch.uint8)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3, (pts.shape, T, R)
+    check(lib.na_render_volsdf_siren_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(beta), _ptr(packed), PREC[precision],
+                                        SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace),
+                                        workspace.numel(), _stream()))
+    return out, alpha, weights
+
+
 # ------------------------------------------------------------------------------------------------- forward-mode tangents
 def act_deriv(x: torch.Tensor, act: str, order: int = 1) -> torch.Tensor:
     lib = _lib.load()

