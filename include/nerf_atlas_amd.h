@@ -45,7 +45,7 @@ enum {
   NA_PREC_BF16 = 0,   /* bf16 operands, fp32 accumulate (1 MFMA product)            */
   NA_PREC_BF16X3 = 1, /* 2-way split bf16, 3 MFMA products, fp32-class accuracy     */
   NA_PREC_F16 = 2     /* f16 operands, fp32 accumulate (1 MFMA product, 11-bit operands);
-                         layer-synchronous renderers (na_render_ls_* / na_render_tiny_ls* / na_render_view_ls*) only */
+                         layer-synchronous renderers (na_render_*_ls) only */
 };
 /* weight-stream layouts */
 enum { NA_LAYOUT_GENERIC = 0, NA_LAYOUT_PLAIN_FIRST = 1, NA_LAYOUT_PLAIN_VIEW = 2 };
