@@ -4,7 +4,7 @@ sample groups, ~37 rays each): the same call N times, colour / alpha / weights c
 per-element median over the runs.  This is the test that exposed the timing-dependent differences of DESIGN 3b
 "reproducibility" (16 samples of one block, lanes 16..31, off by ~1e-3 relative in one run of ~20..10^4).
 
-    python tools/ls_repeat.py [bf16x3|bf16|f16] [--tiny] [N]
+    python tools/ls_repeat.py [bf16x3|bf16|f16] [--tiny | --volsdf-mlp | --volsdf-siren] [N]
     python tools/ls_repeat.py variants        # here: timing-stress builds (group lag 3 / 5 / 9, no XCD-aware order) under
                                               # gpurun_ablate/repeat_<name>/; run each with  --lib <dir>
 """
@@ -52,7 +52,18 @@ def main(argv):
     tiny = "--tiny" in argv  # the TinyNeRF schedule of the same engine
     for prec in precs:
         config.set_precision(prec)
-        if tiny:
+        volsdf = "mlp" if "--volsdf-mlp" in argv else "siren" if "--volsdf-siren" in argv else None
+        if volsdf and prec == "f16" and volsdf == "mlp":
+            continue  # (the Fourier SDF network is a generic fused MLP: no f16 instantiation)
+        if volsdf:
+            from nerf_atlas_amd import sdf as nsdf, refl
+            m = nerf.VolSDF(sdf=nsdf.SDF(nsdf.sdf_kinds[volsdf](intermediate_size=64), refl.View(latent_size=64, act="upshifted", out_features=3),
+                                         t_near=2.0, t_far=6.0), steps=128, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted").cuda().eval()
+
+            def call(m=m):
+                out = m(rays)  # SDF MLP + View-half kernel (mlp) or the one-kernel model (siren)
+                return out, m.alpha, m.weights
+        elif tiny:
             m = nerf.TinyNeRF(steps=128, t_near=2.0, t_far=6.0, sigmoid_kind="upshifted").cuda().eval()
             call = lambda: ops.render_tiny_ls(rays, ts, m.packed_ls(prec), prec, "upshifted", "black", True)
         else:
