@@ -148,3 +148,24 @@ def test_volsdf_dtu_tile_and_properties(na, kind):
     # VolSDF has no 1e10 closing interval in its density (relu path): weights sum to <= 1
     m(slab)
     assert float(m.weights.sum(0).max()) <= 1 + 1e-5
+
+
+@pytest.mark.parametrize("kind", ["mlp", "siren"])
+def test_volsdf_fused_kernels_on_awkward_shapes(na, kind):
+    """The View-half kernel (mlp) / the one-kernel model (siren) against the CPU oracle on a single ray, fewer rays than
+    sample groups and T = 1 / 5 / 33 / 130 (one step, a ragged block, one step into the second block, five blocks)."""
+    h = load_golden(f"g10_volsdf_{kind}")
+    p = golden_params(h)
+    cam, pose, K = dtu_cam(na)
+    for crop, steps in (((400, 400, 1, 1), 130), ((10, 20, 3, 5), 33), ((380, 390, 9, 7), 5), ((0, 0, 2, 2), 1)):
+        under = na.sdf.sdf_kinds[kind](intermediate_size=64)
+        r = na.refl.View(latent_size=64, act="upshifted", out_features=3)
+        m = na.nerf.VolSDF(sdf=na.sdf.SDF(under, r, isect=None, t_near=0.3, t_far=1.8), steps=steps, t_near=0.3, t_far=1.8,
+                           sigmoid_kind="upshifted").cuda().eval()
+        load_params(m, p)
+        rays = cam.sample_positions(crop, size=SIZE)
+        out = m(rays)
+        aux = {}
+        ref = O.volsdf(dict(p, scale=h["scale"]), rays.cpu(), 0.3, 1.8, steps, sdf_kind=kind, act="upshifted", aux=aux)
+        assert maxdiff(out, ref) <= 1e-4, (crop, steps)
+        assert maxdiff(m.weights, aux["weights"]) <= 2e-4 and maxdiff(m.alpha, aux["alpha"]) <= 2e-4, (crop, steps)
