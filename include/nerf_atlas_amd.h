@@ -44,8 +44,8 @@ enum { NA_ENC_NONE = 0, NA_ENC_HASH = 1, NA_ENC_FOURIER = 2 };
 enum {
   NA_PREC_BF16 = 0,   /* bf16 operands, fp32 accumulate (1 MFMA product)            */
   NA_PREC_BF16X3 = 1, /* 2-way split bf16, 3 MFMA products, fp32-class accuracy     */
-  NA_PREC_F16 = 2     /* f16 operands, fp32 accumulate (1 MFMA product, 11-bit operands);
-                         layer-synchronous renderers (na_render_*_ls) only */
+  NA_PREC_F16 = 2     /* f16 operands, fp32 accumulate (1 MFMA product, 11-bit operands): the layer-synchronous
+                         renderers (na_render_*_ls) and na_mlp_pack / na_mlp_forward; not na_render_plain_view */
 };
 /* weight-stream layouts */
 enum { NA_LAYOUT_GENERIC = 0, NA_LAYOUT_PLAIN_FIRST = 1, NA_LAYOUT_PLAIN_VIEW = 2 };

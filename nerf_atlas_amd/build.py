@@ -28,6 +28,7 @@ UNITS = [
     ("mlp_fused.hip", [], ""),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),
+    ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=2"], "_f16"),
     ("render_fused.hip", ["-DNA_PREC_INST=0"], "_bf16"),
     ("render_fused.hip", ["-DNA_PREC_INST=1"], "_bf16x3"),
     # -fno-slp-vectorize: no compiler-formed packed-fp32 (v_pk_*_f32) arithmetic in the layer-synchronous kernel.  With it

@@ -3,7 +3,8 @@
 # MLP arithmetic: "bf16x3" = 2-way split bf16 with 3 MFMA products (fp32-class accuracy, meets the
 # 1e-4 RGB parity bound); "bf16" = plain bf16 operands with fp32 accumulation (fast mode); "f16" = IEEE half operands
 # with fp32 accumulation: the fast mode's speed with 11-bit instead of 8-bit operands (L-inf 3e-4 instead of 3e-3 on the
-# bench frame) -- implemented by the layer-synchronous fused renderer only, every other kernel rejects it.
+# bench frame) -- implemented by the layer-synchronous renderers and the generic fused MLP kernels (not by the register-
+# engine renderer, `set_engine("reg")`, which rejects it).
 precision = "bf16x3"
 
 

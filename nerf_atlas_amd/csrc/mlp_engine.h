@@ -275,7 +275,7 @@ struct WeightStream {
 #ifdef NA_KSTAGE
 template <int PREC> constexpr int stage_depth() { return NA_KSTAGE; }
 #else
-template <int PREC> constexpr int stage_depth() { return PREC == NA_PREC_BF16 ? 2 : 4; }
+template <int PREC> constexpr int stage_depth() { return PREC == NA_PREC_BF16X3 ? 4 : 2; }
 #endif
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -378,7 +378,13 @@ __device__ __forceinline__ void mma_chunks(WS& ws, f32x16 (&acc)[NB], const char
               acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][c], Bf.hi, acc[b], 0, 0, 0);
               acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], Bf.lo, acc[b], 0, 0, 0);
             }
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], Bf.hi, acc[b], 0, 0, 0);
+            if constexpr (PREC == NA_PREC_F16) {
+              typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[cur][c]), __builtin_bit_cast(f16x8, Bf.hi),
+                                                              acc[b], 0, 0, 0);
+            } else {
+              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][c], Bf.hi, acc[b], 0, 0, 0);
+            }
           }
           const int m = (m0 + cc) * NB + b;
           if (m == 0) ws.mark(1);

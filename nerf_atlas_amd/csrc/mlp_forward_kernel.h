@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
               // Cody-Waite + polynomial (1.6e-7 / 5e-7 for |m| <= 3e3; the fp32 argument itself carries 6e-5 at
               // |m| = 1e3) -- libm's sinf/cosf with their large-argument path cost 30-40 % of this kernel;
               // fast mode: hardware v_sin / v_cos on the fractional revolution
-              if constexpr (PREC == NA_PREC_BF16) {
+              if constexpr (PREC != NA_PREC_BF16X3) {
                 const float rev = __builtin_amdgcn_fractf(m * 0.15915494309189535f);
                 sv[e] = __builtin_amdgcn_sinf(rev);
                 cv[e] = __builtin_amdgcn_cosf(rev);
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
             float xl;
             if constexpr (GEN != 0) {
               const bool is_gen = li < gen;
-              const float xg = chunk_gen ? mip_feature<PREC == NA_PREC_BF16>(gm0, gm1, gm2, gc0, gc1, gc2, is_gen ? li : 0,
+              const float xg = chunk_gen ? mip_feature<PREC != NA_PREC_BF16X3>(gm0, gm1, gm2, gc0, gc1, gc2, is_gen ? li : 0,
                                                                              a.mip.nd, a.mip.min_deg) : 0.f;
               // (the hash instantiation is PlainNeRF.first: its whole latent is generated, there is no stored column to load)
               if constexpr (ENC == NA_ENC_HASH) xl = xg;
@@ -237,5 +237,6 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
 
 int dispatch_forward_bf16(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s);
 int dispatch_forward_bf16x3(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s);
+int dispatch_forward_f16(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s);
 
 }  // namespace na

@@ -14,7 +14,7 @@ __device__ __forceinline__ uint16_t bf16_bits(float v) {
 
 // One launch per Linear.  W [out_dim, in_dim] fp32 (nn.Linear layout), bias [out_dim].
 __global__ void pack_layer_kernel(NaMlpDesc d, int kind, const float* __restrict__ W, const float* __restrict__ bias,
-                                  int in_dim, int out_dim, int ntile, int nfrag, int NI, int planes,
+                                  int in_dim, int out_dim, int ntile, int nfrag, int NI, int planes, int f16,
                                   char* __restrict__ dst) {
   const int tile_bytes = (nfrag * planes + 1) * 1024;
   const int64_t nelem = (int64_t)ntile * nfrag * 512;  // bf16 elements per plane
@@ -35,7 +35,7 @@ __global__ void pack_layer_kernel(NaMlpDesc d, int kind, const float* __restrict
       float w = 0.f;
       if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) w = W[(int64_t)row * in_dim + col];
       char* p = dst + (int64_t)j * tile_bytes + 1024 + (int64_t)c * planes * 1024 + l * 16 + e * 2;
-      __bf16 h = (__bf16)w;
+      __bf16 h = f16 ? to_elem<NA_PREC_F16>(w) : (__bf16)w;
       *(uint16_t*)p = __builtin_bit_cast(uint16_t, h);
       if (planes == 2) *(uint16_t*)(p + 1024) = bf16_bits(w - (float)h);
     } else {
@@ -69,7 +69,7 @@ using namespace na;
 extern "C" {
 
 size_t na_mlp_packed_bytes(const NaMlpDesc* desc, int precision) {
-  if (desc == nullptr || (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3)) return 0;
+  if (desc == nullptr || (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16)) return 0;
   if (mlp_unsupported_reason(*desc) != nullptr) return 0;
   uint32_t blocks = 0;
   if (build_tiles(*desc, precision, nullptr, &blocks) < 0) return 0;
@@ -79,8 +79,8 @@ size_t na_mlp_packed_bytes(const NaMlpDesc* desc, int precision) {
 int na_mlp_pack(const NaMlpDesc* desc, int precision, const float* const* weights, const float* const* biases,
                 void* packed, void* stream) {
   NA_REQUIRE(desc && weights && biases && packed, NA_ENULL, "na_mlp_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_mlp_pack: precision %d",
-             precision);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_mlp_pack: precision %d", precision);
   const char* why = mlp_unsupported_reason(*desc);
   NA_REQUIRE(why == nullptr, NA_EUNSUPPORTED, "na_mlp_pack: %s", why);
   const NaMlpDesc& d = *desc;
@@ -101,7 +101,7 @@ int na_mlp_pack(const NaMlpDesc* desc, int precision, const float* const* weight
   auto launch = [&](int kind, const float* W, const float* b, int in_dim, int out_dim, int ntile, int nfrag) {
     int64_t total = (int64_t)ntile * nfrag * 512 + (int64_t)ntile * 256;
     hipLaunchKernelGGL(pack_layer_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, d, kind, W,
-                       b, in_dim, out_dim, ntile, nfrag, NI, P, dst);
+                       b, in_dim, out_dim, ntile, nfrag, NI, P, precision == NA_PREC_F16 ? 1 : 0, dst);
     dst += (size_t)ntile * (nfrag * P + 1) * 1024;
   };
   launch(LK_INIT, weights[0], biases[0], dim_p, kHidden, 8, NI);
@@ -143,8 +143,8 @@ int na_mlp_forward_mip(const NaMlpDesc* desc, int precision, const void* packed,
   NA_REQUIRE(p_ld >= desc->in_size && (desc->latent_size == gen || latent_ld >= desc->latent_size - gen), NA_EINVAL,
              "na_mlp_forward: row pitch smaller than the row (p_ld=%lld, latent_ld=%lld)", (long long)p_ld,
              (long long)latent_ld);
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_mlp_forward: precision %d",
-             precision);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+             "na_mlp_forward: precision %d", precision);
   const char* why = mlp_unsupported_reason(*desc);
   NA_REQUIRE(why == nullptr, NA_EUNSUPPORTED, "na_mlp_forward: %s", why);
   NA_REQUIRE(desc->layout == NA_LAYOUT_GENERIC, NA_EUNSUPPORTED,
@@ -171,6 +171,7 @@ int na_mlp_forward_mip(const NaMlpDesc* desc, int precision, const void* packed,
   const int NI = effective_ni(*desc);
   a.buf_bytes = (uint32_t)((kHC + NI) * planes_of(precision) + 1) * 1024;
   if (precision == NA_PREC_BF16) return dispatch_forward_bf16(a, tab, NI, (hipStream_t)stream);
+  if (precision == NA_PREC_F16) return dispatch_forward_f16(a, tab, NI, (hipStream_t)stream);
   return dispatch_forward_bf16x3(a, tab, NI, (hipStream_t)stream);
 }
 

@@ -4,7 +4,7 @@
 #include "mlp_forward_kernel.h"
 
 #ifndef NA_PREC_INST
-#error "compile with -DNA_PREC_INST=0 (bf16) or 1 (bf16x3)"
+#error "compile with -DNA_PREC_INST=0 (bf16), 1 (bf16x3) or 2 (f16)"
 #endif
 
 namespace na {
@@ -72,9 +72,13 @@ static int dispatch_forward(MlpArgs& a, const TileTab& tab, int NI, hipStream_t 
 int dispatch_forward_bf16(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s) {
   return dispatch_forward<NA_PREC_BF16>(a, tab, NI, s);
 }
-#else
+#elif NA_PREC_INST == 1
 int dispatch_forward_bf16x3(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s) {
   return dispatch_forward<NA_PREC_BF16X3>(a, tab, NI, s);
+}
+#else
+int dispatch_forward_f16(MlpArgs& a, const TileTab& tab, int NI, hipStream_t s) {
+  return dispatch_forward<NA_PREC_F16>(a, tab, NI, s);
 }
 #endif
 

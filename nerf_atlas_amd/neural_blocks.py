@@ -15,10 +15,6 @@ from . import autograd as ag
 from . import config, ops, utils
 
 
-def _lib_error(msg):
-    from ._lib import NaError
-    return NaError(-3, msg)
-
 
 class PositionalEncoder(nn.Module):
     """src/neural_blocks.py:14-34."""
@@ -219,10 +215,6 @@ class SkipConnMLP(nn.Module):
     def packed(self, precision: str, layout: str = "generic"):
         """Packed MFMA weight stream (cached; re-packed when any parameter changed), or None if this shape has
         no fused kernel."""
-        if precision == "f16":
-            # (not a silent fall-through to the exact-fp32 per-layer path, which is 20x slower)
-            raise _lib_error("precision f16 exists for the layer-synchronous fused PlainNeRF(view) renderer only; "
-                             "this SkipConnMLP runs in bf16 or bf16x3")
         desc = self.desc(layout)
         if desc is None or ops.mlp_packed_bytes(desc, precision) == 0:
             return None, None

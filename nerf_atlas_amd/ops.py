@@ -14,7 +14,7 @@ from ._lib import NaMlpDesc, check
 
 ACT = {"none": 0, "leaky_relu": 1, "sin": 2}
 ENC = {"none": 0, "hash": 1, "fourier": 2}
-PREC = {"bf16": 0, "bf16x3": 1, "f16": 2}  # f16: na_render_ls_pack / na_render_plain_view_ls only
+PREC = {"bf16": 0, "bf16x3": 1, "f16": 2}  # (f16: everything but the register-engine renderer na_render_plain_view)
 LAYOUT = {"generic": 0, "plain_first": 1, "plain_view": 2}
 BG = {"black": 0, "white": 1}
 SIGMOID = {"normal": 0, "thin": 1, "fat": 2, "tanh": 3, "upshifted": 4, "relu": 5, "sin": 6, "leaky_relu": 7,
@@ -524,8 +524,6 @@ def mlp_pack(desc: NaMlpDesc, precision: str, weights: Sequence[torch.Tensor],
              biases: Sequence[torch.Tensor]) -> torch.Tensor:
     """weights/biases in the order init, layers[0..L-1], out (nn.Linear layout).  Returns the packed stream."""
     lib = _lib.load()
-    if precision == "f16":
-        raise _lib.NaError(-3, "precision f16 exists for the layer-synchronous fused renderer only (render_ls_pack)")
     nbytes = mlp_packed_bytes(desc, precision)
     if nbytes == 0:
         raise _lib.NaError(-3, "this SkipConnMLP shape has no MFMA kernel (use linear_f32 per layer)")

@@ -181,14 +181,16 @@ def test_ls_rays_straddle_passes_in_both_precisions(ops, T):
             assert float((cw - aw).abs().max()) <= 2e-3 and float((cw.sum(0) - 1).abs().max()) <= 1e-5
 
 
-def test_f16_is_rejected_outside_the_ls_renderer(ops):
-    """NA_PREC_F16 exists for na_render_ls_pack / na_render_plain_view_ls only: the generic packers and the register
-    engine fail loudly instead of running another precision."""
+def test_f16_is_rejected_by_the_register_engine(ops):
+    """NA_PREC_F16 is implemented by the layer-synchronous renderers and the generic fused MLP kernels; the register-engine
+    renderer (na_render_plain_view) fails loudly instead of running another precision."""
     from test_gpu_render import pack_plain
     h = load_golden("g11_plain_view_b1")
     p = golden_params(h)
+    pf, pv, tables = pack_plain(ops, p, "bf16")
+    ts, _ = ops.compute_ts(2.0, 6.0, 16, "cuda")
     with pytest.raises(Exception, match="precision"):
-        pack_plain(ops, p, "f16")
+        ops.render_plain_view(h["rays"].cuda(), ts, tables, pf, pv, "f16", "upshifted", "black")
 
 
 def test_tiny_ls_edge_shapes_pts_mode_and_repeatability(ops):

@@ -103,19 +103,19 @@ def main():
     }
     M = min(N, 8 * 1024 * 1024)
     x = flat[:M].contiguous()
-    for prec in ("bf16", "bf16x3"):
+    for prec in ("bf16", "f16", "bf16x3"):
         config.set_precision(prec)
         for name, (kw, _, flop) in mlps.items():
             m = nb.SkipConnMLP(**kw).to(dev)
             with torch.no_grad():
                 dt = timed(lambda: m(x), iters=10)
             fl = M * flop / dt
-            peak = 2.5e15 if prec == "bf16" else 2.5e15 / 3
+            peak = 2.5e15 / 3 if prec == "bf16x3" else 2.5e15
             rows.append(dict(kernel=f"mlp_forward {name} [{prec}]", units=M, unit="samples", us=round(dt * 1e6, 1),
                              Msamples_per_s=round(M / dt / 1e6, 1), TFLOPs=round(fl / 1e12, 1),
                              frac_of_mfma_peak=round(fl / peak, 3)))
             print(f"mlp {name:30s} [{prec:6s}] {dt * 1e6:9.1f} us  {M / dt / 1e6:8.1f} Msamples/s  {fl / 1e12:7.1f} TFLOP/s "
-                  f"({fl / peak:5.1%} of {'bf16' if prec == 'bf16' else 'bf16/3'} peak)")
+                  f"({fl / peak:5.1%} of {'bf16/3' if prec == 'bf16x3' else 'bf16'} peak)")
     # whole models of the other BASELINE configs on one tile (operator chains except PlainNeRF(view) and TinyNeRF)
     import nerf_atlas_amd.nerf as nerf
     import nerf_atlas_amd.refl as refl
@@ -145,7 +145,7 @@ def main():
         "5 VolSDF mlp": (lambda: volsdf("mlp"), 1814016, False),
         "5 VolSDF siren": (lambda: volsdf("siren"), 1289728, False),
     }
-    for prec in ("bf16", "bf16x3"):
+    for prec in ("bf16", "f16", "bf16x3"):
         config.set_precision(prec)
         for name, (cons, flop, dyn) in models.items():
             try:
@@ -157,7 +157,7 @@ def main():
                 print(f"model {name}: {type(e).__name__}: {e}")
                 continue
             n = Rm * T
-            peak = 2.5e15 if prec == "bf16" else 2.5e15 / 3
+            peak = 2.5e15 / 3 if prec == "bf16x3" else 2.5e15
             rows.append(dict(kernel=f"model {name} [{prec}]", units=n, unit="samples", us=round(dt * 1e6, 1),
                              Msamples_per_s=round(n / dt / 1e6, 1), frac_of_mfma_peak=round(n * flop / dt / peak, 3)))
             print(f"model {name:30s} [{prec:6s}] {dt * 1e3:8.2f} ms  {n / dt / 1e6:8.1f} Msamples/s  ({n * flop / dt / peak:5.1%} of peak)")

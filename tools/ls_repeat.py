@@ -53,8 +53,6 @@ def main(argv):
     for prec in precs:
         config.set_precision(prec)
         volsdf = "mlp" if "--volsdf-mlp" in argv else "siren" if "--volsdf-siren" in argv else None
-        if volsdf and prec == "f16" and volsdf == "mlp":
-            continue  # (the Fourier SDF network is a generic fused MLP: no f16 instantiation)
         if volsdf:
             from nerf_atlas_amd import sdf as nsdf, refl
             m = nerf.VolSDF(sdf=nsdf.SDF(nsdf.sdf_kinds[volsdf](intermediate_size=64), refl.View(latent_size=64, act="upshifted", out_features=3),
