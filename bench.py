@@ -5,6 +5,7 @@
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no torchrun environment: spawns the N ranks itself (127.0.0.1, a free port)
 
 A step = ray generation -> fused sample/hash/MLP/MLP/composite kernel -> finalize, for this rank's row band of
 the frame, plus ONE RCCL gather of the finished RGB band to rank 0 (strong scaling: the frame is fixed, rays shard).
@@ -36,6 +37,7 @@ SIZE, STEPS_PER_RAY, FOV, NEAR, FAR = 800, 128, 0.6911, 2.0, 6.0
 # command (separate passes, KiB units, FETCH doubled for gfx950 per MI355X_MICROARCH.md "HBM"); profiles/r02/pmc_*.json.
 # None = not measured for that (engine, precision).
 HBM_TRAFFIC_FULL_FRAME = {("reg", "bf16"): int((2 * 51177 + 80000) * 1024)}
+TRAFFIC_SOURCE = "profiles/r02/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this command, separate passes)"
 try:
     with open(os.path.join(REPO, "profiles", "r02", "hbm_traffic.json")) as _f:
         for _k, _v in json.load(_f).items():
@@ -94,6 +96,101 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
                       f"torch-CPU fp32 oracle on {best} threads"}, out, rays
 
 
+OTHER_SLAB = (300, 0, 200, SIZE)   # rows 300..499 of the 800-wide frame: 160 000 rays x 128 = 20.48 M samples
+
+
+def other_configs(dev, precisions=("bf16x3", "bf16"), iters=2):
+    """BASELINE configs 1, 3, 4 and 5 (both SDF networks) through the model layer on a fixed 200 x 800 x 128 slab: whole
+    forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
+    calls per (config, precision).  FLOP/sample = sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same
+    numbers); `frac` is against the dense bf16 MFMA peak for every precision."""
+    import types
+    import nerf_atlas_amd.nerf as nerf
+    import nerf_atlas_amd.refl as refl
+    import nerf_atlas_amd.sdf as sdf
+    from nerf_atlas_amd import config, ops
+    from nerf_atlas_amd.utils import load_mip
+    T = STEPS_PER_RAY
+    focal = 0.5 * SIZE / math.tan(0.5 * FOV)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]], device=dev)
+    rays = ops.raygen(c2w, focal, SIZE, OTHER_SLAB)
+    n = OTHER_SLAB[2] * OTHER_SLAB[3] * T
+    common = dict(steps=T, t_near=NEAR, t_far=FAR, sigmoid_kind="upshifted")
+
+    def volsdf(kind):
+        r = refl.View(latent_size=64, act="upshifted", out_features=3)
+        return nerf.VolSDF(sdf=sdf.SDF(sdf.sdf_kinds[kind](intermediate_size=64), r, isect=None, t_near=0.3, t_far=1.8),
+                           steps=T, t_near=0.3, t_far=1.8, sigmoid_kind="upshifted")
+    models = [
+        ("1 TinyNeRF", lambda: nerf.TinyNeRF(**common), 793088, False),
+        ("3 PlainNeRF + mip (cylinder IPE)", lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False),
+        ("4 D-NeRF (spline 6) at t = 0.5", lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True),
+        ("5 VolSDF, Fourier-MLP SDF", lambda: volsdf("mlp"), 1814016, False),
+        ("5 VolSDF, SIREN SDF", lambda: volsdf("siren"), 1289728, False),
+    ]
+    rows = []
+    keep = config.precision
+    t_all = time.perf_counter()
+    for name, cons, flop, dyn in models:
+        torch.manual_seed(2)
+        try:
+            m = cons().to(dev).eval()
+        except Exception as e:  # noqa: BLE001
+            rows.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            continue
+        inp = (rays, torch.tensor([0.5], device=dev)) if dyn else rays
+        for prec in precisions:
+            try:
+                config.set_precision(prec)
+                with torch.no_grad():
+                    m(inp)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        m(inp)
+                    e1.record()
+                    torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / iters
+                rows.append({"config": name, "workload": f"{OTHER_SLAB[2]}x{OTHER_SLAB[3]} slab x {T} samples/ray ({n} samples)",
+                             "dtype": prec, "Msamples_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 3),
+                             "flop_per_sample": flop, "frac": round(n * flop / (ms * 1e-3) / PEAK_BF16, 4)})
+            except Exception as e:  # noqa: BLE001
+                rows.append({"config": name, "dtype": prec, "error": f"{type(e).__name__}: {e}"})
+        del m
+    config.set_precision(keep)
+    return rows, round(time.perf_counter() - t_all, 2)
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set like torch.distributed.run does), rank 0 inherits stdout and prints the one JSON
+    line.  A rank that fails takes the others down (by PID) and its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NA_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    while procs:
+        for p in list(procs):
+            c = p.poll()
+            if c is None:
+                continue
+            procs.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in procs:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,17 +201,28 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3", "f16"])
     ap.add_argument("--engine", default=None, choices=["ls", "reg"], help="fused renderer engine (default: config.engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the slab timings of BASELINE configs 1, 3, 4, 5")
     args = ap.parse_args()
+    if args.engine == "reg" and args.precision == "f16":
+        ap.error("--precision f16 exists on the layer-synchronous engine only (--engine ls)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))
 
     from nerf_atlas_amd import config, ops, dist as nd
     import torch.distributed as dist
     rank, world, local = nd.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or without any torchrun environment (bench.py then spawns its ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     # NA_DIST_BACKEND=gloo lets several ranks share one GPU (flow test on a 1-GPU box); normally one rank per GPU
     ndev = torch.cuda.device_count()
-    local = local % ndev if os.environ.get("NA_DIST_BACKEND") == "gloo" else local
+    if os.environ.get("NA_DIST_BACKEND") == "gloo":
+        local = local % ndev
+    elif local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {ndev} are visible (one rank per GPU; "
+                         f"NA_DIST_BACKEND=gloo shares one GPU between ranks for flow tests)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.engine is not None:
@@ -147,6 +255,7 @@ def main():
         torch.cuda.synchronize()
 
     red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    gather = nd.BandGather(SIZE, 3, rank, world, dev)  # receive / send buffers of the frame gather, allocated once
 
     def rmax(x):
         t = torch.tensor([x], device=red_dev, dtype=torch.float64)
@@ -164,7 +273,7 @@ def main():
             if i is not None: ev[i][0].record()
             out = render(rays)
             if i is not None: ev[i][1].record()
-            frame = nd.gather_bands(out.reshape(nrows, SIZE, 3), SIZE, rank, world)
+            frame = gather(out.reshape(nrows, SIZE, 3))
             if i is not None: ev[i][2].record()
             return frame
         for _ in range(warmup):
@@ -193,10 +302,14 @@ def main():
                 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE
                 # doubled per MI355X_MICROARCH.md "HBM"); None when the shard differs from the profiled full frame
                 "traffic": HBM_TRAFFIC_FULL_FRAME.get((engine, prec)) if world == 1 else None,
-                "traffic_unit": "bytes/launch"}
+                "traffic_unit": "bytes/launch",
+                # NOT measured by this run: the PMC passes need rocprofv3 around the process
+                "traffic_source": TRAFFIC_SOURCE if (world == 1 and (engine, prec) in HBM_TRAFFIC_FULL_FRAME) else None}
 
     prec = args.precision
     dt, kern_ms, gath_ms, per_rank, frame = timed(prec, args.steps, args.warmup)
+    # (now: with N > 1 `frame` is the gather's persistent receive buffer, which the next timed() call overwrites)
+    checksum = round(float(frame.double().sum()), 3) if frame is not None else None
     other = "bf16x3" if prec == "bf16" else "bf16"
     dt2, kern2_ms, _, _, _ = timed(other, args.steps, 1)
     # third line: the f16-operand mode of the layer-synchronous engine (the fast mode's speed class, 11-bit operands)
@@ -219,8 +332,8 @@ def main():
             "roofline": roofline(prec, kern_ms),
             "per_rank_kernel_ms": [round(x, 3) for x in per_rank], "gather_ms": round(gath_ms, 3),
         }
-        if frame is not None:
-            res["config"]["frame_checksum"] = round(float(frame.double().sum()), 3)
+        if checksum is not None:
+            res["config"]["frame_checksum"] = checksum
         res["other_precision"] = {"precision": other, "dtype": DTYPE_NAME[other], "value": round(samples * args.steps / dt2 / 1e6, 2),
                                   "unit": "Msamples/s", "steps": args.steps, "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                                   "roofline": roofline(other, kern2_ms)}
@@ -228,6 +341,8 @@ def main():
             res["f16_precision"] = {"precision": third, "dtype": DTYPE_NAME[third], "value": round(samples * args.steps / dt3 / 1e6, 2),
                                     "unit": "Msamples/s", "steps": args.steps, "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                                     "roofline": roofline(third, kern3_ms)}
+        if world == 1 and not args.no_other_configs:
+            res["other_configs"], res["other_configs_s"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, rays_cpu = cpu_baseline(model)
             res["cpu_baseline"] = cb

@@ -47,7 +47,11 @@ _det_ws = None
 
 
 def set_deterministic(on: bool, device="cuda"):
-    """Process-wide.  Keeps a 16-MiB device workspace alive while on."""
+    """Process-wide.  Keeps a 16-MiB device workspace alive while on.  Limits (csrc/common.h): addends are quantised to
+    2^-40 (anything below 4.5e-13 vanishes), the int64 sum holds |sum| < 8.4e6; addends of 2^20 and more and non-finite ones
+    bypass the accumulator (plain fp32 atomics), so a diverged step still reads Inf / NaN.  The workspace is bound to
+    `device`: deterministic entry points called with another current device raise, and they must not run concurrently on
+    several streams."""
     global _det_ws
     import torch
     from . import _lib

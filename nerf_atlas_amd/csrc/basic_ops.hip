@@ -10,6 +10,7 @@ namespace na {
 static thread_local char g_err[512] = "";
 
 static DetWs g_det = {nullptr, 0};  // process-wide: autograd runs backward kernels on its own threads
+static int g_det_device = -1;        // device the workspace lives on
 DetWs det_workspace() { return g_det; }
 
 __global__ void det_fold_kernel(const long long* __restrict__ fix, int64_t n, float* __restrict__ out) {
@@ -23,6 +24,13 @@ __global__ void det_fold_kernel(const long long* __restrict__ fix, int64_t n, fl
 long long* det_begin(size_t n, hipStream_t stream, const char* who, int* rc) {
   *rc = NA_OK;
   if (g_det.ptr == nullptr) return nullptr;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != g_det_device) {
+    set_error("%s: the deterministic workspace lives on device %d, the current device is %d (na_set_deterministic)", who,
+              g_det_device, dev);
+    *rc = NA_EINVAL;
+    return nullptr;
+  }
   if (g_det.bytes < n * sizeof(long long)) {
     set_error("%s: deterministic workspace %zu < %zu bytes (na_set_deterministic)", who, g_det.bytes, n * sizeof(long long));
     *rc = NA_EWORKSPACE;
@@ -427,7 +435,15 @@ int na_version(void) { return NA_VERSION; }
 int na_set_deterministic(void* workspace, size_t bytes) {
   NA_REQUIRE(workspace == nullptr || ((uintptr_t)workspace % 8 == 0 && bytes >= 8), NA_EINVAL,
              "na_set_deterministic: workspace must be 8-byte aligned");
+  int dev = -1;
+  if (workspace != nullptr) {
+    hipPointerAttribute_t attr;
+    NA_REQUIRE(hipPointerGetAttributes(&attr, workspace) == hipSuccess && attr.type == hipMemoryTypeDevice, NA_EINVAL,
+               "na_set_deterministic: workspace is not device memory");
+    dev = attr.device;
+  }
   na::g_det = {(long long*)workspace, workspace ? bytes : 0};
+  na::g_det_device = dev;
   return NA_OK;
 }
 const char* na_last_error(void) { return na::g_err; }

@@ -35,9 +35,17 @@ inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
 }
 
 // Deterministic accumulation (na_set_deterministic): gradients that are summed across workgroups go through 64-bit
-// FIXED-POINT atomics (2^-40 resolution, +-8.4e6 range) instead of fp32 atomics: integer addition is associative, so
-// the result is bitwise independent of the order in which workgroups arrive.  The int64 accumulator lives in a caller
-// workspace that the entry point zeroes, fills and folds into the fp32 output (det_begin / det_finish).
+// FIXED-POINT atomics instead of fp32 atomics: integer addition is associative, so the result is bitwise independent of
+// the order in which workgroups arrive.  The int64 accumulator lives in a caller workspace that the entry point zeroes,
+// fills and folds into the fp32 output (det_begin / det_finish).
+//   resolution  2^-40 (9.1e-13) per addend: addends below 4.5e-13 in magnitude vanish (fp32 atomics keep ~6e-8 RELATIVE; the
+//               1e-4-scale hash-table gradients of a fresh model sit 8 decades above the step, Adam's scale invariance does
+//               not reach below it);
+//   range       |sum| < 2^23 (8.4e6) before the int64 wraps; addends of 2^20 and more, and every non-finite addend, bypass
+//               the accumulator and go to the fp32 output with a plain atomic (order-dependent rounding for those, but a
+//               diverged step still shows up as Inf / NaN instead of as finite garbage from __float2ll_rn);
+//   scope       ONE workspace per process, bound to the device it was allocated on (det_begin refuses another current
+//               device); the entry points that use it must not run concurrently on several streams.
 constexpr float kFixScale = 1099511627776.0f;  // 2^40
 struct DetWs { long long* ptr; size_t bytes; };
 DetWs det_workspace();  // {nullptr, 0} when the deterministic mode is off (basic_ops.hip)
@@ -52,7 +60,8 @@ HashRes hash_resolutions();
 // ---- device helpers ---------------------------------------------------------------------------
 // out[idx] += v: fp32 atomic (fast, order-dependent rounding) or fixed-point atomic (deterministic)
 __device__ __forceinline__ void accumulate(float* out, long long* fix, int64_t idx, float v) {
-  if (fix != nullptr) atomicAdd((unsigned long long*)(fix + idx), (unsigned long long)__float2ll_rn(v * kFixScale));
+  // (!(|v| < 2^20) is true for NaN as well)
+  if (fix != nullptr && fabsf(v) < 1048576.0f) atomicAdd((unsigned long long*)(fix + idx), (unsigned long long)__float2ll_rn(v * kFixScale));
   else atomicAdd(out + idx, v);
 }
 

@@ -79,7 +79,9 @@ template <int ACT, int PREC = NA_PREC_BF16X3>
 __device__ __forceinline__ float act_apply(float v) {
   // leaky_relu(v) = max(v, 0.01 v) = median(v, 0.01 v, +big): v_med3_f32 needs no canonicalising v_max
   if constexpr ((NA_ABLATE & 2) != 0) return v;
-  if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, 3.0e38f);
+  // (f16 operands: the upper bound doubles as the clamp to the largest finite half, so a large pre-activation becomes 65504
+  // instead of +inf -> NaN downstream; the negative side is safe down to v = -6.5e6)
+  if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, PREC == NA_PREC_F16 ? 65504.0f : 3.0e38f);
   else if constexpr (ACT == NA_ACT_SIN) return PREC == NA_PREC_BF16X3 ? sin_hw2(v) : sin_hw(v);
   else return v;
 }
@@ -87,10 +89,15 @@ __device__ __forceinline__ float act_apply(float v) {
 // ------------------------------------------------------------------------------------------------ fragments
 // One 16-bit operand element.  NA_PREC_F16 keeps IEEE half values in the same 16-byte containers (bit patterns in
 // bf16x8); only these two conversions, the element pair packing of the epilogue and the MFMA builtin differ.
-template <int PREC>
+// CLAMP: values beyond the half range saturate at +-65504 instead of becoming +-inf (NaN after a sine or 0 * inf); bf16 has
+// fp32's range and needs nothing.  The hidden-layer epilogues pass CLAMP = false: their activations bound the value already
+// (sine; LeakyReLU through the med3 above).
+template <int PREC, bool CLAMP = true>
 __device__ __forceinline__ __bf16 to_elem(float v) {
-  if constexpr (PREC == NA_PREC_F16) return __builtin_bit_cast(__bf16, (_Float16)v);
-  else return (__bf16)v;
+  if constexpr (PREC == NA_PREC_F16) {
+    if constexpr (CLAMP) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    return __builtin_bit_cast(__bf16, (_Float16)v);
+  } else return (__bf16)v;
 }
 template <int PREC>
 __device__ __forceinline__ float from_elem(__bf16 h) {
@@ -281,11 +288,11 @@ template <int PREC> constexpr int stage_depth() { return PREC == NA_PREC_BF16X3 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-template <int PREC = NA_PREC_BF16>
+template <int PREC = NA_PREC_BF16, bool CLAMP = true>
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   bf16x2 v;
-  v[0] = to_elem<PREC>(a);
-  v[1] = to_elem<PREC>(b);
+  v[0] = to_elem<PREC, CLAMP>(a);
+  v[1] = to_elem<PREC, CLAMP>(b);
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
@@ -304,7 +311,7 @@ struct Epilogue {
     const int b = u >> 3, d = u & 7;
     const float x = act_apply<ACT, PREC>(acc[b][2 * d]);
     const float y = act_apply<ACT, PREC>(acc[b][2 * d + 1]);
-    hi[b][d] = pack_bf16x2<PREC>(x, y);
+    hi[b][d] = pack_bf16x2<PREC, ACT == NA_ACT_NONE>(x, y);
     // the volatile asm orders this dword with the surrounding scheduling fences, i.e. keeps its VALU work
     // between the two MFMAs it was written between (pure VALU would otherwise sink to the end of the tile)
     asm volatile("" : "+v"(hi[b][d]));

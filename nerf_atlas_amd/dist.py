@@ -40,23 +40,65 @@ def shard_tiles(tiles: list, rank: int, world: int) -> list:
     return tiles[rank::world]
 
 
+class BandGather:
+    """The frame-reassembly collective with its buffers allocated ONCE: a persistent `[world, tall, size, C]` receive
+    tensor on `dst` (the frame itself when all bands have the same height: no concatenation) and, only when bands differ
+    by a row, a padded send buffer.  One `dist.gather` per frame (RCCL over xGMI with backend "nccl"; with "gloo" and CUDA
+    tensors -- several ranks on one GPU, a debug mode -- the band goes through a persistent host buffer)."""
+
+    def __init__(self, size: int, channels: int, rank: int, world: int, device, dtype=torch.float32, dst: int = 0):
+        self.size, self.rank, self.world, self.dst = size, rank, world, dst
+        self.bands = row_bands(size, world)
+        self.tall = max(n for _, n in self.bands)
+        self.even = all(n == self.tall for _, n in self.bands)
+        self.device = torch.device(device)
+        self.via_host = world > 1 and dist.get_backend() == "gloo" and self.device.type == "cuda"
+        cdev = torch.device("cpu") if self.via_host else self.device
+        self.nrows = self.bands[rank][1]
+        self.send = None if (self.even and not self.via_host) else torch.zeros(self.tall, size, channels, device=cdev, dtype=dtype)
+        self.recv = torch.empty(world, self.tall, size, channels, device=cdev, dtype=dtype) if rank == dst else None
+        self.recv_list = list(self.recv.unbind(0)) if rank == dst else None
+        self.frame = torch.empty(size, size, channels, device=self.device, dtype=dtype) if (rank == dst and (self.via_host or not self.even)) else None
+
+    def __call__(self, local: torch.Tensor) -> Optional[torch.Tensor]:
+        if self.world == 1:
+            return local
+        assert local.shape[0] == self.nrows, (local.shape, self.nrows)
+        if self.send is None:
+            send = local.contiguous()
+        else:
+            self.send[: self.nrows].copy_(local)
+            send = self.send
+        dist.gather(send, self.recv_list, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        if self.even:
+            full = self.recv.view(self.world * self.tall, self.size, -1)
+            if self.frame is None:
+                return full
+            self.frame.copy_(full)
+            return self.frame
+        r0 = 0
+        for o, (_, n) in zip(self.recv_list, self.bands):
+            self.frame[r0:r0 + n].copy_(o[:n])
+            r0 += n
+        return self.frame
+
+
+_band_plans = {}
+
+
 def gather_bands(local: torch.Tensor, size: int, rank: int, world: int, dst: int = 0) -> Optional[torch.Tensor]:
     """local: [nrows_rank, size, C] band of this rank.  Returns the [size,size,C] frame on `dst`, None elsewhere.
-    Bands may differ by one row, so they are padded to the tallest band for the collective."""
+    Bands may differ by one row; the buffers of the collective are allocated on the first call and reused (`BandGather`).
+    The returned frame is that persistent buffer: clone it to keep it across calls."""
     if world == 1:
         return local
-    bands = row_bands(size, world)
-    tall = max(n for _, n in bands)
-    dev = local.device
-    if dist.get_backend() == "gloo" and local.is_cuda:
-        local = local.cpu()  # debug mode (several ranks on one GPU): gloo gathers through host memory
-    pad = torch.zeros(tall, size, local.shape[-1], device=local.device, dtype=local.dtype)
-    pad[: local.shape[0]] = local
-    outs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, outs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([o[:n] for o, (_, n) in zip(outs, bands)], dim=0).to(dev)
+    key = (size, local.shape[-1], rank, world, str(local.device), local.dtype, dst, dist.get_backend())
+    plan = _band_plans.get(key)
+    if plan is None:
+        plan = _band_plans[key] = BandGather(size, local.shape[-1], rank, world, local.device, local.dtype, dst)
+    return plan(local)
 
 
 def merge_tile_frames(frame: torch.Tensor, rank: int, world: int, dst: int = 0) -> Optional[torch.Tensor]:

@@ -22,11 +22,19 @@ def summary(name, psnrs, training=False):
             f"\tmax {max(psnrs):.03f}\n\tvar {np.var(psnrs):.03f}")
 
 
-def load_state(path):
-    """--load: a state_dict written by --save here, or a reference checkpoint (runner.py:1141-1166 pickles the whole
-    module with torch.save(model, path): anything exposing .state_dict() is accepted; parameter names are the
-    reference's, so its tensors load into this package's modules unchanged)."""
-    obj = torch.load(path, map_location="cpu", weights_only=False)
+def load_state(path, allow_pickled_module=False):
+    """--load: a state_dict written by --save here (tensors only: loaded with weights_only=True, which executes no pickled
+    code), or -- only with --load-pickled-module -- a reference checkpoint (runner.py:1141-1166 pickles the whole module with
+    torch.save(model, path); unpickling it runs arbitrary code from the file, so it must be a file you trust).  Anything
+    exposing .state_dict() is accepted; parameter names are the reference's, so its tensors load into this package's modules
+    unchanged."""
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:  # noqa: BLE001  (pickle.UnpicklingError and friends: not a plain tensor dict)
+        if not allow_pickled_module:
+            raise ValueError(f"{path} is not a plain state_dict ({type(e).__name__}: {str(e)[:120]}); a checkpoint that pickles "
+                             f"a whole module executes code from the file when loaded: pass --load-pickled-module to accept it") from e
+        obj = torch.load(path, map_location="cpu", weights_only=False)
     if hasattr(obj, "state_dict"):
         obj = obj.state_dict()
     if not isinstance(obj, dict):
@@ -36,15 +44,16 @@ def load_state(path):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    outdir, save, load, keep = "outputs/", None, None, []
+    outdir, save, load, keep, pickled = "outputs/", None, None, [], False
     it = iter(argv)
     for a in it:  # flags owned by this wrapper
         if a == "--outdir": outdir = next(it)
         elif a == "--save": save = next(it)
         elif a == "--load": load = next(it)
+        elif a == "--load-pickled-module": pickled = True
         else: keep.append(a)
     args = T.args_from_argv(keep)
-    state = load_state(load) if load else None
+    state = load_state(load, pickled) if load else None
     quiet = args.quiet
 
     def on_iter(i, l2):
@@ -56,8 +65,11 @@ def main(argv=None):
             missing, unexpected = model.load_state_dict(state, strict=False)
             if unexpected:
                 raise ValueError(f"--load: parameters of another architecture: {sorted(unexpected)[:4]} ...")
-            if missing and not quiet:
-                print(f"--load: {len(missing)} parameters keep their initial values", flush=True)
+            if missing:  # always reported: a silently half-loaded model trains / renders from random weights
+                print(f"--load: {len(missing)} parameters are not in the checkpoint and keep their initial values: "
+                      f"{sorted(missing)[:6]}{' ...' if len(missing) > 6 else ''}", file=sys.stderr, flush=True)
+            from .utils import invalidate_packed
+            invalidate_packed(model)
     res = T.fit(args, on_iter=on_iter, init=init)
     if res["rank"] != 0:
         return res

@@ -165,14 +165,16 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
         train_choices = list(train_choices) + [0] * args.higher_end_chance + [labels.shape[0] - 1] * args.higher_end_chance
     next_idxs = (lambda i: [i % len(cam)] * batch_size) if args.serial_idxs else (lambda _: random.sample(train_choices, batch_size))
 
+    if world > 1 and batch_size % world != 0:
+        # equal shards: the mean of the per-replica mean losses is then the single-process batch loss
+        raise ValueError(f"--batch-size {batch_size} must be a multiple of the {world} training replicas "
+                         f"(every replica renders batch_size / world views per step)")
     losses = []
     model.train()
     opt.zero_grad()
     for i in range(args.epochs):
         idxs = next_idxs(i)
         if world > 1:
-            # equal shards: the mean of the per-replica mean losses is then the single-process batch loss
-            assert len(idxs) % world == 0, f"batch_size {len(idxs)} must be a multiple of the {world} replicas"
             idxs = na_dist.shard_batch(idxs, rank, world)
         ts = None if times is None else times[idxs]
         c0, c1, c2, c3 = crop = get_crop()

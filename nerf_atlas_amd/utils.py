@@ -143,3 +143,22 @@ def set_random_source(src):
 
 def rand(shape, device): return random_source.rand(tuple(shape), device)
 def randn(shape, device): return random_source.randn(tuple(shape), device)
+
+
+PACK_CACHE_ATTRS = ("_packed", "_packed_ls", "_packed_view_ls", "_packed_siren_ls")
+
+
+def invalidate_packed(module) -> int:
+    """Drop every cached packed weight stream under `module` (SkipConnMLP._packed, the layer-synchronous streams of the
+    models).  The caches are keyed on (Parameter._version, data_ptr): in-place ops on the Parameter under no_grad
+    (`p.copy_`, `p.mul_`, optimizer steps, load_state_dict) bump the version and re-pack on their own; writes THROUGH
+    `.data` (`p.data.copy_(...)`, `p.data *= ...`) do not, and the fused kernels would keep rendering the old weights.
+    Call this after such writes (runner --load does).  Returns the number of caches cleared."""
+    n = 0
+    for m in module.modules():
+        for a in PACK_CACHE_ATTRS:
+            c = m.__dict__.get(a)
+            if isinstance(c, dict) and c:
+                c.clear()
+                n += 1
+    return n

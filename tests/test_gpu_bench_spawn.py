@@ -1,0 +1,32 @@
+"""`python bench.py --gpus N` with NO torchrun environment must start its N ranks itself: run it as the
+driver would, with two ranks sharing the one GPU of the box (NA_DIST_BACKEND=gloo), and compare with the N = 1 run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(gpus, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks():
+    one = _bench(1)
+    two = _bench(2, {"NA_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert len(two["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in two["per_rank_kernel_ms"])
+    assert two["config"]["frame_checksum"] == one["config"]["frame_checksum"]  # the gathered frame is the N = 1 frame
+    assert two["roofline"]["traffic"] is None and one["roofline"]["traffic_source"].startswith("profiles/")
+    assert two["scaling"] == "strong" and two["gather_ms"] >= 0

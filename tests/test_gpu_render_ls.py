@@ -51,7 +51,8 @@ def test_ls_render_vs_reference_golden(ops, B):
     # f16 operands: the same speed class with 11-bit operands (5e-4 on these weights, 3e-4 on the bench's)
     packed, tables = pack_ls(ops, p, "f16")
     half, ha, hw = ops.render_plain_view_ls(h["rays"].cuda(), ts, tables, packed, "f16", "upshifted", str(h["bg"]), want_weights=True)
-    assert float((half - out).abs().max()) <= 2e-3 and float((ha - alpha).abs().max()) <= 2e-3
+    # (gates = 1.5 x the 5e-4 measured on these golden weights: VERDICT r2 item 10)
+    assert float((half - out).abs().max()) <= 8e-4 and float((ha - alpha).abs().max()) <= 8e-4
     assert float((half - out).abs().max()) <= 0.34 * float((fast - out).abs().max())
     assert -10 * math.log10(max(float(((half - out) ** 2).mean()), 1e-20)) >= 58.0
     assert float((hw.sum(0) - 1).abs().max()) <= 1e-5
@@ -83,7 +84,7 @@ def test_ls_render_tile_800_geometry(ops, T):
     assert float((fast - out).abs().max()) <= 2e-2
     packedh, _ = pack_ls(ops, p, "f16")
     half, _, _ = ops.render_plain_view_ls(rays, ts, tables, packedh, "f16", "upshifted", "black")
-    assert float((half.cpu() - ref).abs().max()) <= 2e-3
+    assert float((half.cpu() - ref).abs().max()) <= 8e-4
 
 
 def test_ls_render_ragged_steps_white_bg_and_errors(ops):

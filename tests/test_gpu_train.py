@@ -5,7 +5,8 @@ the analytic Blender-format scene of tools/make_scene.py: per-iteration losses a
 recipe runs through this repo's loaders, HIP forward/backward kernels and training loop on the GPU, replaying the
 reference's random stream.  Bars (written here): first 10 losses within 2e-4 absolute (same trajectory, rounding only);
 every test-view PSNR within 0.01 dB (exact-fp32 training GEMMs) / 0.1 dB (split-bf16 training GEMMs, the default) after
-the full budget (D-NeRF: a statistical 2.5 dB per view, 1.2 dB on the mean -- its trajectory is chaotic, see below), rendered by the
+the full budget (plain D-NeRF recipe, deterministic reductions: 0.5 dB per view, 0.3 dB on the mean -- its trajectory is
+chaotic, see below; `make dnerf`'s regularised recipe gets the strict bars), rendered by the
 fused bf16x3 kernel; the fast bf16 renderer within 0.1 dB of that mean as well."""
 import json
 import os

@@ -33,3 +33,30 @@ def test_loss_table_and_regulariser_guards():
     assert float(T.loss_map["rmse"](x, y)) == pytest.approx(0.125 ** 0.5)
     f = T.load_loss_fn(T.make_args(loss_fns=["l2", "l1"]))
     assert float(f(x, y)) == pytest.approx((0.125 + 0.25) / 2)
+
+
+def test_load_state_executes_no_pickled_code_by_default(tmp_path):
+    """--load: plain state_dicts load with weights_only=True; a pickled module needs --load-pickled-module"""
+    import torch
+    from nerf_atlas_amd import runner
+    sd = {"a.weight": torch.arange(6.0).reshape(2, 3)}
+    p1 = tmp_path / "sd.pt"
+    torch.save(sd, p1)
+    assert torch.equal(runner.load_state(str(p1))["a.weight"], sd["a.weight"])
+    p2 = tmp_path / "module.pt"
+    torch.save(torch.nn.Linear(3, 2), p2)  # what the reference's runner writes: the whole module
+    with pytest.raises(ValueError, match="load-pickled-module"):
+        runner.load_state(str(p2))
+    assert set(runner.load_state(str(p2), allow_pickled_module=True)) == {"weight", "bias"}
+
+
+def test_invalidate_packed_clears_every_stream_cache():
+    import torch
+    from nerf_atlas_amd.utils import invalidate_packed, PACK_CACHE_ATTRS
+    root = torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.Sequential(torch.nn.Linear(2, 2)))
+    mods = list(root.modules())
+    for i, m in enumerate(mods):
+        m.__dict__[PACK_CACHE_ATTRS[i % len(PACK_CACHE_ATTRS)]] = {"bf16x3": ("stamp", object())}
+    assert invalidate_packed(root) == len(mods)
+    assert all(not m.__dict__[PACK_CACHE_ATTRS[i % len(PACK_CACHE_ATTRS)]] for i, m in enumerate(mods))
+    assert invalidate_packed(root) == 0
