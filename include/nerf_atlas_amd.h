@@ -44,8 +44,12 @@ enum { NA_ENC_NONE = 0, NA_ENC_HASH = 1, NA_ENC_FOURIER = 2 };
 enum {
   NA_PREC_BF16 = 0,   /* bf16 operands, fp32 accumulate (1 MFMA product)            */
   NA_PREC_BF16X3 = 1, /* 2-way split bf16, 3 MFMA products, fp32-class accuracy     */
-  NA_PREC_F16 = 2     /* f16 operands, fp32 accumulate (1 MFMA product, 11-bit operands): the layer-synchronous
+  NA_PREC_F16 = 2,    /* f16 operands, fp32 accumulate (1 MFMA product, 11-bit operands): the layer-synchronous
                          renderers (na_render_*_ls) and na_mlp_pack / na_mlp_forward; not na_render_plain_view */
+  NA_PREC_F16X = 3    /* f16 main product + two MX-fp6 (e2m3, E8M0 scale per 32 k) correction products
+                         fp6(W - f16 W) x fp6(x) + fp6(W) x fp6(x - f16 x) on v_mfma_scale_f32_32x32x64_f8f6f4: 1.5 MFMA
+                         products per k, ~15-bit operands (init / geometry chunks: f16 hi + lo, 3 products).
+                         na_render_ls_pack / na_render_plain_view_ls only */
 };
 /* weight-stream layouts */
 enum { NA_LAYOUT_GENERIC = 0, NA_LAYOUT_PLAIN_FIRST = 1, NA_LAYOUT_PLAIN_VIEW = 2 };

@@ -40,6 +40,7 @@ UNITS = [
     ("render_ls.hip", ["-DNA_PREC_INST=0", "-fno-slp-vectorize"], "_bf16", True),
     ("render_ls.hip", ["-DNA_PREC_INST=1", "-fno-slp-vectorize"], "_bf16x3", True),
     ("render_ls.hip", ["-DNA_PREC_INST=2", "-fno-slp-vectorize"], "_f16", True),
+    ("render_ls.hip", ["-DNA_PREC_INST=3", "-fno-slp-vectorize"], "_f16x", True),
 ]
 UNITS = [u if len(u) == 4 else u + (False,) for u in UNITS]
 ISA_FORBIDDEN = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32)\b")

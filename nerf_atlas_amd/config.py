@@ -4,15 +4,27 @@
 # 1e-4 RGB parity bound); "bf16" = plain bf16 operands with fp32 accumulation (fast mode); "f16" = IEEE half operands
 # with fp32 accumulation: the fast mode's speed with 11-bit instead of 8-bit operands (L-inf 3e-4 instead of 3e-3 on the
 # bench frame) -- implemented by the layer-synchronous renderers and the generic fused MLP kernels (not by the register-
-# engine renderer, `set_engine("reg")`, which rejects it).
+# engine renderer, `set_engine("reg")`, which rejects it).  (Range: half saturates at 65504; the f16 kernels clamp instead of
+# producing inf, see csrc/mlp_engine.h to_elem.)
+# "f16x" = f16 main product + two MX-fp6 correction products (1.5 MFMA products per k, ~15-bit operands: a parity-class mode,
+# L-inf ~2e-5): implemented by the layer-synchronous PlainNeRF(view) renderer only -- every other kernel runs its parity mode
+# "bf16x3" when this is selected (`kernel_precision`).
 precision = "bf16x3"
 
 
 def set_precision(p: str):
     global precision
-    if p not in ("bf16", "bf16x3", "f16"):
+    if p not in ("bf16", "bf16x3", "f16", "f16x"):
         raise ValueError(p)
     precision = p
+
+
+def kernel_precision(has_f16x: bool = False) -> str:
+    """The precision a kernel family runs at: `precision`, except that "f16x" exists only where `has_f16x` says so and is
+    replaced by the other parity-class mode, "bf16x3", everywhere else."""
+    if precision == "f16x" and not (has_f16x and engine == "ls"):
+        return "bf16x3"
+    return precision
 
 
 # Training-step GEMMs (forward / input gradient / weight gradient of every Linear while gradients are recorded):

@@ -75,14 +75,18 @@ __device__ __forceinline__ float sin_hw2(float x) {
   return __builtin_amdgcn_sinf(r);
 }
 
+// precision traits: two operand planes (hi + lo) per fragment; IEEE-half elements in the 16-bit containers
+template <int PREC> constexpr bool kTwoPlane = PREC == NA_PREC_BF16X3 || PREC == NA_PREC_F16X;
+template <int PREC> constexpr bool kHalfElem = PREC == NA_PREC_F16 || PREC == NA_PREC_F16X;
+
 template <int ACT, int PREC = NA_PREC_BF16X3>
 __device__ __forceinline__ float act_apply(float v) {
   // leaky_relu(v) = max(v, 0.01 v) = median(v, 0.01 v, +big): v_med3_f32 needs no canonicalising v_max
   if constexpr ((NA_ABLATE & 2) != 0) return v;
   // (f16 operands: the upper bound doubles as the clamp to the largest finite half, so a large pre-activation becomes 65504
   // instead of +inf -> NaN downstream; the negative side is safe down to v = -6.5e6)
-  if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, PREC == NA_PREC_F16 ? 65504.0f : 3.0e38f);
-  else if constexpr (ACT == NA_ACT_SIN) return PREC == NA_PREC_BF16X3 ? sin_hw2(v) : sin_hw(v);
+  if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, kHalfElem<PREC> ? 65504.0f : 3.0e38f);
+  else if constexpr (ACT == NA_ACT_SIN) return kTwoPlane<PREC> ? sin_hw2(v) : sin_hw(v);
   else return v;
 }
 
@@ -94,14 +98,14 @@ __device__ __forceinline__ float act_apply(float v) {
 // (sine; LeakyReLU through the med3 above).
 template <int PREC, bool CLAMP = true>
 __device__ __forceinline__ __bf16 to_elem(float v) {
-  if constexpr (PREC == NA_PREC_F16) {
+  if constexpr (kHalfElem<PREC>) {
     if constexpr (CLAMP) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
     return __builtin_bit_cast(__bf16, (_Float16)v);
   } else return (__bf16)v;
 }
 template <int PREC>
 __device__ __forceinline__ float from_elem(__bf16 h) {
-  if constexpr (PREC == NA_PREC_F16) return (float)__builtin_bit_cast(_Float16, h);
+  if constexpr (kHalfElem<PREC>) return (float)__builtin_bit_cast(_Float16, h);
   else return (float)h;
 }
 
@@ -112,7 +116,7 @@ __device__ __forceinline__ Frag<PREC> make_frag(const float (&v)[8]) {
   for (int e = 0; e < 8; ++e) {
     __bf16 h = to_elem<PREC>(v[e]);
     f.hi[e] = h;
-    if constexpr (PREC == NA_PREC_BF16X3) f.lo[e] = (__bf16)(v[e] - (float)h);
+    if constexpr (kTwoPlane<PREC>) f.lo[e] = to_elem<PREC, false>(v[e] - from_elem<PREC>(h));
   }
   return f;
 }
@@ -120,14 +124,14 @@ __device__ __forceinline__ Frag<PREC> make_frag(const float (&v)[8]) {
 template <int PREC>
 __device__ __forceinline__ float frag_value(const Frag<PREC>& f, int e) {
   float v = from_elem<PREC>(f.hi[e]);
-  if constexpr (PREC == NA_PREC_BF16X3) v = v + (float)f.lo[e];
+  if constexpr (kTwoPlane<PREC>) v = v + from_elem<PREC>(f.lo[e]);
   return v;
 }
 
 template <int PREC>
 __device__ __forceinline__ void pin_frag(Frag<PREC>& f) {
   asm volatile("" : "+v"(f.hi));
-  if constexpr (PREC == NA_PREC_BF16X3) asm volatile("" : "+v"(f.lo));
+  if constexpr (kTwoPlane<PREC>) asm volatile("" : "+v"(f.lo));
 }
 
 // act() applied in place to an input fragment (the skip connection re-enters through the activation,
@@ -318,6 +322,10 @@ struct Epilogue {
     if constexpr (PREC == NA_PREC_BF16X3) {
       lo[b][d] = pack_bf16x2(x - bf16_round(x), y - bf16_round(y));
       asm volatile("" : "+v"(lo[b][d]));
+    } else if constexpr (kTwoPlane<PREC>) {  // f16 hi + f16 lo
+      const bf16x2 hv = __builtin_bit_cast(bf16x2, hi[b][d]);
+      lo[b][d] = pack_bf16x2<PREC, false>(x - from_elem<PREC>(hv[0]), y - from_elem<PREC>(hv[1]));
+      asm volatile("" : "+v"(lo[b][d]));
     }
   }
   __device__ __forceinline__ void steps(int u0, int u1) {
@@ -331,7 +339,7 @@ struct Epilogue {
     u32x4 a = {hi[b][0], hi[b][1], hi[b][2], hi[b][3]}, c = {hi[b][4], hi[b][5], hi[b][6], hi[b][7]};
     f0.hi = __builtin_bit_cast(bf16x8, a);
     f1.hi = __builtin_bit_cast(bf16x8, c);
-    if constexpr (PREC == NA_PREC_BF16X3) {
+    if constexpr (kTwoPlane<PREC>) {
       u32x4 al = {lo[b][0], lo[b][1], lo[b][2], lo[b][3]}, cl = {lo[b][4], lo[b][5], lo[b][6], lo[b][7]};
       f0.lo = __builtin_bit_cast(bf16x8, al);
       f1.lo = __builtin_bit_cast(bf16x8, cl);

@@ -31,7 +31,7 @@
 #include "encoders.h"
 
 #ifndef NA_PREC_INST
-#error "compile with -DNA_PREC_INST=0 (bf16), 1 (bf16x3) or 2 (f16)"
+#error "compile with -DNA_PREC_INST=0 (bf16), 1 (bf16x3), 2 (f16) or 3 (f16x)"
 #endif
 // NA_LS_TRACE: waves 0 and 4 of workgroup 0 stamp s_memtime before and after every barrier of their second pass
 // (tools/ls_trace.py).  Timing experiments only.
@@ -78,19 +78,41 @@ constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB bloc
 constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"
 constexpr int kPartialFloats = 8;
 
+// ---- NA_PREC_F16X (PlainNeRF schedule only): hidden activations and hidden-layer weights in the f16 + 2 x MX-fp6 format
+// (tools/proto/ls_mlp_f16x.hip is the measured prototype of this data flow).
+//   LDS, per (block, K64 group Q = the row group that produced those 64 features): 4 f16 fragments (4 KiB) | R = fp6 of the f16
+//   rounding residual (16 B + 8 B per lane) | T = fp6 of the value | one dword per lane with the two E8M0 scale bytes (R, T).
+//   A lane's 32 values of a group = its accumulator registers of the producer's two tiles: the producing lane is the consuming
+//   lane (lane = (sample, k half)), as for the 16-byte f16 fragments.
+//   Weight stream per row group: 16 init / geometry chunk PAIRS in the bf16x3 layout with f16 elements (f16 hi + f16 lo planes,
+//   three f16 products), then 40 uniform hidden RECORDS (one per (Linear, Q); the out Linears use tile 0 only):
+//   2 tiles x 4 f16 fragments (8 KiB) | 2 tiles x {WL6 = fp6(W - f16 W), WT6 = fp6(W)} (16 B + 8 B per lane each) | one dword
+//   per lane with the four E8M0 scale bytes (WL6 t0, WT6 t0, WL6 t1, WT6 t1).
+namespace x {
+constexpr int KQ = 4096 + 2 * 1536 + 256;    // LDS bytes per (block, K64 group)
+constexpr int BLKH = 4 * KQ;                 // hidden activations of one block
+constexpr int REC = 8192 + 4 * 1536 + 256;   // stream bytes per record
+constexpr int PAIRB = 4096;                  // stream bytes per init / geometry chunk pair
+constexpr int kNPair = 16;                   // first.init 3, first.L0 3, view.init 4 + geometry, view.L0 4 + geometry
+constexpr int kNRec = 40;                    // first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4
+constexpr int kStreamRG = kNPair * PAIRB + kNRec * REC;
+constexpr int kHdrUnits = kNPair + kNRec;    // header word 2 of an F16X stream
+}  // namespace x
+
 template <int PREC>
 struct Cfg {
-  static constexpr int P = PREC == NA_PREC_BF16X3 ? 2 : 1;
-  static constexpr int NBLK = PREC == NA_PREC_BF16X3 ? 2 : 4;  // 32-sample blocks per sample group
+  static constexpr int P = kTwoPlane<PREC> ? 2 : 1;
+  static constexpr int NBLK = kTwoPlane<PREC> ? 2 : 4;         // 32-sample blocks per sample group
   static constexpr int FRAG = 1024 * P;                         // bytes of one fragment (hi plane [, lo plane])
   static constexpr int PAIR = 2 * FRAG;
-  static constexpr int HREG = NBLK * 16 * FRAG;                 // hidden activations of one group
+  static constexpr int HREG = PREC == NA_PREC_F16X ? NBLK * x::BLKH : NBLK * 16 * FRAG;  // hidden activations of one group
   static constexpr int IREG = NBLK * 4 * FRAG;                  // init-input chunks of one group
-  static constexpr int GROUP = HREG + IREG;                     // 80 KiB
+  static constexpr int GROUP = HREG + IREG;                     // 80 KiB (f16x: 74 KiB)
   static constexpr int STREAM = kPairsPerPass * PAIR;           // weight stream of one row group
 };
 
 inline size_t packed_bytes(int precision, int pairs = kPairsPerPass) {
+  if (precision == NA_PREC_F16X) return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)x::kStreamRG;
   const int pair = 2048 * (precision == NA_PREC_BF16X3 ? 2 : 1);
   return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)pairs * pair;
 }
@@ -122,11 +144,19 @@ struct Args {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+struct XPackArgs {          // na_render_ls_pack(NA_PREC_F16X): the twelve Linears of PlainNeRF(view), nn.Linear layout [out,in]
+  const float* w_first[6];  // init, layers.0..3, out
+  const float* b_first[6];
+  const float* w_view[6];
+  const float* b_view[6];
+};
+int render_lsx_pack(const XPackArgs& w, char* packed, hipStream_t stream);  // defined in the NA_PREC_INST == 3 unit
+
 template <int PREC, int AUX = 0>
 __device__ __forceinline__ Frag<PREC> wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
   Frag<PREC> f;
   f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
-  if constexpr (PREC == NA_PREC_BF16X3)
+  if constexpr (kTwoPlane<PREC>)
     f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024, AUX));
   return f;
 }
@@ -136,24 +166,28 @@ template <int PREC>
 __device__ __forceinline__ Frag<PREC> fread(const char* p) {
   Frag<PREC> f;
   f.hi = *(const bf16x8*)p;
-  if constexpr (PREC == NA_PREC_BF16X3) f.lo = *(const bf16x8*)(p + 1024);
+  if constexpr (kTwoPlane<PREC>) f.lo = *(const bf16x8*)(p + 1024);
   return f;
 }
 
 template <int PREC>
 __device__ __forceinline__ void fwrite(char* p, const Frag<PREC>& f) {
   *(bf16x8*)p = f.hi;
-  if constexpr (PREC == NA_PREC_BF16X3) *(bf16x8*)(p + 1024) = f.lo;
+  if constexpr (kTwoPlane<PREC>) *(bf16x8*)(p + 1024) = f.lo;
 }
 
 template <int PREC>
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<PREC>& A, const Frag<PREC>& B) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
   if constexpr (PREC == NA_PREC_BF16X3) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc, 0, 0, 0);
   }
-  if constexpr (PREC == NA_PREC_F16) {
-    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  if constexpr (PREC == NA_PREC_F16X) {  // (init / geometry chunks: f16 hi + f16 lo, three products)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.lo), __builtin_bit_cast(f16x8, B.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.hi), __builtin_bit_cast(f16x8, B.lo), acc, 0, 0, 0);
+  }
+  if constexpr (kHalfElem<PREC>) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.hi), __builtin_bit_cast(f16x8, B.hi), acc, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
@@ -377,6 +411,236 @@ __device__ __forceinline__ void activate_init(char* ib, int blk, int lane) {
   }
 }
 
+// ================================================================================================ NA_PREC_F16X phases
+namespace x {
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(6))) int i32x6;
+
+struct MX {  // one fp6 operand of the scaled MFMA: 32 values per lane
+  u32x4 a;
+  u32x2 b;
+};
+__device__ __forceinline__ i32x8 mx8(const MX& m) {
+  return i32x8{(int)m.a[0], (int)m.a[1], (int)m.a[2], (int)m.a[3], (int)m.b[0], (int)m.b[1], 0, 0};
+}
+// acc += A (fp6 e2m3, E8M0 scale = byte SA of sa) x B (fp6 e2m3, byte SB of sb)
+template <int SA, int SB>
+__device__ __forceinline__ void mma6(f32x16& acc, const MX& A, int sa, const MX& B, int sb) {
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx8(A), mx8(B), acc, 2, 2, SA, sa, SB, sb);
+}
+struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo planes
+  Frag<NA_PREC_F16X> t0, t1;
+};
+struct Regs {   // weight registers that live across phases
+  PairR pr[2];       // pair ring: slot i & 1 holds pair i
+  f16x8 a16[4][2];   // f16 fragments of the current record, refilled in place with the next record's
+  MX a6[2][4];       // fp6 operands: record i in buffer i & 1 (the next record loads into the other one)
+  int asc[2];
+};
+
+__device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int xbase, int i) {
+  PairR p;
+  p.t0 = wload<NA_PREC_F16X>(rs, lane * 16, xbase + i * PAIRB);
+  p.t1 = wload<NA_PREC_F16X>(rs, lane * 16, xbase + i * PAIRB + 2048);
+  return p;
+}
+__device__ __forceinline__ f16x8 wload16(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t, int c) {
+  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + (t * 4 + c) * 1024, 0));
+}
+__device__ __forceinline__ MX wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int k) {  // k = 2 t + {0: WL6, 1: WT6}
+  MX m;
+  m.a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + 8192 + k * 1536, 0);
+  const uint64_t q = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8, roff + 8192 + k * 1536 + 1024, 0));
+  m.b = u32x2{(uint32_t)q, (uint32_t)(q >> 32)};
+  return m;
+}
+__device__ __forceinline__ int wloadsc(__amdgpu_buffer_rsrc_t rs, int lane, int roff) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, roff + 8192 + 6144, 0);
+}
+
+// ---- N init chunk pairs (pairs I0 .. I0+N-1 of the pass) against the init chunks 0..N-1 of the NB blocks: three f16 products
+template <int I0, int N, int NB>
+__device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, const char* ib, int lane) {
+  constexpr int PREC = NA_PREC_F16X, FR = 2048;
+  __builtin_amdgcn_s_setprio(1);
+  Frag<PREC> Bq[2][NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) Bq[0][b] = fread<PREC>(ib + (b * 4) * FR + lane * 16);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const int i = I0 + q;
+    if (q + 1 < N) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) Bq[(q + 1) & 1][b] = fread<PREC>(ib + (b * 4 + q + 1) * FR + lane * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      mma<PREC>(acc[0][b], R.pr[i & 1].t0, Bq[q & 1][b]);
+      mma<PREC>(acc[1][b], R.pr[i & 1].t1, Bq[q & 1][b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    R.pr[i & 1] = wpair(rs, lane, xbase, (i + 2) % kNPair);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// ---- the geometry chunk pair (pair I of the pass): block b's fragment is built in registers by geo_make
+template <int I, int NB, class GeoRawT, class GeoMake>
+__device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, int lane,
+                                         const GeoRawT (&graw)[NB], GeoMake geo_make, bool act) {
+  constexpr int PREC = NA_PREC_F16X;
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const Frag<PREC> B = geo_make(b, graw[b], act);
+    mma<PREC>(acc[0][b], R.pr[I & 1].t0, B);
+    mma<PREC>(acc[1][b], R.pr[I & 1].t1, B);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  R.pr[I & 1] = wpair(rs, lane, xbase, (I + 2) % kNPair);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// ---- four records (one Linear, K = 256 hidden features) starting at record rec0 (a multiple of 4): per K64 group the four
+// f16 chunks, then the two fp6 correction products.  NT tiles (2: hidden Linear; 1: out Linear, tile 0 of the record) x NBk blocks
+// whose hidden activations start at hb0 + b * BLKH.
+template <int NT, int NBk>
+__device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec, int rec0, const char* hb0,
+                                     int lane) {
+  __builtin_amdgcn_s_setprio(1);
+  auto b16 = [&](int b, int Q, int c) -> f16x8 { return *(const f16x8*)(hb0 + b * BLKH + Q * KQ + c * 1024 + lane * 16); };
+  auto b6 = [&](int b, int Q, int k) -> MX {  // k: 0 R, 1 T
+    const char* p = hb0 + b * BLKH + Q * KQ + 4096 + k * 1536;
+    MX m;
+    m.a = *(const u32x4*)(p + lane * 16);
+    m.b = *(const u32x2*)(p + 1024 + lane * 8);
+    return m;
+  };
+  auto bsc = [&](int b, int Q) -> int { return *(const int*)(hb0 + b * BLKH + Q * KQ + 4096 + 3072 + lane * 4); };
+  f16x8 Bq[2][NBk];
+  MX B6[NBk][2];
+  int Bsc[NBk];
+#pragma unroll
+  for (int b = 0; b < NBk; ++b) Bq[0][b] = b16(b, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int Q = 0; Q < 4; ++Q) {
+    int nrc = rec0 + Q + 1;
+    nrc = nrc >= kNRec ? 0 : nrc;
+    const int noff = __builtin_amdgcn_readfirstlane(xrec + nrc * REC);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ci = Q * 4 + c;
+      if (ci + 1 < 16) {
+#pragma unroll
+        for (int b = 0; b < NBk; ++b) Bq[(ci + 1) & 1][b] = b16(b, (ci + 1) >> 2, (ci + 1) & 3);
+      }
+      if (c == 1) {  // this group's fp6 B operands: two chunks of lead
+#pragma unroll
+        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = b6(b, Q, 1); Bsc[b] = bsc(b, Q); }
+      }
+      if (c == 0) {  // the NEXT record's fp6 A operands into the other buffer
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R.a6[(Q + 1) & 1][k] = wload6(rs, lane, noff, k);
+        R.asc[(Q + 1) & 1] = wloadsc(rs, lane, noff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 A0 = R.a16[c][0], A1 = R.a16[c][1];
+#pragma unroll
+      for (int b = 0; b < NBk; ++b) {
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], acc[0][b], 0, 0, 0);
+        if constexpr (NT == 2) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], acc[1][b], 0, 0, 0);
+        if (b == 0) {
+          R.a16[c][0] = wload16(rs, lane, noff, 0, c);
+          R.a16[c][1] = wload16(rs, lane, noff, 1, c);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int b = 0; b < NBk; ++b) {
+      // W_lo x T(x) and W_top x R(x).  scale bytes: A (WL6 t0, WT6 t0, WL6 t1, WT6 t1), B (R, T)
+      mma6<0, 1>(acc[0][b], R.a6[Q & 1][0], R.asc[Q & 1], B6[b][1], Bsc[b]);
+      mma6<1, 0>(acc[0][b], R.a6[Q & 1][1], R.asc[Q & 1], B6[b][0], Bsc[b]);
+      if constexpr (NT == 2) {
+        mma6<2, 1>(acc[1][b], R.a6[Q & 1][2], R.asc[Q & 1], B6[b][1], Bsc[b]);
+        mma6<3, 0>(acc[1][b], R.a6[Q & 1][3], R.asc[Q & 1], B6[b][0], Bsc[b]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// ---- epilogue of a hidden Linear: the lane's 32 values of block b (accumulators of the row group's two tiles) -> the LDS
+// operands of K64 group rg: f16 fragments, fp6 residual plane R, fp6 value plane T, scale bytes
+template <int ACT>
+__device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f32x16& a1, int lane) {
+  constexpr int PREC = NA_PREC_F16X;
+  f32x16 v0, v1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { v0[r] = act_apply<ACT, PREC>(a0[r]); v1[r] = act_apply<ACT, PREC>(a1[r]); }
+  uint32_t pk[16];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    pk[u] = __builtin_bit_cast(uint32_t, f16x2{(_Float16)v0[2 * u], (_Float16)v0[2 * u + 1]});
+    pk[8 + u] = __builtin_bit_cast(uint32_t, f16x2{(_Float16)v1[2 * u], (_Float16)v1[2 * u + 1]});
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) *(u32x4*)(kq + c * 1024 + lane * 16) = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
+  // E8M0 scales from the block maximum: T = v / 2^(e-2) lands in [4, 8) (fp6 e2m3 saturates at 7.5: 3 % at worst on a
+  // correction operand), R = (v - f16 v) / 2^(e-13) in [-4, 4].  After a sine |v| <= 1: fixed scales, no maximum.
+  int eT, eR;
+  if constexpr (ACT == NA_ACT_SIN) {
+    eT = 125; eR = 114;
+  } else {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v0[r]), "v"(v0[r + 1]));
+      asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v1[r]), "v"(v1[r + 1]));
+    }
+    const int ev = (int)(__builtin_bit_cast(uint32_t, m) >> 23);
+    eT = ev > 3 ? ev - 2 : 1;
+    eR = ev > 14 ? ev - 13 : 1;
+  }
+  const float sT = __builtin_bit_cast(float, (uint32_t)eT << 23);
+  const float sR = __builtin_bit_cast(float, (uint32_t)eR << 23);
+  f32x16 r0, r1;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    // v - float(f16 half of the packed dword) in ONE instruction (the compiler's own sequence re-converts: 3.5 ops per value)
+    float a, b, c, d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(a) : "v"(v0[2 * u]), "v"(pk[u]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(b) : "v"(v0[2 * u + 1]), "v"(pk[u]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c) : "v"(v1[2 * u]), "v"(pk[8 + u]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v1[2 * u + 1]), "v"(pk[8 + u]));
+    r0[2 * u] = a; r0[2 * u + 1] = b; r1[2 * u] = c; r1[2 * u + 1] = d;
+  }
+  // v_cvt_scalef32_2xpk16_fp6_f32 divides by the scale's power of two, rounds to nearest even, saturates, and puts a[i] into
+  // slot 2 i, b[i] into slot 2 i + 1 (probed on the hardware: tools/proto/ls_f16x.py calibrate)
+  const i32x6 Rr = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(r0, r1, sR);
+  const i32x6 Tt = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(v0, v1, sT);
+  char* p = kq + 4096;
+  *(u32x4*)(p + lane * 16) = u32x4{(uint32_t)Rr[0], (uint32_t)Rr[1], (uint32_t)Rr[2], (uint32_t)Rr[3]};
+  *(u32x2*)(p + 1024 + lane * 8) = u32x2{(uint32_t)Rr[4], (uint32_t)Rr[5]};
+  *(u32x4*)(p + 1536 + lane * 16) = u32x4{(uint32_t)Tt[0], (uint32_t)Tt[1], (uint32_t)Tt[2], (uint32_t)Tt[3]};
+  *(u32x2*)(p + 2560 + lane * 8) = u32x2{(uint32_t)Tt[4], (uint32_t)Tt[5]};
+  *(uint32_t*)(p + 3072 + lane * 4) = (uint32_t)eR | ((uint32_t)eT << 8);
+}
+template <int ACT, int NB, int T0 = 0, int T1 = 2>
+__device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) store_block<ACT>(hb + b * BLKH + rg * KQ, acc[0][b], acc[1][b], lane);
+}
+}  // namespace x
+
 // ---- compositing arithmetic: fast_exp / fast_sigmoid / fast_softplus live in common.h (hardware transcendentals).
 __device__ __forceinline__ float fast_sigmoid_kind(float v, int kind) {
   switch (kind) {  // the sigmoid family on the fast path, everything else as in apply_sigmoid_kind
@@ -413,7 +677,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
-  constexpr int PPP = MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
+  static_assert(PREC != NA_PREC_F16X || MODEL == 0, "NA_PREC_F16X: PlainNeRF schedule only");
+  constexpr int PPP = PREC == NA_PREC_F16X ? x::kHdrUnits
+                      : MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
   __builtin_amdgcn_s_dcache_inv();
@@ -715,17 +981,31 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       h[e] = to_elem<PREC>(f[e]);
-      l[e] = (__bf16)(f[e] - (float)h[e]);  // (bf16x3 only)
+      l[e] = to_elem<PREC, false>(f[e] - from_elem<PREC>(h[e]));  // (two-plane precisions only)
     }
     char* dst = ib + (blk * 4 + (k >> 1)) * FR + lane * 16 + (k & 1) * 8;
     *(bf16x4*)dst = h;
-    if constexpr (PREC == NA_PREC_BF16X3) *(bf16x4*)(dst + 1024) = l;
+    if constexpr (kTwoPlane<PREC>) *(bf16x4*)(dst + 1024) = l;
   };
   Frag<PREC> ring[kPF][2];
+  x::Regs XR;  // (NA_PREC_F16X only)
+  // scalar bases of this row group's pair and record streams (F16X)
+  const int xpair = kHeaderBytes + kBiasBytes + rg * x::kStreamRG;
+  const int xrec = xpair + x::kNPair * x::PAIRB;
+  if constexpr (PREC == NA_PREC_F16X) {
+    XR.pr[0] = x::wpair(wrs, lane, xpair, 0);
+    XR.pr[1] = x::wpair(wrs, lane, xpair, 1);
 #pragma unroll
-  for (int p = 0; p < kPF; ++p) {
-    ring[p][0] = wload<PREC>(wrs, wvoff, p * C::PAIR);
-    ring[p][1] = wload<PREC>(wrs, wvoff, p * C::PAIR + FR);
+    for (int c = 0; c < 4; ++c) { XR.a16[c][0] = x::wload16(wrs, lane, xrec, 0, c); XR.a16[c][1] = x::wload16(wrs, lane, xrec, 1, c); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) XR.a6[0][k] = x::wload6(wrs, lane, xrec, k);
+    XR.asc[0] = x::wloadsc(wrs, lane, xrec);
+  } else {
+#pragma unroll
+    for (int p = 0; p < kPF; ++p) {
+      ring[p][0] = wload<PREC>(wrs, wvoff, p * C::PAIR);
+      ring[p][1] = wload<PREC>(wrs, wvoff, p * C::PAIR + FR);
+    }
   }
 
   f32x16 oc[1];
@@ -1115,6 +1395,117 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
     }
+    if constexpr (PREC == NA_PREC_F16X) {
+      // ================= NA_PREC_F16X: the same twelve phases on pairs (init / geometry chunks) and records (hidden K)
+      auto load_bias2 = [&](int ph, f32x16 (&bv)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + ph * 1024, t, lane);
+      };
+      auto set_acc = [&](const f32x16 (&bv)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      };
+      x::pairs<0, 3, NB>(acc, XR, wrs, xpair, ib, lane);                                   // first.init
+      SYNC();
+      {
+        f32x16 bv[2];
+        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+        load_bias2(1, bv);
+        if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
+        set_acc(bv);
+      }
+      SYNC();
+      x::pairs<3, 3, NB>(acc, XR, wrs, xpair, ib, lane);                                   // first.L0: skip chunks, then K = 256
+      x::recs<2, NB>(acc, XR, wrs, xrec, 0, hb, lane);
+      SYNC();
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) {
+        f32x16 bv[2];
+        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+        load_bias2(2 + i, bv);
+        set_acc(bv);
+        SYNC();
+        x::recs<2, NB>(acc, XR, wrs, xrec, 4 + 4 * i, hb, lane);                            // first.L1..L3
+        SYNC();
+      }
+      f32x16 oq[1][NB];  // first.out: this row group's tile (0, 1: latent rows 0..63; 2: density row 64) for the NB blocks
+      {
+        const f32x16 bo = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? rg : 2, lane);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) oq[0][b] = bo;
+        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+      }
+      SYNC();
+      x::recs<1, NB>(oq, XR, wrs, xrec, 16, hb, lane);                                      // first.out (row-major)
+      SYNC();
+      {
+        f32x16 bv[2];
+        load_bias2(6, bv);
+        geo_setup(pass);
+        if (rg < 2) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            Frag<PREC> f0, f1;
+            acc_to_frags<PREC, NA_ACT_NONE>(oq[0][b], f0, f1);
+            char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
+            fwrite<PREC>(dst, f0);
+            fwrite<PREC>(dst + FR, f1);
+          }
+        } else if (rg == 2 && hi == 0) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[0][b][0];
+        }
+        set_acc(bv);
+      }
+      SYNC();
+      if (owner) density = ((const float*)hb)[blk * 32 + ln];
+      {
+        GeoRaw graw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+        x::pairs<6, 4, NB>(acc, XR, wrs, xpair, ib, lane);                                 // view.init: latent chunks + geometry
+        x::geo_pair<10, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
+      }
+      SYNC();
+      {
+        f32x16 bv[2];
+        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        load_bias2(7, bv);
+        if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
+        set_acc(bv);
+      }
+      SYNC();
+      {
+        GeoRaw graw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+        x::pairs<11, 4, NB>(acc, XR, wrs, xpair, ib, lane);                                // view.L0: skip chunks, K = 256, geometry
+        x::recs<2, NB>(acc, XR, wrs, xrec, 20, hb, lane);
+        x::geo_pair<15, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+      }
+      SYNC();
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) {
+        f32x16 bv[2];
+        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        load_bias2(8 + i, bv);
+        set_acc(bv);
+        SYNC();
+        x::recs<2, NB>(acc, XR, wrs, xrec, 24 + 4 * i, hb, lane);                           // view.L1..L3
+        SYNC();
+      }
+      f32x16 ocx[1][1];
+      {
+        ocx[0][0] = bias_tile(wrs, bias_rg + 11 * 1024, 0, lane);
+        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+      }
+      SYNC();
+      x::recs<1, 1>(ocx, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);                       // view.out (block per wave)
+      oc[0] = ocx[0][0];
+      SYNC();
+    } else {
     // ================= `first` MLP (LeakyReLU)
     m_hidden<PREC, 0, 3, 0, 0, false>(acc, ring, cur, wrs, wvoff, hb, ib, lane, [](int) { return 0; }, [](int, int, bool) { return 0; });
     SYNC();
@@ -1233,6 +1624,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     SYNC();
     m_out<PREC, 0, 1, true>(oc, ring, cur, wrs, wvoff, hb, lane, blk);
     SYNC();
+    }  // (PREC != NA_PREC_F16X)
     prev = pass;
   }
   if (prev >= 0 && (NB == 4 || owner)) {
@@ -1617,7 +2009,164 @@ static int launch(Args& a, hipStream_t stream) {
 
 }  // namespace ls
 
-#if NA_PREC_INST == 0
+#if NA_PREC_INST == 3
+namespace ls {
+// ---- NA_PREC_F16X stream of PlainNeRF(view): pairs, records, bias blocks (layout: namespace x above)
+// which Linear a record belongs to: (view, lp) with lp 1..4 = layers.0..3, 5 = out; Q = record & 3
+__device__ __forceinline__ void rec_layer(int i, bool& view, int& lp) {
+  view = i >= 20;
+  const int j = view ? i - 20 : i;
+  lp = 1 + (j >> 2);
+}
+// one thread per 16-bit element of the f16 planes of the pairs and of the records' f16 fragments
+__global__ void pack_lsx_f16_kernel(XPackArgs w, char* __restrict__ dst) {
+  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  const int64_t npair_e = 4ll * x::kNPair * 2 * 512;  // [rg][pair][tile][lane][8]
+  const int64_t nrec_e = 4ll * x::kNRec * 8 * 512;    // [rg][rec][tile*4+chunk][lane][8]
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npair_e + nrec_e; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < npair_e) {
+      const int e = (int)(i & 7), l = (int)((i >> 3) & 63), t = (int)((i >> 9) & 1);
+      const int pi = (int)((i >> 10) % x::kNPair), rg = (int)((i >> 10) / x::kNPair);
+      const int kappa = 8 * (l >> 5) + e;
+      // pair -> (Linear, init chunk q): first.init 0..2 | first.L0 skip 0..2 | view.init 0..3, geometry | view.L0 skip 0..3, geometry
+      const bool view = pi >= 6;
+      const bool skip = view ? pi >= 11 : pi >= 3;
+      const int q = view ? (pi >= 11 ? pi - 11 : pi - 6) : (pi >= 3 ? pi - 3 : pi);
+      const NaMlpDesc& d = view ? d2 : d1;
+      const float* W = view ? w.w_view[skip ? 1 : 0] : w.w_first[skip ? 1 : 0];
+      const int dim_p = d.in_size + d.enc_dims + d.latent_size;
+      int col = init_slot_feature(d, q, kappa);
+      if (col >= 0 && skip) col += kHidden;
+      const int in_dim = skip ? kHidden + dim_p : dim_p;
+      const int row = 32 * (2 * rg + t) + (l & 31);
+      float v = 0.f;
+      if (col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      const __bf16 h = to_elem<NA_PREC_F16X>(v);
+      const __bf16 lo = to_elem<NA_PREC_F16X, false>(v - from_elem<NA_PREC_F16X>(h));
+      char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + pi * x::PAIRB + t * 2048 + l * 16 + e * 2;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
+      *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
+    } else {
+      const int64_t k = i - npair_e;
+      const int e = (int)(k & 7), l = (int)((k >> 3) & 63), f = (int)((k >> 9) & 7);
+      const int ri = (int)((k >> 12) % x::kNRec), rg = (int)((k >> 12) / x::kNRec);
+      const int t = f >> 2, c = f & 3, Q = ri & 3;
+      bool view; int lp;
+      rec_layer(ri, view, lp);
+      const NaMlpDesc& d = view ? d2 : d1;
+      const float* W = view ? w.w_view[lp] : w.w_first[lp];
+      const int dim_p = d.in_size + d.enc_dims + d.latent_size;
+      const int col = 64 * Q + 16 * c + pi_perm(8 * (l >> 5) + e);  // hidden feature (the skip layers store [hidden | init])
+      int row, in_dim, out_dim;
+      if (lp == 5) {  // out Linears: tile 0 only (first.out: row group rg holds tile min(rg, 2) of the 65 rows)
+        row = t == 0 ? out_row_map(d, (view ? 0 : 32 * (rg < 2 ? rg : 2)) + (l & 31)) : -1;
+        in_dim = kHidden; out_dim = d.out_size;
+      } else {
+        row = 32 * (2 * rg + t) + (l & 31);
+        in_dim = lp == 1 ? kHidden + dim_p : kHidden; out_dim = kHidden;
+      }
+      float v = 0.f;
+      if (row >= 0 && row < out_dim) v = W[(int64_t)row * in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + x::kNPair * x::PAIRB + (int64_t)ri * x::REC + f * 1024 + l * 16 + e * 2;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, to_elem<NA_PREC_F16X>(v));
+    }
+  }
+}
+// one thread per (row group, record, tile, lane): the lane's 32 weights of the K64 group -> WL6, WT6 and their scale bytes.
+// Slot order = what v_cvt_scalef32_2xpk16_fp6_f32 gives the activations: slot 2 r <-> (producer tile 0, register r),
+// slot 2 r + 1 <-> (producer tile 1, register r), i.e. hidden feature 64 Q + 32 tt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+__global__ void pack_lsx_fp6_kernel(XPackArgs w, char* __restrict__ dst) {
+  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  const int64_t n = 4ll * x::kNRec * 2 * 64;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63), t = (int)((i >> 6) & 1);
+    const int ri = (int)((i >> 7) % x::kNRec), rg = (int)((i >> 7) / x::kNRec);
+    const int Q = ri & 3, h = l >> 5;
+    bool view; int lp;
+    rec_layer(ri, view, lp);
+    const NaMlpDesc& d = view ? d2 : d1;
+    const float* W = view ? w.w_view[lp] : w.w_first[lp];
+    const int dim_p = d.in_size + d.enc_dims + d.latent_size;
+    int row, in_dim, out_dim;
+    if (lp == 5) {
+      row = t == 0 ? out_row_map(d, (view ? 0 : 32 * (rg < 2 ? rg : 2)) + (l & 31)) : -1;
+      in_dim = kHidden; out_dim = d.out_size;
+    } else {
+      row = 32 * (2 * rg + t) + (l & 31);
+      in_dim = lp == 1 ? kHidden + dim_p : kHidden; out_dim = kHidden;
+    }
+    f32x16 wt0, wt1, wl0, wl1;
+    float mt = 0.f, ml = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c0 = 64 * Q + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float a = 0.f, b = 0.f;
+      if (row >= 0 && row < out_dim) { a = W[(int64_t)row * in_dim + c0]; b = W[(int64_t)row * in_dim + c0 + 32]; }
+      wt0[r] = a; wt1[r] = b;
+      wl0[r] = a - from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(a));
+      wl1[r] = b - from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(b));
+      mt = fmaxf(mt, fmaxf(fabsf(a), fabsf(b)));
+      ml = fmaxf(ml, fmaxf(fabsf(wl0[r]), fabsf(wl1[r])));
+    }
+    // block scale 2^(floor(log2 max) - 2): the largest element lands in [4, 8) (saturating at 7.5)
+    auto scale_byte = [](float m) { const int ev = (int)(__builtin_bit_cast(uint32_t, m) >> 23); return ev > 3 ? ev - 2 : 1; };
+    const int et = scale_byte(mt), el = scale_byte(ml);
+    const x::i32x6 T6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wt0, wt1, __builtin_bit_cast(float, (uint32_t)et << 23));
+    const x::i32x6 L6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wl0, wl1, __builtin_bit_cast(float, (uint32_t)el << 23));
+    char* rec = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + x::kNPair * x::PAIRB + (int64_t)ri * x::REC;
+    char* pl = rec + 8192 + (2 * t) * 1536;      // WL6 of tile t
+    char* pt = rec + 8192 + (2 * t + 1) * 1536;  // WT6 of tile t
+    *(u32x4*)(pl + l * 16) = u32x4{(uint32_t)L6[0], (uint32_t)L6[1], (uint32_t)L6[2], (uint32_t)L6[3]};
+    *(x::u32x2*)(pl + 1024 + l * 8) = x::u32x2{(uint32_t)L6[4], (uint32_t)L6[5]};
+    *(u32x4*)(pt + l * 16) = u32x4{(uint32_t)T6[0], (uint32_t)T6[1], (uint32_t)T6[2], (uint32_t)T6[3]};
+    *(x::u32x2*)(pt + 1024 + l * 8) = x::u32x2{(uint32_t)T6[4], (uint32_t)T6[5]};
+    uint8_t* sc = (uint8_t*)(rec + 8192 + 6144 + l * 4);
+    sc[2 * t] = (uint8_t)el;
+    sc[2 * t + 1] = (uint8_t)et;
+  }
+}
+// bias blocks: the layout of pack_ls_kernel ([row group][phase] 1-KiB blocks, floats [slot][hi(2)][16])
+__global__ void pack_lsx_bias_kernel(XPackArgs w, char* __restrict__ dst) {
+  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  const int64_t nbias = 4 * kNPhase * 256;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nbias; q += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
+    const bool view = p >= 6;
+    const NaMlpDesc& d = view ? d2 : d1;
+    const int lp = view ? p - 6 : p;
+    const float* B = p >= 12 ? nullptr : view ? w.b_view[lp] : w.b_first[lp];
+    const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
+    const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float v = 0.f;
+    if (lp == 5) {
+      const int row = slot < (view ? 1 : 3) ? out_row_map(d, 32 * slot + rin) : -1;
+      if (row >= 0 && row < d.out_size && B != nullptr) v = B[row];
+    } else if (slot < 2 && B != nullptr) {
+      v = B[32 * (2 * rg + slot) + rin];
+    }
+    *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
+  }
+}
+__global__ void pack_lsx_header_kernel(uint32_t* __restrict__ dst) {
+  if (threadIdx.x == 0) { dst[0] = kMagic; dst[1] = (uint32_t)NA_PREC_F16X; dst[2] = (uint32_t)x::kHdrUnits; dst[3] = kNPhase; }
+}
+int render_lsx_pack(const XPackArgs& w, char* packed, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_lsx_header_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)packed);
+  const int64_t ne = 4ll * x::kNPair * 2 * 512 + 4ll * x::kNRec * 8 * 512;
+  hipLaunchKernelGGL(pack_lsx_f16_kernel, dim3(grid_for(ne, 256, 4096)), dim3(256), 0, stream, w, packed);
+  hipLaunchKernelGGL(pack_lsx_fp6_kernel, dim3(grid_for(4ll * x::kNRec * 2 * 64, 64, 4096)), dim3(64), 0, stream, w, packed);
+  hipLaunchKernelGGL(pack_lsx_bias_kernel, dim3(grid_for(4 * kNPhase * 256, 256, 4096)), dim3(256), 0, stream, w, packed);
+  return check_launch("na_render_ls_pack");
+}
+}  // namespace ls
+int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model) {
+  if (model != 0) { set_error("NA_PREC_F16X: the PlainNeRF(view) renderer only"); return NA_EUNSUPPORTED; }
+  return ls::launch<NA_PREC_F16X>(a, s);
+}
+#elif NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_BF16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16, 2>(a, s)
          : model == 3 ? ls::launch<NA_PREC_BF16, 3>(a, s) : ls::launch<NA_PREC_BF16>(a, s);
@@ -1627,7 +2176,7 @@ int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16X3, 2>(a, s)
          : model == 3 ? ls::launch<NA_PREC_BF16X3, 3>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
 }
-#else
+#elif NA_PREC_INST == 2
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_F16, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16, 2>(a, s)
          : model == 3 ? ls::launch<NA_PREC_F16, 3>(a, s) : ls::launch<NA_PREC_F16>(a, s);
@@ -1636,6 +2185,7 @@ int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model);
+int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model);
 
 }  // namespace na
 
@@ -1643,15 +2193,24 @@ int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model);
 using namespace na;
 
 extern "C" size_t na_render_ls_packed_bytes(int precision) {
-  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16 && precision != NA_PREC_F16X) return 0;
   return ls::packed_bytes(precision);
 }
 
 extern "C" int na_render_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
                                  const float* const* w_view, const float* const* b_view, void* packed, void* stream) {
   NA_REQUIRE(w_first && b_first && w_view && b_view && packed, NA_ENULL, "na_render_ls_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
-             "na_render_ls_pack: precision %d", precision);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X,
+             NA_EUNSUPPORTED, "na_render_ls_pack: precision %d", precision);
+  if (precision == NA_PREC_F16X) {
+    ls::XPackArgs xw;
+    for (int i = 0; i < 6; ++i) {
+      NA_REQUIRE(w_first[i] && w_view[i], NA_ENULL, "na_render_ls_pack: weights[%d] is null", i);
+      xw.w_first[i] = w_first[i]; xw.b_first[i] = b_first[i];
+      xw.w_view[i] = w_view[i]; xw.b_view[i] = b_view[i];
+    }
+    return ls::render_lsx_pack(xw, (char*)packed, (hipStream_t)stream);
+  }
   ls::PackArgs w;
   for (int i = 0; i < 6; ++i) {
     NA_REQUIRE(w_first[i] && w_view[i], NA_ENULL, "na_render_ls_pack: weights[%d] is null", i);
@@ -1681,8 +2240,8 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;  // empty batch: a no-op before any pointer check (zero-size tensors carry null pointers)
   NA_REQUIRE(rays && ts && hash_tables && packed && out && workspace, NA_ENULL, "na_render_plain_view_ls: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
-             "na_render_plain_view_ls: precision %d", precision);
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X,
+             NA_EUNSUPPORTED, "na_render_plain_view_ls: precision %d", precision);
   NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_plain_view_ls: sigmoid %d",
              sigmoid_kind);
   NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_plain_view_ls: bg %d", bg_kind);
@@ -1703,6 +2262,7 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 0);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 0);
+  if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 0);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 0);
 }
 

@@ -230,7 +230,7 @@ class SkipConnMLP(nn.Module):
     def _mip_prologue_shape(self):
         """the shapes csrc/mlp_fwd_inst.hip instantiates with the IPE prologue: PlainNeRF.first (hash, 38 + 96 inputs)
         and View.mlp (sin, 5 + 96 + 64 inputs)"""
-        if self.init.out_features != 256 or self.packed(config.precision)[1] is None:
+        if self.init.out_features != 256 or self.packed(config.kernel_precision())[1] is None:
             return False
         if isinstance(self.enc, HashEncoder):
             return self.act_name == "leaky_relu" and self.dim_p == 38 + 96
@@ -263,17 +263,17 @@ class SkipConnMLP(nn.Module):
             latent = None
         out_size = self.out.out_features
         if mip is not None:
-            desc, packed = self.packed(config.precision)
+            desc, packed = self.packed(config.kernel_precision())
             assert packed is not None and self.latent_size == mip.width + (0 if latent is None else latent.shape[-1])
-            y = ops.mlp_forward(desc, config.precision, packed, p.reshape(-1, p.shape[-1]),
+            y = ops.mlp_forward(desc, config.kernel_precision(), packed, p.reshape(-1, p.shape[-1]),
                                 None if latent is None else latent.reshape(-1, latent.shape[-1]), self.enc_params(),
                                 mip=mip.args())
             return y.reshape(batches + (out_size,))
         if not ag.needs_grad(p, latent, *self.parameters()):
-            desc, packed = (None, None) if self.last_layer_act else self.packed(config.precision)
+            desc, packed = (None, None) if self.last_layer_act else self.packed(config.kernel_precision())
             if packed is not None:
                 # column slices of wider buffers (`first_out[..., 1:]`) go down with their row pitch: no copy
-                y = ops.mlp_forward(desc, config.precision, packed, p.reshape(-1, p.shape[-1]),
+                y = ops.mlp_forward(desc, config.kernel_precision(), packed, p.reshape(-1, p.shape[-1]),
                                     None if latent is None else latent.reshape(-1, self.latent_size), self.enc_params())
                 return y.reshape(batches + (out_size,))
         flat = p.reshape(-1, p.shape[-1]).contiguous()

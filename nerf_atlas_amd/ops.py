@@ -14,7 +14,8 @@ from ._lib import NaMlpDesc, check
 
 ACT = {"none": 0, "leaky_relu": 1, "sin": 2}
 ENC = {"none": 0, "hash": 1, "fourier": 2}
-PREC = {"bf16": 0, "bf16x3": 1, "f16": 2}  # (f16: everything but the register-engine renderer na_render_plain_view)
+# (f16: everything but the register-engine renderer na_render_plain_view; f16x: render_ls_pack / render_plain_view_ls only)
+PREC = {"bf16": 0, "bf16x3": 1, "f16": 2, "f16x": 3}
 LAYOUT = {"generic": 0, "plain_first": 1, "plain_view": 2}
 BG = {"black": 0, "white": 1}
 SIGMOID = {"normal": 0, "thin": 1, "fat": 2, "tanh": 3, "upshifted": 4, "relu": 5, "sin": 6, "leaky_relu": 7,
