@@ -428,8 +428,8 @@ __device__ __forceinline__ i32x8 mx8(const MX& m) {
 }
 // acc += A (fp6 e2m3, E8M0 scale = byte SA of sa) x B (fp6 e2m3, byte SB of sb)
 template <int SA, int SB>
-__device__ __forceinline__ void mma6(f32x16& acc, const MX& A, int sa, const MX& B, int sb) {
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx8(A), mx8(B), acc, 2, 2, SA, sa, SB, sb);
+__device__ __forceinline__ void mma6(f32x16& acc, const i32x8& A, int sa, const i32x8& B, int sb) {
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 2, 2, SA, sa, SB, sb);
 }
 struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo planes
   Frag<NA_PREC_F16X> t0, t1;
@@ -437,7 +437,10 @@ struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo 
 struct Regs {   // weight registers that live across phases
   PairR pr[2];       // pair ring: slot i & 1 holds pair i
   f16x8 a16[4][2];   // f16 fragments of the current record, refilled in place with the next record's
-  MX a6[2][4];       // fp6 operands: record i in buffer i & 1 (the next record loads into the other one)
+  // fp6 operands: record i in buffer i & 1 (the next record loads into the other one).  Kept in the MFMA's own operand type
+  // (8 dwords, the upper two never materialised): as {u32x4, u32x2} pairs the optimiser merged neighbouring elements into
+  // 32-byte loads and the whole member stayed in scratch memory
+  i32x8 a6[2][4];
   int asc[2];
 };
 
@@ -462,7 +465,7 @@ __device__ __forceinline__ int wloadsc(__amdgpu_buffer_rsrc_t rs, int lane, int 
 }
 
 // ---- N init chunk pairs (pairs I0 .. I0+N-1 of the pass) against the init chunks 0..N-1 of the NB blocks: three f16 products
-template <int I0, int N, int NB>
+template <int I0, int N, int NB, bool TAIL = false>
 __device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, const char* ib, int lane) {
   constexpr int PREC = NA_PREC_F16X, FR = 2048;
   __builtin_amdgcn_s_setprio(1);
@@ -484,10 +487,16 @@ __device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_bu
       mma<PREC>(acc[1][b], R.pr[i & 1].t1, Bq[q & 1][b]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    R.pr[i & 1] = wpair(rs, lane, xbase, (i + 2) % kNPair);
+    if (q + 2 < N + (TAIL ? 1 : 0)) R.pr[i & 1] = wpair(rs, lane, xbase, i + 2);  // (the phase's own pairs only, TAIL: + geometry)
     __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_s_setprio(0);
+}
+// the first two pairs of the NEXT pair phase: issued at the end of the epilogue in front of it (holding them across the
+// epilogues of the hidden layers costs 32 registers the residual / fp6 conversion needs)
+__device__ __forceinline__ void pairs_prefetch(Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, int lane, int i0) {
+  R.pr[i0 & 1] = wpair(rs, lane, xbase, i0);
+  R.pr[(i0 + 1) & 1] = wpair(rs, lane, xbase, i0 + 1);
 }
 
 // ---- the geometry chunk pair (pair I of the pass): block b's fragment is built in registers by geo_make
@@ -502,8 +511,6 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
     mma<PREC>(acc[0][b], R.pr[I & 1].t0, B);
     mma<PREC>(acc[1][b], R.pr[I & 1].t1, B);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  R.pr[I & 1] = wpair(rs, lane, xbase, (I + 2) % kNPair);
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -547,7 +554,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
       }
       if (c == 0) {  // the NEXT record's fp6 A operands into the other buffer
 #pragma unroll
-        for (int k = 0; k < 4; ++k) R.a6[(Q + 1) & 1][k] = wload6(rs, lane, noff, k);
+        for (int k = 0; k < 4; ++k) R.a6[(Q + 1) & 1][k] = mx8(wload6(rs, lane, noff, k));
         R.asc[(Q + 1) & 1] = wloadsc(rs, lane, noff);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -566,11 +573,11 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
 #pragma unroll
     for (int b = 0; b < NBk; ++b) {
       // W_lo x T(x) and W_top x R(x).  scale bytes: A (WL6 t0, WT6 t0, WL6 t1, WT6 t1), B (R, T)
-      mma6<0, 1>(acc[0][b], R.a6[Q & 1][0], R.asc[Q & 1], B6[b][1], Bsc[b]);
-      mma6<1, 0>(acc[0][b], R.a6[Q & 1][1], R.asc[Q & 1], B6[b][0], Bsc[b]);
+      mma6<0, 1>(acc[0][b], R.a6[Q & 1][0], R.asc[Q & 1], mx8(B6[b][1]), Bsc[b]);
+      mma6<1, 0>(acc[0][b], R.a6[Q & 1][1], R.asc[Q & 1], mx8(B6[b][0]), Bsc[b]);
       if constexpr (NT == 2) {
-        mma6<2, 1>(acc[1][b], R.a6[Q & 1][2], R.asc[Q & 1], B6[b][1], Bsc[b]);
-        mma6<3, 0>(acc[1][b], R.a6[Q & 1][3], R.asc[Q & 1], B6[b][0], Bsc[b]);
+        mma6<2, 1>(acc[1][b], R.a6[Q & 1][2], R.asc[Q & 1], mx8(B6[b][1]), Bsc[b]);
+        mma6<3, 0>(acc[1][b], R.a6[Q & 1][3], R.asc[Q & 1], mx8(B6[b][0]), Bsc[b]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -993,12 +1000,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   const int xpair = kHeaderBytes + kBiasBytes + rg * x::kStreamRG;
   const int xrec = xpair + x::kNPair * x::PAIRB;
   if constexpr (PREC == NA_PREC_F16X) {
-    XR.pr[0] = x::wpair(wrs, lane, xpair, 0);
-    XR.pr[1] = x::wpair(wrs, lane, xpair, 1);
 #pragma unroll
     for (int c = 0; c < 4; ++c) { XR.a16[c][0] = x::wload16(wrs, lane, xrec, 0, c); XR.a16[c][1] = x::wload16(wrs, lane, xrec, 1, c); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) XR.a6[0][k] = x::wload6(wrs, lane, xrec, k);
+    for (int k = 0; k < 4; ++k) XR.a6[0][k] = x::mx8(x::wload6(wrs, lane, xrec, k));
     XR.asc[0] = x::wloadsc(wrs, lane, xrec);
   } else {
 #pragma unroll
@@ -1388,6 +1393,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       f32x16 bv[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+      if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0);
       SYNC();
       if (prev >= 0) combine(prev);  // the accumulators are not live yet: 32 bias registers instead of 32 x NB
 #pragma unroll
@@ -1415,6 +1421,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         load_bias2(1, bv);
         if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
         set_acc(bv);
+        x::pairs_prefetch(XR, wrs, xpair, lane, 3);
       }
       SYNC();
       x::pairs<3, 3, NB>(acc, XR, wrs, xpair, ib, lane);                                   // first.L0: skip chunks, then K = 256
@@ -1458,6 +1465,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[0][b][0];
         }
         set_acc(bv);
+        x::pairs_prefetch(XR, wrs, xpair, lane, 6);
       }
       SYNC();
       if (owner) density = ((const float*)hb)[blk * 32 + ln];
@@ -1465,7 +1473,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::pairs<6, 4, NB>(acc, XR, wrs, xpair, ib, lane);                                 // view.init: latent chunks + geometry
+        x::pairs<6, 4, NB, true>(acc, XR, wrs, xpair, ib, lane);                                // view.init: latent chunks + geometry
         x::geo_pair<10, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
       }
       SYNC();
@@ -1475,13 +1483,14 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         load_bias2(7, bv);
         if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
         set_acc(bv);
+        x::pairs_prefetch(XR, wrs, xpair, lane, 11);
       }
       SYNC();
       {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::pairs<11, 4, NB>(acc, XR, wrs, xpair, ib, lane);                                // view.L0: skip chunks, K = 256, geometry
+        x::pairs<11, 4, NB, true>(acc, XR, wrs, xpair, ib, lane);                               // view.L0: skip chunks, K = 256, geometry
         x::recs<2, NB>(acc, XR, wrs, xrec, 20, hb, lane);
         x::geo_pair<15, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       }
