@@ -75,6 +75,10 @@ __device__ __forceinline__ float sin_hw2(float x) {
   return __builtin_amdgcn_sinf(r);
 }
 
+#ifndef NA_F16X_FAST_SIN
+#define NA_F16X_FAST_SIN 1  // the f16x mode takes the three-instruction sine (v_mul, v_fract, v_sin) of the fast modes: measured the
+                            // same L-inf as the exact reduction (1.6e-5 golden / 9e-6 bench weights), 128 fewer VALU per sine epilogue
+#endif
 // precision traits: two operand planes (hi + lo) per fragment; IEEE-half elements in the 16-bit containers
 template <int PREC> constexpr bool kTwoPlane = PREC == NA_PREC_BF16X3 || PREC == NA_PREC_F16X;
 template <int PREC> constexpr bool kHalfElem = PREC == NA_PREC_F16 || PREC == NA_PREC_F16X;
@@ -86,7 +90,7 @@ __device__ __forceinline__ float act_apply(float v) {
   // (f16 operands: the upper bound doubles as the clamp to the largest finite half, so a large pre-activation becomes 65504
   // instead of +inf -> NaN downstream; the negative side is safe down to v = -6.5e6)
   if constexpr (ACT == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, kHalfElem<PREC> ? 65504.0f : 3.0e38f);
-  else if constexpr (ACT == NA_ACT_SIN) return kTwoPlane<PREC> ? sin_hw2(v) : sin_hw(v);
+  else if constexpr (ACT == NA_ACT_SIN) return (kTwoPlane<PREC> && !(PREC == NA_PREC_F16X && NA_F16X_FAST_SIN)) ? sin_hw2(v) : sin_hw(v);
   else return v;
 }
 

@@ -80,18 +80,18 @@ constexpr int kPartialFloats = 8;
 
 // ---- NA_PREC_F16X (PlainNeRF schedule only): hidden activations and hidden-layer weights in the f16 + 2 x MX-fp6 format
 // (tools/proto/ls_mlp_f16x.hip is the measured prototype of this data flow).
+//   An fp6 OPERAND is 32 bytes per lane, two lane-linear 16-byte parts (1 KiB each): dwords 0..5 = the 32 fp6 values, dword 6 =
+//   its E8M0 scale (byte 0), dword 7 unused -- two 16-byte loads give the scaled MFMA's 8-dword operand AND its scale register.
 //   LDS, per (block, K64 group Q = the row group that produced those 64 features): 4 f16 fragments (4 KiB) | R = fp6 of the f16
-//   rounding residual (16 B + 8 B per lane) | T = fp6 of the value | one dword per lane with the two E8M0 scale bytes (R, T).
-//   A lane's 32 values of a group = its accumulator registers of the producer's two tiles: the producing lane is the consuming
-//   lane (lane = (sample, k half)), as for the 16-byte f16 fragments.
+//   rounding residual (2 KiB) | T = fp6 of the value (2 KiB).  A lane's 32 values of a group = its accumulator registers of
+//   the producer's two tiles: the producing lane is the consuming lane (lane = (sample, k half)), as for the f16 fragments.
 //   Weight stream per row group: 16 init / geometry chunk PAIRS in the bf16x3 layout with f16 elements (f16 hi + f16 lo planes,
 //   three f16 products), then 40 uniform hidden RECORDS (one per (Linear, Q); the out Linears use tile 0 only):
-//   2 tiles x 4 f16 fragments (8 KiB) | 2 tiles x {WL6 = fp6(W - f16 W), WT6 = fp6(W)} (16 B + 8 B per lane each) | one dword
-//   per lane with the four E8M0 scale bytes (WL6 t0, WT6 t0, WL6 t1, WT6 t1).
+//   2 tiles x 4 f16 fragments (8 KiB) | 2 tiles x {WL6 = fp6(W - f16 W), WT6 = fp6(W)} (2 KiB each).
 namespace x {
-constexpr int KQ = 4096 + 2 * 1536 + 256;    // LDS bytes per (block, K64 group)
-constexpr int BLKH = 4 * KQ;                 // hidden activations of one block
-constexpr int REC = 8192 + 4 * 1536 + 256;   // stream bytes per record
+constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
+constexpr int BLKH = 4 * KQ;                 // hidden activations of one block (32 KiB)
+constexpr int REC = 8192 + 4 * 2048;         // stream bytes per record (16 KiB)
 constexpr int PAIRB = 4096;                  // stream bytes per init / geometry chunk pair
 constexpr int kNPair = 16;                   // first.init 3, first.L0 3, view.init 4 + geometry, view.L0 4 + geometry
 constexpr int kNRec = 40;                    // first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4
@@ -419,17 +419,9 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(6))) int i32x6;
 
-struct MX {  // one fp6 operand of the scaled MFMA: 32 values per lane
-  u32x4 a;
-  u32x2 b;
-};
-__device__ __forceinline__ i32x8 mx8(const MX& m) {
-  return i32x8{(int)m.a[0], (int)m.a[1], (int)m.a[2], (int)m.a[3], (int)m.b[0], (int)m.b[1], 0, 0};
-}
-// acc += A (fp6 e2m3, E8M0 scale = byte SA of sa) x B (fp6 e2m3, byte SB of sb)
-template <int SA, int SB>
-__device__ __forceinline__ void mma6(f32x16& acc, const i32x8& A, int sa, const i32x8& B, int sb) {
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 2, 2, SA, sa, SB, sb);
+// acc += A x B, both fp6 e2m3 operands of 8 dwords: 0..5 the values, 6 the E8M0 scale (byte 0)
+__device__ __forceinline__ void mma6(f32x16& acc, const i32x8& A, const i32x8& B) {
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 2, 2, 0, A[6], 0, B[6]);
 }
 struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo planes
   Frag<NA_PREC_F16X> t0, t1;
@@ -437,11 +429,10 @@ struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo 
 struct Regs {   // weight registers that live across phases
   PairR pr[2];       // pair ring: slot i & 1 holds pair i
   f16x8 a16[4][2];   // f16 fragments of the current record, refilled in place with the next record's
-  // fp6 operands: record i in buffer i & 1 (the next record loads into the other one).  Kept in the MFMA's own operand type
-  // (8 dwords, the upper two never materialised): as {u32x4, u32x2} pairs the optimiser merged neighbouring elements into
-  // 32-byte loads and the whole member stayed in scratch memory
-  i32x8 a6[2][4];
-  int asc[2];
+  // fp6 operands (+ scale dword) of the current record; the next record's are requested right behind the group's scaled
+  // MFMAs and have the next group's sixteen f16 MFMAs to arrive (a second buffer costs 32 registers the kernel does not have).
+  // Kept in the MFMA's own operand type: as {u32x4, u32x2} structs the whole member stayed in scratch memory
+  i32x8 a6[4];
 };
 
 __device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int xbase, int i) {
@@ -450,18 +441,14 @@ __device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int 
   p.t1 = wload<NA_PREC_F16X>(rs, lane * 16, xbase + i * PAIRB + 2048);
   return p;
 }
+// record loads: soff = a 4-KiB-aligned scalar base inside the record, the rest of the offset is an instruction immediate
 __device__ __forceinline__ f16x8 wload16(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t, int c) {
-  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + (t * 4 + c) * 1024, 0));
+  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + c * 1024, roff + t * 4096, 0));
 }
-__device__ __forceinline__ MX wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int k) {  // k = 2 t + {0: WL6, 1: WT6}
-  MX m;
-  m.a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + 8192 + k * 1536, 0);
-  const uint64_t q = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8, roff + 8192 + k * 1536 + 1024, 0));
-  m.b = u32x2{(uint32_t)q, (uint32_t)(q >> 32)};
-  return m;
-}
-__device__ __forceinline__ int wloadsc(__amdgpu_buffer_rsrc_t rs, int lane, int roff) {
-  return (int)__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, roff + 8192 + 6144, 0);
+__device__ __forceinline__ i32x8 wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int k) {  // k = 2 t + {0: WL6, 1: WT6}
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + (k & 1) * 2048, roff + 8192 + (k >> 1) * 4096, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + (k & 1) * 2048 + 1024, roff + 8192 + (k >> 1) * 4096, 0);
+  return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
 }
 
 // ---- N init chunk pairs (pairs I0 .. I0+N-1 of the pass) against the init chunks 0..N-1 of the NB blocks: three f16 products
@@ -522,17 +509,13 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
                                      int lane) {
   __builtin_amdgcn_s_setprio(1);
   auto b16 = [&](int b, int Q, int c) -> f16x8 { return *(const f16x8*)(hb0 + b * BLKH + Q * KQ + c * 1024 + lane * 16); };
-  auto b6 = [&](int b, int Q, int k) -> MX {  // k: 0 R, 1 T
-    const char* p = hb0 + b * BLKH + Q * KQ + 4096 + k * 1536;
-    MX m;
-    m.a = *(const u32x4*)(p + lane * 16);
-    m.b = *(const u32x2*)(p + 1024 + lane * 8);
-    return m;
+  auto b6 = [&](int b, int Q, int k) -> i32x8 {  // k: 0 R, 1 T
+    const char* p = hb0 + b * BLKH + Q * KQ + 4096 + k * 2048 + lane * 16;
+    const u32x4 a = *(const u32x4*)p, c = *(const u32x4*)(p + 1024);
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
   };
-  auto bsc = [&](int b, int Q) -> int { return *(const int*)(hb0 + b * BLKH + Q * KQ + 4096 + 3072 + lane * 4); };
   f16x8 Bq[2][NBk];
-  MX B6[NBk][2];
-  int Bsc[NBk];
+  i32x8 B6[NBk][2];
 #pragma unroll
   for (int b = 0; b < NBk; ++b) Bq[0][b] = b16(b, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -550,12 +533,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
       }
       if (c == 1) {  // this group's fp6 B operands: two chunks of lead
 #pragma unroll
-        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = b6(b, Q, 1); Bsc[b] = bsc(b, Q); }
-      }
-      if (c == 0) {  // the NEXT record's fp6 A operands into the other buffer
-#pragma unroll
-        for (int k = 0; k < 4; ++k) R.a6[(Q + 1) & 1][k] = mx8(wload6(rs, lane, noff, k));
-        R.asc[(Q + 1) & 1] = wloadsc(rs, lane, noff);
+        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = b6(b, Q, 1); }
       }
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 A0 = R.a16[c][0], A1 = R.a16[c][1];
@@ -572,14 +550,17 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
     }
 #pragma unroll
     for (int b = 0; b < NBk; ++b) {
-      // W_lo x T(x) and W_top x R(x).  scale bytes: A (WL6 t0, WT6 t0, WL6 t1, WT6 t1), B (R, T)
-      mma6<0, 1>(acc[0][b], R.a6[Q & 1][0], R.asc[Q & 1], mx8(B6[b][1]), Bsc[b]);
-      mma6<1, 0>(acc[0][b], R.a6[Q & 1][1], R.asc[Q & 1], mx8(B6[b][0]), Bsc[b]);
+      // W_lo x T(x) and W_top x R(x)
+      mma6(acc[0][b], R.a6[0], B6[b][1]);
+      mma6(acc[0][b], R.a6[1], B6[b][0]);
       if constexpr (NT == 2) {
-        mma6<2, 1>(acc[1][b], R.a6[Q & 1][2], R.asc[Q & 1], mx8(B6[b][1]), Bsc[b]);
-        mma6<3, 0>(acc[1][b], R.a6[Q & 1][3], R.asc[Q & 1], mx8(B6[b][0]), Bsc[b]);
+        mma6(acc[1][b], R.a6[2], B6[b][1]);
+        mma6(acc[1][b], R.a6[3], B6[b][0]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) R.a6[k] = wload6(rs, lane, noff, k);
     __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_s_setprio(0);
@@ -634,12 +615,11 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
   // slot 2 i, b[i] into slot 2 i + 1 (probed on the hardware: tools/proto/ls_f16x.py calibrate)
   const i32x6 Rr = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(r0, r1, sR);
   const i32x6 Tt = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(v0, v1, sT);
-  char* p = kq + 4096;
-  *(u32x4*)(p + lane * 16) = u32x4{(uint32_t)Rr[0], (uint32_t)Rr[1], (uint32_t)Rr[2], (uint32_t)Rr[3]};
-  *(u32x2*)(p + 1024 + lane * 8) = u32x2{(uint32_t)Rr[4], (uint32_t)Rr[5]};
-  *(u32x4*)(p + 1536 + lane * 16) = u32x4{(uint32_t)Tt[0], (uint32_t)Tt[1], (uint32_t)Tt[2], (uint32_t)Tt[3]};
-  *(u32x2*)(p + 2560 + lane * 8) = u32x2{(uint32_t)Tt[4], (uint32_t)Tt[5]};
-  *(uint32_t*)(p + 3072 + lane * 4) = (uint32_t)eR | ((uint32_t)eT << 8);
+  char* p = kq + 4096 + lane * 16;
+  *(u32x4*)p = u32x4{(uint32_t)Rr[0], (uint32_t)Rr[1], (uint32_t)Rr[2], (uint32_t)Rr[3]};
+  *(u32x4*)(p + 1024) = u32x4{(uint32_t)Rr[4], (uint32_t)Rr[5], (uint32_t)eR, 0u};
+  *(u32x4*)(p + 2048) = u32x4{(uint32_t)Tt[0], (uint32_t)Tt[1], (uint32_t)Tt[2], (uint32_t)Tt[3]};
+  *(u32x4*)(p + 3072) = u32x4{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT, 0u};
 }
 template <int ACT, int NB, int T0 = 0, int T1 = 2>
 __device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane) {
@@ -1003,8 +983,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { XR.a16[c][0] = x::wload16(wrs, lane, xrec, 0, c); XR.a16[c][1] = x::wload16(wrs, lane, xrec, 1, c); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) XR.a6[0][k] = x::mx8(x::wload6(wrs, lane, xrec, k));
-    XR.asc[0] = x::wloadsc(wrs, lane, xrec);
+    for (int k = 0; k < 4; ++k) XR.a6[k] = x::wload6(wrs, lane, xrec, k);
   } else {
 #pragma unroll
     for (int p = 0; p < kPF; ++p) {
@@ -2125,15 +2104,12 @@ __global__ void pack_lsx_fp6_kernel(XPackArgs w, char* __restrict__ dst) {
     const x::i32x6 T6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wt0, wt1, __builtin_bit_cast(float, (uint32_t)et << 23));
     const x::i32x6 L6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wl0, wl1, __builtin_bit_cast(float, (uint32_t)el << 23));
     char* rec = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + x::kNPair * x::PAIRB + (int64_t)ri * x::REC;
-    char* pl = rec + 8192 + (2 * t) * 1536;      // WL6 of tile t
-    char* pt = rec + 8192 + (2 * t + 1) * 1536;  // WT6 of tile t
-    *(u32x4*)(pl + l * 16) = u32x4{(uint32_t)L6[0], (uint32_t)L6[1], (uint32_t)L6[2], (uint32_t)L6[3]};
-    *(x::u32x2*)(pl + 1024 + l * 8) = x::u32x2{(uint32_t)L6[4], (uint32_t)L6[5]};
-    *(u32x4*)(pt + l * 16) = u32x4{(uint32_t)T6[0], (uint32_t)T6[1], (uint32_t)T6[2], (uint32_t)T6[3]};
-    *(x::u32x2*)(pt + 1024 + l * 8) = x::u32x2{(uint32_t)T6[4], (uint32_t)T6[5]};
-    uint8_t* sc = (uint8_t*)(rec + 8192 + 6144 + l * 4);
-    sc[2 * t] = (uint8_t)el;
-    sc[2 * t + 1] = (uint8_t)et;
+    char* pl = rec + 8192 + (2 * t) * 2048 + l * 16;      // WL6 of tile t: two lane-linear 16-byte parts
+    char* pt = rec + 8192 + (2 * t + 1) * 2048 + l * 16;  // WT6 of tile t
+    *(u32x4*)pl = u32x4{(uint32_t)L6[0], (uint32_t)L6[1], (uint32_t)L6[2], (uint32_t)L6[3]};
+    *(u32x4*)(pl + 1024) = u32x4{(uint32_t)L6[4], (uint32_t)L6[5], (uint32_t)el, 0u};
+    *(u32x4*)pt = u32x4{(uint32_t)T6[0], (uint32_t)T6[1], (uint32_t)T6[2], (uint32_t)T6[3]};
+    *(u32x4*)(pt + 1024) = u32x4{(uint32_t)T6[4], (uint32_t)T6[5], (uint32_t)et, 0u};
   }
 }
 // bias blocks: the layout of pack_ls_kernel ([row group][phase] 1-KiB blocks, floats [slot][hi(2)][16])

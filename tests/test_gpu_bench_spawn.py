@@ -28,5 +28,8 @@ def test_bench_spawns_its_own_ranks():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert len(two["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in two["per_rank_kernel_ms"])
     assert two["config"]["frame_checksum"] == one["config"]["frame_checksum"]  # the gathered frame is the N = 1 frame
-    assert two["roofline"]["traffic"] is None and one["roofline"]["traffic_source"].startswith("profiles/")
+    assert two["roofline"]["traffic"] is None and two["roofline"]["traffic_source"] is None
+    # the N = 1 line names the profile its HBM bytes come from (or carries none): never an unlabelled constant
+    assert (one["roofline"]["traffic"] is None) == (one["roofline"]["traffic_source"] is None)
+    assert one["roofline"]["traffic_source"] is None or one["roofline"]["traffic_source"].startswith("profiles/")
     assert two["scaling"] == "strong" and two["gather_ms"] >= 0

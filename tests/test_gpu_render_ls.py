@@ -10,6 +10,8 @@ import oracle as O
 from conftest import load_golden, golden_params
 
 pytestmark = pytest.mark.gpu
+# the two modes that have to meet north_star's 1e-4 L-inf: the 3-product bf16 split and the 1.5-product f16 + MX-fp6 mode
+PARITY = ("bf16x3", "f16x")
 
 
 @pytest.fixture(scope="module")
@@ -37,12 +39,13 @@ def test_ls_render_vs_reference_golden(ops, B):
     p = golden_params(h)
     T = int(h["steps"])
     ts, _ = ops.compute_ts(float(h["near"]), float(h["far"]), T, "cuda")
-    packed, tables = pack_ls(ops, p, "bf16x3")
-    out, alpha, weights = ops.render_plain_view_ls(h["rays"].cuda(), ts, tables, packed, "bf16x3", "upshifted",
-                                                   str(h["bg"]), want_weights=True)
-    assert float((out.cpu() - h["out"]).abs().max()) <= 1e-4
-    assert float((alpha.cpu() - h["alpha"]).abs().max()) <= 1e-4
-    assert float((weights.cpu() - h["weights"]).abs().max()) <= 1e-4
+    for prec in reversed(PARITY):
+        packed, tables = pack_ls(ops, p, prec)
+        out, alpha, weights = ops.render_plain_view_ls(h["rays"].cuda(), ts, tables, packed, prec, "upshifted",
+                                                       str(h["bg"]), want_weights=True)
+        assert float((out.cpu() - h["out"]).abs().max()) <= 1e-4, prec
+        assert float((alpha.cpu() - h["alpha"]).abs().max()) <= 1e-4, prec
+        assert float((weights.cpu() - h["weights"]).abs().max()) <= 1e-4, prec
     packed, tables = pack_ls(ops, p, "bf16")
     fast, _, _ = ops.render_plain_view_ls(h["rays"].cuda(), ts, tables, packed, "bf16", "upshifted", str(h["bg"]))
     mse = float(((fast - out) ** 2).mean())
@@ -70,15 +73,16 @@ def test_ls_render_tile_800_geometry(ops, T):
     crop = (380, 390, 37, 41)
     rays = ops.raygen(c2w.cuda(), focal, size, crop)
     ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
-    packed, tables = pack_ls(ops, p, "bf16x3")
-    out, alpha, weights = ops.render_plain_view_ls(rays, ts, tables, packed, "bf16x3", "upshifted", "black",
-                                                   want_weights=True)
     aux = {}
     ref = O.plain_nerf(p, rays.cpu(), 2.0, 6.0, T, "view", act="upshifted", aux=aux)
-    assert float((out.cpu() - ref).abs().max()) <= 1e-4
-    assert float((weights.cpu() - aux["weights"]).abs().max()) <= 1e-4
-    assert float((alpha.cpu() - aux["alpha"]).abs().max()) <= 1e-4
-    assert float((weights.sum(0) - 1).abs().max()) <= 1e-5
+    for prec in reversed(PARITY):
+        packed, tables = pack_ls(ops, p, prec)
+        out, alpha, weights = ops.render_plain_view_ls(rays, ts, tables, packed, prec, "upshifted", "black",
+                                                       want_weights=True)
+        assert float((out.cpu() - ref).abs().max()) <= 1e-4, prec
+        assert float((weights.cpu() - aux["weights"]).abs().max()) <= 1e-4, prec
+        assert float((alpha.cpu() - aux["alpha"]).abs().max()) <= 1e-4, prec
+        assert float((weights.sum(0) - 1).abs().max()) <= 1e-5, prec
     packed16, _ = pack_ls(ops, p, "bf16")
     fast, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed16, "bf16", "upshifted", "black")
     assert float((fast - out).abs().max()) <= 2e-2
@@ -87,28 +91,30 @@ def test_ls_render_tile_800_geometry(ops, T):
     assert float((half.cpu() - ref).abs().max()) <= 8e-4
 
 
-def test_ls_render_ragged_steps_white_bg_and_errors(ops):
+@pytest.mark.parametrize("prec", PARITY)
+def test_ls_render_ragged_steps_white_bg_and_errors(ops, prec):
     from nerf_atlas_amd._lib import NaError
     h = load_golden("g11_plain_view_b1")
     p = golden_params(h)
-    packed, tables = pack_ls(ops, p, "bf16x3")
+    packed, tables = pack_ls(ops, p, prec)
     rays = h["rays"].cuda()
     for T in (1, 7, 33, 48):  # not multiples of the 32-step block
         ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
-        out, _, w = ops.render_plain_view_ls(rays, ts, tables, packed, "bf16x3", "upshifted", "white", want_weights=True)
+        out, _, w = ops.render_plain_view_ls(rays, ts, tables, packed, prec, "upshifted", "white", want_weights=True)
         aux = {}
         ref = O.plain_nerf(p, h["rays"], 2.0, 6.0, T, "view", act="upshifted", bg="white", aux=aux)
         assert float((out.cpu() - ref).abs().max()) <= 1e-4, T
         assert float((w.cpu() - aux["weights"]).abs().max()) <= 1e-4, T
     with pytest.raises(NaError):
         ts, _ = ops.compute_ts(2.0, 6.0, 16, "cuda")
-        ops.render_plain_view_ls(rays, ts, tables, packed, "bf16x3", workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+        ops.render_plain_view_ls(rays, ts, tables, packed, prec, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
     # empty batch: a no-op
-    out, _, _ = ops.render_plain_view_ls(rays[:0], ts, tables, packed, "bf16x3")
+    out, _, _ = ops.render_plain_view_ls(rays[:0], ts, tables, packed, prec)
     assert out.shape[0] == 0
 
 
-def test_ls_render_explicit_points(ops):
+@pytest.mark.parametrize("prec", PARITY)
+def test_ls_render_explicit_points(ops, prec):
     """from_pts with deformed sample positions (D-NeRF canonical half, src/nerf.py:337-361)."""
     h = load_golden("g11_plain_view_b1")
     p = golden_params(h)
@@ -119,8 +125,8 @@ def test_ls_render_explicit_points(ops):
     g = torch.Generator().manual_seed(5)
     pts = O.compute_pts(r_o, r_d, ts_c) + 0.05 * torch.randn(T, *rays.shape[:-1], 3, generator=g)
     ref = O.plain_nerf_from_pts(p, pts, ts_c, r_o, r_d, "view", act="upshifted")
-    packed, tables = pack_ls(ops, p, "bf16x3")
-    out, _, _ = ops.render_plain_view_ls(rays.cuda(), ts_c.cuda(), tables, packed, "bf16x3", "upshifted", "black",
+    packed, tables = pack_ls(ops, p, prec)
+    out, _, _ = ops.render_plain_view_ls(rays.cuda(), ts_c.cuda(), tables, packed, prec, "upshifted", "black",
                                          pts=pts.cuda())
     assert float((out.cpu() - ref).abs().max()) <= 1e-4
 
@@ -145,6 +151,12 @@ def test_ls_matches_register_engine_and_bands(ops):
         band = ops.raygen(c2w, focal, size, (316, 200, 16, 200))
         c, _, _ = ops.render_plain_view_ls(band, ts, tables, packed, prec, "upshifted", "black")
         assert torch.equal(c, a[:, 16:32]), prec
+        if prec == "bf16x3":  # the other parity mode (layer-synchronous engine only) against this one, and its own band
+            packed_x, _ = pack_ls(ops, p, "f16x")
+            ax, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed_x, "f16x", "upshifted", "black")
+            assert float((ax - a).abs().max()) <= 1e-4
+            cx, _, _ = ops.render_plain_view_ls(band, ts, tables, packed_x, "f16x", "upshifted", "black")
+            assert torch.equal(cx, ax[:, 16:32])
 
 
 @pytest.mark.parametrize("T", [72, 160])
@@ -175,6 +187,11 @@ def test_ls_rays_straddle_passes_in_both_precisions(ops, T):
             ref = O.plain_nerf(p, rays.cpu(), 2.0, 6.0, T, "view", act="upshifted", bg="white", aux=aux)
             assert float((a.cpu() - ref).abs().max()) <= 1e-4
             assert float((aw.cpu() - aux["weights"]).abs().max()) <= 1e-4
+            # f16x: 2 blocks per pass like bf16x3, its own epilogue / weight stream
+            packed_x, _ = pack_ls(ops, p, "f16x")
+            x, xa, xw = ops.render_plain_view_ls(rays, ts, tables, packed_x, "f16x", "upshifted", "white", want_weights=True)
+            assert float((x.cpu() - ref).abs().max()) <= 1e-4 and float((xw.cpu() - aux["weights"]).abs().max()) <= 1e-4
+            assert float((xa.cpu() - aux["alpha"]).abs().max()) <= 1e-4 and float((xw.sum(0) - 1).abs().max()) <= 1e-5
             # f16 (layer-synchronous engine only: 4 blocks per pass like bf16) against the parity outputs
             packed, tables = pack_ls(ops, p, "f16")
             c, ca, cw = ops.render_plain_view_ls(rays, ts, tables, packed, "f16", "upshifted", "white", want_weights=True)
@@ -251,9 +268,18 @@ def test_ls_kernels_refuse_a_stream_packed_for_something_else(ops):
     assert torch.isfinite(good).all()
     bad, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed_x3[: packed_16.numel()].clone(), "bf16", "upshifted", "black")
     assert torch.isnan(bad).all()
+    packed_fx, _ = pack_ls(ops, p, "f16x")
+    assert packed_fx.numel() > packed_x3.numel()
+    assert torch.isnan(ops.render_plain_view_ls(rays, ts, tables, packed_fx, "bf16x3", "upshifted", "black")[0]).all()
+    assert torch.isnan(ops.render_plain_view_ls(rays, ts, tables, torch.cat([packed_x3, packed_x3])[: packed_fx.numel()].contiguous(),
+                                                "f16x", "upshifted", "black")[0]).all()
     t = load_golden("g13_tiny")
     tp = golden_params(t)
     names = ["estim.init"] + [f"estim.layers.{i}" for i in range(6)] + ["estim.out"]
     tiny = ops.render_tiny_ls_pack("bf16", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])
     assert torch.isfinite(ops.render_tiny_ls(rays, ts, tiny, "bf16", "upshifted", "black")[0]).all()
     assert torch.isnan(ops.render_tiny_ls(rays, ts, packed_16, "bf16", "upshifted", "black")[0]).all()  # PlainNeRF stream
+    # f16x exists for the PlainNeRF(view) renderer only: the other schedules refuse it
+    from nerf_atlas_amd._lib import NaError
+    with pytest.raises(NaError):
+        ops.render_tiny_ls_pack("f16x", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])

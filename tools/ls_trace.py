@@ -26,7 +26,7 @@ def build(*extra):
     os.makedirs(d, exist_ok=True)
 
     def one(u):
-        src, fl, suf = u
+        src, fl, suf = u[:3]
         o = os.path.join(d, os.path.splitext(src)[0] + suf + ".o")
         subprocess.run([B.hipcc()] + B.FLAGS + fl + ["-DNA_LS_TRACE=1", *extra, "-c", os.path.join(B.CSRC, src), "-o", o], check=True)
         return o
