@@ -87,11 +87,14 @@ constexpr int kPartialFloats = 8;
 //   the producer's two tiles: the producing lane is the consuming lane (lane = (sample, k half)), as for the f16 fragments.
 //   Weight stream per row group: 16 init / geometry chunk PAIRS in the bf16x3 layout with f16 elements (f16 hi + f16 lo planes,
 //   three f16 products), then 40 uniform hidden RECORDS (one per (Linear, Q); the out Linears use tile 0 only):
-//   2 tiles x 4 f16 fragments (8 KiB) | 2 tiles x {WL6 = fp6(W - f16 W), WT6 = fp6(W)} (2 KiB each).
+//   2 tiles x 4 f16 fragments (8 KiB) | 2 tiles x 48 bytes per lane {WL6 = fp6(W - f16 W) | WT6 = fp6(W)} as three lane-linear
+//   16-byte parts (3 KiB per tile: twelve consecutive registers hold both operands) | one dword per lane with the four E8M0
+//   scale bytes (WL6 t0, WT6 t0, WL6 t1, WT6 t1).  The MFMA phase is bound by the 64 B/clk the vector memory path delivers
+//   per CU (a record feeds 24 MFMAs = 768 cycles; four waves x 14.25 KiB = 912 cycles of that path), so every byte counts.
 namespace x {
 constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
 constexpr int BLKH = 4 * KQ;                 // hidden activations of one block (32 KiB)
-constexpr int REC = 8192 + 4 * 2048;         // stream bytes per record (16 KiB)
+constexpr int REC = 8192 + 2 * 3072 + 256;   // stream bytes per record (14.25 KiB)
 constexpr int PAIRB = 4096;                  // stream bytes per init / geometry chunk pair
 constexpr int kNPair = 16;                   // first.init 3, first.L0 3, view.init 4 + geometry, view.L0 4 + geometry
 constexpr int kNRec = 40;                    // first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4
@@ -418,10 +421,13 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(6))) int i32x6;
+typedef __attribute__((ext_vector_type(12))) uint32_t u32x12;
 
-// acc += A x B, both fp6 e2m3 operands of 8 dwords: 0..5 the values, 6 the E8M0 scale (byte 0)
-__device__ __forceinline__ void mma6(f32x16& acc, const i32x8& A, const i32x8& B) {
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 2, 2, 0, A[6], 0, B[6]);
+// acc += A x B, both fp6 e2m3: A = 6 dwords with its E8M0 scale in byte SA of sa, B = 8 dwords from LDS: 0..5 the values, 6 its
+// scale (byte 0)
+template <int SA>
+__device__ __forceinline__ void mma6(f32x16& acc, const i32x8& A, int sa, const i32x8& B) {
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 2, 2, SA, sa, 0, B[6]);
 }
 struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo planes
   Frag<NA_PREC_F16X> t0, t1;
@@ -431,8 +437,9 @@ struct Regs {   // weight registers that live across phases
   f16x8 a16[4][2];   // f16 fragments of the current record, refilled in place with the next record's
   // fp6 operands (+ scale dword) of the current record; the next record's are requested right behind the group's scaled
   // MFMAs and have the next group's sixteen f16 MFMAs to arrive (a second buffer costs 32 registers the kernel does not have).
-  // Kept in the MFMA's own operand type: as {u32x4, u32x2} structs the whole member stayed in scratch memory
-  i32x8 a6[4];
+  // Clang vectors (one 12-dword vector per tile = both operands): as {u32x4, u32x2} structs the member stayed in scratch memory
+  u32x12 a6[2];
+  int asc;
 };
 
 __device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int xbase, int i) {
@@ -445,11 +452,18 @@ __device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int 
 __device__ __forceinline__ f16x8 wload16(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t, int c) {
   return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + c * 1024, roff + t * 4096, 0));
 }
-__device__ __forceinline__ i32x8 wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int k) {  // k = 2 t + {0: WL6, 1: WT6}
-  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + (k & 1) * 2048, roff + 8192 + (k >> 1) * 4096, 0);
-  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + (k & 1) * 2048 + 1024, roff + 8192 + (k >> 1) * 4096, 0);
-  return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+// the two fp6 operands of tile t: dwords 0..5 WL6, 6..11 WT6
+__device__ __forceinline__ u32x12 wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t) {
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + 8192 + t * 3072, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 1024, roff + 8192 + t * 3072, 0);
+  const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 2048, roff + 8192 + t * 3072, 0);
+  return u32x12{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
 }
+__device__ __forceinline__ int wloadsc(__amdgpu_buffer_rsrc_t rs, int lane, int roff) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, roff + 8192 + 6144, 0);
+}
+__device__ __forceinline__ i32x8 lo6(const u32x12& v) { return i32x8{(int)v[0], (int)v[1], (int)v[2], (int)v[3], (int)v[4], (int)v[5], 0, 0}; }
+__device__ __forceinline__ i32x8 hi6(const u32x12& v) { return i32x8{(int)v[6], (int)v[7], (int)v[8], (int)v[9], (int)v[10], (int)v[11], 0, 0}; }
 
 // ---- N init chunk pairs (pairs I0 .. I0+N-1 of the pass) against the init chunks 0..N-1 of the NB blocks: three f16 products
 template <int I0, int N, int NB, bool TAIL = false>
@@ -551,16 +565,17 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
 #pragma unroll
     for (int b = 0; b < NBk; ++b) {
       // W_lo x T(x) and W_top x R(x)
-      mma6(acc[0][b], R.a6[0], B6[b][1]);
-      mma6(acc[0][b], R.a6[1], B6[b][0]);
+      mma6<0>(acc[0][b], lo6(R.a6[0]), R.asc, B6[b][1]);
+      mma6<1>(acc[0][b], hi6(R.a6[0]), R.asc, B6[b][0]);
       if constexpr (NT == 2) {
-        mma6(acc[1][b], R.a6[2], B6[b][1]);
-        mma6(acc[1][b], R.a6[3], B6[b][0]);
+        mma6<2>(acc[1][b], lo6(R.a6[1]), R.asc, B6[b][1]);
+        mma6<3>(acc[1][b], hi6(R.a6[1]), R.asc, B6[b][0]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R.a6[k] = wload6(rs, lane, noff, k);
+    R.a6[0] = wload6(rs, lane, noff, 0);
+    R.a6[1] = wload6(rs, lane, noff, 1);
+    R.asc = wloadsc(rs, lane, noff);
     __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_s_setprio(0);
@@ -983,7 +998,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { XR.a16[c][0] = x::wload16(wrs, lane, xrec, 0, c); XR.a16[c][1] = x::wload16(wrs, lane, xrec, 1, c); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) XR.a6[k] = x::wload6(wrs, lane, xrec, k);
+    for (int t = 0; t < 2; ++t) XR.a6[t] = x::wload6(wrs, lane, xrec, t);
+    XR.asc = x::wloadsc(wrs, lane, xrec);
   } else {
 #pragma unroll
     for (int p = 0; p < kPF; ++p) {
@@ -2104,12 +2120,13 @@ __global__ void pack_lsx_fp6_kernel(XPackArgs w, char* __restrict__ dst) {
     const x::i32x6 T6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wt0, wt1, __builtin_bit_cast(float, (uint32_t)et << 23));
     const x::i32x6 L6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wl0, wl1, __builtin_bit_cast(float, (uint32_t)el << 23));
     char* rec = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + x::kNPair * x::PAIRB + (int64_t)ri * x::REC;
-    char* pl = rec + 8192 + (2 * t) * 2048 + l * 16;      // WL6 of tile t: two lane-linear 16-byte parts
-    char* pt = rec + 8192 + (2 * t + 1) * 2048 + l * 16;  // WT6 of tile t
+    char* pl = rec + 8192 + t * 3072 + l * 16;  // {WL6 | WT6} of tile t: three lane-linear 16-byte parts
     *(u32x4*)pl = u32x4{(uint32_t)L6[0], (uint32_t)L6[1], (uint32_t)L6[2], (uint32_t)L6[3]};
-    *(u32x4*)(pl + 1024) = u32x4{(uint32_t)L6[4], (uint32_t)L6[5], (uint32_t)el, 0u};
-    *(u32x4*)pt = u32x4{(uint32_t)T6[0], (uint32_t)T6[1], (uint32_t)T6[2], (uint32_t)T6[3]};
-    *(u32x4*)(pt + 1024) = u32x4{(uint32_t)T6[4], (uint32_t)T6[5], (uint32_t)et, 0u};
+    *(u32x4*)(pl + 1024) = u32x4{(uint32_t)L6[4], (uint32_t)L6[5], (uint32_t)T6[0], (uint32_t)T6[1]};
+    *(u32x4*)(pl + 2048) = u32x4{(uint32_t)T6[2], (uint32_t)T6[3], (uint32_t)T6[4], (uint32_t)T6[5]};
+    uint8_t* sc = (uint8_t*)(rec + 8192 + 6144 + l * 4);
+    sc[2 * t] = (uint8_t)el;
+    sc[2 * t + 1] = (uint8_t)et;
   }
 }
 // bias blocks: the layout of pack_ls_kernel ([row group][phase] 1-KiB blocks, floats [slot][hi(2)][16])
