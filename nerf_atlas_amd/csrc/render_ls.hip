@@ -91,6 +91,9 @@ constexpr int kPartialFloats = 8;
 //   16-byte parts (3 KiB per tile: twelve consecutive registers hold both operands) | one dword per lane with the four E8M0
 //   scale bytes (WL6 t0, WT6 t0, WL6 t1, WT6 t1).  The MFMA phase is bound by the 64 B/clk the vector memory path delivers
 //   per CU (a record feeds 24 MFMAs = 768 cycles; four waves x 14.25 KiB = 912 cycles of that path), so every byte counts.
+#ifndef NA_LSX_PRIO
+#define NA_LSX_PRIO 0  // experiments: 0 the MFMA phases run at s_setprio 1 (like the other precisions), 1 no priorities, 2 the epilogues
+#endif
 namespace x {
 constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
 constexpr int BLKH = 4 * KQ;                 // hidden activations of one block (32 KiB)
@@ -195,6 +198,16 @@ __device__ __forceinline__ void mma(f32x16& acc, const Frag<PREC>& A, const Frag
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
   }
+}
+
+// acc = cin + A x B (the first product of a phase reads the bias registers as its C operand: no copy into the accumulators)
+template <int PREC>
+__device__ __forceinline__ void mma_c(f32x16& acc, const f32x16& cin, const Frag<PREC>& A, const Frag<PREC>& B) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  static_assert(PREC == NA_PREC_F16X, "mma_c: f16x only so far");
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.lo), __builtin_bit_cast(f16x8, B.hi), cin, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.hi), __builtin_bit_cast(f16x8, B.lo), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A.hi), __builtin_bit_cast(f16x8, B.hi), acc, 0, 0, 0);
 }
 
 // floats [slot][hi(2)][16] of one phase's bias block -> accumulator init of tile `slot`.  Buffer loads with the
@@ -466,10 +479,12 @@ __device__ __forceinline__ i32x8 lo6(const u32x12& v) { return i32x8{(int)v[0], 
 __device__ __forceinline__ i32x8 hi6(const u32x12& v) { return i32x8{(int)v[6], (int)v[7], (int)v[8], (int)v[9], (int)v[10], (int)v[11], 0, 0}; }
 
 // ---- N init chunk pairs (pairs I0 .. I0+N-1 of the pass) against the init chunks 0..N-1 of the NB blocks: three f16 products
+// (the phase's first products take the bias registers `cb` as their C operand: the accumulators are written, never initialised)
 template <int I0, int N, int NB, bool TAIL = false>
-__device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, const char* ib, int lane) {
+__device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], const f32x16 (&cb)[2], Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase,
+                                      const char* ib, int lane) {
   constexpr int PREC = NA_PREC_F16X, FR = 2048;
-  __builtin_amdgcn_s_setprio(1);
+  if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
   Frag<PREC> Bq[2][NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) Bq[0][b] = fread<PREC>(ib + (b * 4) * FR + lane * 16);
@@ -484,14 +499,19 @@ __device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_bu
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      mma<PREC>(acc[0][b], R.pr[i & 1].t0, Bq[q & 1][b]);
-      mma<PREC>(acc[1][b], R.pr[i & 1].t1, Bq[q & 1][b]);
+      if (q == 0) {
+        mma_c<PREC>(acc[0][b], cb[0], R.pr[i & 1].t0, Bq[q & 1][b]);
+        mma_c<PREC>(acc[1][b], cb[1], R.pr[i & 1].t1, Bq[q & 1][b]);
+      } else {
+        mma<PREC>(acc[0][b], R.pr[i & 1].t0, Bq[q & 1][b]);
+        mma<PREC>(acc[1][b], R.pr[i & 1].t1, Bq[q & 1][b]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (q + 2 < N + (TAIL ? 1 : 0)) R.pr[i & 1] = wpair(rs, lane, xbase, i + 2);  // (the phase's own pairs only, TAIL: + geometry)
     __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_s_setprio(0);
+  if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(0);
 }
 // the first two pairs of the NEXT pair phase: issued at the end of the epilogue in front of it (holding them across the
 // epilogues of the hidden layers costs 32 registers the residual / fp6 conversion needs)
@@ -505,23 +525,24 @@ template <int I, int NB, class GeoRawT, class GeoMake>
 __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, int lane,
                                          const GeoRawT (&graw)[NB], GeoMake geo_make, bool act) {
   constexpr int PREC = NA_PREC_F16X;
-  __builtin_amdgcn_s_setprio(1);
+  if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const Frag<PREC> B = geo_make(b, graw[b], act);
     mma<PREC>(acc[0][b], R.pr[I & 1].t0, B);
     mma<PREC>(acc[1][b], R.pr[I & 1].t1, B);
   }
-  __builtin_amdgcn_s_setprio(0);
+  if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- four records (one Linear, K = 256 hidden features) starting at record rec0 (a multiple of 4): per K64 group the four
 // f16 chunks, then the two fp6 correction products.  NT tiles (2: hidden Linear; 1: out Linear, tile 0 of the record) x NBk blocks
 // whose hidden activations start at hb0 + b * BLKH.
-template <int NT, int NBk>
-__device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec, int rec0, const char* hb0,
-                                     int lane) {
-  __builtin_amdgcn_s_setprio(1);
+// CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
+template <int NT, int NBk, bool CB>
+__device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
+                                     int rec0, const char* hb0, int lane) {
+  if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
   auto b16 = [&](int b, int Q, int c) -> f16x8 { return *(const f16x8*)(hb0 + b * BLKH + Q * KQ + c * 1024 + lane * 16); };
   auto b6 = [&](int b, int Q, int k) -> i32x8 {  // k: 0 R, 1 T
     const char* p = hb0 + b * BLKH + Q * KQ + 4096 + k * 2048 + lane * 16;
@@ -553,8 +574,9 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
       const f16x8 A0 = R.a16[c][0], A1 = R.a16[c][1];
 #pragma unroll
       for (int b = 0; b < NBk; ++b) {
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], acc[0][b], 0, 0, 0);
-        if constexpr (NT == 2) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], acc[1][b], 0, 0, 0);
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], (CB && ci == 0) ? cb[0] : acc[0][b], 0, 0, 0);
+        if constexpr (NT == 2)
+          acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], (CB && ci == 0) ? cb[NT - 1] : acc[1][b], 0, 0, 0);
         if (b == 0) {
           R.a16[c][0] = wload16(rs, lane, noff, 0, c);
           R.a16[c][1] = wload16(rs, lane, noff, 1, c);
@@ -578,7 +600,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], Regs& R, __amdgpu_b
     R.asc = wloadsc(rs, lane, noff);
     __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_s_setprio(0);
+  if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- epilogue of a hidden Linear: the lane's 32 values of block b (accumulators of the row group's two tiles) -> the LDS
@@ -638,8 +660,10 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
 }
 template <int ACT, int NB, int T0 = 0, int T1 = 2>
 __device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane) {
+  if (NA_LSX_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int b = 0; b < NB; ++b) store_block<ACT>(hb + b * BLKH + rg * KQ, acc[0][b], acc[1][b], lane);
+  if (NA_LSX_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 }
 }  // namespace x
 
@@ -991,6 +1015,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   };
   Frag<PREC> ring[kPF][2];
   x::Regs XR;  // (NA_PREC_F16X only)
+  f32x16 bvx[2];
   // scalar bases of this row group's pair and record streams (F16X)
   const int xpair = kHeaderBytes + kBiasBytes + rg * x::kStreamRG;
   const int xrec = xpair + x::kNPair * x::PAIRB;
@@ -1391,60 +1416,53 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0);
       SYNC();
       if (prev >= 0) combine(prev);  // the accumulators are not live yet: 32 bias registers instead of 32 x NB
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
-    }
-    if constexpr (PREC == NA_PREC_F16X) {
-      // ================= NA_PREC_F16X: the same twelve phases on pairs (init / geometry chunks) and records (hidden K)
-      auto load_bias2 = [&](int ph, f32x16 (&bv)[2]) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + ph * 1024, t, lane);
-      };
-      auto set_acc = [&](const f32x16 (&bv)[2]) {
+      if constexpr (PREC == NA_PREC_F16X) {
+        bvx[0] = bv[0]; bvx[1] = bv[1];  // (C operand of first.init's first products)
+      } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+      }
+    }
+    if constexpr (PREC == NA_PREC_F16X) {
+      // ================= NA_PREC_F16X: the same twelve phases on pairs (init / geometry chunks) and records (hidden K)
+      // the bias of the NEXT phase waits in bvx and becomes the C operand of that phase's first MFMAs (no accumulator init)
+      auto load_bias2 = [&](int ph) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bvx[t] = bias_tile(wrs, bias_rg + ph * 1024, t, lane);
       };
-      x::pairs<0, 3, NB>(acc, XR, wrs, xpair, ib, lane);                                   // first.init
+      x::pairs<0, 3, NB>(acc, bvx, XR, wrs, xpair, ib, lane);                              // first.init
       SYNC();
       {
-        f32x16 bv[2];
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
-        load_bias2(1, bv);
+        load_bias2(1);
         if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
-        set_acc(bv);
         x::pairs_prefetch(XR, wrs, xpair, lane, 3);
       }
       SYNC();
-      x::pairs<3, 3, NB>(acc, XR, wrs, xpair, ib, lane);                                   // first.L0: skip chunks, then K = 256
-      x::recs<2, NB>(acc, XR, wrs, xrec, 0, hb, lane);
+      x::pairs<3, 3, NB>(acc, bvx, XR, wrs, xpair, ib, lane);                              // first.L0: skip chunks, then K = 256
+      x::recs<2, NB, false>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
-        f32x16 bv[2];
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
-        load_bias2(2 + i, bv);
-        set_acc(bv);
+        load_bias2(2 + i);
         SYNC();
-        x::recs<2, NB>(acc, XR, wrs, xrec, 4 + 4 * i, hb, lane);                            // first.L1..L3
+        x::recs<2, NB, true>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);                // first.L1..L3
         SYNC();
       }
       f32x16 oq[1][NB];  // first.out: this row group's tile (0, 1: latent rows 0..63; 2: density row 64) for the NB blocks
+      f32x16 bo[1];
       {
-        const f32x16 bo = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? rg : 2, lane);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) oq[0][b] = bo;
+        bo[0] = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? rg : 2, lane);
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
       }
       SYNC();
-      x::recs<1, NB>(oq, XR, wrs, xrec, 16, hb, lane);                                      // first.out (row-major)
+      x::recs<1, NB, true>(oq, bo, XR, wrs, xrec, 16, hb, lane);                            // first.out (row-major)
       SYNC();
       {
-        f32x16 bv[2];
-        load_bias2(6, bv);
+        load_bias2(6);
         geo_setup(pass);
         if (rg < 2) {
 #pragma unroll
@@ -1459,7 +1477,6 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[0][b][0];
         }
-        set_acc(bv);
         x::pairs_prefetch(XR, wrs, xpair, lane, 6);
       }
       SYNC();
@@ -1468,16 +1485,14 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::pairs<6, 4, NB, true>(acc, XR, wrs, xpair, ib, lane);                                // view.init: latent chunks + geometry
+        x::pairs<6, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                       // view.init: latent chunks + geometry
         x::geo_pair<10, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
       }
       SYNC();
       {
-        f32x16 bv[2];
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
-        load_bias2(7, bv);
+        load_bias2(7);
         if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
-        set_acc(bv);
         x::pairs_prefetch(XR, wrs, xpair, lane, 11);
       }
       SYNC();
@@ -1485,28 +1500,26 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::pairs<11, 4, NB, true>(acc, XR, wrs, xpair, ib, lane);                               // view.L0: skip chunks, K = 256, geometry
-        x::recs<2, NB>(acc, XR, wrs, xrec, 20, hb, lane);
+        x::pairs<11, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                      // view.L0: skip chunks, K = 256, geometry
+        x::recs<2, NB, false>(acc, bvx, XR, wrs, xrec, 20, hb, lane);
         x::geo_pair<15, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       }
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
-        f32x16 bv[2];
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
-        load_bias2(8 + i, bv);
-        set_acc(bv);
+        load_bias2(8 + i);
         SYNC();
-        x::recs<2, NB>(acc, XR, wrs, xrec, 24 + 4 * i, hb, lane);                           // view.L1..L3
+        x::recs<2, NB, true>(acc, bvx, XR, wrs, xrec, 24 + 4 * i, hb, lane);                // view.L1..L3
         SYNC();
       }
       f32x16 ocx[1][1];
       {
-        ocx[0][0] = bias_tile(wrs, bias_rg + 11 * 1024, 0, lane);
+        bo[0] = bias_tile(wrs, bias_rg + 11 * 1024, 0, lane);
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
       }
       SYNC();
-      x::recs<1, 1>(ocx, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);                       // view.out (block per wave)
+      x::recs<1, 1, true>(ocx, bo, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);             // view.out (block per wave)
       oc[0] = ocx[0][0];
       SYNC();
     } else {
