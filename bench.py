@@ -101,14 +101,17 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
                       f"torch-CPU fp32 oracle on {best} threads"}, out, rays
 
 
+KERNELS_F16X = {"4": "deformation MLP bf16x3 + canonical model f16x", "5m": "SDF MLP bf16x3 + View half f16x"}
 OTHER_SLAB = (300, 0, 200, SIZE)   # rows 300..499 of the 800-wide frame: 160 000 rays x 128 = 20.48 M samples
 
 
-def other_configs(dev, precisions=("bf16x3", "bf16"), iters=2):
+def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
     """BASELINE configs 1, 3, 4 and 5 (both SDF networks) through the model layer on a fixed 200 x 800 x 128 slab: whole
     forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
     calls per (config, precision).  FLOP/sample = sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same
-    numbers); `frac` is against the dense bf16 MFMA peak for every precision."""
+    numbers); `frac` is against the dense bf16 MFMA peak for every precision.  "f16x" rows: the one-kernel renderers run f16x, the
+    generic fused MLP launches of a config (mip: both MLPs; D-NeRF: the deformation network; VolSDF: the Fourier-MLP SDF network)
+    stay in bf16x3 -- `kernels` says which."""
     import types
     import nerf_atlas_amd.nerf as nerf
     import nerf_atlas_amd.refl as refl
@@ -130,7 +133,7 @@ def other_configs(dev, precisions=("bf16x3", "bf16"), iters=2):
         ("1 TinyNeRF", lambda: nerf.TinyNeRF(**common), 793088, False),
         ("3 PlainNeRF + mip (cylinder IPE)", lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False),
         ("4 D-NeRF (spline 6) at t = 0.5", lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True),
-        ("5 VolSDF, Fourier-MLP SDF", lambda: volsdf("mlp"), 1814016, False),
+        ("5m VolSDF, Fourier-MLP SDF", lambda: volsdf("mlp"), 1814016, False),
         ("5 VolSDF, SIREN SDF", lambda: volsdf("siren"), 1289728, False),
     ]
     rows = []
@@ -145,6 +148,8 @@ def other_configs(dev, precisions=("bf16x3", "bf16"), iters=2):
             continue
         inp = (rays, torch.tensor([0.5], device=dev)) if dyn else rays
         for prec in precisions:
+            if prec == "f16x" and name.split()[0] == "3":
+                continue  # (config 3 has no one-kernel renderer: its f16x row would be the bf16x3 row)
             try:
                 config.set_precision(prec)
                 with torch.no_grad():
@@ -157,7 +162,8 @@ def other_configs(dev, precisions=("bf16x3", "bf16"), iters=2):
                     torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / iters
                 rows.append({"config": name, "workload": f"{OTHER_SLAB[2]}x{OTHER_SLAB[3]} slab x {T} samples/ray ({n} samples)",
-                             "dtype": prec, "Msamples_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 3),
+                             "dtype": prec, "kernels": KERNELS_F16X.get(name.split()[0], "f16x") if prec == "f16x" else prec,
+                             "Msamples_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 3),
                              "flop_per_sample": flop, "frac": round(n * flop / (ms * 1e-3) / PEAK_BF16, 4)})
             except Exception as e:  # noqa: BLE001
                 rows.append({"config": name, "dtype": prec, "error": f"{type(e).__name__}: {e}"})

@@ -49,7 +49,7 @@ enum {
   NA_PREC_F16X = 3    /* f16 main product + two MX-fp6 (e2m3, E8M0 scale per 32 k) correction products
                          fp6(W - f16 W) x fp6(x) + fp6(W) x fp6(x - f16 x) on v_mfma_scale_f32_32x32x64_f8f6f4: 1.5 MFMA
                          products per k, ~15-bit operands (init / geometry chunks: f16 hi + lo, 3 products).
-                         na_render_ls_pack / na_render_plain_view_ls only */
+                         The layer-synchronous renderers only (na_render_*_ls_pack / na_render_*_ls) */
 };
 /* weight-stream layouts */
 enum { NA_LAYOUT_GENERIC = 0, NA_LAYOUT_PLAIN_FIRST = 1, NA_LAYOUT_PLAIN_VIEW = 2 };

@@ -7,8 +7,9 @@
 # engine renderer, `set_engine("reg")`, which rejects it).  (Range: half saturates at 65504; the f16 kernels clamp instead of
 # producing inf, see csrc/mlp_engine.h to_elem.)
 # "f16x" = f16 main product + two MX-fp6 correction products (1.5 MFMA products per k, ~15-bit operands: a parity-class mode,
-# L-inf ~2e-5): implemented by the layer-synchronous PlainNeRF(view) renderer only -- every other kernel runs its parity mode
-# "bf16x3" when this is selected (`kernel_precision`).
+# L-inf ~2e-5): implemented by the layer-synchronous one-kernel renderers (PlainNeRF(view), TinyNeRF, VolSDF's View half and
+# SIREN VolSDF) -- every other kernel (the generic fused MLPs, the register engine) runs its parity mode "bf16x3" when this is
+# selected (`kernel_precision`).
 precision = "bf16x3"
 
 

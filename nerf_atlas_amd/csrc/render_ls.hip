@@ -27,6 +27,7 @@
 //
 // Compiled once per precision (-DNA_PREC_INST=0|1|2).
 #include <atomic>
+#include <cstring>
 #include "mlp_layout.h"
 #include "encoders.h"
 
@@ -99,10 +100,14 @@ constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
 constexpr int BLKH = 4 * KQ;                 // hidden activations of one block (32 KiB)
 constexpr int REC = 8192 + 2 * 3072 + 256;   // stream bytes per record (14.25 KiB)
 constexpr int PAIRB = 4096;                  // stream bytes per init / geometry chunk pair
-constexpr int kNPair = 16;                   // first.init 3, first.L0 3, view.init 4 + geometry, view.L0 4 + geometry
-constexpr int kNRec = 40;                    // first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4
-constexpr int kStreamRG = kNPair * PAIRB + kNRec * REC;
-constexpr int kHdrUnits = kNPair + kNRec;    // header word 2 of an F16X stream
+// pairs / records per pass and row group of the four schedules (MODEL 0 PlainNeRF: first.init 3, first.L0 3, view.init 4 +
+// geometry, view.L0 4 + geometry | first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4;  1 TinyNeRF: init, two skip
+// chunks | six Linears + out;  2 View half: 4 + geometry twice | four Linears + out;  3 SIREN VolSDF: init, two skip chunks,
+// the View half's ten | five Linears + sdf.out + the View half's twenty)
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : 16; }
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : 40; }
+__host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
+__host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
 
 template <int PREC>
@@ -117,8 +122,9 @@ struct Cfg {
   static constexpr int STREAM = kPairsPerPass * PAIR;           // weight stream of one row group
 };
 
+inline int model_of_pairs(int pairs) { return pairs == kTinyPairs ? 1 : pairs == kViewPairs ? 2 : pairs == kSirenPairs ? 3 : 0; }
 inline size_t packed_bytes(int precision, int pairs = kPairsPerPass) {
-  if (precision == NA_PREC_F16X) return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)x::kStreamRG;
+  if (precision == NA_PREC_F16X) return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)x::stream_rg(model_of_pairs(pairs));
   const int pair = 2048 * (precision == NA_PREC_BF16X3 ? 2 : 1);
   return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)pairs * pair;
 }
@@ -150,13 +156,22 @@ struct Args {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-struct XPackArgs {          // na_render_ls_pack(NA_PREC_F16X): the twelve Linears of PlainNeRF(view), nn.Linear layout [out,in]
-  const float* w_first[6];  // init, layers.0..3, out
-  const float* b_first[6];
-  const float* w_view[6];
-  const float* b_view[6];
+// NA_PREC_F16X stream schedules (pack side): the Linears of the model and which of them every pair / record / bias block packs
+struct XLin { const float* W; const float* B; int in_dim, out_dim, desc; };  // nn.Linear layout [out,in]
+struct XPairD { int8_t lin, q, skip; };      // init chunk q of Linear lin (skip: its columns sit behind the kHidden hidden ones)
+struct XRecD { int8_t lin, q, out_mode; };   // K64 group q of Linear lin; out_mode 0 hidden rows, 1 out row-major, 2 out, one tile
+struct XSched {
+  int npair, nrec, nphase, nlin, ndesc;
+  XLin lin[13];
+  NaMlpDesc desc[2];
+  XPairD pair[16];
+  XRecD rec[44];
+  int8_t bias_lin[16], bias_mode[16];
 };
-int render_lsx_pack(const XPackArgs& w, char* packed, hipStream_t stream);  // defined in the NA_PREC_INST == 3 unit
+// model: 0 PlainNeRF(view) (w0 = first, w1 = View), 1 TinyNeRF (w0), 2 View half (w0), 3 SIREN VolSDF (w0 = SDF net, w1 = View).
+// Defined in the NA_PREC_INST == 3 unit.
+int render_lsx_pack(int model, const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1,
+                    char* packed, hipStream_t stream);
 
 template <int PREC, int AUX = 0>
 __device__ __forceinline__ Frag<PREC> wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -515,9 +530,9 @@ __device__ __forceinline__ void pairs(f32x16 (&acc)[2][NB], const f32x16 (&cb)[2
 }
 // the first two pairs of the NEXT pair phase: issued at the end of the epilogue in front of it (holding them across the
 // epilogues of the hidden layers costs 32 registers the residual / fp6 conversion needs)
-__device__ __forceinline__ void pairs_prefetch(Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, int lane, int i0) {
+__device__ __forceinline__ void pairs_prefetch(Regs& R, __amdgpu_buffer_rsrc_t rs, int xbase, int lane, int i0, int n = 2) {
   R.pr[i0 & 1] = wpair(rs, lane, xbase, i0);
-  R.pr[(i0 + 1) & 1] = wpair(rs, lane, xbase, i0 + 1);
+  if (n > 1) R.pr[(i0 + 1) & 1] = wpair(rs, lane, xbase, i0 + 1);
 }
 
 // ---- the geometry chunk pair (pair I of the pass): block b's fragment is built in registers by geo_make
@@ -539,7 +554,7 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
 // f16 chunks, then the two fp6 correction products.  NT tiles (2: hidden Linear; 1: out Linear, tile 0 of the record) x NBk blocks
 // whose hidden activations start at hb0 + b * BLKH.
 // CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
-template <int NT, int NBk, bool CB>
+template <int NT, int NBk, bool CB, int NREC>
 __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
                                      int rec0, const char* hb0, int lane) {
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
@@ -557,7 +572,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
 #pragma unroll
   for (int Q = 0; Q < 4; ++Q) {
     int nrc = rec0 + Q + 1;
-    nrc = nrc >= kNRec ? 0 : nrc;
+    nrc = nrc >= NREC ? 0 : nrc;
     const int noff = __builtin_amdgcn_readfirstlane(xrec + nrc * REC);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -703,8 +718,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
-  static_assert(PREC != NA_PREC_F16X || MODEL == 0, "NA_PREC_F16X: PlainNeRF schedule only");
-  constexpr int PPP = PREC == NA_PREC_F16X ? x::kHdrUnits
+  constexpr int PPP = PREC == NA_PREC_F16X ? x::hdr_units(MODEL)
                       : MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
@@ -1017,8 +1031,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   x::Regs XR;  // (NA_PREC_F16X only)
   f32x16 bvx[2];
   // scalar bases of this row group's pair and record streams (F16X)
-  const int xpair = kHeaderBytes + kBiasBytes + rg * x::kStreamRG;
-  const int xrec = xpair + x::kNPair * x::PAIRB;
+  const int xpair = kHeaderBytes + kBiasBytes + rg * x::stream_rg(MODEL);
+  const int xrec = xpair + x::npair(MODEL) * x::PAIRB;
+  constexpr int XNR = x::nrec(MODEL);
   if constexpr (PREC == NA_PREC_F16X) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { XR.a16[c][0] = x::wload16(wrs, lane, xrec, 0, c); XR.a16[c][1] = x::wload16(wrs, lane, xrec, 1, c); }
@@ -1055,6 +1070,11 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
   }
 
+  // (NA_PREC_F16X) the bias of the NEXT phase waits in bvx and becomes the C operand of that phase's first MFMAs
+  auto xbias = [&](int ph) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bvx[t] = bias_tile(wrs, bias_rg + ph * 1024, t, lane);
+  };
   for (int pass = 0; pass < a.npg; ++pass) {
     int cur = 0;
 #if NA_LS_TRACE
@@ -1083,12 +1103,134 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 bv[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+        if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0, MODEL == 2 ? 2 : 1);
         SYNC();
         if (prev >= 0) combine(prev);
+        if constexpr (PREC == NA_PREC_F16X) {
+          bvx[0] = bv[0]; bvx[1] = bv[1];
+        } else {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+            for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+        }
+      }
+      if constexpr (PREC == NA_PREC_F16X) {
+        // ---- NA_PREC_F16X: sdf.init (pair 0), L0 (skip pair 1 + records 0..3), L1, L2, L3 (skip pair 2 + records 12..15), L4,
+        // sdf.out (records 20..23, row-major), then the View half (pairs 3..12, records 24..43)
+        x::pairs<0, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
+        SYNC();
+        {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(1);
+          if (owner) activate_init<PREC, NA_ACT_SIN, 1>(ib, blk, lane);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 1, 1);
+        }
+        SYNC();
+        x::pairs<1, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
+        x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);                    // L0 (skip)
+        SYNC();
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(2 + i);
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);             // L1, L2
+          SYNC();
+        }
+        {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(4);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 2, 1);
+        }
+        SYNC();
+        x::pairs<2, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
+        x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 12, hb, lane);                   // L3 (skip)
+        SYNC();
+        {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(5);
+        }
+        SYNC();
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 16, hb, lane);                     // L4
+        SYNC();
+        f32x16 oq[1][NB], bo[1];
+        {
+          bo[0] = bias_tile(wrs, bias_rg + 6 * 1024, rg < 2 ? rg : 2, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        }
+        SYNC();
+        x::recs<1, NB, true, XNR>(oq, bo, XR, wrs, xrec, 20, hb, lane);                       // sdf.out (row-major)
+        SYNC();
+        {
+          xbias(7);
+          geo_setup(pass);
+          if (rg < 2) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              Frag<PREC> f0, f1;
+              acc_to_frags<PREC, NA_ACT_NONE>(oq[0][b], f0, f1);
+              char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
+              fwrite<PREC>(dst, f0);
+              fwrite<PREC>(dst + FR, f1);
+            }
+          } else if (rg == 2 && hi == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[0][b][0];
+          }
+          x::pairs_prefetch(XR, wrs, xpair, lane, 3);
+        }
+        SYNC();
+        if (owner) {  // signed distance -> Laplace density (src/utils.py:50-58, src/nerf.py:1000-1003), composited one pass later
+          const float sdfv = ((const float*)hb)[blk * 32 + ln];
+          const float sc = a.beta[0];
+          const float scaled = (-sdfv) / sc;
+          const float cdf = scaled <= 0.f ? fast_exp(fminf(scaled, 0.f)) * 0.5f : 1.f - fast_exp(-fmaxf(scaled, 0.f)) * 0.5f;
+          density = (1.0f / sc) * cdf;
+        }
+        {
+          GeoRaw graw[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+          x::pairs<3, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                  // view.init: latent chunks + geometry
+          x::geo_pair<7, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
+        }
+        SYNC();
+        {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(8);
+          if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 8);
+        }
+        SYNC();
+        {
+          GeoRaw graw[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+          x::pairs<8, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                // view.L0: skip chunks, K = 256, geometry
+          x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 24, hb, lane);
+          x::geo_pair<12, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+        }
+        SYNC();
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(9 + i);
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 28 + 4 * i, hb, lane);        // view.L1..L3
+          SYNC();
+        }
+        f32x16 ocx[1][1], bo1[1];
+        {
+          bo1[0] = bias_tile(wrs, bias_rg + 12 * 1024, 0, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        }
+        SYNC();
+        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 40, hb + blk * x::BLKH, lane);   // view.out (block per wave)
+        oc[0] = ocx[0][0];
+        SYNC();
+        prev = pass;
+        continue;
       }
       m_hidden<PREC, 0, 2, 0, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // sdf.init
       SYNC();
@@ -1226,12 +1368,63 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 bv[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+        if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0, MODEL == 2 ? 2 : 1);
         SYNC();
         if (prev >= 0) combine(prev);
+        if constexpr (PREC == NA_PREC_F16X) {
+          bvx[0] = bv[0]; bvx[1] = bv[1];
+        } else {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+            for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+        }
+      }
+      if constexpr (PREC == NA_PREC_F16X) {
+        // ---- NA_PREC_F16X: the View half (pairs 0..9, records 0..19)
+        {
+          GeoRaw graw[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+          x::pairs<0, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                  // view.init: latent chunks + geometry
+          x::geo_pair<4, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
+        }
+        SYNC();
+        {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(1);
+          if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 5);
+        }
+        SYNC();
+        {
+          GeoRaw graw[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+          x::pairs<5, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                // view.L0: skip chunks, K = 256, geometry
+          x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
+          x::geo_pair<9, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+        }
+        SYNC();
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          xbias(2 + i);
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);        // view.L1..L3
+          SYNC();
+        }
+        f32x16 ocx[1][1], bo1[1];
+        {
+          bo1[0] = bias_tile(wrs, bias_rg + 5 * 1024, 0, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        }
+        SYNC();
+        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 16, hb + blk * x::BLKH, lane);   // view.out (block per wave)
+        oc[0] = ocx[0][0];
+        SYNC();
+        prev = pass;
+        continue;
       }
       m_hidden<PREC, 0, 4, 1, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, geo_load, geo_make);  // view.init
       SYNC();
@@ -1298,12 +1491,69 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 bv[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+        if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0, MODEL == 2 ? 2 : 1);
         SYNC();
         if (prev >= 0) combine(prev);
+        if constexpr (PREC == NA_PREC_F16X) {
+          bvx[0] = bv[0]; bvx[1] = bv[1];
+        } else {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+            for (int b = 0; b < NB; ++b) acc[t][b] = bv[t];
+        }
+      }
+      if constexpr (PREC == NA_PREC_F16X) {
+        // ---- NA_PREC_F16X: init (pair 0), L0 (skip pair 1 + records 0..3), L1, L2, L3 (skip pair 2 + records 12..15), L4, L5,
+        // out (records 24..27, one tile, block per wave)
+        x::pairs<0, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
+        SYNC();
+        {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          xbias(1);
+          if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 1>(ib, blk, lane);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 1, 1);
+        }
+        SYNC();
+        x::pairs<1, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
+        x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);                    // L0 (skip)
+        SYNC();
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          xbias(2 + i);
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);             // L1, L2
+          SYNC();
+        }
+        {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          xbias(4);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 2, 1);
+        }
+        SYNC();
+        x::pairs<2, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
+        x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 12, hb, lane);                   // L3 (skip)
+        SYNC();
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          xbias(5 + i);
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 16 + 4 * i, hb, lane);            // L4, L5
+          SYNC();
+        }
+        f32x16 ocx[1][1], bo1[1];
+        {
+          bo1[0] = bias_tile(wrs, bias_rg + 7 * 1024, 0, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+        }
+        SYNC();
+        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 24, hb + blk * x::BLKH, lane);       // out
+        oc[0] = ocx[0][0];
+        SYNC();
+        prev = pass;
+        continue;
       }
       m_hidden<PREC, 0, 2, 0, 0, false, PPP>(acc, ring, cur, wrs, wvoff, hb, ib, lane, none_l, none_m);  // init
       SYNC();
@@ -1442,14 +1692,14 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       }
       SYNC();
       x::pairs<3, 3, NB>(acc, bvx, XR, wrs, xpair, ib, lane);                              // first.L0: skip chunks, then K = 256
-      x::recs<2, NB, false>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
+      x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
         load_bias2(2 + i);
         SYNC();
-        x::recs<2, NB, true>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);                // first.L1..L3
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);                // first.L1..L3
         SYNC();
       }
       f32x16 oq[1][NB];  // first.out: this row group's tile (0, 1: latent rows 0..63; 2: density row 64) for the NB blocks
@@ -1459,7 +1709,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
       }
       SYNC();
-      x::recs<1, NB, true>(oq, bo, XR, wrs, xrec, 16, hb, lane);                            // first.out (row-major)
+      x::recs<1, NB, true, XNR>(oq, bo, XR, wrs, xrec, 16, hb, lane);                            // first.out (row-major)
       SYNC();
       {
         load_bias2(6);
@@ -1501,7 +1751,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
         x::pairs<11, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                      // view.L0: skip chunks, K = 256, geometry
-        x::recs<2, NB, false>(acc, bvx, XR, wrs, xrec, 20, hb, lane);
+        x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 20, hb, lane);
         x::geo_pair<15, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       }
       SYNC();
@@ -1510,7 +1760,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
         load_bias2(8 + i);
         SYNC();
-        x::recs<2, NB, true>(acc, bvx, XR, wrs, xrec, 24 + 4 * i, hb, lane);                // view.L1..L3
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 24 + 4 * i, hb, lane);                // view.L1..L3
         SYNC();
       }
       f32x16 ocx[1][1];
@@ -1519,7 +1769,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
       }
       SYNC();
-      x::recs<1, 1, true>(ocx, bo, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);             // view.out (block per wave)
+      x::recs<1, 1, true, XNR>(ocx, bo, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);             // view.out (block per wave)
       oc[0] = ocx[0][0];
       SYNC();
     } else {
@@ -2028,64 +2278,43 @@ static int launch(Args& a, hipStream_t stream) {
 
 #if NA_PREC_INST == 3
 namespace ls {
-// ---- NA_PREC_F16X stream of PlainNeRF(view): pairs, records, bias blocks (layout: namespace x above)
-// which Linear a record belongs to: (view, lp) with lp 1..4 = layers.0..3, 5 = out; Q = record & 3
-__device__ __forceinline__ void rec_layer(int i, bool& view, int& lp) {
-  view = i >= 20;
-  const int j = view ? i - 20 : i;
-  lp = 1 + (j >> 2);
-}
-// one thread per 16-bit element of the f16 planes of the pairs and of the records' f16 fragments
-__global__ void pack_lsx_f16_kernel(XPackArgs w, char* __restrict__ dst) {
-  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
-  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
-  const int64_t npair_e = 4ll * x::kNPair * 2 * 512;  // [rg][pair][tile][lane][8]
-  const int64_t nrec_e = 4ll * x::kNRec * 8 * 512;    // [rg][rec][tile*4+chunk][lane][8]
+// ---- NA_PREC_F16X weight streams (layout: namespace x above), built from a schedule table: which Linear every pair / record /
+// bias block belongs to.  One set of kernels for the four schedules.
+__global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
+  // one thread per 16-bit element of the f16 planes of the pairs and of the records' f16 fragments
+  const int srg = sc.npair * x::PAIRB + sc.nrec * x::REC;
+  const int64_t npair_e = 4ll * sc.npair * 2 * 512;  // [rg][pair][tile][lane][8]
+  const int64_t nrec_e = 4ll * sc.nrec * 8 * 512;    // [rg][rec][tile*4+chunk][lane][8]
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npair_e + nrec_e; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < npair_e) {
       const int e = (int)(i & 7), l = (int)((i >> 3) & 63), t = (int)((i >> 9) & 1);
-      const int pi = (int)((i >> 10) % x::kNPair), rg = (int)((i >> 10) / x::kNPair);
-      const int kappa = 8 * (l >> 5) + e;
-      // pair -> (Linear, init chunk q): first.init 0..2 | first.L0 skip 0..2 | view.init 0..3, geometry | view.L0 skip 0..3, geometry
-      const bool view = pi >= 6;
-      const bool skip = view ? pi >= 11 : pi >= 3;
-      const int q = view ? (pi >= 11 ? pi - 11 : pi - 6) : (pi >= 3 ? pi - 3 : pi);
-      const NaMlpDesc& d = view ? d2 : d1;
-      const float* W = view ? w.w_view[skip ? 1 : 0] : w.w_first[skip ? 1 : 0];
-      const int dim_p = d.in_size + d.enc_dims + d.latent_size;
-      int col = init_slot_feature(d, q, kappa);
-      if (col >= 0 && skip) col += kHidden;
-      const int in_dim = skip ? kHidden + dim_p : dim_p;
+      const int pi = (int)((i >> 10) % sc.npair), rg = (int)((i >> 10) / sc.npair);
+      const XPairD pd = sc.pair[pi];
+      const XLin L = sc.lin[pd.lin];
+      int col = init_slot_feature(sc.desc[L.desc], pd.q, 8 * (l >> 5) + e);
+      if (col >= 0 && pd.skip) col += kHidden;
       const int row = 32 * (2 * rg + t) + (l & 31);
       float v = 0.f;
-      if (col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      if (col >= 0 && col < L.in_dim) v = L.W[(int64_t)row * L.in_dim + col];
       const __bf16 h = to_elem<NA_PREC_F16X>(v);
       const __bf16 lo = to_elem<NA_PREC_F16X, false>(v - from_elem<NA_PREC_F16X>(h));
-      char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + pi * x::PAIRB + t * 2048 + l * 16 + e * 2;
+      char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * srg + pi * x::PAIRB + t * 2048 + l * 16 + e * 2;
       *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
       *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
     } else {
       const int64_t k = i - npair_e;
       const int e = (int)(k & 7), l = (int)((k >> 3) & 63), f = (int)((k >> 9) & 7);
-      const int ri = (int)((k >> 12) % x::kNRec), rg = (int)((k >> 12) / x::kNRec);
-      const int t = f >> 2, c = f & 3, Q = ri & 3;
-      bool view; int lp;
-      rec_layer(ri, view, lp);
-      const NaMlpDesc& d = view ? d2 : d1;
-      const float* W = view ? w.w_view[lp] : w.w_first[lp];
-      const int dim_p = d.in_size + d.enc_dims + d.latent_size;
-      const int col = 64 * Q + 16 * c + pi_perm(8 * (l >> 5) + e);  // hidden feature (the skip layers store [hidden | init])
-      int row, in_dim, out_dim;
-      if (lp == 5) {  // out Linears: tile 0 only (first.out: row group rg holds tile min(rg, 2) of the 65 rows)
-        row = t == 0 ? out_row_map(d, (view ? 0 : 32 * (rg < 2 ? rg : 2)) + (l & 31)) : -1;
-        in_dim = kHidden; out_dim = d.out_size;
-      } else {
-        row = 32 * (2 * rg + t) + (l & 31);
-        in_dim = lp == 1 ? kHidden + dim_p : kHidden; out_dim = kHidden;
-      }
+      const int ri = (int)((k >> 12) % sc.nrec), rg = (int)((k >> 12) / sc.nrec);
+      const int t = f >> 2, c = f & 3;
+      const XRecD rd = sc.rec[ri];
+      const XLin L = sc.lin[rd.lin];
+      const int col = 64 * rd.q + 16 * c + pi_perm(8 * (l >> 5) + e);  // hidden feature (the skip layers store [hidden | init])
+      int row;
+      if (rd.out_mode == 0) row = 32 * (2 * rg + t) + (l & 31);
+      else row = t == 0 ? out_row_map(sc.desc[L.desc], (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
       float v = 0.f;
-      if (row >= 0 && row < out_dim) v = W[(int64_t)row * in_dim + col];
-      char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + x::kNPair * x::PAIRB + (int64_t)ri * x::REC + f * 1024 + l * 16 + e * 2;
+      if (row >= 0 && row < L.out_dim) v = L.W[(int64_t)row * L.in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * srg + sc.npair * x::PAIRB + (int64_t)ri * x::REC + f * 1024 + l * 16 + e * 2;
       *(uint16_t*)o = __builtin_bit_cast(uint16_t, to_elem<NA_PREC_F16X>(v));
     }
   }
@@ -2093,34 +2322,25 @@ __global__ void pack_lsx_f16_kernel(XPackArgs w, char* __restrict__ dst) {
 // one thread per (row group, record, tile, lane): the lane's 32 weights of the K64 group -> WL6, WT6 and their scale bytes.
 // Slot order = what v_cvt_scalef32_2xpk16_fp6_f32 gives the activations: slot 2 r <-> (producer tile 0, register r),
 // slot 2 r + 1 <-> (producer tile 1, register r), i.e. hidden feature 64 Q + 32 tt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-__global__ void pack_lsx_fp6_kernel(XPackArgs w, char* __restrict__ dst) {
-  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
-  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
-  const int64_t n = 4ll * x::kNRec * 2 * 64;
+__global__ void pack_lsx_fp6_kernel(XSched sc, char* __restrict__ dst) {
+  const int srg = sc.npair * x::PAIRB + sc.nrec * x::REC;
+  const int64_t n = 4ll * sc.nrec * 2 * 64;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int l = (int)(i & 63), t = (int)((i >> 6) & 1);
-    const int ri = (int)((i >> 7) % x::kNRec), rg = (int)((i >> 7) / x::kNRec);
-    const int Q = ri & 3, h = l >> 5;
-    bool view; int lp;
-    rec_layer(ri, view, lp);
-    const NaMlpDesc& d = view ? d2 : d1;
-    const float* W = view ? w.w_view[lp] : w.w_first[lp];
-    const int dim_p = d.in_size + d.enc_dims + d.latent_size;
-    int row, in_dim, out_dim;
-    if (lp == 5) {
-      row = t == 0 ? out_row_map(d, (view ? 0 : 32 * (rg < 2 ? rg : 2)) + (l & 31)) : -1;
-      in_dim = kHidden; out_dim = d.out_size;
-    } else {
-      row = 32 * (2 * rg + t) + (l & 31);
-      in_dim = lp == 1 ? kHidden + dim_p : kHidden; out_dim = kHidden;
-    }
+    const int ri = (int)((i >> 7) % sc.nrec), rg = (int)((i >> 7) / sc.nrec);
+    const int h = l >> 5;
+    const XRecD rd = sc.rec[ri];
+    const XLin L = sc.lin[rd.lin];
+    int row;
+    if (rd.out_mode == 0) row = 32 * (2 * rg + t) + (l & 31);
+    else row = t == 0 ? out_row_map(sc.desc[L.desc], (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
     f32x16 wt0, wt1, wl0, wl1;
     float mt = 0.f, ml = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c0 = 64 * Q + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int c0 = 64 * rd.q + (r & 3) + 8 * (r >> 2) + 4 * h;
       float a = 0.f, b = 0.f;
-      if (row >= 0 && row < out_dim) { a = W[(int64_t)row * in_dim + c0]; b = W[(int64_t)row * in_dim + c0 + 32]; }
+      if (row >= 0 && row < L.out_dim) { a = L.W[(int64_t)row * L.in_dim + c0]; b = L.W[(int64_t)row * L.in_dim + c0 + 32]; }
       wt0[r] = a; wt1[r] = b;
       wl0[r] = a - from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(a));
       wl1[r] = b - from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(b));
@@ -2132,54 +2352,105 @@ __global__ void pack_lsx_fp6_kernel(XPackArgs w, char* __restrict__ dst) {
     const int et = scale_byte(mt), el = scale_byte(ml);
     const x::i32x6 T6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wt0, wt1, __builtin_bit_cast(float, (uint32_t)et << 23));
     const x::i32x6 L6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(wl0, wl1, __builtin_bit_cast(float, (uint32_t)el << 23));
-    char* rec = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * x::kStreamRG + x::kNPair * x::PAIRB + (int64_t)ri * x::REC;
+    char* rec = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * srg + sc.npair * x::PAIRB + (int64_t)ri * x::REC;
     char* pl = rec + 8192 + t * 3072 + l * 16;  // {WL6 | WT6} of tile t: three lane-linear 16-byte parts
     *(u32x4*)pl = u32x4{(uint32_t)L6[0], (uint32_t)L6[1], (uint32_t)L6[2], (uint32_t)L6[3]};
     *(u32x4*)(pl + 1024) = u32x4{(uint32_t)L6[4], (uint32_t)L6[5], (uint32_t)T6[0], (uint32_t)T6[1]};
     *(u32x4*)(pl + 2048) = u32x4{(uint32_t)T6[2], (uint32_t)T6[3], (uint32_t)T6[4], (uint32_t)T6[5]};
-    uint8_t* sc = (uint8_t*)(rec + 8192 + 6144 + l * 4);
-    sc[2 * t] = (uint8_t)el;
-    sc[2 * t + 1] = (uint8_t)et;
+    uint8_t* scb = (uint8_t*)(rec + 8192 + 6144 + l * 4);
+    scb[2 * t] = (uint8_t)el;
+    scb[2 * t + 1] = (uint8_t)et;
   }
 }
 // bias blocks: the layout of pack_ls_kernel ([row group][phase] 1-KiB blocks, floats [slot][hi(2)][16])
-__global__ void pack_lsx_bias_kernel(XPackArgs w, char* __restrict__ dst) {
-  const NaMlpDesc d1 = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
-  const NaMlpDesc d2 = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+__global__ void pack_lsx_bias_kernel(XSched sc, char* __restrict__ dst) {
   const int64_t nbias = 4 * kNPhase * 256;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nbias; q += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
-    const bool view = p >= 6;
-    const NaMlpDesc& d = view ? d2 : d1;
-    const int lp = view ? p - 6 : p;
-    const float* B = p >= 12 ? nullptr : view ? w.b_view[lp] : w.b_first[lp];
     const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
     const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
     float v = 0.f;
-    if (lp == 5) {
-      const int row = slot < (view ? 1 : 3) ? out_row_map(d, 32 * slot + rin) : -1;
-      if (row >= 0 && row < d.out_size && B != nullptr) v = B[row];
-    } else if (slot < 2 && B != nullptr) {
-      v = B[32 * (2 * rg + slot) + rin];
+    if (p < sc.nphase) {
+      const XLin L = sc.lin[sc.bias_lin[p]];
+      const int mode = sc.bias_mode[p];  // 0 hidden rows, 1 out Linear row-major (3 tiles), 2 out Linear, one tile
+      if (L.B != nullptr) {
+        if (mode == 0) { if (slot < 2) v = L.B[32 * (2 * rg + slot) + rin]; }
+        else {
+          const int row = slot < (mode == 1 ? 3 : 1) ? out_row_map(sc.desc[L.desc], 32 * slot + rin) : -1;
+          if (row >= 0 && row < L.out_dim) v = L.B[row];
+        }
+      }
     }
     *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
   }
 }
-__global__ void pack_lsx_header_kernel(uint32_t* __restrict__ dst) {
-  if (threadIdx.x == 0) { dst[0] = kMagic; dst[1] = (uint32_t)NA_PREC_F16X; dst[2] = (uint32_t)x::kHdrUnits; dst[3] = kNPhase; }
+__global__ void pack_lsx_header_kernel(uint32_t* __restrict__ dst, uint32_t units) {
+  if (threadIdx.x == 0) { dst[0] = kMagic; dst[1] = (uint32_t)NA_PREC_F16X; dst[2] = units; dst[3] = kNPhase; }
 }
-int render_lsx_pack(const XPackArgs& w, char* packed, hipStream_t stream) {
-  hipLaunchKernelGGL(pack_lsx_header_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)packed);
-  const int64_t ne = 4ll * x::kNPair * 2 * 512 + 4ll * x::kNRec * 8 * 512;
-  hipLaunchKernelGGL(pack_lsx_f16_kernel, dim3(grid_for(ne, 256, 4096)), dim3(256), 0, stream, w, packed);
-  hipLaunchKernelGGL(pack_lsx_fp6_kernel, dim3(grid_for(4ll * x::kNRec * 2 * 64, 64, 4096)), dim3(64), 0, stream, w, packed);
-  hipLaunchKernelGGL(pack_lsx_bias_kernel, dim3(grid_for(4 * kNPhase * 256, 256, 4096)), dim3(256), 0, stream, w, packed);
-  return check_launch("na_render_ls_pack");
+
+// `nl` Linears of one SkipConnMLP appended to the schedule: init (NI chunk pairs), hidden Linears (skip layers take the NI init
+// chunks again, + kHidden), out.  geo: the View MLP's fifth init chunk is its own pair behind the init / skip chunks.
+static void xs_add_mlp(XSched& sc, const NaMlpDesc& d, const float* const* w, const float* const* b, int nl, int ni, bool geo,
+                       int out_mode) {
+  const int di = sc.ndesc++;
+  sc.desc[di] = d;
+  const int dim_p = d.in_size + d.enc_dims + d.latent_size;
+  const int l0 = sc.nlin;
+  for (int i = 0; i < nl; ++i) {
+    const bool first = i == 0, last = i == nl - 1;
+    const bool skip = !first && !last && ((i - 1) % d.skip) == 0 && (i - 1) != d.num_layers - 1;
+    XLin L;
+    L.W = w[i]; L.B = b[i]; L.desc = di;
+    L.in_dim = first ? dim_p : skip ? kHidden + dim_p : kHidden;
+    L.out_dim = last ? d.out_size : kHidden;
+    sc.lin[sc.nlin++] = L;
+    sc.bias_lin[sc.nphase] = (int8_t)(l0 + i);
+    sc.bias_mode[sc.nphase++] = (int8_t)(last ? out_mode : 0);
+    if (first || skip) {
+      for (int q = 0; q < ni; ++q) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(skip ? 1 : 0)};
+    }
+    if (!first) {
+      for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(last ? out_mode : 0)};
+    }
+    if ((first || skip) && geo) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), 4, (int8_t)(skip ? 1 : 0)};
+  }
+}
+
+int render_lsx_pack(int model, const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1,
+                    char* packed, hipStream_t stream) {
+  XSched sc;
+  memset(&sc, 0, sizeof(sc));
+  const NaMlpDesc view = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
+  if (model == 0) {
+    const NaMlpDesc first = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+    xs_add_mlp(sc, first, w0, b0, 6, 3, false, 1);
+    xs_add_mlp(sc, view, w1, b1, 6, 4, true, 2);
+  } else if (model == 1) {
+    const NaMlpDesc tiny = {3, NA_ENC_NONE, 0, 0, 6, 256, 4, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
+    xs_add_mlp(sc, tiny, w0, b0, 8, 1, false, 2);
+  } else if (model == 2) {
+    xs_add_mlp(sc, view, w0, b0, 6, 4, true, 2);
+  } else {
+    const NaMlpDesc siren = {3, NA_ENC_NONE, 0, 0, 5, 256, 65, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_FIRST};
+    xs_add_mlp(sc, siren, w0, b0, 7, 1, false, 1);
+    xs_add_mlp(sc, view, w1, b1, 6, 4, true, 2);
+  }
+  if (sc.npair != x::npair(model) || sc.nrec != x::nrec(model)) {
+    set_error("render_lsx_pack: schedule of model %d has %d pairs / %d records, the kernel expects %d / %d", model, sc.npair,
+              sc.nrec, x::npair(model), x::nrec(model));
+    return NA_EINVAL;
+  }
+  hipLaunchKernelGGL(pack_lsx_header_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)packed, (uint32_t)x::hdr_units(model));
+  const int64_t ne = 4ll * sc.npair * 2 * 512 + 4ll * sc.nrec * 8 * 512;
+  hipLaunchKernelGGL(pack_lsx_f16_kernel, dim3(grid_for(ne, 256, 4096)), dim3(256), 0, stream, sc, packed);
+  hipLaunchKernelGGL(pack_lsx_fp6_kernel, dim3(grid_for(4ll * sc.nrec * 2 * 64, 64, 4096)), dim3(64), 0, stream, sc, packed);
+  hipLaunchKernelGGL(pack_lsx_bias_kernel, dim3(grid_for(4 * kNPhase * 256, 256, 4096)), dim3(256), 0, stream, sc, packed);
+  return check_launch("na_render_*_ls_pack (f16x)");
 }
 }  // namespace ls
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model) {
-  if (model != 0) { set_error("NA_PREC_F16X: the PlainNeRF(view) renderer only"); return NA_EUNSUPPORTED; }
-  return ls::launch<NA_PREC_F16X>(a, s);
+  return model == 1 ? ls::launch<NA_PREC_F16X, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16X, 2>(a, s)
+         : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : ls::launch<NA_PREC_F16X>(a, s);
 }
 #elif NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
@@ -2218,13 +2489,8 @@ extern "C" int na_render_ls_pack(int precision, const float* const* w_first, con
   NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X,
              NA_EUNSUPPORTED, "na_render_ls_pack: precision %d", precision);
   if (precision == NA_PREC_F16X) {
-    ls::XPackArgs xw;
-    for (int i = 0; i < 6; ++i) {
-      NA_REQUIRE(w_first[i] && w_view[i], NA_ENULL, "na_render_ls_pack: weights[%d] is null", i);
-      xw.w_first[i] = w_first[i]; xw.b_first[i] = b_first[i];
-      xw.w_view[i] = w_view[i]; xw.b_view[i] = b_view[i];
-    }
-    return ls::render_lsx_pack(xw, (char*)packed, (hipStream_t)stream);
+    for (int i = 0; i < 6; ++i) NA_REQUIRE(w_first[i] && w_view[i], NA_ENULL, "na_render_ls_pack: weights[%d] is null", i);
+    return ls::render_lsx_pack(0, w_first, b_first, w_view, b_view, (char*)packed, (hipStream_t)stream);
   }
   ls::PackArgs w;
   for (int i = 0; i < 6; ++i) {
@@ -2283,19 +2549,20 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
 
 // ---- TinyNeRF on the same engine (src/nerf.py:278-305)
 extern "C" size_t na_render_tiny_ls_packed_bytes(int precision) {
-  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16 && precision != NA_PREC_F16X) return 0;
   return ls::packed_bytes(precision, ls::kTinyPairs);
 }
 
 extern "C" int na_render_tiny_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream) {
   NA_REQUIRE(w && b && packed, NA_ENULL, "na_render_tiny_ls_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X, NA_EUNSUPPORTED,
              "na_render_tiny_ls_pack: precision %d", precision);
   ls::TinyPackArgs pa;
   for (int i = 0; i < 8; ++i) {
     NA_REQUIRE(w[i], NA_ENULL, "na_render_tiny_ls_pack: weights[%d] is null", i);
     pa.w[i] = w[i]; pa.b[i] = b[i];
   }
+  if (precision == NA_PREC_F16X) return ls::render_lsx_pack(1, w, b, nullptr, nullptr, (char*)packed, (hipStream_t)stream);
   const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
   hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
                      (uint32_t*)packed, (uint32_t)ls::kTinyPairs);
@@ -2311,7 +2578,7 @@ extern "C" int na_render_tiny_ls(const float* rays, const float* pts, int64_t R,
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_tiny_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;
   NA_REQUIRE(rays && ts && packed && out, NA_ENULL, "na_render_tiny_ls: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X, NA_EUNSUPPORTED,
              "na_render_tiny_ls: precision %d", precision);
   NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_tiny_ls: sigmoid %d", sigmoid_kind);
   NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_tiny_ls: bg %d", bg_kind);
@@ -2327,24 +2594,26 @@ extern "C" int na_render_tiny_ls(const float* rays, const float* pts, int64_t R,
   a.trace = nullptr;
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 1);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 1);
+  if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 1);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 1);
 }
 
 // ---- View head + compositing on per-sample (density source, latent) rows: VolSDF's second half (src/nerf.py:981-1013)
 extern "C" size_t na_render_view_ls_packed_bytes(int precision) {
-  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16 && precision != NA_PREC_F16X) return 0;
   return ls::packed_bytes(precision, ls::kViewPairs);
 }
 
 extern "C" int na_render_view_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream) {
   NA_REQUIRE(w && b && packed, NA_ENULL, "na_render_view_ls_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X, NA_EUNSUPPORTED,
              "na_render_view_ls_pack: precision %d", precision);
   ls::ViewPackArgs pa;
   for (int i = 0; i < 6; ++i) {
     NA_REQUIRE(w[i], NA_ENULL, "na_render_view_ls_pack: weights[%d] is null", i);
     pa.w[i] = w[i]; pa.b[i] = b[i];
   }
+  if (precision == NA_PREC_F16X) return ls::render_lsx_pack(2, w, b, nullptr, nullptr, (char*)packed, (hipStream_t)stream);
   const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
   hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
                      (uint32_t*)packed, (uint32_t)ls::kViewPairs);
@@ -2362,7 +2631,7 @@ extern "C" int na_render_view_ls(const float* rays, const float* pts, int64_t R,
   if (R == 0) return NA_OK;
   NA_REQUIRE(rays && ts && feat && beta && packed && out && workspace, NA_ENULL, "na_render_view_ls: null pointer");
   NA_REQUIRE(feat_ld >= 65, NA_EINVAL, "na_render_view_ls: feat_ld %d < 65 (signed distance + 64 latent columns)", feat_ld);
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X, NA_EUNSUPPORTED,
              "na_render_view_ls: precision %d", precision);
   NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_view_ls: sigmoid %d", sigmoid_kind);
   NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_view_ls: bg %d", bg_kind);
@@ -2382,19 +2651,20 @@ extern "C" int na_render_view_ls(const float* rays, const float* pts, int64_t R,
   a.trace = nullptr;
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 2);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 2);
+  if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 2);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 2);
 }
 
 // ---- VolSDF with the SIREN SDF network as one kernel (src/sdf.py:278-287 + src/nerf.py:981-1013)
 extern "C" size_t na_render_volsdf_siren_ls_packed_bytes(int precision) {
-  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16) return 0;
+  if (precision != NA_PREC_BF16 && precision != NA_PREC_BF16X3 && precision != NA_PREC_F16 && precision != NA_PREC_F16X) return 0;
   return ls::packed_bytes(precision, ls::kSirenPairs);
 }
 
 extern "C" int na_render_volsdf_siren_ls_pack(int precision, const float* const* w_sdf, const float* const* b_sdf,
                                               const float* const* w_view, const float* const* b_view, void* packed, void* stream) {
   NA_REQUIRE(w_sdf && b_sdf && w_view && b_view && packed, NA_ENULL, "na_render_volsdf_siren_ls_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X, NA_EUNSUPPORTED,
              "na_render_volsdf_siren_ls_pack: precision %d", precision);
   ls::SirenPackArgs pa;
   for (int i = 0; i < 7; ++i) {
@@ -2405,6 +2675,7 @@ extern "C" int na_render_volsdf_siren_ls_pack(int precision, const float* const*
     NA_REQUIRE(w_view[i], NA_ENULL, "na_render_volsdf_siren_ls_pack: view weights[%d] is null", i);
     pa.wv[i] = w_view[i]; pa.bv[i] = b_view[i];
   }
+  if (precision == NA_PREC_F16X) return ls::render_lsx_pack(3, w_sdf, b_sdf, w_view, b_view, (char*)packed, (hipStream_t)stream);
   const int planes = precision == NA_PREC_BF16X3 ? 2 : 1;
   hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
                      (uint32_t*)packed, (uint32_t)ls::kSirenPairs);
@@ -2420,7 +2691,7 @@ extern "C" int na_render_volsdf_siren_ls(const float* rays, const float* pts, in
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_volsdf_siren_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;
   NA_REQUIRE(rays && ts && beta && packed && out && workspace, NA_ENULL, "na_render_volsdf_siren_ls: null pointer");
-  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16, NA_EUNSUPPORTED,
+  NA_REQUIRE(precision == NA_PREC_BF16 || precision == NA_PREC_BF16X3 || precision == NA_PREC_F16 || precision == NA_PREC_F16X, NA_EUNSUPPORTED,
              "na_render_volsdf_siren_ls: precision %d", precision);
   NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_volsdf_siren_ls: sigmoid %d", sigmoid_kind);
   NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_volsdf_siren_ls: bg %d", bg_kind);
@@ -2440,6 +2711,7 @@ extern "C" int na_render_volsdf_siren_ls(const float* rays, const float* pts, in
   a.trace = nullptr;
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 3);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 3);
+  if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 3);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 3);
 }
 #endif

@@ -155,7 +155,7 @@ class TinyNeRF(CommonNeRF):
     def forward(self, rays, want_weights: bool = True):
         if self._fusable():
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
-            prec = config.kernel_precision()
+            prec = config.kernel_precision(has_f16x=True)
             out, self.alpha, self.weights = ops.render_tiny_ls(rays, self.ts, self.packed_ls(prec), prec, self.sigmoid_kind,
                                                                 self.bg, want_weights)
             return out
@@ -166,7 +166,7 @@ class TinyNeRF(CommonNeRF):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1)
         if self._fusable() and refl_latent is None and not ag.needs_grad(pts):
             # explicit sample positions (a deformation field in front of TinyNeRF) through the same kernel
-            prec = config.kernel_precision()
+            prec = config.kernel_precision(has_f16x=True)
             out, self.alpha, self.weights = ops.render_tiny_ls(rays.contiguous(), ts, self.packed_ls(prec), prec, self.sigmoid_kind,
                                                                 self.bg, True, pts=pts.contiguous())
             return out
@@ -304,7 +304,7 @@ class VolSDF(CommonNeRF):
             # the SIREN SDF network fits the layer-synchronous engine too: the whole model is ONE kernel (MODEL 3)
             scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
             object.__setattr__(self, "scale_post_act", scale)
-            prec = config.kernel_precision()
+            prec = config.kernel_precision(has_f16x=True)
             out, self.alpha, self.weights = ops.render_volsdf_siren_ls(rays.contiguous(), ts, scale, self.packed_siren_ls(prec), prec,
                                                                         self.sdf.refl.act_kind, "black", True, pts=pts.contiguous())
             return out
@@ -314,7 +314,7 @@ class VolSDF(CommonNeRF):
             raw = self.sdf.underlying(pts)
             scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
             object.__setattr__(self, "scale_post_act", scale)
-            prec = config.kernel_precision()
+            prec = config.kernel_precision(has_f16x=True)
             out, self.alpha, self.weights = ops.render_view_ls(rays.contiguous(), ts, raw, scale, self.packed_view_ls(prec), prec,
                                                                 self.sdf.refl.act_kind, "black", True, pts=pts.contiguous())
             return out

@@ -21,8 +21,10 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(scope="module")
-def na():
+# both parity-class precisions: the 3-product bf16 split and f16x (f16 + two MX-fp6 corrections; the one-kernel renderers run
+# it, the generic fused MLP launches of D-NeRF's deformation network and of the Fourier-MLP SDF stay in bf16x3)
+@pytest.fixture(scope="module", params=["bf16x3", "f16x"])
+def na(request):
     assert torch.cuda.is_available()
     import nerf_atlas_amd.nerf as nerf
     import nerf_atlas_amd.refl as refl
@@ -30,11 +32,12 @@ def na():
     import nerf_atlas_amd.cameras as cameras
     import nerf_atlas_amd.render as render
     from nerf_atlas_amd import config, ops
-    config.set_precision("bf16x3")
+    config.set_precision(request.param)
     class NS: pass
     ns = NS()
     ns.nerf, ns.refl, ns.sdf, ns.cameras, ns.render, ns.ops = nerf, refl, sdf, cameras, render, ops
-    return ns
+    yield ns
+    config.set_precision("bf16x3")
 
 
 def load_params(model, params):

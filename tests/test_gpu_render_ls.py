@@ -269,8 +269,8 @@ def test_ls_kernels_refuse_a_stream_packed_for_something_else(ops):
     bad, _, _ = ops.render_plain_view_ls(rays, ts, tables, packed_x3[: packed_16.numel()].clone(), "bf16", "upshifted", "black")
     assert torch.isnan(bad).all()
     packed_fx, _ = pack_ls(ops, p, "f16x")
-    assert packed_fx.numel() > packed_x3.numel()
-    assert torch.isnan(ops.render_plain_view_ls(rays, ts, tables, packed_fx, "bf16x3", "upshifted", "black")[0]).all()
+    wrong = torch.cat([packed_fx, packed_fx])[: packed_x3.numel()].contiguous()  # an f16x stream where a bf16x3 one is expected
+    assert torch.isnan(ops.render_plain_view_ls(rays, ts, tables, wrong, "bf16x3", "upshifted", "black")[0]).all()
     assert torch.isnan(ops.render_plain_view_ls(rays, ts, tables, torch.cat([packed_x3, packed_x3])[: packed_fx.numel()].contiguous(),
                                                 "f16x", "upshifted", "black")[0]).all()
     t = load_golden("g13_tiny")
@@ -279,7 +279,7 @@ def test_ls_kernels_refuse_a_stream_packed_for_something_else(ops):
     tiny = ops.render_tiny_ls_pack("bf16", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])
     assert torch.isfinite(ops.render_tiny_ls(rays, ts, tiny, "bf16", "upshifted", "black")[0]).all()
     assert torch.isnan(ops.render_tiny_ls(rays, ts, packed_16, "bf16", "upshifted", "black")[0]).all()  # PlainNeRF stream
-    # f16x exists for the PlainNeRF(view) renderer only: the other schedules refuse it
-    from nerf_atlas_amd._lib import NaError
-    with pytest.raises(NaError):
-        ops.render_tiny_ls_pack("f16x", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])
+    # f16x streams carry their own unit count: a TinyNeRF f16x stream is refused by the PlainNeRF kernel and vice versa
+    tiny_x = ops.render_tiny_ls_pack("f16x", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])
+    assert torch.isfinite(ops.render_tiny_ls(rays, ts, tiny_x, "f16x", "upshifted", "black")[0]).all()
+    assert torch.isnan(ops.render_tiny_ls(rays, ts, packed_fx, "f16x", "upshifted", "black")[0]).all()
