@@ -328,22 +328,39 @@ __global__ void composite_kernel(const float* __restrict__ density, const float*
     float acc[C > 0 ? C : 8];
     for (int c = 0; c < CC; ++c) acc[c] = 0.f;
     float wsum_head = 0.f;  // sum of weights[:-1] for the white background (Q4)
-    for (int t = 0; t < T; ++t) {
-      float d = density[(int64_t)t * R + r];
-      // hardware transcendentals (common.h): with libm's log1pf(expf()) / expf() this kernel was ALU-bound at ~300
-      // instructions per sample (198 us for 20.5 M samples; now 165 us).  One thread per (ray, 32-step segment) with the
-      // segments meeting in LDS -- 4x the threads -- measured slower in both versions (242 us with libm, 188 us with these)
-      float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? fast_softplus(d - 1.0f) : fmaxf(d, 0.f);
-      float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
-      dist = dist * nrm;
-      float a = 1.0f - fast_exp(-sigma * dist);
-      float w = a * trans;
-      trans = trans * ((1.0f - a) + 1e-10f);
-      if (alpha_out != nullptr) alpha_out[(int64_t)t * R + r] = a;
-      if (weights_out != nullptr) weights_out[(int64_t)t * R + r] = w;
-      const float* f = feat + ((int64_t)t * R + r) * CC;
-      for (int c = 0; c < CC; ++c) acc[c] = acc[c] + w * f[c];
-      if (t < T - 1) wsum_head = wsum_head + w;
+    // The walk is a dependent chain of T steps, and a step that waits for its own loads costs one HBM latency (165 us for
+    // 128 steps = 1.3 us per step with ~10 waves per CU: latency-bound, 37 % of the HBM rate).  Rows are therefore fetched
+    // U = 8 steps at a time -- 8 x (1 + C) independent loads in flight per thread -- before the 8 dependent updates run.
+    constexpr int U = 8;
+    for (int t0 = 0; t0 < T; t0 += U) {
+      float dv[U], fv[U][C > 0 ? C : 8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u < T ? t0 + u : T - 1;  // (clamped: the tail re-reads the last row and ignores it)
+        dv[u] = density[(int64_t)t * R + r];
+        const float* f = feat + ((int64_t)t * R + r) * CC;
+        for (int c = 0; c < CC; ++c) fv[u][c] = f[c];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u;
+        if (t < T) {
+          const float d = dv[u];
+          // hardware transcendentals (common.h): with libm's log1pf(expf()) / expf() this kernel was ALU-bound at ~300
+          // instructions per sample.  One thread per (ray, 32-step segment) with the segments meeting in LDS -- 4x the
+          // threads -- measured slower.
+          float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? fast_softplus(d - 1.0f) : fmaxf(d, 0.f);
+          float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
+          dist = dist * nrm;
+          float a = 1.0f - fast_exp(-sigma * dist);
+          float w = a * trans;
+          trans = trans * ((1.0f - a) + 1e-10f);
+          if (alpha_out != nullptr) alpha_out[(int64_t)t * R + r] = a;
+          if (weights_out != nullptr) weights_out[(int64_t)t * R + r] = w;
+          for (int c = 0; c < CC; ++c) acc[c] = acc[c] + w * fv[u][c];
+          if (t < T - 1) wsum_head = wsum_head + w;
+        }
+      }
     }
     float sky = bg_kind == NA_BG_WHITE ? 1.0f - wsum_head : 0.f;
     for (int c = 0; c < CC; ++c) out[r * CC + c] = acc[c] + sky;
@@ -363,14 +380,24 @@ __global__ void integrate_kernel(const float* __restrict__ weights, const float*
 }
 
 // src/utils.py:50-58 + src/nerf.py:1000-1003
+__device__ __forceinline__ float laplace_density_of(float sdf, float sc, float inv) {
+  const float scaled = (-sdf) / sc;
+  // (fast_exp: v_exp_f32 with the product's rounding error recovered, 2e-7 relative -- libm's expf made this elementwise
+  // kernel ALU-bound at 30 % of the HBM rate)
+  const float cdf = scaled <= 0.f ? fast_exp(fminf(scaled, 0.f)) / 2.f : 1.f - fast_exp(-fmaxf(scaled, 0.f)) / 2.f;
+  return inv * cdf;
+}
 __global__ void laplace_density_kernel(const float* __restrict__ sdf, int64_t N, const float* __restrict__ beta,
                                        float* __restrict__ density) {
-  float sc = beta[0];
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-    float scaled = (-sdf[i]) / sc;
-    float cdf = scaled <= 0.f ? expf(fminf(scaled, 0.f)) / 2.f : 1.f - expf(-fmaxf(scaled, 0.f)) / 2.f;
-    density[i] = (1.0f / sc) * cdf;
+  const float sc = beta[0], inv = 1.0f / sc;
+  const int64_t n4 = (((uintptr_t)sdf | (uintptr_t)density) & 15) == 0 ? N / 4 : 0;  // 16-byte rows when both are aligned
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = ((const float4*)sdf)[i];
+    ((float4*)density)[i] = make_float4(laplace_density_of(v.x, sc, inv), laplace_density_of(v.y, sc, inv),
+                                        laplace_density_of(v.z, sc, inv), laplace_density_of(v.w, sc, inv));
   }
+  for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    density[i] = laplace_density_of(sdf[i], sc, inv);
 }
 
 // src/nerf.py:1173-1178 (de Casteljau), 1201-1206 (cubic), 1267-1278 (warp)
