@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run-to-run determinism of the layer-synchronous renderer: the same call N times (ts mode and explicit-position mode,
-both precisions, alpha / weights requested), every output compared bit for bit with the first run.
+the parity modes f16x and bf16x3 and the bf16 fast mode, alpha / weights requested), every output compared bit for bit with the first run.
     python tools/ls_determinism.py [N]"""
 import math, os, sys
 import torch
@@ -12,7 +12,7 @@ torch.manual_seed(0)
 bad = 0
 c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
 cam = cameras.NeRFCamera(cam_to_world=c2w, focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
-for prec in ("bf16x3", "bf16"):
+for prec in ("f16x", "bf16x3", "bf16"):
     config.set_precision(prec)
     m = nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").cuda().eval()
     with torch.no_grad():
@@ -40,7 +40,7 @@ from nerf_atlas_amd.utils import load_mip
 import types
 rays = cam.sample_positions((380, 390, 40, 40), size=800)
 times = torch.tensor([0.5], device="cuda")
-for prec in ("bf16x3", "bf16"):
+for prec in ("f16x", "bf16x3", "bf16"):
     config.set_precision(prec)
     canon = nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
     models = {

@@ -4,7 +4,7 @@ sample groups, ~37 rays each): the same call N times, colour / alpha / weights c
 per-element median over the runs.  This is the test that exposed the timing-dependent differences of DESIGN 3b
 "reproducibility" (16 samples of one block, lanes 16..31, off by ~1e-3 relative in one run of ~20..10^4).
 
-    python tools/ls_repeat.py [bf16x3|bf16|f16] [--tiny | --volsdf-mlp | --volsdf-siren] [N]
+    python tools/ls_repeat.py [f16x|bf16x3|bf16|f16] [--tiny | --volsdf-mlp | --volsdf-siren] [N]
     python tools/ls_repeat.py variants        # here: timing-stress builds (group lag 3 / 5 / 9, no XCD-aware order) under
                                               # gpurun_ablate/repeat_<name>/; run each with  --lib <dir>
 """
@@ -40,7 +40,7 @@ def main(argv):
     sys.path.insert(0, lib or REPO)
     import torch
     from nerf_atlas_amd import nerf, config, cameras, ops
-    precs = [argv[0]] if argv and argv[0] in ("bf16", "bf16x3", "f16") else ["bf16x3", "bf16", "f16"]
+    precs = [argv[0]] if argv and argv[0] in ("bf16", "bf16x3", "f16", "f16x") else ["f16x", "bf16x3", "bf16", "f16"]
     n = int([x for x in argv if x.isdigit()][-1]) if any(x.isdigit() for x in argv) else 200
     torch.manual_seed(0)
     c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
@@ -66,7 +66,7 @@ def main(argv):
             call = lambda: ops.render_tiny_ls(rays, ts, m.packed_ls(prec), prec, "upshifted", "black", True)
         else:
             m = nerf.PlainNeRF(steps=128, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").cuda().eval()
-            call = lambda: m._render_fused(rays, ts, True)
+            call = lambda: m._render_fused(rays, ts, True)  # (config.precision picks the kernel: f16x included)
         with torch.no_grad():
             outs = []
             for i in range(n):
