@@ -193,7 +193,7 @@ def pi16(r, h):  # accumulator register r of lane half h -> feature inside the 3
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
 
-def pack_weights(Wh, sigma):
+def pack_weights(Wh, sigma, layout="v1"):
     """Wh: list of L [256,256] float64 -> the stream [L][4 rg][4 Q][REC bytes] (uint8 tensor) + emulation planes"""
     import torch
     L = len(Wh)
@@ -236,9 +236,16 @@ def pack_weights(Wh, sigma):
                         (Wl6v if which == 0 else Wt6v)[rows[:, None], cols] = dec
                         words = pack_bits6(codes)  # [64,6]
                         i = 2 * t + which
-                        base = 8192 + i * 1536
-                        rec[base:base + 1024] = words[:, :4].contiguous().view(torch.uint8).reshape(-1)
-                        rec[base + 1024:base + 1536] = words[:, 4:].contiguous().view(torch.uint8).reshape(-1)
+                        if layout == "v1":  # per operand: a 16-byte part and an 8-byte part per lane
+                            base = 8192 + i * 1536
+                            rec[base:base + 1024] = words[:, :4].contiguous().view(torch.uint8).reshape(-1)
+                            rec[base + 1024:base + 1536] = words[:, 4:].contiguous().view(torch.uint8).reshape(-1)
+                        else:  # "v2": per tile {WL6 | WT6} = 12 dwords per lane as three lane-linear 16-byte parts
+                            base = 8192 + t * 3072
+                            view = rec[base:base + 3072].view(torch.int32).reshape(3, 64, 4)
+                            for dw in range(6):
+                                g = 6 * which + dw
+                                view[g // 4, :, g % 4] = words[:, dw]
                         sc = (e + 127).to(torch.uint8)
                         rec[8192 + 6144 + i:8192 + 6144 + 256:4] = sc
         emu.append((Wh16, Wl6v, Wt6v))
@@ -358,8 +365,88 @@ def run(L=12):
     print(json.dumps(dict(L=L, N=N, ref_max=sc, calibration=cal, results=results)))
 
 
+W4X_VARIANTS = {"w4x": (0, 0), "w4x_pipe": (0, 1), "w4x_now": (2, 0), "w4x_pipe_now": (2, 1)}
+
+
+def build_w4x():
+    for name, (ab, pipe) in W4X_VARIANTS.items():
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared",
+                        "-mllvm", "-pragma-unroll-threshold=1000000",  # the pipelined slots exceed the default 16 k: acc[] would stay in scratch
+                        f"-DW4X_ABLATE={ab}", f"-DW4X_PIPE={pipe}", os.path.join(HERE, "ls_mlp_w4x.hip"), "-o", lib_path(name)], check=True)
+        print(lib_path(name))
+
+
+def run_w4x(L=12):
+    """tools/proto/ls_mlp_w4x.hip: one wave per SIMD works for both sample groups, f16 weights resident per layer"""
+    import torch
+    torch.manual_seed(0)
+    dev = "cuda"
+    sigma = [2 * i for i in range(16)] + [2 * i + 1 for i in range(16)]  # probed by `run` (calibrate)
+    N = 4 * 1024 * 1024
+    Wi = (torch.randn(256, 16, dtype=torch.float64) * (6 / 16) ** 0.5 * 0.5).to(torch.float16).double()
+    Wh = [(torch.randn(256, 256, dtype=torch.float64) * (2 / 256) ** 0.5).float().double() for _ in range(L)]
+    bi, bh = (torch.randn(256) * 0.1).double(), (torch.randn(L, 256) * 0.1).double()
+    lanes = torch.arange(64)
+    w_init = torch.empty(8, 64, 8, dtype=torch.float16)
+    for t in range(8):
+        for e in range(8):
+            w_init[t, :, e] = Wi[32 * t + (lanes & 31), 8 * (lanes >> 5) + e].to(torch.float16)
+    stream_w, emu = pack_weights(Wh, sigma, layout="v2")
+    b_pack = torch.empty(L, 4, 2, 2, 16)
+    for rg in range(4):
+        for t in range(2):
+            for hh in range(2):
+                for r in range(16):
+                    b_pack[:, rg, t, hh, r] = bh[:, 64 * rg + 32 * t + pi16(r, hh)].float()
+    x = torch.randn(N, 16).to(torch.float16).float()
+    M = 4096
+    sel = (torch.arange(M) % 128) >= 64  # the prototype reports the second sample group of every pass
+    xr = x[:M].double()
+    ref = emulate(xr, Wi, bi, Wh, bh, emu, "exact")[sel]
+    e16 = emulate(xr, Wi, bi, Wh, bh, emu, "f16")[sel]
+    sc = float(ref.abs().max())
+    print(f"host emulation (|ref| max {sc:.2f}): f16 L-inf {float((e16 - ref).abs().max()):.3e}")
+    d = dict(w_init=w_init.contiguous().to(dev), w=stream_w.contiguous().to(dev), bi=bi.float().to(dev), bp=b_pack.contiguous().to(dev),
+             x=x.to(dev), y=torch.zeros(N, 32, device=dev))
+    flop = 2 * (16 * 256 + L * 256 * 256)
+    for name in W4X_VARIANTS:
+        if not os.path.exists(lib_path(name)):
+            continue
+        lib = C.CDLL(lib_path(name))
+        fn = lib.ls_w4x_forward
+        fn.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        st = torch.cuda.current_stream().cuda_stream
+        d["y"].zero_()
+        args = [d["w_init"].data_ptr(), d["w"].data_ptr(), d["bi"].data_ptr(), d["bp"].data_ptr(), d["x"].data_ptr(), d["y"].data_ptr(),
+                N, L, st, None]
+        assert fn(*args) == 0
+        torch.cuda.synchronize()
+        err = float((d["y"][:M].cpu().double()[sel] - ref).abs().max())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            fn(*args)
+        e0.record()
+        for _ in range(10):
+            fn(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) / 10 * 1e-3
+        tr = torch.zeros(64, dtype=torch.int64, device=dev)
+        args[-1] = tr.data_ptr()
+        fn(*args)
+        torch.cuda.synchronize()
+        t = tr.cpu()[: 2 * min(L, 32)].double()
+        ph = (t[1:] - t[:-1])[2:-2]
+        print(f"{name:14s} L-inf {err:.3e}  {dt * 1e3:7.2f} ms  {N / dt / 1e6:7.0f} Msamples/s  {N * flop / dt / 2.5e15:6.1%} of bf16 peak"
+              f" | phase {ph.mean():.0f} cycles (96 MFMAs: {ph.mean() / 96:.1f} per MFMA)", flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "build_w4x":
+        build_w4x()
+    elif sys.argv[1] == "run_w4x":
+        run_w4x(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     else:
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
