@@ -95,6 +95,9 @@ constexpr int kPartialFloats = 8;
 #ifndef NA_LSX_PRIO
 #define NA_LSX_PRIO 0  // experiments: 0 the MFMA phases run at s_setprio 1 (like the other precisions), 1 no priorities, 2 the epilogues
 #endif
+#ifndef NA_LSX_EXP
+#define NA_LSX_EXP 0  // timing experiments (tools/ls_variant.py): 1 two of three fp6 parts, 2 no fp6 loads, 4 no f16 refills
+#endif
 namespace x {
 constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
 constexpr int BLKH = 4 * KQ;                 // hidden activations of one block (32 KiB)
@@ -484,7 +487,11 @@ __device__ __forceinline__ f16x8 wload16(__amdgpu_buffer_rsrc_t rs, int lane, in
 __device__ __forceinline__ u32x12 wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t) {
   const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + 8192 + t * 3072, 0);
   const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 1024, roff + 8192 + t * 3072, 0);
+#if NA_LSX_EXP & 1  // timing experiment: two of the three parts
+  const u32x4 c = b;
+#else
   const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 2048, roff + 8192 + t * 3072, 0);
+#endif
   return u32x12{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
 }
 __device__ __forceinline__ int wloadsc(__amdgpu_buffer_rsrc_t rs, int lane, int roff) {
@@ -592,7 +599,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
         acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], (CB && ci == 0) ? cb[0] : acc[0][b], 0, 0, 0);
         if constexpr (NT == 2)
           acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], (CB && ci == 0) ? cb[NT - 1] : acc[1][b], 0, 0, 0);
-        if (b == 0) {
+        if (b == 0 && !(NA_LSX_EXP & 4)) {
           R.a16[c][0] = wload16(rs, lane, noff, 0, c);
           R.a16[c][1] = wload16(rs, lane, noff, 1, c);
         }
@@ -610,9 +617,11 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    R.a6[0] = wload6(rs, lane, noff, 0);
-    R.a6[1] = wload6(rs, lane, noff, 1);
-    R.asc = wloadsc(rs, lane, noff);
+    if (!(NA_LSX_EXP & 2)) {
+      R.a6[0] = wload6(rs, lane, noff, 0);
+      R.a6[1] = wload6(rs, lane, noff, 1);
+      R.asc = wloadsc(rs, lane, noff);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(0);

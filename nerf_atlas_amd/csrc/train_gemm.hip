@@ -13,6 +13,10 @@
 // double-buffered LDS tile pair [rows][32 k] of hi and lo bf16 with an 80-byte row pitch (conflict-free ds_read_b128
 // fragments), global loads for stage k+1 in flight under the MFMAs of stage k, one barrier per stage.  The activation
 // (and the split) is applied once per element by the loader; with BN = 256 a sample's row is activated exactly once.
+#include <atomic>
+#include <type_traits>
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace na {
@@ -21,6 +25,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #ifndef TG_ABLATE
 #define TG_ABLATE 0  // experiments only: 1 no MFMA, 2 no global loads, 4 no LDS stash, 8 no fragment reads
@@ -467,9 +472,421 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
   return launch_nt<4, 1, MODE>(a, ncols, st, what);
 }
 
+
+// ================================================================================ layer-synchronous NT kernel (round 3)
+// The same GEMM  C[samples, M] = A[samples, K] . B[M, K]^T  organised like the renderer (render_ls.hip) instead of a
+// K-staged tile pair: a workgroup keeps a 128-sample tile of A in LDS as split bf16 planes, 128 k at a time, and streams the
+// pre-packed bf16 hi/lo fragments of B from L2 straight into registers (a 4-deep fragment ring refilled in place), so B never
+// passes through LDS or the split arithmetic again, A is read from HBM as whole contiguous rows, and each 4-KiB fragment set of
+// B feeds 24 MFMAs (the K-staged kernel moved 48 KiB through the vector memory path per 24: it was bound by that path).
+// Two roles of four waves: PRODUCERS (waves 4-7) fetch the rows two units ahead into registers, activate + split them and fill
+// the other LDS buffer; CONSUMERS (waves 0-3, one 64-column group of C each) run the MFMAs and the epilogue.  The roles have
+// their own vmcnt queues, so the HBM latency of the row fetches never stands in front of a weight fragment (loads of one wave
+// return in order).  One barrier per unit = (tile, pass over 256 columns of C, k chunk).
+#ifndef TGL_ABLATE
+#define TGL_ABLATE 0  // timing experiments: 1 no row fetches, 2 no epilogue stores, 4 no MFMAs, 8 no weight refills, 16 no LDS fill
+#endif
+#ifndef TGL_TRACE
+#define TGL_TRACE 0  // experiment builds (tools/ls_variant.py): s_memtime stamps of workgroup 0, waves 0 (consumer) and 4 (producer)
+#endif
+namespace lsnt {
+#if TGL_TRACE
+__device__ unsigned long long tgl_trace[2][32][4];
+#define TGL_STAMP(role, u, slot) do { if (blockIdx.x == 0 && lane == 0 && (u) < 32) tgl_trace[role][(u)][slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TGL_STAMP(role, u, slot) do {} while (0)
+#endif
+constexpr int TS = 128;             // samples per tile
+constexpr int KC = 128;             // k per LDS fill
+constexpr int PITCH = KC * 2 + 16;  // row pitch of a plane: 68 dwords = 4 mod 64 -> conflict-free b128 fragment reads
+constexpr int PLANE = TS * PITCH;
+constexpr int BUF = 2 * PLANE;      // hi | lo
+constexpr int LDS = 2 * BUF;        // two buffers: 136 KiB
+constexpr int NPF = TS * (KC / 4) / 256;  // 16-byte pieces per producer thread and unit
+constexpr int SP = 36;               // float pitch of the consumers' 32 x 32 transpose tiles (4 x 4.5 KiB behind the buffers)
+constexpr int STG = 4 * 32 * SP * 4;
+
+struct Args {
+  RowSrc a;          // [samples, K] (concat)
+  const char* wp;    // packed B: [column group of 64][k step][tile 2][plane 2][lane 64][8 bf16]
+  int M, KS, act;    // KS = k steps of 16, a multiple of 4 (zero padded)
+  const float* bias;
+  float* y0;
+  float* y1;
+  const float* x0;
+  const float* x1;
+  int c0, c1;
+  int64_t ntiles;
+};
+
+// one thread per (column group, k step, tile, lane): 8 consecutive k of row m of B, split
+__global__ void pack_kernel(const float* __restrict__ W, int M, int K, int KS, int nrg, char* __restrict__ dst) {
+  const int64_t total = (int64_t)nrg * KS * 128;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), t = (int)((i >> 6) & 1);
+    const int s = (int)((i >> 7) % KS), rg = (int)((i >> 7) / KS);
+    const int m = 64 * rg + 32 * t + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (m < M && k0 + e < K) ? W[(int64_t)m * K + k0 + e] : 0.f;
+      const __bf16 h = (__bf16)v;
+      hi[e] = h;
+      lo[e] = (__bf16)(v - (float)h);
+    }
+    char* o = dst + (((int64_t)rg * KS + s) * 4 + t * 2) * 1024 + lane * 16;
+    *(bf16x8*)o = hi;
+    *(bf16x8*)(o + 1024) = lo;
+  }
+}
+
+// MODE 0 forward, 1 input gradient; DACT: the input gradient is scaled by act'(forward input) in the epilogue
+template <int MODE, bool DACT>
+__global__ __launch_bounds__(512) void kernel(Args g) {
+  constexpr int RD = 4;  // depth of the weight fragment ring (k steps)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NCH = (g.KS + 7) >> 3;
+  const int nrg = (g.M + 63) >> 6;
+  const int NP = (nrg + 3) >> 2;  // passes over the tile: 256 columns of C each
+  const int UPT = NCH * NP;       // units per tile
+  const int64_t my_tiles = (g.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  const int64_t nunits = my_tiles * UPT;
+  // the bias vector (zero padded to whole column groups) lives in LDS behind the two tile buffers: the epilogue reads it with
+  // LDS loads, which do not queue behind the wave's outstanding stores the way a global load would
+  float* lbias = (float*)(smem + LDS + STG);
+  if (MODE == 0) {
+    for (int i = tid; i < nrg * 64; i += 512) lbias[i] = (g.bias != nullptr && i < g.M) ? g.bias[i] : 0.f;
+  }
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ producers
+    const int ptid = tid - 256, c4 = ptid & 31, r0 = ptid >> 5;  // piece c4 (4 k) of rows r0 + 8 j
+    f32x4 pf0[NPF], pf1[NPF];
+    auto load = [&](f32x4 (&pf)[NPF], int64_t u) {
+      if (TGL_ABLATE & 1) return;
+      const int64_t m0 = (blockIdx.x + (u / UPT) * gridDim.x) * TS;
+      const int ch = (int)(u % NCH);
+      const int left = g.KS - 8 * ch;
+      const int kc4 = (left < 8 ? left : 8) * 4;  // 16-byte pieces per row of this chunk
+      const int k = ch * KC + c4 * 4;
+      if (ch * KC + kc4 * 4 <= g.a.k0 && (g.a.k0 & 3) == 0) {  // the chunk lies inside the first source: whole aligned pieces
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+          const int64_t row = m0 + r0 + 8 * j;
+          pf[j] = (c4 < kc4 && row < g.a.rows) ? *(const f32x4*)(g.a.p0 + row * g.a.k0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) pf[j] = c4 < kc4 ? load_k4(g.a, m0 + r0 + 8 * j, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    // (the activation is a runtime argument: one specialised copy of the loop per kind, chosen once per unit -- with the switch
+    // inside, every element carried the sine polynomial next to the LeakyReLU select: 180 instructions per 4 values)
+    auto convert_as = [&](const f32x4 (&pf)[NPF], char* buf, auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+      for (int j = 0; j < NPF; ++j) {
+        f32x4 v = pf[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tact(v[e], ACT);
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        char* d = buf + (r0 + 8 * j) * PITCH + c4 * 8;
+        *(bf16x4*)d = hi;
+        *(bf16x4*)(d + PLANE) = lo;
+      }
+    };
+    auto convert = [&](const f32x4 (&pf)[NPF], int64_t u, char* buf) {
+      const int ch = (int)(u % NCH);
+      const int left = g.KS - 8 * ch;
+      const int kc4 = (left < 8 ? left : 8) * 4;
+      if (c4 >= kc4 || (TGL_ABLATE & 16)) return;
+      if (MODE == 0 && g.act == NA_ACT_LEAKY_RELU) convert_as(pf, buf, std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
+      else if (MODE == 0 && g.act == NA_ACT_SIN) convert_as(pf, buf, std::integral_constant<int, NA_ACT_SIN>{});
+      else convert_as(pf, buf, std::integral_constant<int, NA_ACT_NONE>{});
+    };
+    load(pf0, 0);
+    if (nunits > 1) load(pf1, 1);
+    convert(pf0, 0, smem);
+    if (nunits > 2) load(pf0, 2);
+    __syncthreads();
+    for (int64_t u = 0; u < nunits; u += 2) {
+      if (wave == 4) TGL_STAMP(1, u, 0);
+      if (u + 1 < nunits) {  // during unit u: unit u + 1 into buffer 1
+        convert(pf1, u + 1, smem + BUF);
+        if (wave == 4) TGL_STAMP(1, u, 1);
+        if (u + 3 < nunits) load(pf1, u + 3);
+      }
+      if (wave == 4) TGL_STAMP(1, u, 2);
+      __syncthreads();
+      if (wave == 4) TGL_STAMP(1, u, 3);
+      if (u + 1 < nunits) {
+        if (wave == 4) TGL_STAMP(1, u + 1, 0);
+        if (u + 2 < nunits) {  // during unit u + 1: unit u + 2 into buffer 0
+          convert(pf0, u + 2, smem);
+          if (wave == 4) TGL_STAMP(1, u + 1, 1);
+          if (u + 4 < nunits) load(pf0, u + 4);
+        }
+        if (wave == 4) TGL_STAMP(1, u + 1, 2);
+        __syncthreads();
+        if (wave == 4) TGL_STAMP(1, u + 1, 3);
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumers
+  const int ncols = g.c0 + g.c1;
+  f32x16 acc[2][4];         // [column tile][32-sample block]: rows = 32 columns of C, columns = samples
+  bf16x8 ring[RD][2][2];    // [slot][tile][plane]
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.wp, 0, nrg * g.KS * 4096, 0x00020000);
+  auto wfrag = [&](int R, int sg, int t, int p) -> bf16x8 {  // scalar offset of the (column group, k step), the rest an immediate
+    const int soff = __builtin_amdgcn_readfirstlane((R * g.KS + sg) * 4096);
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16 + (t * 2 + p) * 1024, soff, 0));
+  };
+  // the weight stream of this wave: pass 0 .. NP-1, k steps 0 .. KS-1 each, then again for the next tile.  Column groups past
+  // M (the last pass of a narrow C) are skipped by the whole wave.
+  auto group_of = [&](int pass) { const int R = wave + 4 * pass; return R < nrg ? R : -1; };
+  {
+    const int R = group_of(0);
+    if (R >= 0) {
+#pragma unroll
+      for (int i = 0; i < RD; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { ring[i][t][0] = wfrag(R, i, t, 0); ring[i][t][1] = wfrag(R, i, t, 1); }
+    }
+  }
+  const bool all_vec = ((g.c0 | g.c1) & 3) == 0;  // every row of both outputs is written as aligned 16-byte pieces
+  constexpr bool dact = DACT;
+  constexpr uint32_t OOB = 0x78000000u;           // a byte offset past every buffer below: the hardware drops the access
+  __syncthreads();
+  for (int64_t u = 0; u < nunits; ++u) {
+    const int64_t m0 = (blockIdx.x + (u / UPT) * gridDim.x) * TS;
+    const int ch = (int)(u % NCH), pass = (int)((u / NCH) % NP);
+    const int left = g.KS - 8 * ch;
+    const int ns = left < 8 ? left : 8;
+    const char* buf = smem + (u & 1) * BUF;
+    const int R = group_of(pass);
+    if (wave == 0) TGL_STAMP(0, u, 0);
+    if (R >= 0) {
+      if (ch == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
+      }
+      const char* brow = buf + (lane & 31) * PITCH + (lane >> 5) * 16;
+      bf16x8 xh[2], xl[2];
+      auto xfrag = [&](int sl, int b, int slot) {
+        const char* p = brow + b * 32 * PITCH + sl * 32;
+        xh[slot] = *(const bf16x8*)p;
+        xl[slot] = *(const bf16x8*)(p + PLANE);
+      };
+      xfrag(0, 0, 0);
+      for (int s = 0; s < ns; s += RD) {
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+          // the ring slot's next occupant: RD k steps on, in the next pass (or the next tile's first pass) past the end
+          int sn = 8 * ch + s + i + RD, Rn = R;
+          if (sn >= g.KS) {
+            sn -= g.KS;
+            const int pn = pass + 1 == NP ? 0 : pass + 1;
+            Rn = group_of(pn);
+            if (Rn < 0) Rn = group_of(0);  // this wave sits out the last pass: fetch for the next tile's pass 0
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int cur = b & 1;
+            if (b < 3) xfrag(s + i, b + 1, cur ^ 1);           // the next block's fragments under this block's MFMAs
+            else if (s + i + 1 < ns) xfrag(s + i + 1, 0, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const bf16x8 wh = ring[i][t][0], wl = ring[i][t][1];
+              if (TGL_ABLATE & 4) { acc[t][b][0] += (float)wl[0] + (float)xh[cur][0] + (float)wh[1] + (float)xl[cur][1]; continue; }
+              acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[cur], acc[t][b], 0, 0, 0);
+              acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[cur], acc[t][b], 0, 0, 0);
+              acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[cur], acc[t][b], 0, 0, 0);
+            }
+            // refill in place, behind the slot's last MFMAs: needed RD k steps from now.  (dgrad with an activation: the ring is
+            // not carried across the epilogue, whose 64 registers of forward inputs it would sit next to)
+            if (b == 3 && !(TGL_ABLATE & 8) && !(dact && 8 * ch + s + i + RD >= g.KS)) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t) { ring[i][t][0] = wfrag(Rn, sn, t, 0); ring[i][t][1] = wfrag(Rn, sn, t, 1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (wave == 0) TGL_STAMP(0, u, 1);
+      if (ch == NCH - 1 && !((TGL_ABLATE & 2) && acc[0][0][0] != 1.2345f)) {
+        // Epilogue.  The accumulators hold 4 consecutive columns per register quad and one SAMPLE per lane: stored like that, a
+        // 16-byte store touches 32 rows with 32 bytes each (4096 partial-line requests per tile: measured 8-23 k cycles).  Every
+        // 32 x 32 block goes through a wave-private LDS tile instead and leaves as whole 128-byte lines (8 lanes per row).
+        // Branch-free: buffer accesses whose offsets fall outside the (tile-relative) buffer are dropped by the hardware -- rows
+        // past the batch, columns past M, a null output -- so no store waits for a compare.
+        const int64_t left_rows = g.a.rows - m0;
+        auto rsrc_of = [&](const float* base, int ld) {
+          int64_t bytes = base == nullptr ? 0 : left_rows * ld * 4;
+          if (bytes > 0x70000000ll) bytes = 0x70000000ll;
+          return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)g.wp : base + m0 * ld), 0, (int)bytes, 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t ry0 = rsrc_of(g.y0, g.c0), ry1 = rsrc_of(g.y1, g.c1);
+        const __amdgpu_buffer_rsrc_t rx0 = rsrc_of(dact ? g.x0 : nullptr, g.c0);
+        const __amdgpu_buffer_rsrc_t rx1 = rsrc_of(dact ? g.x1 : nullptr, g.c1);
+        float* stg = (float*)(smem + LDS) + wave * (32 * SP);
+        const int rrow = lane >> 3, rc4 = (lane & 7) * 4;  // after the transpose: row rrow + 8 j of the block, columns rc4 .. rc4 + 3
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int tc0 = 64 * R + 32 * t;                      // the tile's first column
+          const bool side0 = tc0 < g.c0, side1 = tc0 + 32 > g.c0 && g.c1 > 0;  // wave-uniform: which outputs the tile touches
+          const int col = tc0 + rc4;
+          const uint32_t o0 = (col < g.c0) ? (uint32_t)((rrow * g.c0 + col) * 4) : OOB;
+          const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((rrow * g.c1 + col - g.c0) * 4) : OOB;
+          f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+          if (MODE == 0) bj = *(const f32x4*)(lbias + col);
+          f32x4 xq[4][4];  // dgrad with an activation: the tile's forward inputs, all 16 loads in flight together
+          if (dact && all_vec) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int s0 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c0 * 4), s1 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c1 * 4);
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+                if (side0) xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx0, o0, s0, 0));
+                if (side1) {
+                  const f32x4 x1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, o1, s1, 0));
+                  xv = (side0 && col < g.c0) ? xv : x1v;
+                }
+                xq[b][j] = xv;
+              }
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(f32x4*)(stg + (lane & 31) * SP + 8 * q + 4 * (lane >> 5)) =
+                  f32x4{acc[t][b][4 * q], acc[t][b][4 * q + 1], acc[t][b][4 * q + 2], acc[t][b][4 * q + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 v = *(const f32x4*)(stg + (rrow + 8 * j) * SP + rc4);
+              if (MODE == 0) v += bj;
+              const int s0 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c0 * 4), s1 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c1 * 4);
+              if (all_vec) {
+                if (dact) {
+                  if (g.act == NA_ACT_SIN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xq[b][j][e], NA_ACT_SIN);
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xq[b][j][e], NA_ACT_LEAKY_RELU);
+                  }
+                }
+                if (side0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, s0, 0);
+                if (side1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, s1, 0);
+              } else {
+                // rows that are not 16-byte aligned (a column count that is no multiple of 4): element by element
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const int ce = col + e;
+                  const uint32_t p0 = (ce < g.c0) ? (uint32_t)((rrow * g.c0 + ce) * 4) : OOB;
+                  const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((rrow * g.c1 + ce - g.c0) * 4) : OOB;
+                  if (side0) {
+                    float w = v[e];
+                    if (dact) w *= tact_grad(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx0, p0, s0, 0)), g.act);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, s0, 0);
+                  }
+                  if (side1) {
+                    float w = v[e];
+                    if (dact) w *= tact_grad(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx1, p1, s1, 0)), g.act);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, s1, 0);
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (dact) {  // the ring for the next pass (or the next tile's first): k steps 0 .. RD-1
+          const int pn = pass + 1 == NP ? 0 : pass + 1;
+          int Rn = group_of(pn);
+          if (Rn < 0) Rn = group_of(0);
+#pragma unroll
+          for (int i = 0; i < RD; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { ring[i][t][0] = wfrag(Rn, i, t, 0); ring[i][t][1] = wfrag(Rn, i, t, 1); }
+        }
+      }
+    }
+    if (wave == 0) TGL_STAMP(0, u, 2);
+    __syncthreads();
+    if (wave == 0) TGL_STAMP(0, u, 3);
+  }
+}
+
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
+// Bmat = the [M, K] row-major operand (weights, or their transpose for the input gradient)
+template <int MODE>
+static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* what) {
+  const int Kp = (K + 63) / 64 * 64;
+  a.KS = Kp / 16;
+  const int nrg = (a.M + 63) / 64;
+  if (nrg > 16) { set_error("%s: more than 1024 output columns", what); return NA_EUNSUPPORTED; }
+  const size_t wbytes = (size_t)nrg * a.KS * 4096;
+  char* wp = nullptr;
+  hipError_t e = hipMallocAsync((void**)&wp, wbytes, st);
+  if (e != hipSuccess) { set_error("%s: hipMallocAsync(%zu): %s", what, wbytes, hipGetErrorString(e)); return NA_EHIP; }
+  const int64_t nthr = (int64_t)nrg * a.KS * 128;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.KS, nrg, wp);
+  a.wp = wp;
+  a.ntiles = (a.a.rows + TS - 1) / TS;
+  const int grid = a.ntiles < cu_count() ? (int)a.ntiles : cu_count();
+  const bool dact = MODE == 1 && a.act != NA_ACT_NONE;
+  auto k = kernel<MODE, false>;
+  if constexpr (MODE == 1) { if (dact) k = kernel<MODE, true>; }
+  static std::atomic<uint64_t> done[2];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  int rc = NA_OK;
+  if (!(done[dact].load(std::memory_order_acquire) & bit)) {
+    hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + STG + 4096);
+    if (e2 != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e2)); rc = NA_EHIP; }
+    else done[dact].fetch_or(bit, std::memory_order_release);
+  }
+  if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS + STG + nrg * 256, st, a);
+  (void)hipFreeAsync(wp, st);
+  if (rc != NA_OK) return rc;
+  return check_launch(what);
+}
+}  // namespace lsnt
+#if TGL_TRACE
+extern "C" int na_debug_tgl_trace(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(na::lsnt::tgl_trace), sizeof(na::lsnt::tgl_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 }  // namespace na
 
 using namespace na;
+
+// The layer-synchronous kernel takes every shape once the batch is worth a persistent launch; NA_TRAIN_GEMM=
+// tiled (environment) keeps round 1's K-staged kernels for A/B measurements.
+static bool lsnt_wanted(int64_t N, int M) {
+  static const bool tiled = [] { const char* e = getenv("NA_TRAIN_GEMM"); return e != nullptr && strcmp(e, "tiled") == 0; }();
+  return !tiled && N >= 2048 && M <= 1024;
+}
 
 extern "C" {
 
@@ -487,6 +904,11 @@ int na_linear_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t
   a.bias = b;
   a.y0 = y;
   a.c0 = out;
+  if (lsnt_wanted(N, out)) {
+    lsnt::Args l{};
+    l.a = a.a; l.M = out; l.act = pre_act; l.bias = b; l.y0 = y; l.c0 = out;
+    return lsnt::launch<0>(l, W, in0 + in1, (hipStream_t)stream, "na_linear_bf16x3");
+  }
   return dispatch_nt<0>(a, out, (hipStream_t)stream, "na_linear_bf16x3");
 }
 
@@ -508,6 +930,11 @@ int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt,
   a.x1 = x1;
   a.c0 = in0;
   a.c1 = in1;
+  if (lsnt_wanted(N, in0 + in1)) {
+    lsnt::Args l{};
+    l.a = a.a; l.M = in0 + in1; l.act = pre_act; l.y0 = a.y0; l.y1 = a.y1; l.x0 = x0; l.x1 = x1; l.c0 = in0; l.c1 = in1;
+    return lsnt::launch<1>(l, Wt, out, (hipStream_t)stream, "na_linear_dgrad_bf16x3");
+  }
   return dispatch_nt<1>(a, in0 + in1, (hipStream_t)stream, "na_linear_dgrad_bf16x3");
 }
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Training GEMMs (csrc/train_gemm.hip) against an fp64 torch reference over the shapes the five configs use, and their times.
+
+  python tools/gemm_check.py [--time]
+"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nerf_atlas_amd import ops
+
+ACTS = {"none": (lambda v: v, lambda v: torch.ones_like(v)),
+        "leaky_relu": (lambda v: torch.where(v > 0, v, 0.01 * v), lambda v: torch.where(v > 0, 1.0, 0.01).to(v.dtype)),
+        "sin": (torch.sin, torch.cos)}
+
+
+def t_us(f, n=10):
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+
+
+def main():
+    timing = "--time" in sys.argv
+    dev = "cuda"
+    torch.manual_seed(0)
+    worst = 0.0
+    # (N, in0, in1, out)
+    shapes = [(262144, 256, 0, 256), (262144, 38, 0, 256), (262144, 256, 38, 256), (262144, 256, 69, 256), (262144, 69, 0, 256),
+              (262144, 256, 0, 65), (262144, 256, 0, 3), (262144, 256, 0, 64), (5013, 256, 0, 256), (70001, 256, 38, 256), (2048, 16, 0, 256)]
+    for (N, in0, in1, out) in shapes:
+        for act in ("leaky_relu", "sin", "none"):
+            x0 = torch.randn(N, in0, device=dev)
+            x1 = torch.randn(N, in1, device=dev) if in1 else None
+            W = torch.randn(out, in0 + in1, device=dev) * (1.0 / (in0 + in1)) ** 0.5
+            b = torch.randn(out, device=dev)
+            gy = torch.randn(N, out, device=dev)
+            f, df = ACTS[act]
+            n_ref = min(N, 4096)  # fp64 reference on the first and last rows
+            sel = torch.cat([torch.arange(0, n_ref // 2), torch.arange(N - n_ref // 2, N)]).to(dev)
+            xin = torch.cat([x0, x1], 1) if in1 else x0
+            xr = xin[sel].double()
+            y_ref = f(xr) @ W.double().t() + b.double()
+            g_ref = (gy[sel].double() @ W.double()) * df(xr)
+            y = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True)
+            g0, g1 = ops.linear_dgrad(gy, W, x0, act, x1=x1)
+            g = torch.cat([g0, g1], 1) if in1 else g0
+            ey = float((y[sel].double() - y_ref).abs().max() / y_ref.abs().max())
+            eg = float((g[sel].double() - g_ref).abs().max() / g_ref.abs().max())
+            dW, db = ops.linear_wgrad(x0, gy, act, x1=x1, split_bf16=True)
+            # wgrad reference on a slice would not match the full sum: fp32 torch on the whole batch, looser
+            dW_ref = gy.t() @ f(xin)
+            ew = float((dW - dW_ref).abs().max() / dW_ref.abs().max())
+            eb = float((db - gy.sum(0)).abs().max() / gy.sum(0).abs().max())
+            worst = max(worst, ey, eg)
+            line = f"N {N:7d} in {in0:3d}+{in1:2d} out {out:3d} {act:10s} rel L-inf: fwd {ey:.2e} dgrad {eg:.2e} wgrad {ew:.2e} db {eb:.2e}"
+            if timing and N == 262144:
+                line += "  | us: fwd %.0f dgrad %.0f wgrad %.0f" % (
+                    t_us(lambda: ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True)),
+                    t_us(lambda: ops.linear_dgrad(gy, W, x0, act, x1=x1)),
+                    t_us(lambda: ops.linear_wgrad(x0, gy, act, x1=x1, split_bf16=True)))
+            print(line, flush=True)
+            assert ey < 1e-4 and eg < 1e-4 and ew < 1e-3, "parity"
+    print("worst fwd/dgrad rel L-inf %.2e" % worst)
+
+
+if __name__ == "__main__":
+    main()

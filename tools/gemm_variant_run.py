@@ -1,0 +1,28 @@
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nerf_atlas_amd import _lib
+N = 262144
+x = torch.randn(N, 256, device="cuda"); W = torch.randn(256, 256, device="cuda") * 0.06; b = torch.zeros(256, device="cuda"); y = torch.empty(N, 256, device="cuda")
+for name in sys.argv[1:]:
+    path = os.path.join("nerf_atlas_amd", "libnerf_atlas_amd.so") if name == "shipped" else os.path.join("gpurun_ablate", f"lib_var_{name}.so")
+    lib = C.CDLL(path)
+    fn = lib.na_linear_bf16x3
+    fn.argtypes = _lib.SIGNATURES["na_linear_bf16x3"][1]; fn.restype = C.c_int
+    st = torch.cuda.current_stream().cuda_stream
+    def f(): assert fn(x.data_ptr(), 256, None, 0, N, W.data_ptr(), b.data_ptr(), 256, 1, y.data_ptr(), st) == 0
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): f()
+    torch.cuda.synchronize()
+    print(f"{name:10s} fwd 262144x256x256: {(time.perf_counter() - t0) / 10 * 1e6:.0f} us", flush=True)
+    if hasattr(lib, "na_debug_tgl_trace"):
+        import numpy as np
+        buf = np.zeros((2, 32, 4), dtype=np.uint64)
+        lib.na_debug_tgl_trace.argtypes = [C.c_void_p]
+        assert lib.na_debug_tgl_trace(buf.ctypes.data) == 0
+        t0 = int(buf[0, 0, 0])
+        print("  consumer wave 0 (unit: start, MFMA done, epilogue done, barrier passed), cycles since unit 0:")
+        for u in range(16): print("   ", u, [int(v) - t0 for v in buf[0, u]], " MFMA", int(buf[0, u, 1]) - int(buf[0, u, 0]), "epi", int(buf[0, u, 2]) - int(buf[0, u, 1]), "wait", int(buf[0, u, 3]) - int(buf[0, u, 2]))
+        print("  producer wave 4 (unit: start, converted, loads issued, barrier passed):")
+        for u in range(16): print("   ", u, [int(v) - t0 for v in buf[1, u]], " convert(+wait for rows)", int(buf[1, u, 1]) - int(buf[1, u, 0]), "issue", int(buf[1, u, 2]) - int(buf[1, u, 1]), "wait", int(buf[1, u, 3]) - int(buf[1, u, 2]))
