@@ -475,19 +475,24 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 
 // ================================================================================ layer-synchronous NT kernel (round 3)
 // The same GEMM  C[samples, M] = A[samples, K] . B[M, K]^T  organised like the renderer (render_ls.hip) instead of a
-// K-staged tile pair: a workgroup keeps a 128-sample tile of A in LDS as split bf16 planes, 128 k at a time, and streams the
-// pre-packed bf16 hi/lo fragments of B from L2 straight into registers (a 4-deep fragment ring refilled in place), so B never
-// passes through LDS or the split arithmetic again, A is read from HBM as whole contiguous rows, and each 4-KiB fragment set of
-// B feeds 24 MFMAs (the K-staged kernel moved 48 KiB through the vector memory path per 24: it was bound by that path).
-// Two roles of four waves: PRODUCERS (waves 4-7) fetch the rows two units ahead into registers, activate + split them and fill
-// the other LDS buffer; CONSUMERS (waves 0-3, one 64-column group of C each) run the MFMAs and the epilogue.  The roles have
-// their own vmcnt queues, so the HBM latency of the row fetches never stands in front of a weight fragment (loads of one wave
-// return in order).  One barrier per unit = (tile, pass over 256 columns of C, k chunk).
+// K-staged tile pair: a workgroup keeps a 64-sample tile of A in LDS as split bf16 planes, 128 k at a time, and streams the
+// pre-packed bf16 hi/lo fragments of B from L2 straight into registers (an 8-deep fragment ring refilled in place), so B never
+// passes through LDS or the split arithmetic again and A is read from HBM as whole contiguous rows (the K-staged kernel
+// moved 48 KiB through the vector memory path per 24 MFMAs and was bound by that path).
+// Two roles of four waves.  PRODUCERS (waves 4-7) fetch the rows two units ahead into registers, activate + split them and
+// fill the other LDS buffer; for the input gradient with an activation they also bring the tile of forward inputs into LDS.
+// CONSUMERS (waves 0-3, one 64-column group of C each) run the MFMAs and the epilogue and never load from HBM: loads of one
+// wave return in order, so a row fetch (HBM latency) in front of a weight fragment (L2) would stall the matrix pipe.
+// A unit = (tile, pass over 256 columns of C, k chunk), one barrier per unit.  Inside a unit a consumer finishes its column tile
+// t = 0 before it starts t = 1: the stores of tile 0 drain under the MFMAs of tile 1, those of tile 1 under the next unit's.
 #ifndef TGL_ABLATE
 #define TGL_ABLATE 0  // timing experiments: 1 no row fetches, 2 no epilogue stores, 4 no MFMAs, 8 no weight refills, 16 no LDS fill
 #endif
 #ifndef TGL_TRACE
 #define TGL_TRACE 0  // experiment builds (tools/ls_variant.py): s_memtime stamps of workgroup 0, waves 0 (consumer) and 4 (producer)
+#endif
+#ifndef TGL_PRIO
+#define TGL_PRIO 0   // s_setprio of the producer waves
 #endif
 namespace lsnt {
 #if TGL_TRACE
@@ -496,20 +501,24 @@ __device__ unsigned long long tgl_trace[2][32][4];
 #else
 #define TGL_STAMP(role, u, slot) do {} while (0)
 #endif
-constexpr int TS = 128;             // samples per tile
-constexpr int KC = 128;             // k per LDS fill
+constexpr int TS = 64;              // samples per tile
+constexpr int KC = 128;             // k per LDS fill = 8 k steps = one segment of the weight stream per column tile
 constexpr int PITCH = KC * 2 + 16;  // row pitch of a plane: 68 dwords = 4 mod 64 -> conflict-free b128 fragment reads
 constexpr int PLANE = TS * PITCH;
 constexpr int BUF = 2 * PLANE;      // hi | lo
-constexpr int LDS = 2 * BUF;        // two buffers: 136 KiB
-constexpr int NPF = TS * (KC / 4) / 256;  // 16-byte pieces per producer thread and unit
-constexpr int SP = 36;               // float pitch of the consumers' 32 x 32 transpose tiles (4 x 4.5 KiB behind the buffers)
-constexpr int STG = 4 * 32 * SP * 4;
+constexpr int LDS = 2 * BUF;        // two buffers: 68 KiB
+constexpr int NPF = TS * (KC / 4) / 256;  // 16-byte pieces per producer thread and unit (8)
+constexpr int SP = 36;              // float pitch of the consumers' 32 x 32 transpose tiles
+constexpr int STG = 4 * 32 * SP * 4;       // 18 KiB behind the buffers
+constexpr int XP = 260;             // float pitch of the forward-input tile (input gradient with an activation)
+constexpr int XB = TS * XP * 4;     // 65 KiB
+constexpr int NXF = TS * 64 / 256;  // its 16-byte pieces per producer thread (16)
+constexpr int SEG = 8 * 2048;       // stream bytes of one (column group, chunk, column tile): 8 k steps x (hi | lo) fragments
 
 struct Args {
   RowSrc a;          // [samples, K] (concat)
-  const char* wp;    // packed B: [column group of 64][k step][tile 2][plane 2][lane 64][8 bf16]
-  int M, KS, act;    // KS = k steps of 16, a multiple of 4 (zero padded)
+  const char* wp;    // packed B: [column group of 64][chunk][tile 2][k step 8][plane 2][lane 64][8 bf16]
+  int M, NCH, act;   // NCH = chunks of 128 k (zero padded)
   const float* bias;
   float* y0;
   float* y1;
@@ -519,13 +528,13 @@ struct Args {
   int64_t ntiles;
 };
 
-// one thread per (column group, k step, tile, lane): 8 consecutive k of row m of B, split
-__global__ void pack_kernel(const float* __restrict__ W, int M, int K, int KS, int nrg, char* __restrict__ dst) {
-  const int64_t total = (int64_t)nrg * KS * 128;
+// one thread per (column group, chunk, tile, k step, lane): 8 consecutive k of row m of B, split
+__global__ void pack_kernel(const float* __restrict__ W, int M, int K, int NCH, int nrg, char* __restrict__ dst) {
+  const int64_t total = (int64_t)nrg * NCH * 2 * 8 * 64;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63), t = (int)((i >> 6) & 1);
-    const int s = (int)((i >> 7) % KS), rg = (int)((i >> 7) / KS);
-    const int m = 64 * rg + 32 * t + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    const int lane = (int)(i & 63), ks = (int)((i >> 6) & 7), t = (int)((i >> 9) & 1);
+    const int c = (int)((i >> 10) % NCH), rg = (int)((i >> 10) / NCH);
+    const int m = 64 * rg + 32 * t + (lane & 31), k0 = KC * c + 16 * ks + 8 * (lane >> 5);
     bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -534,52 +543,94 @@ __global__ void pack_kernel(const float* __restrict__ W, int M, int K, int KS, i
       hi[e] = h;
       lo[e] = (__bf16)(v - (float)h);
     }
-    char* o = dst + (((int64_t)rg * KS + s) * 4 + t * 2) * 1024 + lane * 16;
+    char* o = dst + (int64_t)(i >> 6) * 2048 + lane * 16;
     *(bf16x8*)o = hi;
     *(bf16x8*)(o + 1024) = lo;
   }
 }
 
+// Four consecutive columns `col` .. `col + 3` of row `row` (tile-relative) of the concatenation [p0 (k0 columns) | p1 (k1)],
+// zero outside, WITHOUT branches or waits between pieces: buffer loads whose offset lies outside the tile's buffer return
+// zero, so every piece issues the same few loads and only the offsets differ (a branchy loader made the compiler wait for
+// each piece before it issued the next).  The column counts decide (uniformly) between 16-byte and 4-byte loads.
+struct Src2 {
+  __amdgpu_buffer_rsrc_t r0, r1;
+  int k0, k1;
+};
+constexpr uint32_t OOB = 0x78000000u;  // a byte offset past every tile buffer: the hardware drops the access
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, int ld, int64_t m0, int64_t rows, const void* dummy) {
+  int64_t bytes = base == nullptr ? 0 : (rows - m0) * ld * 4;
+  if (bytes > 0x70000000ll) bytes = 0x70000000ll;
+  if (bytes < 0) bytes = 0;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)dummy : base + m0 * ld), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 load_piece(const Src2& s, int row, int col) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if ((s.k0 & 3) == 0) {
+    const uint32_t o = col < s.k0 ? (uint32_t)((row * s.k0 + col) * 4) : OOB;
+    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r0, o, 0, 0));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t o = col + e < s.k0 ? (uint32_t)((row * s.k0 + col + e) * 4) : OOB;
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.r0, o, 0, 0));
+    }
+  }
+  if (s.k1 > 0) {
+    if (((s.k0 | s.k1) & 3) == 0) {
+      const uint32_t o = (col >= s.k0 && col < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + col - s.k0) * 4) : OOB;
+      v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r1, o, 0, 0));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ce = col + e;
+        const uint32_t o = (ce >= s.k0 && ce < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + ce - s.k0) * 4) : OOB;
+        v[e] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.r1, o, 0, 0));
+      }
+    }
+  }
+  return v;
+}
+
 // MODE 0 forward, 1 input gradient; DACT: the input gradient is scaled by act'(forward input) in the epilogue
 template <int MODE, bool DACT>
 __global__ __launch_bounds__(512) void kernel(Args g) {
-  constexpr int RD = 4;  // depth of the weight fragment ring (k steps)
+  constexpr int RD = 8;  // depth of the weight fragment ring = the k steps of one segment
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NCH = (g.KS + 7) >> 3;
+  const int NCH = g.NCH;
   const int nrg = (g.M + 63) >> 6;
   const int NP = (nrg + 3) >> 2;  // passes over the tile: 256 columns of C each
   const int UPT = NCH * NP;       // units per tile
-  const int64_t my_tiles = (g.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-  const int64_t nunits = my_tiles * UPT;
-  // the bias vector (zero padded to whole column groups) lives in LDS behind the two tile buffers: the epilogue reads it with
-  // LDS loads, which do not queue behind the wave's outstanding stores the way a global load would
-  float* lbias = (float*)(smem + LDS + STG);
+  const int my_tiles = (int)((g.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const int nunits = my_tiles * UPT;
+  const int K = g.a.k0 + g.a.k1;
+  // x goes through LDS (any column layout: the producers' loader handles unaligned rows); that needs a unit in which the
+  // consumers do not read it, so the launcher gives a DACT launch at least two chunks (a zero chunk if K <= 128)
+  constexpr bool xlds = DACT;
+  float* stg_all = (float*)(smem + LDS);
+  float* xbuf = (float*)(smem + LDS + STG);
+  // the bias vector (zero padded to whole column groups) lives in LDS: the epilogue reads it with LDS loads, which do not queue
+  // behind the wave's outstanding stores the way a global load would
+  float* lbias = (float*)(smem + LDS + STG + (DACT ? XB : 0));
   if (MODE == 0) {
     for (int i = tid; i < nrg * 64; i += 512) lbias[i] = (g.bias != nullptr && i < g.M) ? g.bias[i] : 0.f;
   }
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------------ producers
+    if (TGL_PRIO) __builtin_amdgcn_s_setprio(TGL_PRIO);
     const int ptid = tid - 256, c4 = ptid & 31, r0 = ptid >> 5;  // piece c4 (4 k) of rows r0 + 8 j
-    f32x4 pf0[NPF], pf1[NPF];
-    auto load = [&](f32x4 (&pf)[NPF], int64_t u) {
+    const int xc4 = ptid & 63, xr0 = ptid >> 6;                  // x tile: piece xc4 (4 columns) of rows xr0 + 4 j
+    f32x4 pf0[NPF], pf1[NPF], xs[NXF];
+    auto tile_of = [&](int u) __attribute__((always_inline)) -> int64_t { return blockIdx.x + (int64_t)(u / UPT) * gridDim.x; };
+    auto load = [&](f32x4 (&pf)[NPF], int u) {
       if (TGL_ABLATE & 1) return;
-      const int64_t m0 = (blockIdx.x + (u / UPT) * gridDim.x) * TS;
-      const int ch = (int)(u % NCH);
-      const int left = g.KS - 8 * ch;
-      const int kc4 = (left < 8 ? left : 8) * 4;  // 16-byte pieces per row of this chunk
-      const int k = ch * KC + c4 * 4;
-      if (ch * KC + kc4 * 4 <= g.a.k0 && (g.a.k0 & 3) == 0) {  // the chunk lies inside the first source: whole aligned pieces
+      const int64_t m0 = tile_of(u) * TS;
+      const int k = (u % NCH) * KC + c4 * 4;
+      const Src2 src{tile_rsrc(g.a.p0, g.a.k0, m0, g.a.rows, g.wp), tile_rsrc(g.a.p1, g.a.k1, m0, g.a.rows, g.wp), g.a.k0, g.a.k1};
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-          const int64_t row = m0 + r0 + 8 * j;
-          pf[j] = (c4 < kc4 && row < g.a.rows) ? *(const f32x4*)(g.a.p0 + row * g.a.k0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) pf[j] = c4 < kc4 ? load_k4(g.a, m0 + r0 + 8 * j, k) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int j = 0; j < NPF; ++j) pf[j] = load_piece(src, r0 + 8 * j, k);
     };
     // (the activation is a runtime argument: one specialised copy of the loop per kind, chosen once per unit -- with the switch
     // inside, every element carried the sine polynomial next to the LeakyReLU select: 180 instructions per 4 values)
@@ -597,150 +648,142 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
         *(bf16x4*)(d + PLANE) = lo;
       }
     };
-    auto convert = [&](const f32x4 (&pf)[NPF], int64_t u, char* buf) {
-      const int ch = (int)(u % NCH);
-      const int left = g.KS - 8 * ch;
-      const int kc4 = (left < 8 ? left : 8) * 4;
-      if (c4 >= kc4 || (TGL_ABLATE & 16)) return;
+    auto convert = [&](const f32x4 (&pf)[NPF], char* buf) {
+      if (TGL_ABLATE & 16) return;
       if (MODE == 0 && g.act == NA_ACT_LEAKY_RELU) convert_as(pf, buf, std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
       else if (MODE == 0 && g.act == NA_ACT_SIN) convert_as(pf, buf, std::integral_constant<int, NA_ACT_SIN>{});
       else convert_as(pf, buf, std::integral_constant<int, NA_ACT_NONE>{});
     };
-    load(pf0, 0);
-    if (nunits > 1) load(pf1, 1);
-    convert(pf0, 0, smem);
-    if (nunits > 2) load(pf0, 2);
-    __syncthreads();
-    for (int64_t u = 0; u < nunits; u += 2) {
+    // forward inputs of (tile, pass) = unit u's: columns 256 pass + 4 xc4 .. + 3 of the concatenated [x0 | x1]
+    auto xload = [&](int u) __attribute__((always_inline)) {
+      const int64_t m0 = tile_of(u) * TS;
+      const int col = 256 * ((u / NCH) % NP) + 4 * xc4;
+      const Src2 src{tile_rsrc(g.x0, g.c0, m0, g.a.rows, g.wp), tile_rsrc(g.x1, g.c1, m0, g.a.rows, g.wp), g.c0, g.c1};
+#pragma unroll
+      for (int j = 0; j < NXF; ++j) xs[j] = load_piece(src, xr0 + 4 * j, col);
+    };
+    auto xstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NXF; ++j) *(f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4) = xs[j];
+    };
+    // producer step during unit u: fill the other buffer with unit u + 1, fetch unit u + 3; x of the (tile, pass) whose last
+    // chunk comes next is parked in LDS one unit before the consumers read it, and the following (tile, pass)'s is requested
+    auto step = [&](f32x4 (&pf)[NPF], int u, char* other) {
       if (wave == 4) TGL_STAMP(1, u, 0);
-      if (u + 1 < nunits) {  // during unit u: unit u + 1 into buffer 1
-        convert(pf1, u + 1, smem + BUF);
+      if (u + 1 < nunits) {
+        convert(pf, other);
         if (wave == 4) TGL_STAMP(1, u, 1);
-        if (u + 3 < nunits) load(pf1, u + 3);
+        if (u + 3 < nunits) load(pf, u + 3);
+      }
+      if (xlds && u % NCH == NCH - 2) {
+        xstore();
+        if (u + NCH < nunits) xload(u + NCH);
       }
       if (wave == 4) TGL_STAMP(1, u, 2);
       __syncthreads();
       if (wave == 4) TGL_STAMP(1, u, 3);
-      if (u + 1 < nunits) {
-        if (wave == 4) TGL_STAMP(1, u + 1, 0);
-        if (u + 2 < nunits) {  // during unit u + 1: unit u + 2 into buffer 0
-          convert(pf0, u + 2, smem);
-          if (wave == 4) TGL_STAMP(1, u + 1, 1);
-          if (u + 4 < nunits) load(pf0, u + 4);
-        }
-        if (wave == 4) TGL_STAMP(1, u + 1, 2);
-        __syncthreads();
-        if (wave == 4) TGL_STAMP(1, u + 1, 3);
-      }
+    };
+    load(pf0, 0);
+    if (xlds) xload(0);
+    if (nunits > 1) load(pf1, 1);
+    convert(pf0, smem);
+    if (nunits > 2) load(pf0, 2);
+    __syncthreads();
+    for (int u = 0; u < nunits; u += 2) {
+      step(pf1, u, smem + BUF);
+      if (u + 1 < nunits) step(pf0, u + 1, smem);
     }
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- consumers
   const int ncols = g.c0 + g.c1;
-  f32x16 acc[2][4];         // [column tile][32-sample block]: rows = 32 columns of C, columns = samples
-  bf16x8 ring[RD][2][2];    // [slot][tile][plane]
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.wp, 0, nrg * g.KS * 4096, 0x00020000);
-  auto wfrag = [&](int R, int sg, int t, int p) -> bf16x8 {  // scalar offset of the (column group, k step), the rest an immediate
-    const int soff = __builtin_amdgcn_readfirstlane((R * g.KS + sg) * 4096);
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16 + (t * 2 + p) * 1024, soff, 0));
+  f32x16 acc[2][2];      // [column tile][32-sample block]: rows = 32 columns of C, columns = samples
+  bf16x8 ring[RD][2];    // [k step of the segment][plane]
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.wp, 0, nrg * NCH * 2 * SEG, 0x00020000);
+  // the weight stream of this wave: per tile, pass 0 .. NP-1 (column group wave + 4 pass; passes whose group lies past M are
+  // skipped by the whole wave), chunk 0 .. NCH-1, column tile 0, 1: one segment of 8 k steps each
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto group_of = [&](int pass) __attribute__((always_inline)) { const int R = wave_s + 4 * pass; return R < nrg ? R : -1; };
+  auto seg_off = [&](int R, int ch, int t) __attribute__((always_inline)) { return ((R * NCH + ch) * 2 + t) * SEG; };
+  auto wfrag = [&](int soff, int i, int p) __attribute__((always_inline)) -> bf16x8 {  // (k step in the scalar offset: 12-bit immediates end at 4095)
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16 + p * 1024, soff + i * 2048, 0));
   };
-  // the weight stream of this wave: pass 0 .. NP-1, k steps 0 .. KS-1 each, then again for the next tile.  Column groups past
-  // M (the last pass of a narrow C) are skipped by the whole wave.
-  auto group_of = [&](int pass) { const int R = wave + 4 * pass; return R < nrg ? R : -1; };
-  {
-    const int R = group_of(0);
-    if (R >= 0) {
+  if (group_of(0) >= 0) {
+    const int so = seg_off(group_of(0), 0, 0);
 #pragma unroll
-      for (int i = 0; i < RD; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { ring[i][t][0] = wfrag(R, i, t, 0); ring[i][t][1] = wfrag(R, i, t, 1); }
-    }
+    for (int i = 0; i < RD; ++i) { ring[i][0] = wfrag(so, i, 0); ring[i][1] = wfrag(so, i, 1); }
   }
   const bool all_vec = ((g.c0 | g.c1) & 3) == 0;  // every row of both outputs is written as aligned 16-byte pieces
   constexpr bool dact = DACT;
-  constexpr uint32_t OOB = 0x78000000u;           // a byte offset past every buffer below: the hardware drops the access
+  float* stg = stg_all + wave * (32 * SP);
+  const int rrow = lane >> 3, rc4 = (lane & 7) * 4;  // after the transpose: row rrow + 8 j of the block, columns rc4 .. rc4 + 3
   __syncthreads();
-  for (int64_t u = 0; u < nunits; ++u) {
-    const int64_t m0 = (blockIdx.x + (u / UPT) * gridDim.x) * TS;
-    const int ch = (int)(u % NCH), pass = (int)((u / NCH) % NP);
-    const int left = g.KS - 8 * ch;
-    const int ns = left < 8 ? left : 8;
+  for (int u = 0; u < nunits; ++u) {
+    const int64_t m0 = (blockIdx.x + (int64_t)(u / UPT) * gridDim.x) * TS;
+    const int ch = u % NCH, pass = (u / NCH) % NP;
     const char* buf = smem + (u & 1) * BUF;
     const int R = group_of(pass);
     if (wave == 0) TGL_STAMP(0, u, 0);
     if (R >= 0) {
-      if (ch == 0) {
+      const char* brow = buf + (lane & 31) * PITCH + (lane >> 5) * 16;
+      const bool last = ch == NCH - 1;
+      // epilogue resources (cheap scalar work; used in the last chunk only)
+      auto rsrc_of = [&](const float* base, int ld) __attribute__((always_inline)) { return tile_rsrc(base, ld, m0, g.a.rows, g.wp); };
+      const __amdgpu_buffer_rsrc_t ry0 = rsrc_of(g.y0, g.c0), ry1 = rsrc_of(g.y1, g.c1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        if (ch == 0) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
-      }
-      const char* brow = buf + (lane & 31) * PITCH + (lane >> 5) * 16;
-      bf16x8 xh[2], xl[2];
-      auto xfrag = [&](int sl, int b, int slot) {
-        const char* p = brow + b * 32 * PITCH + sl * 32;
-        xh[slot] = *(const bf16x8*)p;
-        xl[slot] = *(const bf16x8*)(p + PLANE);
-      };
-      xfrag(0, 0, 0);
-      for (int s = 0; s < ns; s += RD) {
+        }
+        // the segment after this one: the other column tile, the next chunk, the next pass with a column group, the next tile
+        int nso;
+        if (t == 0) nso = seg_off(R, ch, 1);
+        else if (!last) nso = seg_off(R, ch + 1, 0);
+        else {
+          const int pn = pass + 1 == NP ? 0 : pass + 1;
+          int Rn = group_of(pn);
+          if (Rn < 0) Rn = group_of(0);
+          nso = seg_off(Rn, 0, 0);
+        }
+        nso = __builtin_amdgcn_readfirstlane(nso);
+        bf16x8 xh[2][2], xl[2][2];  // [buffer][block]
+        auto xfrag = [&](int ks, int slot) __attribute__((always_inline)) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const char* p = brow + b * 32 * PITCH + ks * 32;
+            xh[slot][b] = *(const bf16x8*)p;
+            xl[slot][b] = *(const bf16x8*)(p + PLANE);
+          }
+        };
+        xfrag(0, 0);
 #pragma unroll
         for (int i = 0; i < RD; ++i) {
-          // the ring slot's next occupant: RD k steps on, in the next pass (or the next tile's first pass) past the end
-          int sn = 8 * ch + s + i + RD, Rn = R;
-          if (sn >= g.KS) {
-            sn -= g.KS;
-            const int pn = pass + 1 == NP ? 0 : pass + 1;
-            Rn = group_of(pn);
-            if (Rn < 0) Rn = group_of(0);  // this wave sits out the last pass: fetch for the next tile's pass 0
+          const int cur = i & 1;
+          if (i + 1 < RD) xfrag(i + 1, cur ^ 1);  // the next k step's fragments under this one's MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 wh = ring[i][0], wl = ring[i][1];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if (TGL_ABLATE & 4) { acc[t][b][0] += (float)wl[0] + (float)xh[cur][b][0] + (float)wh[1] + (float)xl[cur][b][1]; continue; }
+            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[cur][b], acc[t][b], 0, 0, 0);
+            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[cur][b], acc[t][b], 0, 0, 0);
+            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[cur][b], acc[t][b], 0, 0, 0);
           }
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int cur = b & 1;
-            if (b < 3) xfrag(s + i, b + 1, cur ^ 1);           // the next block's fragments under this block's MFMAs
-            else if (s + i + 1 < ns) xfrag(s + i + 1, 0, cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const bf16x8 wh = ring[i][t][0], wl = ring[i][t][1];
-              if (TGL_ABLATE & 4) { acc[t][b][0] += (float)wl[0] + (float)xh[cur][0] + (float)wh[1] + (float)xl[cur][1]; continue; }
-              acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[cur], acc[t][b], 0, 0, 0);
-              acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[cur], acc[t][b], 0, 0, 0);
-              acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[cur], acc[t][b], 0, 0, 0);
-            }
-            // refill in place, behind the slot's last MFMAs: needed RD k steps from now.  (dgrad with an activation: the ring is
-            // not carried across the epilogue, whose 64 registers of forward inputs it would sit next to)
-            if (b == 3 && !(TGL_ABLATE & 8) && !(dact && 8 * ch + s + i + RD >= g.KS)) {
-#pragma unroll
-              for (int t = 0; t < 2; ++t) { ring[i][t][0] = wfrag(Rn, sn, t, 0); ring[i][t][1] = wfrag(Rn, sn, t, 1); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          // refill in place, behind the slot's MFMAs: needed one segment (8 k steps) from now
+          if (!(TGL_ABLATE & 8)) { ring[i][0] = wfrag(nso, i, 0); ring[i][1] = wfrag(nso, i, 1); }
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      if (wave == 0) TGL_STAMP(0, u, 1);
-      if (ch == NCH - 1 && !((TGL_ABLATE & 2) && acc[0][0][0] != 1.2345f)) {
-        // Epilogue.  The accumulators hold 4 consecutive columns per register quad and one SAMPLE per lane: stored like that, a
-        // 16-byte store touches 32 rows with 32 bytes each (4096 partial-line requests per tile: measured 8-23 k cycles).  Every
-        // 32 x 32 block goes through a wave-private LDS tile instead and leaves as whole 128-byte lines (8 lanes per row).
-        // Branch-free: buffer accesses whose offsets fall outside the (tile-relative) buffer are dropped by the hardware -- rows
-        // past the batch, columns past M, a null output -- so no store waits for a compare.
-        const int64_t left_rows = g.a.rows - m0;
-        auto rsrc_of = [&](const float* base, int ld) {
-          int64_t bytes = base == nullptr ? 0 : left_rows * ld * 4;
-          if (bytes > 0x70000000ll) bytes = 0x70000000ll;
-          return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)g.wp : base + m0 * ld), 0, (int)bytes, 0x00020000);
-        };
-        const __amdgpu_buffer_rsrc_t ry0 = rsrc_of(g.y0, g.c0), ry1 = rsrc_of(g.y1, g.c1);
-        const __amdgpu_buffer_rsrc_t rx0 = rsrc_of(dact ? g.x0 : nullptr, g.c0);
-        const __amdgpu_buffer_rsrc_t rx1 = rsrc_of(dact ? g.x1 : nullptr, g.c1);
-        float* stg = (float*)(smem + LDS) + wave * (32 * SP);
-        const int rrow = lane >> 3, rc4 = (lane & 7) * 4;  // after the transpose: row rrow + 8 j of the block, columns rc4 .. rc4 + 3
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        if (wave == 0 && t == 1) TGL_STAMP(0, u, 1);
+        if (last && !((TGL_ABLATE & 2) && acc[0][0][0] != 1.2345f)) {
+          // Epilogue of column tile t.  The accumulators hold 4 consecutive columns per register quad and one SAMPLE per lane:
+          // stored like that, a 16-byte store touches 32 rows with 32 bytes each (4096 partial-line requests per 128 samples:
+          // measured 8-23 k cycles).  Every 32 x 32 block goes through a wave-private LDS tile instead and leaves as whole
+          // 128-byte lines (8 lanes per row).  Branch-free: buffer accesses whose offsets fall outside the (tile-relative) buffer
+          // are dropped by the hardware -- rows past the batch, columns past M, a null output.
           const int tc0 = 64 * R + 32 * t;                      // the tile's first column
           const bool side0 = tc0 < g.c0, side1 = tc0 + 32 > g.c0 && g.c1 > 0;  // wave-uniform: which outputs the tile touches
           const int col = tc0 + rc4;
@@ -748,75 +791,48 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
           const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((rrow * g.c1 + col - g.c0) * 4) : OOB;
           f32x4 bj = {0.f, 0.f, 0.f, 0.f};
           if (MODE == 0) bj = *(const f32x4*)(lbias + col);
-          f32x4 xq[4][4];  // dgrad with an activation: the tile's forward inputs, all 16 loads in flight together
-          if (dact && all_vec) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int s0 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c0 * 4), s1 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c1 * 4);
-                f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-                if (side0) xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx0, o0, s0, 0));
-                if (side1) {
-                  const f32x4 x1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, o1, s1, 0));
-                  xv = (side0 && col < g.c0) ? xv : x1v;
-                }
-                xq[b][j] = xv;
-              }
-          }
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
+          for (int b = 0; b < 2; ++b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               *(f32x4*)(stg + (lane & 31) * SP + 8 * q + 4 * (lane >> 5)) =
                   f32x4{acc[t][b][4 * q], acc[t][b][4 * q + 1], acc[t][b][4 * q + 2], acc[t][b][4 * q + 3]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              f32x4 v = *(const f32x4*)(stg + (rrow + 8 * j) * SP + rc4);
-              if (MODE == 0) v += bj;
               const int s0 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c0 * 4), s1 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c1 * 4);
+              const float* xrow = xbuf + (32 * b + rrow + 8 * j) * XP + 64 * wave + 32 * t + rc4;
               if (all_vec) {
+                f32x4 v = *(const f32x4*)(stg + (rrow + 8 * j) * SP + rc4);
+                if (MODE == 0) v += bj;
                 if (dact) {
+                  const f32x4 xv = *(const f32x4*)xrow;
                   if (g.act == NA_ACT_SIN) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xq[b][j][e], NA_ACT_SIN);
+                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
                   } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xq[b][j][e], NA_ACT_LEAKY_RELU);
+                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
                   }
                 }
                 if (side0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, s0, 0);
                 if (side1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, s1, 0);
               } else {
-                // rows that are not 16-byte aligned (a column count that is no multiple of 4): element by element
+                // rows that are not 16-byte aligned (a column count that is no multiple of 4): element by element, scalars
+                // straight from the LDS tiles
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const int ce = col + e;
+                  float w = stg[(rrow + 8 * j) * SP + rc4 + e];
+                  if (MODE == 0) w += lbias[ce];
+                  if (dact) w *= tact_grad(xrow[e], g.act);
                   const uint32_t p0 = (ce < g.c0) ? (uint32_t)((rrow * g.c0 + ce) * 4) : OOB;
                   const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((rrow * g.c1 + ce - g.c0) * 4) : OOB;
-                  if (side0) {
-                    float w = v[e];
-                    if (dact) w *= tact_grad(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx0, p0, s0, 0)), g.act);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, s0, 0);
-                  }
-                  if (side1) {
-                    float w = v[e];
-                    if (dact) w *= tact_grad(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx1, p1, s1, 0)), g.act);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, s1, 0);
-                  }
+                  if (side0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, s0, 0);
+                  if (side1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, s1, 0);
                 }
               }
             }
           }
-        }
-        if (dact) {  // the ring for the next pass (or the next tile's first): k steps 0 .. RD-1
-          const int pn = pass + 1 == NP ? 0 : pass + 1;
-          int Rn = group_of(pn);
-          if (Rn < 0) Rn = group_of(0);
-#pragma unroll
-          for (int i = 0; i < RD; ++i)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { ring[i][t][0] = wfrag(Rn, i, t, 0); ring[i][t][1] = wfrag(Rn, i, t, 1); }
         }
       }
     }
@@ -839,33 +855,34 @@ static int cu_count() {
 // Bmat = the [M, K] row-major operand (weights, or their transpose for the input gradient)
 template <int MODE>
 static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* what) {
-  const int Kp = (K + 63) / 64 * 64;
-  a.KS = Kp / 16;
+  const bool dact = MODE == 1 && a.act != NA_ACT_NONE;
+  a.NCH = (K + KC - 1) / KC;
+  if (dact && a.NCH < 2) a.NCH = 2;  // the forward inputs are parked in LDS one unit before the tile's last
   const int nrg = (a.M + 63) / 64;
   if (nrg > 16) { set_error("%s: more than 1024 output columns", what); return NA_EUNSUPPORTED; }
-  const size_t wbytes = (size_t)nrg * a.KS * 4096;
+  const size_t wbytes = (size_t)nrg * a.NCH * 2 * SEG;
   char* wp = nullptr;
   hipError_t e = hipMallocAsync((void**)&wp, wbytes, st);
   if (e != hipSuccess) { set_error("%s: hipMallocAsync(%zu): %s", what, wbytes, hipGetErrorString(e)); return NA_EHIP; }
-  const int64_t nthr = (int64_t)nrg * a.KS * 128;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.KS, nrg, wp);
+  const int64_t nthr = (int64_t)nrg * a.NCH * 2 * 8 * 64;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.NCH, nrg, wp);
   a.wp = wp;
   a.ntiles = (a.a.rows + TS - 1) / TS;
   const int grid = a.ntiles < cu_count() ? (int)a.ntiles : cu_count();
-  const bool dact = MODE == 1 && a.act != NA_ACT_NONE;
   auto k = kernel<MODE, false>;
   if constexpr (MODE == 1) { if (dact) k = kernel<MODE, true>; }
+  const int lds = LDS + STG + (dact ? XB : 0) + nrg * 256;
   static std::atomic<uint64_t> done[2];
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   int rc = NA_OK;
   if (!(done[dact].load(std::memory_order_acquire) & bit)) {
-    hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + STG + 4096);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + STG + (dact ? XB : 0) + 4096);
     if (e2 != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e2)); rc = NA_EHIP; }
     else done[dact].fetch_or(bit, std::memory_order_release);
   }
-  if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS + STG + nrg * 256, st, a);
+  if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
   (void)hipFreeAsync(wp, st);
   if (rc != NA_OK) return rc;
   return check_launch(what);

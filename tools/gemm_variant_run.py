@@ -4,18 +4,26 @@ import torch
 from nerf_atlas_amd import _lib
 N = 262144
 x = torch.randn(N, 256, device="cuda"); W = torch.randn(256, 256, device="cuda") * 0.06; b = torch.zeros(256, device="cuda"); y = torch.empty(N, 256, device="cuda")
+MODE = "fwd"
+if sys.argv[1] in ("fwd", "dgrad"):
+    MODE = sys.argv.pop(1)
+gy = torch.randn(N, 256, device="cuda"); Wt = W.t().contiguous(); gx = torch.empty(N, 256, device="cuda")
 for name in sys.argv[1:]:
     path = os.path.join("nerf_atlas_amd", "libnerf_atlas_amd.so") if name == "shipped" else os.path.join("gpurun_ablate", f"lib_var_{name}.so")
     lib = C.CDLL(path)
     fn = lib.na_linear_bf16x3
     fn.argtypes = _lib.SIGNATURES["na_linear_bf16x3"][1]; fn.restype = C.c_int
     st = torch.cuda.current_stream().cuda_stream
-    def f(): assert fn(x.data_ptr(), 256, None, 0, N, W.data_ptr(), b.data_ptr(), 256, 1, y.data_ptr(), st) == 0
+    fd = lib.na_linear_dgrad_bf16x3
+    fd.argtypes = _lib.SIGNATURES["na_linear_dgrad_bf16x3"][1]; fd.restype = C.c_int
+    def f():
+        if MODE == "fwd": assert fn(x.data_ptr(), 256, None, 0, N, W.data_ptr(), b.data_ptr(), 256, 1, y.data_ptr(), st) == 0
+        else: assert fd(gy.data_ptr(), 256, N, Wt.data_ptr(), x.data_ptr(), 256, None, 0, 1, gx.data_ptr(), None, st) == 0
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): f()
     torch.cuda.synchronize()
-    print(f"{name:10s} fwd 262144x256x256: {(time.perf_counter() - t0) / 10 * 1e6:.0f} us", flush=True)
+    print(f"{name:10s} {MODE} 262144x256x256: {(time.perf_counter() - t0) / 10 * 1e6:.0f} us", flush=True)
     if hasattr(lib, "na_debug_tgl_trace"):
         import numpy as np
         buf = np.zeros((2, 32, 4), dtype=np.uint64)
