@@ -289,7 +289,8 @@ struct TnArgs {
   RowSrc x;         // [N, in] (concat) -- RowSrc.rows = N
   int act;
   int64_t slice;    // samples per workgroup (multiple of TK)
-  float* dW;        // [out, in]
+  float* dW;        // [out, in] (or a column block of a wider matrix: ldw)
+  int ldw;          // leading dimension of dW and of the fixed-point accumulators
   float* db;        // [out] or null
   long long* fixW;  // deterministic mode: int64 fixed-point accumulators parallel to dW / db (else null)
   long long* fixb;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = o0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.out) accumulate(g.dW, g.fixW, (int64_t)row * in + col, acc[mi][ni][r]);
+        if (row < g.out) accumulate(g.dW, g.fixW, (int64_t)row * g.ldw + col, acc[mi][ni][r]);
       }
   }
   if (want_db) {
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const int ptid = tid - 256, c4 = ptid & 31, r0 = ptid >> 5;  // piece c4 (4 k) of rows r0 + 8 j
     const int xc4 = ptid & 63, xr0 = ptid >> 6;                  // x tile: piece xc4 (4 columns) of rows xr0 + 4 j
     f32x4 pf0[NPF], pf1[NPF], xs[NXF];
-    auto tile_of = [&](int u) __attribute__((always_inline)) -> int64_t { return blockIdx.x + (int64_t)(u / UPT) * gridDim.x; };
+    auto tile_of = [&](int u) __attribute__((always_inline)) -> int64_t { return u < nunits ? blockIdx.x + (int64_t)(u / UPT) * gridDim.x : g.ntiles; };
     auto load = [&](f32x4 (&pf)[NPF], int u) {
       if (TGL_ABLATE & 1) return;
       const int64_t m0 = tile_of(u) * TS;
@@ -670,14 +671,14 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     // chunk comes next is parked in LDS one unit before the consumers read it, and the following (tile, pass)'s is requested
     auto step = [&](f32x4 (&pf)[NPF], int u, char* other) {
       if (wave == 4) TGL_STAMP(1, u, 0);
-      if (u + 1 < nunits) {
-        convert(pf, other);
-        if (wave == 4) TGL_STAMP(1, u, 1);
-        if (u + 3 < nunits) load(pf, u + 3);
-      }
+      // (no conditions around the fetches: units past the end read rows past the batch = zeros; conditional fetches made the
+      // compiler's wait-count pass wait with vmcnt(0), i.e. for the rows just requested)
+      convert(pf, other);
+      if (wave == 4) TGL_STAMP(1, u, 1);
+      load(pf, u + 3);
       if (xlds && u % NCH == NCH - 2) {
         xstore();
-        if (u + NCH < nunits) xload(u + NCH);
+        xload(u + NCH);
       }
       if (wave == 4) TGL_STAMP(1, u, 2);
       __syncthreads();
@@ -685,9 +686,9 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     };
     load(pf0, 0);
     if (xlds) xload(0);
-    if (nunits > 1) load(pf1, 1);
+    load(pf1, 1);
     convert(pf0, smem);
-    if (nunits > 2) load(pf0, 2);
+    load(pf0, 2);
     __syncthreads();
     for (int u = 0; u < nunits; u += 2) {
       step(pf1, u, smem + BUF);
@@ -894,6 +895,237 @@ extern "C" int na_debug_tgl_trace(unsigned long long* host_out) {
 }
 #endif
 
+// ================================================================================ layer-synchronous TN kernel (round 3)
+// Weight gradient  dW[out, in] += dY[N, out]^T . act(X)[N, in]  (+ db = column sums of dY) with the samples as the MFMA's K.
+// One workgroup of eight waves owns the whole 256 x 256 gradient -- a wave 64 x 128 of it = 2 x 4 tiles = 128 accumulator
+// registers, two waves per SIMD so that one's MFMAs cover the other's loads and conversions -- and every row of dY and X is
+// read from HBM exactly once (the K-staged kernel
+// splits dW over two workgroups: both read all of X, and 48 KiB per 24 MFMAs cross the vector memory path).  A stage = 32
+// samples: their rows are fetched two stages ahead into registers as whole contiguous rows, activated, split into bf16 hi / lo
+// and stored ROW-MAJOR ([sample][feature], pitch 576 B) into the other LDS buffer; the MFMA operands -- 8 consecutive samples
+// of one feature per lane -- come out of that image through gfx950's transposing LDS read `ds_read_b64_tr_b16`
+// (tools/hw/tr_probe.hip: lane i of a 16-lane group receives halfword i & 3 of the 8 bytes addressed by lane 4 j + (i >> 2),
+// j = 0..3: with lane i pointing at row i >> 2, columns 4 (i & 3).. of a [4 samples][16 features] block it gets column i).
+// Workgroup w reduces its slice of samples into a partial gradient in a workspace; a second kernel sums the partials in a
+// fixed order (bit-reproducible without the fixed-point path, and 17 M float atomics cheaper).
+#ifndef TGW_ABLATE
+#define TGW_ABLATE 0  // timing experiments: 1 no row fetches, 2 no convert / LDS fill, 4 no MFMAs, 8 no fragment reads, 16 no partials
+#endif
+namespace lstn {
+constexpr int SS = 32;                // samples per stage
+constexpr int PW = 576;               // row pitch of a plane: 144 dwords = 16 mod 64 -> the 4 rows of a transposing read do not collide
+constexpr int PLANE = SS * PW;        // 18 KiB
+constexpr int STAGE = 4 * PLANE;      // G hi | G lo | X hi | X lo
+constexpr int LDS = 2 * STAGE;        // 144 KiB
+constexpr int NPC = SS * 64 / 512;    // 16-byte pieces per thread, operand and stage (4)
+constexpr int PART = 256 * 256 + 8 * 256;  // floats of one workgroup's partial: dW | 8 row groups of db
+
+struct Args {
+  const float* dY;   // [N, out]
+  const float* x;    // [N, in]  (one source of the concatenation)
+  int out, in, act;
+  int64_t N;
+  float* part;       // [grid][PART]
+  int want_db;
+};
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s;
+
+__global__ __launch_bounds__(512) void kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;  // 64 rows x 128 columns of dW per wave
+  const int64_t nst_all = (g.N + SS - 1) / SS;
+  const int64_t per = (nst_all + gridDim.x - 1) / gridDim.x;
+  const int64_t st0 = blockIdx.x * per;
+  const int nst = (int)((st0 + per <= nst_all ? per : (nst_all > st0 ? nst_all - st0 : 0)));
+  // 32-column tiles of this wave that hold anything: rows of dW past `out` / columns past `in` are skipped by the whole wave
+  const int ni = (g.out - 64 * wm + 31) / 32, nj = (g.in - 128 * wn + 31) / 32;
+  const int NI = ni < 0 ? 0 : ni > 2 ? 2 : ni, NJ = nj < 0 ? 0 : nj > 4 ? 4 : nj;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int c4 = tid & 63, r0 = tid >> 6;  // piece c4 (4 columns) of rows r0 + 8 j
+  // (column counts are multiples of 4 here: whole 16-byte pieces; pieces past the last column / row read zeros)
+  const uint32_t og = 4 * c4 < g.out ? (uint32_t)((r0 * g.out + 4 * c4) * 4) : lsnt::OOB;
+  const uint32_t ox = 4 * c4 < g.in ? (uint32_t)((r0 * g.in + 4 * c4) * 4) : lsnt::OOB;
+  f32x4 gs0[NPC], xs0[NPC], gs1[NPC], xs1[NPC];
+  auto load = [&](f32x4 (&gs)[NPC], f32x4 (&xs)[NPC], int st) __attribute__((always_inline)) {
+    if (TGW_ABLATE & 1) return;
+    const int64_t m0 = st < nst ? (st0 + st) * SS : g.N;  // past the slice: an empty buffer
+    // (column counts are multiples of 4 here: whole 16-byte pieces; out-of-range pieces return zero)
+    const __amdgpu_buffer_rsrc_t rg = lsnt::tile_rsrc(g.dY, g.out, m0, g.N, g.part), rx = lsnt::tile_rsrc(g.x, g.in, m0, g.N, g.part);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {  // rows r0 + 8 j: one lane offset, the row step in the scalar offset
+      gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og, 8 * j * g.out * 4, 0));
+      xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox, 8 * j * g.in * 4, 0));
+    }
+  };
+  auto convert_as = [&](const f32x4 (&gs)[NPC], const f32x4 (&xs)[NPC], char* buf, auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      char* d = buf + (r0 + 8 * j) * PW + c4 * 8;
+      bf16x4 hi, lo;
+      const f32x4 gv = gs[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bsum[e] += gv[e];
+      split4(gv, hi, lo);
+      *(bf16x4*)d = hi;
+      *(bf16x4*)(d + PLANE) = lo;
+      f32x4 xv = xs[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[e] = tact(xv[e], ACT);
+      split4(xv, hi, lo);
+      *(bf16x4*)(d + 2 * PLANE) = hi;
+      *(bf16x4*)(d + 3 * PLANE) = lo;
+    }
+  };
+  auto convert = [&](const f32x4 (&gs)[NPC], const f32x4 (&xs)[NPC], char* buf) __attribute__((always_inline)) {
+    if (TGW_ABLATE & 2) return;
+    if (g.act == NA_ACT_LEAKY_RELU) convert_as(gs, xs, buf, std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
+    else if (g.act == NA_ACT_SIN) convert_as(gs, xs, buf, std::integral_constant<int, NA_ACT_SIN>{});
+    else convert_as(gs, xs, buf, std::integral_constant<int, NA_ACT_NONE>{});
+  };
+  // one operand fragment: 8 consecutive samples (k = 16 ks + 8 (lane >> 5) + e) of feature 32 tile + (lane & 31)
+  const int li = lane & 15;
+  const int frag_off = (8 * (lane >> 5) + (li >> 2)) * PW + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+  auto frag = [&](const char* plane, int ks, int tile) __attribute__((always_inline)) -> bf16x8 {
+    const char* p = plane + frag_off + ks * 16 * PW + tile * 64;
+    const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)p);
+    const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)(p + 4 * PW));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, v8s{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+  };
+  auto mma = [&](const char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (TGW_ABLATE & 8) { ah[i] = al[i] = *(const bf16x8*)(buf + lane * 16); continue; }
+        if (i < NI) { ah[i] = frag(buf, ks, 2 * wm + i); al[i] = frag(buf + PLANE, ks, 2 * wm + i); }
+      }
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {  // the four column tiles in two halves: 16 fragment registers less
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * jh + jj;
+          if (TGW_ABLATE & 8) { bh[jj] = bl[jj] = *(const bf16x8*)(buf + lane * 16); continue; }
+          if (j < NJ) { bh[jj] = frag(buf + 2 * PLANE, ks, 4 * wn + j); bl[jj] = frag(buf + 3 * PLANE, ks, 4 * wn + j); }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * jh + jj;
+            if (i >= NI || j >= NJ) continue;
+            if (TGW_ABLATE & 4) { acc[i][j][0] += (float)al[i][0] + (float)bh[jj][1] + (float)ah[i][2] + (float)bl[jj][3]; continue; }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jj], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  };
+  // (no conditions around the fetches: stages past the slice read rows past the batch, which the buffer bounds turn into
+  // zeros; with `if (s + 3 < nst)` in front of them the compiler's wait-count pass fell back to vmcnt(0) before every
+  // conversion, i.e. waited for the rows it had just requested)
+  auto stage = [&](f32x4 (&gs)[NPC], f32x4 (&xs)[NPC], int s) __attribute__((always_inline)) {
+    convert(gs, xs, smem + ((s + 1) & 1) * STAGE);
+    load(gs, xs, s + 3);
+    mma(smem + (s & 1) * STAGE);
+    __syncthreads();
+  };
+  load(gs0, xs0, 0);
+  load(gs1, xs1, 1);
+  convert(gs0, xs0, smem);
+  load(gs0, xs0, 2);
+  __syncthreads();
+  for (int s = 0; s < nst; s += 2) {
+    stage(gs1, xs1, s);
+    if (s + 1 < nst) stage(gs0, xs0, s + 1);
+  }
+  // partial gradient of this workgroup: register r of acc[i][j] = row 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
+  // column 128 wn + 32 j + (lane & 31): 128 contiguous bytes per row
+  float* part = g.part + (int64_t)blockIdx.x * PART;
+  if ((TGW_ABLATE & 16) && acc[0][0][0] != 1.2345f) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i >= NI || j >= NJ) continue;  // (the reduction reads rows < out, columns < in only)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        part[(64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 256 + 128 * wn + 32 * j + (lane & 31)] = acc[i][j][r];
+    }
+  if (g.want_db) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[256 * 256 + r0 * 256 + 4 * c4 + e] = bsum[e];
+  }
+}
+
+// dW[row, col0 + col] += sum over workgroups (fixed order); db likewise over workgroups x 4 row groups
+__global__ void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw, float* __restrict__ dW,
+                              float* __restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < out * in) {
+    const int row = idx / in, col = idx % in;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += part[(int64_t)w * PART + row * 256 + col];
+    dW[(int64_t)row * ldw + col] += s;
+  } else if (db != nullptr && idx < out * in + out) {
+    const int col = idx - out * in;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w)
+      for (int q = 0; q < 8; ++q) s += part[(int64_t)w * PART + 256 * 256 + q * 256 + col];
+    db[col] += s;
+  }
+}
+
+// one source of the concatenation: dW[:, 0 .. in) at leading dimension ldw
+static int launch(const float* dY, int out, const float* x, int in, int act, int64_t N, float* dW, int ldw, float* db,
+                  hipStream_t st, const char* what) {
+  Args a{};
+  a.dY = dY; a.x = x; a.out = out; a.in = in; a.act = act; a.N = N; a.want_db = db != nullptr;
+  const int64_t nst = (N + SS - 1) / SS;
+  int grid = lsnt::cu_count();
+  if (nst / 4 < grid) grid = (int)(nst / 4 > 0 ? nst / 4 : 1);  // at least 4 stages per workgroup
+  const size_t bytes = (size_t)grid * PART * sizeof(float);
+  float* part = nullptr;
+  hipError_t e = hipMallocAsync((void**)&part, bytes, st);
+  if (e != hipSuccess) { set_error("%s: hipMallocAsync(%zu): %s", what, bytes, hipGetErrorString(e)); return NA_EHIP; }
+  a.part = part;
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  int rc = NA_OK;
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipError_t e2 = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e2 != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e2)); rc = NA_EHIP; }
+    else done.fetch_or(bit, std::memory_order_release);
+  }
+  if (rc == NA_OK) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), LDS, st, a);
+    const int n = out * in + (db != nullptr ? out : 0);
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, grid, out, in, ldw, dW, db);
+  }
+  (void)hipFreeAsync(part, st);
+  if (rc != NA_OK) return rc;
+  return check_launch(what);
+}
+}  // namespace lstn
+
 }  // namespace na
 
 using namespace na;
@@ -962,15 +1194,25 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_wgrad_bf16x3: bad shape");
   NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_wgrad_bf16x3: in1>0 needs x1");
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_wgrad_bf16x3: activation %d", pre_act);
+  // The layer-synchronous kernel takes the first source when its shapes are whole 16-byte pieces (hidden layers, the hidden
+  // part of a skip layer); the K-staged kernel the rest (narrow outputs, the 38 / 69 encoding columns of a skip layer).
+  const bool ls0 = lsnt_wanted(N, 4) && out <= 256 && (out & 3) == 0 && in0 <= 256 && (in0 & 3) == 0;
+  if (ls0) {
+    int rc = lstn::launch(dY, out, x0, in0, pre_act, N, dW, in0 + in1, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+    if (rc != NA_OK || in1 == 0) return rc;
+  }
   constexpr int WM = 2, WN = 4, BM = 64 * WM, BN = 64 * WN;
-  const int in = in0 + in1;
+  const int ldw = in0 + in1;
+  const int in = ls0 ? in1 : in0 + in1;  // columns this launch computes: all, or the second source behind the first
+  const int col0 = ls0 ? in0 : 0;
   TnArgs a{};
   a.dY = dY;
   a.out = out;
-  a.x = RowSrc{x0, x1, in0, in1, N};
+  a.x = ls0 ? RowSrc{x1, nullptr, in1, 0, N} : RowSrc{x0, x1, in0, in1, N};
   a.act = pre_act;
-  a.dW = dW;
-  a.db = db;
+  a.dW = dW + col0;
+  a.ldw = ldw;
+  a.db = ls0 ? nullptr : db;
   const int64_t tiles = (int64_t)((out + BM - 1) / BM) * ((in + BN - 1) / BN);
   // ~2 workgroups per CU, slices of at least 512 samples (the 32K-atomic epilogue must stay a small fraction)
   int64_t want = (512 + tiles - 1) / tiles;
@@ -990,15 +1232,15 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   dim3 grid((out + BM - 1) / BM, (in + BN - 1) / BN, (unsigned)nz);
   const int lds = smem_bytes<WM, WN>();
   int rc;
-  const size_t nW = (size_t)out * in;
-  long long* fix = det_begin(nW + (db ? out : 0), (hipStream_t)stream, "na_linear_wgrad_bf16x3", &rc);
+  const size_t nW = (size_t)out * ldw;
+  long long* fix = det_begin(nW + (a.db ? out : 0), (hipStream_t)stream, "na_linear_wgrad_bf16x3", &rc);
   if (rc != NA_OK) return rc;
-  a.fixW = fix;
+  a.fixW = fix ? fix + col0 : nullptr;
   a.fixb = fix ? fix + nW : nullptr;
   hipLaunchKernelGGL(k, grid, dim3(64 * WM * WN), lds, (hipStream_t)stream, a);
   if (fix != nullptr) {
     if ((rc = det_finish(fix, nW, dW, (hipStream_t)stream, "na_linear_wgrad_bf16x3")) != NA_OK) return rc;
-    if (db != nullptr) return det_finish(fix + nW, (size_t)out, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+    if (a.db != nullptr) return det_finish(fix + nW, (size_t)out, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
     return NA_OK;
   }
   return check_launch("na_linear_wgrad_bf16x3");

@@ -5,8 +5,9 @@ from nerf_atlas_amd import _lib
 N = 262144
 x = torch.randn(N, 256, device="cuda"); W = torch.randn(256, 256, device="cuda") * 0.06; b = torch.zeros(256, device="cuda"); y = torch.empty(N, 256, device="cuda")
 MODE = "fwd"
-if sys.argv[1] in ("fwd", "dgrad"):
+if sys.argv[1] in ("fwd", "dgrad", "wgrad"):
     MODE = sys.argv.pop(1)
+dWb = torch.zeros(256, 256, device="cuda"); dbb = torch.zeros(256, device="cuda")
 gy = torch.randn(N, 256, device="cuda"); Wt = W.t().contiguous(); gx = torch.empty(N, 256, device="cuda")
 for name in sys.argv[1:]:
     path = os.path.join("nerf_atlas_amd", "libnerf_atlas_amd.so") if name == "shipped" else os.path.join("gpurun_ablate", f"lib_var_{name}.so")
@@ -17,7 +18,11 @@ for name in sys.argv[1:]:
     fd = lib.na_linear_dgrad_bf16x3
     fd.argtypes = _lib.SIGNATURES["na_linear_dgrad_bf16x3"][1]; fd.restype = C.c_int
     def f():
-        if MODE == "fwd": assert fn(x.data_ptr(), 256, None, 0, N, W.data_ptr(), b.data_ptr(), 256, 1, y.data_ptr(), st) == 0
+        if MODE == "wgrad":
+            fw = lib.na_linear_wgrad_bf16x3
+            fw.argtypes = _lib.SIGNATURES["na_linear_wgrad_bf16x3"][1]; fw.restype = C.c_int
+            assert fw(x.data_ptr(), 256, None, 0, N, gy.data_ptr(), 256, 1, dWb.data_ptr(), dbb.data_ptr(), st) == 0
+        elif MODE == "fwd": assert fn(x.data_ptr(), 256, None, 0, N, W.data_ptr(), b.data_ptr(), 256, 1, y.data_ptr(), st) == 0
         else: assert fd(gy.data_ptr(), 256, N, Wt.data_ptr(), x.data_ptr(), 256, None, 0, 1, gx.data_ptr(), None, st) == 0
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
