@@ -932,6 +932,9 @@ struct Args {
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s* lds_v4s;
 
+// GA / XA: the column count of dY / x is a multiple of 4 (whole aligned 16-byte pieces); otherwise that operand is fetched as
+// dwords (the unaligned ones are narrow: 3, 38, 65, 69 columns)
+template <bool GA, bool XA>
 __global__ __launch_bounds__(512) void kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -954,9 +957,18 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   const int c4 = tid & 63, r0 = tid >> 6;  // piece c4 (4 columns) of rows r0 + 8 j
-  // (column counts are multiples of 4 here: whole 16-byte pieces; pieces past the last column / row read zeros)
-  const uint32_t og = 4 * c4 < g.out ? (uint32_t)((r0 * g.out + 4 * c4) * 4) : lsnt::OOB;
-  const uint32_t ox = 4 * c4 < g.in ? (uint32_t)((r0 * g.in + 4 * c4) * 4) : lsnt::OOB;
+  // lane offsets of the thread's piece in row r0 (pieces / elements past the last column read zeros)
+  uint32_t og[GA ? 1 : 4], ox[XA ? 1 : 4];
+  if (GA) og[0] = 4 * c4 < g.out ? (uint32_t)((r0 * g.out + 4 * c4) * 4) : lsnt::OOB;
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) og[e & (GA ? 0 : 3)] = 4 * c4 + e < g.out ? (uint32_t)((r0 * g.out + 4 * c4 + e) * 4) : lsnt::OOB;
+  }
+  if (XA) ox[0] = 4 * c4 < g.in ? (uint32_t)((r0 * g.in + 4 * c4) * 4) : lsnt::OOB;
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ox[e & (XA ? 0 : 3)] = 4 * c4 + e < g.in ? (uint32_t)((r0 * g.in + 4 * c4 + e) * 4) : lsnt::OOB;
+  }
   f32x4 gs0[NPC], xs0[NPC], gs1[NPC], xs1[NPC];
   auto load = [&](f32x4 (&gs)[NPC], f32x4 (&xs)[NPC], int st) __attribute__((always_inline)) {
     if (TGW_ABLATE & 1) return;
@@ -965,8 +977,16 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const __amdgpu_buffer_rsrc_t rg = lsnt::tile_rsrc(g.dY, g.out, m0, g.N, g.part), rx = lsnt::tile_rsrc(g.x, g.in, m0, g.N, g.part);
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {  // rows r0 + 8 j: one lane offset, the row step in the scalar offset
-      gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og, 8 * j * g.out * 4, 0));
-      xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox, 8 * j * g.in * 4, 0));
+      if constexpr (GA) gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, 0));
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, og[e & (GA ? 0 : 3)], 8 * j * g.out * 4, 0));
+      }
+      if constexpr (XA) xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox[0], 8 * j * g.in * 4, 0));
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ox[e & (XA ? 0 : 3)], 8 * j * g.in * 4, 0));
+      }
     }
   };
   auto convert_as = [&](const f32x4 (&gs)[NPC], const f32x4 (&xs)[NPC], char* buf, auto actc) __attribute__((always_inline)) {
@@ -1074,21 +1094,36 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   }
 }
 
-// dW[row, col0 + col] += sum over workgroups (fixed order); db likewise over workgroups x 4 row groups
-__global__ void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw, float* __restrict__ dW,
-                              float* __restrict__ db) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < out * in) {
+// dW[row, col] += sum over workgroups; db likewise over workgroups x 8 row groups.  A block = 64 elements x 4 quarters of the
+// workgroup range: every thread sums its quarter in index order, the quarters are combined in LDS in a fixed order, so the result
+// does not depend on timing (and 256 sequential 256-KiB-strided reads per element became 4 x 64 in parallel).
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw,
+                                                     float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  const int nW = out * in;
+  const int w0 = (int)((int64_t)nwg * q / 4), w1 = (int)((int64_t)nwg * (q + 1) / 4);
+  float s = 0.f;
+  if (idx < nW) {
     const int row = idx / in, col = idx % in;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += part[(int64_t)w * PART + row * 256 + col];
-    dW[(int64_t)row * ldw + col] += s;
-  } else if (db != nullptr && idx < out * in + out) {
-    const int col = idx - out * in;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w)
-      for (int q = 0; q < 8; ++q) s += part[(int64_t)w * PART + 256 * 256 + q * 256 + col];
-    db[col] += s;
+    const float* p = part + row * 256 + col;
+    for (int w = w0; w < w1; ++w) s += p[(int64_t)w * PART];
+  } else if (db != nullptr && idx < nW + out) {
+    const float* p = part + 256 * 256 + (idx - nW);
+    for (int w = w0; w < w1; ++w) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += p[(int64_t)w * PART + k * 256];
+      s += t;
+    }
+  }
+  red[q][e] = s;
+  __syncthreads();
+  if (q == 0) {
+    const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (idx < nW) dW[(int64_t)(idx / in) * ldw + idx % in] += t;
+    else if (db != nullptr && idx < nW + out) db[idx - nW] += t;
   }
 }
 
@@ -1105,20 +1140,23 @@ static int launch(const float* dY, int out, const float* x, int in, int act, int
   hipError_t e = hipMallocAsync((void**)&part, bytes, st);
   if (e != hipSuccess) { set_error("%s: hipMallocAsync(%zu): %s", what, bytes, hipGetErrorString(e)); return NA_EHIP; }
   a.part = part;
-  static std::atomic<uint64_t> done{0};
+  const bool ga = (out & 3) == 0, xa = (in & 3) == 0;
+  auto k = ga ? (xa ? kernel<true, true> : kernel<true, false>) : (xa ? kernel<false, true> : kernel<false, false>);
+  const int which = 2 * ga + xa;
+  static std::atomic<uint64_t> done[4];
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   int rc = NA_OK;
-  if (!(done.load(std::memory_order_acquire) & bit)) {
-    hipError_t e2 = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (!(done[which].load(std::memory_order_acquire) & bit)) {
+    hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e2 != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e2)); rc = NA_EHIP; }
-    else done.fetch_or(bit, std::memory_order_release);
+    else done[which].fetch_or(bit, std::memory_order_release);
   }
   if (rc == NA_OK) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, st, a);
     const int n = out * in + (db != nullptr ? out : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, grid, out, in, ldw, dW, db);
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, grid, out, in, ldw, dW, db);
   }
   (void)hipFreeAsync(part, st);
   if (rc != NA_OK) return rc;
@@ -1194,25 +1232,24 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_wgrad_bf16x3: bad shape");
   NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_wgrad_bf16x3: in1>0 needs x1");
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_wgrad_bf16x3: activation %d", pre_act);
-  // The layer-synchronous kernel takes the first source when its shapes are whole 16-byte pieces (hidden layers, the hidden
-  // part of a skip layer); the K-staged kernel the rest (narrow outputs, the 38 / 69 encoding columns of a skip layer).
-  const bool ls0 = lsnt_wanted(N, 4) && out <= 256 && (out & 3) == 0 && in0 <= 256 && (in0 & 3) == 0;
+  // The layer-synchronous kernel, one launch per source of the concatenation (dY is read again for the second: the sources of
+  // a skip layer are [hidden 256 | encoding 38 or 69]); wider shapes and small batches stay on the K-staged kernel.
+  const bool ls0 = lsnt_wanted(N, 4) && out <= 256 && in0 <= 256 && in1 <= 256;
   if (ls0) {
     int rc = lstn::launch(dY, out, x0, in0, pre_act, N, dW, in0 + in1, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
     if (rc != NA_OK || in1 == 0) return rc;
+    return lstn::launch(dY, out, x1, in1, pre_act, N, dW + in0, in0 + in1, nullptr, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
   }
   constexpr int WM = 2, WN = 4, BM = 64 * WM, BN = 64 * WN;
-  const int ldw = in0 + in1;
-  const int in = ls0 ? in1 : in0 + in1;  // columns this launch computes: all, or the second source behind the first
-  const int col0 = ls0 ? in0 : 0;
+  const int ldw = in0 + in1, in = in0 + in1, col0 = 0;
   TnArgs a{};
   a.dY = dY;
   a.out = out;
-  a.x = ls0 ? RowSrc{x1, nullptr, in1, 0, N} : RowSrc{x0, x1, in0, in1, N};
+  a.x = RowSrc{x0, x1, in0, in1, N};
   a.act = pre_act;
   a.dW = dW + col0;
   a.ldw = ldw;
-  a.db = ls0 ? nullptr : db;
+  a.db = db;
   const int64_t tiles = (int64_t)((out + BM - 1) / BM) * ((in + BN - 1) / BN);
   // ~2 workgroups per CU, slices of at least 512 samples (the 32K-atomic epilogue must stay a small fraction)
   int64_t want = (512 + tiles - 1) / tiles;
