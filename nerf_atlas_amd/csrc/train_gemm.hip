@@ -509,10 +509,8 @@ constexpr int PLANE = TS * PITCH;
 constexpr int BUF = 2 * PLANE;      // hi | lo
 constexpr int LDS = 2 * BUF;        // two buffers: 68 KiB
 constexpr int NPF = TS * (KC / 4) / 256;  // 16-byte pieces per producer thread and unit (8)
-constexpr int SP = 36;              // float pitch of the consumers' 32 x 32 transpose tiles
-constexpr int STG = 4 * 32 * SP * 4;       // 18 KiB behind the buffers
-constexpr int XP = 260;             // float pitch of the forward-input tile (input gradient with an activation)
-constexpr int XB = TS * XP * 4;     // 65 KiB
+constexpr int XP = 260;             // float pitch of the output tile (= the forward-input tile of an input gradient with an activation)
+constexpr int XB = TS * XP * 4;     // 65 KiB behind the buffers
 constexpr int NXF = TS * 64 / 256;  // its 16-byte pieces per producer thread (16)
 constexpr int SEG = 8 * 2048;       // stream bytes of one (column group, chunk, column tile): 8 k steps x (hi | lo) fragments
 
@@ -609,11 +607,16 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   // x goes through LDS (any column layout: the producers' loader handles unaligned rows); that needs a unit in which the
   // consumers do not read it, so the launcher gives a DACT launch at least two chunks (a zero chunk if K <= 128)
   constexpr bool xlds = DACT;
-  float* stg_all = (float*)(smem + LDS);
-  float* xbuf = (float*)(smem + LDS + STG);
+  // The output tile of a (tile, pass): [64 samples][256 columns] fp32.  The consumers write it in the last chunk's unit, the
+  // PRODUCERS store it to HBM during the next unit: loads of a wave return in order behind its older stores, so a consumer
+  // that stored its own results waited ~3 k cycles per column tile for the stores to complete before its next weight
+  // fragments counted as arrived; the producers' queue holds only long-latency work anyway.  For an input gradient with an
+  // activation the same memory first holds the forward inputs x (parked by the producers one unit earlier): a consumer reads
+  // x, scales its accumulators and overwrites x with the result in place.
+  float* xbuf = (float*)(smem + LDS);
   // the bias vector (zero padded to whole column groups) lives in LDS: the epilogue reads it with LDS loads, which do not queue
   // behind the wave's outstanding stores the way a global load would
-  float* lbias = (float*)(smem + LDS + STG + (DACT ? XB : 0));
+  float* lbias = (float*)(smem + LDS + XB);
   if (MODE == 0) {
     for (int i = tid; i < nrg * 64; i += 512) lbias[i] = (g.bias != nullptr && i < g.M) ? g.bias[i] : 0.f;
   }
@@ -667,10 +670,45 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 #pragma unroll
       for (int j = 0; j < NXF; ++j) *(f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4) = xs[j];
     };
-    // producer step during unit u: fill the other buffer with unit u + 1, fetch unit u + 3; x of the (tile, pass) whose last
-    // chunk comes next is parked in LDS one unit before the consumers read it, and the following (tile, pass)'s is requested
-    auto step = [&](f32x4 (&pf)[NPF], int u, char* other) {
+    // the finished output tile of unit u's (tile, pass), from LDS to HBM: whole rows, 16 bytes per lane (the thread's pieces are the
+    // ones it parks x in, so its own program order is all the synchronisation the shared buffer needs)
+    const bool all_vec = ((g.c0 | g.c1) & 3) == 0;
+    const int ncols = g.c0 + g.c1;
+    auto store_out = [&](int u) __attribute__((always_inline)) {
+      if (TGL_ABLATE & 2) return;
+      const int64_t m0 = tile_of(u) * TS;
+      const int col = 256 * ((u / NCH) % NP) + 4 * xc4;
+      const __amdgpu_buffer_rsrc_t ry0 = tile_rsrc(g.y0, g.c0, m0, g.a.rows, g.wp), ry1 = tile_rsrc(g.y1, g.c1, m0, g.a.rows, g.wp);
+      if (all_vec) {
+        const uint32_t o0 = col < g.c0 ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
+        const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < NXF; ++j) {
+          const f32x4 v = *(const f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, 4 * j * g.c0 * 4, 0);
+          if (g.c1 > 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, 4 * j * g.c1 * 4, 0);
+        }
+      } else {  // rows that are not 16-byte aligned (a column count that is no multiple of 4): element by element
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ce = col + e;
+          const uint32_t p0 = ce < g.c0 ? (uint32_t)((xr0 * g.c0 + ce) * 4) : OOB;
+          const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
+#pragma unroll
+          for (int j = 0; j < NXF; ++j) {
+            const float w = xbuf[(xr0 + 4 * j) * XP + 4 * xc4 + e];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, 4 * j * g.c0 * 4, 0);
+            if (g.c1 > 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, 4 * j * g.c1 * 4, 0);
+          }
+        }
+      }
+    };
+    // producer step during unit u: first the previous (tile, pass)'s finished output if this unit opens a new one; then fill the
+    // other buffer with unit u + 1, fetch unit u + 3; x of the (tile, pass) whose last chunk comes next is parked in LDS one unit
+    // before the consumers read it (behind the store of the old tile in the same buffer), and the following one's is requested
+    auto step = [&](f32x4 (&pf)[NPF], int u, char* other) __attribute__((always_inline)) {
       if (wave == 4) TGL_STAMP(1, u, 0);
+      if (u % NCH == 0 && u > 0) store_out(u - 1);
       // (no conditions around the fetches: units past the end read rows past the batch = zeros; conditional fetches made the
       // compiler's wait-count pass wait with vmcnt(0), i.e. for the rows just requested)
       convert(pf, other);
@@ -694,6 +732,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       step(pf1, u, smem + BUF);
       if (u + 1 < nunits) step(pf0, u + 1, smem);
     }
+    store_out(nunits - 1);  // (behind the last unit's barrier)
     return;
   }
 
@@ -715,10 +754,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 #pragma unroll
     for (int i = 0; i < RD; ++i) { ring[i][0] = wfrag(so, i, 0); ring[i][1] = wfrag(so, i, 1); }
   }
-  const bool all_vec = ((g.c0 | g.c1) & 3) == 0;  // every row of both outputs is written as aligned 16-byte pieces
   constexpr bool dact = DACT;
-  float* stg = stg_all + wave * (32 * SP);
-  const int rrow = lane >> 3, rc4 = (lane & 7) * 4;  // after the transpose: row rrow + 8 j of the block, columns rc4 .. rc4 + 3
   __syncthreads();
   for (int u = 0; u < nunits; ++u) {
     const int64_t m0 = (blockIdx.x + (int64_t)(u / UPT) * gridDim.x) * TS;
@@ -729,9 +765,6 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     if (R >= 0) {
       const char* brow = buf + (lane & 31) * PITCH + (lane >> 5) * 16;
       const bool last = ch == NCH - 1;
-      // epilogue resources (cheap scalar work; used in the last chunk only)
-      auto rsrc_of = [&](const float* base, int ld) __attribute__((always_inline)) { return tile_rsrc(base, ld, m0, g.a.rows, g.wp); };
-      const __amdgpu_buffer_rsrc_t ry0 = rsrc_of(g.y0, g.c0), ry1 = rsrc_of(g.y1, g.c1);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (ch == 0) {
@@ -779,59 +812,31 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (wave == 0 && t == 1) TGL_STAMP(0, u, 1);
-        if (last && !((TGL_ABLATE & 2) && acc[0][0][0] != 1.2345f)) {
-          // Epilogue of column tile t.  The accumulators hold 4 consecutive columns per register quad and one SAMPLE per lane:
-          // stored like that, a 16-byte store touches 32 rows with 32 bytes each (4096 partial-line requests per 128 samples:
-          // measured 8-23 k cycles).  Every 32 x 32 block goes through a wave-private LDS tile instead and leaves as whole
-          // 128-byte lines (8 lanes per row).  Branch-free: buffer accesses whose offsets fall outside the (tile-relative) buffer
-          // are dropped by the hardware -- rows past the batch, columns past M, a null output.
-          const int tc0 = 64 * R + 32 * t;                      // the tile's first column
-          const bool side0 = tc0 < g.c0, side1 = tc0 + 32 > g.c0 && g.c1 > 0;  // wave-uniform: which outputs the tile touches
-          const int col = tc0 + rc4;
-          const uint32_t o0 = (col < g.c0) ? (uint32_t)((rrow * g.c0 + col) * 4) : OOB;
-          const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((rrow * g.c1 + col - g.c0) * 4) : OOB;
-          f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-          if (MODE == 0) bj = *(const f32x4*)(lbias + col);
+        if (last) {
+          // Epilogue of column tile t: bias / activation derivative in the accumulator layout -- register 4 q + e of acc[t][b] =
+          // column 64 R + 32 t + 8 q + 4 (lane >> 5) + e, sample 32 b + (lane & 31) -- then the quads go to the output tile in
+          // LDS (row-major; x, where it is needed, sits at the very same places and is overwritten by the result).
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
+          for (int q = 0; q < 4; ++q) {
+            const int cl = 64 * wave + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
+            f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 0) bj = *(const f32x4*)(lbias + 256 * pass + cl);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *(f32x4*)(stg + (lane & 31) * SP + 8 * q + 4 * (lane >> 5)) =
-                  f32x4{acc[t][b][4 * q], acc[t][b][4 * q + 1], acc[t][b][4 * q + 2], acc[t][b][4 * q + 3]};
+            for (int b = 0; b < 2; ++b) {
+              float* o = xbuf + (32 * b + (lane & 31)) * XP + cl;
+              f32x4 v = {acc[t][b][4 * q], acc[t][b][4 * q + 1], acc[t][b][4 * q + 2], acc[t][b][4 * q + 3]};
+              if (MODE == 0) v += bj;
+              if (dact) {
+                const f32x4 xv = *(const f32x4*)o;
+                if (g.act == NA_ACT_SIN) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int s0 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c0 * 4), s1 = __builtin_amdgcn_readfirstlane((32 * b + 8 * j) * g.c1 * 4);
-              const float* xrow = xbuf + (32 * b + rrow + 8 * j) * XP + 64 * wave + 32 * t + rc4;
-              if (all_vec) {
-                f32x4 v = *(const f32x4*)(stg + (rrow + 8 * j) * SP + rc4);
-                if (MODE == 0) v += bj;
-                if (dact) {
-                  const f32x4 xv = *(const f32x4*)xrow;
-                  if (g.act == NA_ACT_SIN) {
+                  for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
-                  } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
-                  }
-                }
-                if (side0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, s0, 0);
-                if (side1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, s1, 0);
-              } else {
-                // rows that are not 16-byte aligned (a column count that is no multiple of 4): element by element, scalars
-                // straight from the LDS tiles
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const int ce = col + e;
-                  float w = stg[(rrow + 8 * j) * SP + rc4 + e];
-                  if (MODE == 0) w += lbias[ce];
-                  if (dact) w *= tact_grad(xrow[e], g.act);
-                  const uint32_t p0 = (ce < g.c0) ? (uint32_t)((rrow * g.c0 + ce) * 4) : OOB;
-                  const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((rrow * g.c1 + ce - g.c0) * 4) : OOB;
-                  if (side0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, s0, 0);
-                  if (side1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, s1, 0);
+                  for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
                 }
               }
+              *(f32x4*)o = v;
             }
           }
         }
@@ -858,7 +863,7 @@ template <int MODE>
 static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* what) {
   const bool dact = MODE == 1 && a.act != NA_ACT_NONE;
   a.NCH = (K + KC - 1) / KC;
-  if (dact && a.NCH < 2) a.NCH = 2;  // the forward inputs are parked in LDS one unit before the tile's last
+  if (a.NCH < 2) a.NCH = 2;  // the output tile in LDS is stored (and x parked) in a unit in which the consumers do not touch it
   const int nrg = (a.M + 63) / 64;
   if (nrg > 16) { set_error("%s: more than 1024 output columns", what); return NA_EUNSUPPORTED; }
   const size_t wbytes = (size_t)nrg * a.NCH * 2 * SEG;
@@ -872,14 +877,14 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
   const int grid = a.ntiles < cu_count() ? (int)a.ntiles : cu_count();
   auto k = kernel<MODE, false>;
   if constexpr (MODE == 1) { if (dact) k = kernel<MODE, true>; }
-  const int lds = LDS + STG + (dact ? XB : 0) + nrg * 256;
+  const int lds = LDS + XB + nrg * 256;
   static std::atomic<uint64_t> done[2];
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   int rc = NA_OK;
   if (!(done[dact].load(std::memory_order_acquire) & bit)) {
-    hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + STG + (dact ? XB : 0) + 4096);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + XB + 4096);
     if (e2 != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e2)); rc = NA_EHIP; }
     else done[dact].fetch_or(bit, std::memory_order_release);
   }
