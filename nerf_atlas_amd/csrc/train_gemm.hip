@@ -563,9 +563,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, i
   if (bytes < 0) bytes = 0;
   return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)dummy : base + m0 * ld), 0, (int)bytes, 0x00020000);
 }
+// WHICH: 0 both sources, 1 the first only, 2 the second only (a caller that knows where its columns lie -- a whole k chunk
+// inside one source -- issues a fifth of the loads a skip layer's unaligned second source would otherwise add to every piece)
+template <int WHICH = 0>
 __device__ __forceinline__ f32x4 load_piece(const Src2& s, int row, int col) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if ((s.k0 & 3) == 0) {
+  if (WHICH == 2) {
+  } else if ((s.k0 & 3) == 0) {
     const uint32_t o = col < s.k0 ? (uint32_t)((row * s.k0 + col) * 4) : OOB;
     v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r0, o, 0, 0));
   } else {
@@ -575,7 +579,7 @@ __device__ __forceinline__ f32x4 load_piece(const Src2& s, int row, int col) {
       v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.r0, o, 0, 0));
     }
   }
-  if (s.k1 > 0) {
+  if (WHICH != 1 && s.k1 > 0) {
     if (((s.k0 | s.k1) & 3) == 0) {
       const uint32_t o = (col >= s.k0 && col < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + col - s.k0) * 4) : OOB;
       v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r1, o, 0, 0));
@@ -628,13 +632,26 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const int xc4 = ptid & 63, xr0 = ptid >> 6;                  // x tile: piece xc4 (4 columns) of rows xr0 + 4 j
     f32x4 pf0[NPF], pf1[NPF], xs[NXF];
     auto tile_of = [&](int u) __attribute__((always_inline)) -> int64_t { return u < nunits ? blockIdx.x + (int64_t)(u / UPT) * gridDim.x : g.ntiles; };
+    // With two chunks per tile both stay in the two LDS buffers, at the same buffer parity, for every further pass over the
+    // output columns (a skip layer's 38 extra gradient columns): those units need neither rows nor a conversion.  (Their row
+    // fetches are still ISSUED, against an empty buffer: conditional fetches cost the wait-count pass its precision.)
+    auto resident = [&](int u) __attribute__((always_inline)) { return NCH == 2 && u < nunits && (u / NCH) % NP >= 1; };
     auto load = [&](f32x4 (&pf)[NPF], int u) {
       if (TGL_ABLATE & 1) return;
-      const int64_t m0 = tile_of(u) * TS;
+      const int64_t m0 = (resident(u) ? g.ntiles : tile_of(u)) * TS;
       const int k = (u % NCH) * KC + c4 * 4;
       const Src2 src{tile_rsrc(g.a.p0, g.a.k0, m0, g.a.rows, g.wp), tile_rsrc(g.a.p1, g.a.k1, m0, g.a.rows, g.wp), g.a.k0, g.a.k1};
+      const int k_lo = (u % NCH) * KC;
+      if (k_lo + KC <= g.a.k0 || g.a.k1 == 0) {  // (uniform) the chunk lies inside the first source
 #pragma unroll
-      for (int j = 0; j < NPF; ++j) pf[j] = load_piece(src, r0 + 8 * j, k);
+        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<1>(src, r0 + 8 * j, k);
+      } else if (k_lo >= g.a.k0) {               // inside the second
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<2>(src, r0 + 8 * j, k);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<0>(src, r0 + 8 * j, k);
+      }
     };
     // (the activation is a runtime argument: one specialised copy of the loop per kind, chosen once per unit -- with the switch
     // inside, every element carried the sine polynomial next to the LeakyReLU select: 180 instructions per 4 values)
@@ -663,8 +680,17 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       const int64_t m0 = tile_of(u) * TS;
       const int col = 256 * ((u / NCH) % NP) + 4 * xc4;
       const Src2 src{tile_rsrc(g.x0, g.c0, m0, g.a.rows, g.wp), tile_rsrc(g.x1, g.c1, m0, g.a.rows, g.wp), g.c0, g.c1};
+      const int c_lo = 256 * ((u / NCH) % NP);
+      if (c_lo + 256 <= g.c0 || g.c1 == 0) {
 #pragma unroll
-      for (int j = 0; j < NXF; ++j) xs[j] = load_piece(src, xr0 + 4 * j, col);
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<1>(src, xr0 + 4 * j, col);
+      } else if (c_lo >= g.c0) {
+#pragma unroll
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<2>(src, xr0 + 4 * j, col);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<0>(src, xr0 + 4 * j, col);
+      }
     };
     auto xstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -672,33 +698,45 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     };
     // the finished output tile of unit u's (tile, pass), from LDS to HBM: whole rows, 16 bytes per lane (the thread's pieces are the
     // ones it parks x in, so its own program order is all the synchronisation the shared buffer needs)
-    const bool all_vec = ((g.c0 | g.c1) & 3) == 0;
     const int ncols = g.c0 + g.c1;
     auto store_out = [&](int u) __attribute__((always_inline)) {
       if (TGL_ABLATE & 2) return;
       const int64_t m0 = tile_of(u) * TS;
-      const int col = 256 * ((u / NCH) % NP) + 4 * xc4;
+      const int c_lo = 256 * ((u / NCH) % NP);
+      const int col = c_lo + 4 * xc4;
       const __amdgpu_buffer_rsrc_t ry0 = tile_rsrc(g.y0, g.c0, m0, g.a.rows, g.wp), ry1 = tile_rsrc(g.y1, g.c1, m0, g.a.rows, g.wp);
-      if (all_vec) {
-        const uint32_t o0 = col < g.c0 ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
-        const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
+      // (uniform) which outputs the pass's 256 columns touch, and whether their rows take aligned 16-byte pieces: a skip layer's
+      // [256 | 38] gradient stores its first 256 columns as vectors and only the 38 element by element
+      const bool side0 = c_lo < g.c0, side1 = g.c1 > 0 && c_lo + 256 > g.c0;
+      const bool vec0 = (g.c0 & 3) == 0, vec1 = ((g.c0 | g.c1) & 3) == 0;
 #pragma unroll
-        for (int j = 0; j < NXF; ++j) {
-          const f32x4 v = *(const f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, 4 * j * g.c0 * 4, 0);
-          if (g.c1 > 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, 4 * j * g.c1 * 4, 0);
+      for (int j = 0; j < NXF; ++j) {
+        const f32x4 v = *(const f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4);
+        if (side0) {
+          if (vec0) {
+            const uint32_t o0 = col < g.c0 ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, 4 * j * g.c0 * 4, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t p0 = col + e < g.c0 ? (uint32_t)((xr0 * g.c0 + col + e) * 4) : OOB;
+              const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, 4 * j * g.c0 * 4, 0);
+            }
+          }
         }
-      } else {  // rows that are not 16-byte aligned (a column count that is no multiple of 4): element by element
+        if (side1) {
+          if (vec1) {
+            const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, 4 * j * g.c1 * 4, 0);
+          } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ce = col + e;
-          const uint32_t p0 = ce < g.c0 ? (uint32_t)((xr0 * g.c0 + ce) * 4) : OOB;
-          const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
-#pragma unroll
-          for (int j = 0; j < NXF; ++j) {
-            const float w = xbuf[(xr0 + 4 * j) * XP + 4 * xc4 + e];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, 4 * j * g.c0 * 4, 0);
-            if (g.c1 > 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, 4 * j * g.c1 * 4, 0);
+            for (int e = 0; e < 4; ++e) {
+              const int ce = col + e;
+              const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
+              const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, 4 * j * g.c1 * 4, 0);
+            }
           }
         }
       }
@@ -711,7 +749,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       if (u % NCH == 0 && u > 0) store_out(u - 1);
       // (no conditions around the fetches: units past the end read rows past the batch = zeros; conditional fetches made the
       // compiler's wait-count pass wait with vmcnt(0), i.e. for the rows just requested)
-      convert(pf, other);
+      if (!resident(u + 1)) convert(pf, other);
       if (wave == 4) TGL_STAMP(1, u, 1);
       load(pf, u + 3);
       if (xlds && u % NCH == NCH - 2) {
@@ -741,53 +779,70 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   f32x16 acc[2][2];      // [column tile][32-sample block]: rows = 32 columns of C, columns = samples
   bf16x8 ring[RD][2];    // [k step of the segment][plane]
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.wp, 0, nrg * NCH * 2 * SEG, 0x00020000);
-  // the weight stream of this wave: per tile, pass 0 .. NP-1 (column group wave + 4 pass; passes whose group lies past M are
-  // skipped by the whole wave), chunk 0 .. NCH-1, column tile 0, 1: one segment of 8 k steps each
+  // Work of this wave in pass p (ng = column groups of the pass, 1..4): with 3 or 4 groups a wave owns a whole group (2 column
+  // tiles x 2 sample blocks); with 2 groups a PAIR of waves shares one (a sample block each); with a single group -- a narrow C,
+  // or the 38 extra columns of a skip layer's gradient -- the four waves take one (column tile, sample block) each instead of
+  // three of them idling through the pass.  The weight stream of a wave: per tile, pass 0 .. NP-1, chunk 0 .. NCH-1, its column
+  // tiles in order: one segment of 8 k steps each.
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  auto group_of = [&](int pass) __attribute__((always_inline)) { const int R = wave_s + 4 * pass; return R < nrg ? R : -1; };
+  struct Work { int R, tmask, bmask; };
+  auto work_of = [&](int pass) __attribute__((always_inline)) -> Work {
+    const int left = nrg - 4 * pass, ng = left > 4 ? 4 : left;
+    if (ng >= 3) return Work{wave_s < ng ? 4 * pass + wave_s : -1, 3, 3};
+    if (ng == 2) return Work{4 * pass + (wave_s >> 1), 3, 1 << (wave_s & 1)};
+    return Work{4 * pass, 1 << (wave_s >> 1), 1 << (wave_s & 1)};
+  };
   auto seg_off = [&](int R, int ch, int t) __attribute__((always_inline)) { return ((R * NCH + ch) * 2 + t) * SEG; };
   auto wfrag = [&](int soff, int i, int p) __attribute__((always_inline)) -> bf16x8 {  // (k step in the scalar offset: 12-bit immediates end at 4095)
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16 + p * 1024, soff + i * 2048, 0));
   };
-  if (group_of(0) >= 0) {
-    const int so = seg_off(group_of(0), 0, 0);
+  // first segment of the wave's stream from pass p on (cyclically: the next tile starts at pass 0 again)
+  auto first_seg = [&](int p0) __attribute__((always_inline)) -> int {
+    for (int k = 0; k < NP; ++k) {
+      const int p = p0 + k >= NP ? p0 + k - NP : p0 + k;
+      const Work w = work_of(p);
+      if (w.R >= 0) return seg_off(w.R, 0, (w.tmask & 1) ? 0 : 1);
+    }
+    return -1;
+  };
+  {
+    const int so = first_seg(0);
+    if (so >= 0) {
 #pragma unroll
-    for (int i = 0; i < RD; ++i) { ring[i][0] = wfrag(so, i, 0); ring[i][1] = wfrag(so, i, 1); }
+      for (int i = 0; i < RD; ++i) { ring[i][0] = wfrag(so, i, 0); ring[i][1] = wfrag(so, i, 1); }
+    }
   }
   constexpr bool dact = DACT;
   __syncthreads();
   for (int u = 0; u < nunits; ++u) {
-    const int64_t m0 = (blockIdx.x + (int64_t)(u / UPT) * gridDim.x) * TS;
     const int ch = u % NCH, pass = (u / NCH) % NP;
     const char* buf = smem + (u & 1) * BUF;
-    const int R = group_of(pass);
+    const Work wk = work_of(pass);
+    const int R = wk.R;
     if (wave == 0) TGL_STAMP(0, u, 0);
     if (R >= 0) {
       const char* brow = buf + (lane & 31) * PITCH + (lane >> 5) * 16;
       const bool last = ch == NCH - 1;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (!((wk.tmask >> t) & 1)) continue;
         if (ch == 0) {
 #pragma unroll
           for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
         }
-        // the segment after this one: the other column tile, the next chunk, the next pass with a column group, the next tile
+        // the segment after this one: the wave's other column tile, the next chunk, the next pass it works in, the next tile
         int nso;
-        if (t == 0) nso = seg_off(R, ch, 1);
-        else if (!last) nso = seg_off(R, ch + 1, 0);
-        else {
-          const int pn = pass + 1 == NP ? 0 : pass + 1;
-          int Rn = group_of(pn);
-          if (Rn < 0) Rn = group_of(0);
-          nso = seg_off(Rn, 0, 0);
-        }
+        if (t == 0 && (wk.tmask & 2)) nso = seg_off(R, ch, 1);
+        else if (!last) nso = seg_off(R, ch + 1, (wk.tmask & 1) ? 0 : 1);
+        else nso = first_seg(pass + 1 == NP ? 0 : pass + 1);
         nso = __builtin_amdgcn_readfirstlane(nso);
         bf16x8 xh[2][2], xl[2][2];  // [buffer][block]
         auto xfrag = [&](int ks, int slot) __attribute__((always_inline)) {
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
+            if (!((wk.bmask >> b) & 1)) continue;
             const char* p = brow + b * 32 * PITCH + ks * 32;
             xh[slot][b] = *(const bf16x8*)p;
             xl[slot][b] = *(const bf16x8*)(p + PLANE);
@@ -802,6 +857,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
           const bf16x8 wh = ring[i][0], wl = ring[i][1];
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
+            if (!((wk.bmask >> b) & 1)) continue;
             if (TGL_ABLATE & 4) { acc[t][b][0] += (float)wl[0] + (float)xh[cur][b][0] + (float)wh[1] + (float)xl[cur][b][1]; continue; }
             acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[cur][b], acc[t][b], 0, 0, 0);
             acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[cur][b], acc[t][b], 0, 0, 0);
@@ -818,11 +874,12 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
           // LDS (row-major; x, where it is needed, sits at the very same places and is overwritten by the result).
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int cl = 64 * wave + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
+            const int cl = 64 * (R & 3) + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
             f32x4 bj = {0.f, 0.f, 0.f, 0.f};
             if (MODE == 0) bj = *(const f32x4*)(lbias + 256 * pass + cl);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
+              if (!((wk.bmask >> b) & 1)) continue;
               float* o = xbuf + (32 * b + (lane & 31)) * XP + cl;
               f32x4 v = {acc[t][b][4 * q], acc[t][b][4 * q + 1], acc[t][b][4 * q + 2], acc[t][b][4 * q + 3]};
               if (MODE == 0) v += bj;
