@@ -105,6 +105,40 @@ KERNELS_F16X = {"4": "deformation MLP bf16x3 + canonical model f16x", "5m": "SDF
 OTHER_SLAB = (300, 0, 200, SIZE)   # rows 300..499 of the 800-wide frame: 160 000 rays x 128 = 20.48 M samples
 
 
+def train_step(dev, crop=64, steps_per_ray=64, iters=10):
+    """SURVEY 8(f) N1 in the driver-run line: one PlainNeRF(view) training step (forward + backward HIP kernels in the split-bf16
+    parity-class arithmetic + torch.optim.Adam) on 64 x 64 rays x 64 samples = 262 144 samples, tools/train_bench.py's workload"""
+    import nerf_atlas_amd.nerf as nerf
+    from nerf_atlas_amd import ops
+    torch.manual_seed(0)
+    focal = 0.5 * SIZE / math.tan(0.5 * FOV)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]], device=dev)
+    m = nerf.PlainNeRF(steps=steps_per_ray, t_near=NEAR, t_far=FAR, intermediate_size=64, sigmoid_kind="upshifted").to(dev)
+    m.eval()  # deterministic sampling; gradients still flow
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    target = torch.rand(1, crop, crop, 3, device=dev)
+
+    def step():
+        rays = ops.raygen(c2w, focal, SIZE, (368, 368, crop, crop))
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m(rays), target)
+        loss.backward()
+        opt.step()
+        return loss
+    t_all = time.perf_counter()
+    with torch.enable_grad():
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters): step()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    n = crop * crop * steps_per_ray
+    return {"workload": f"PlainNeRF(view) training step, {crop} x {crop} rays x {steps_per_ray} samples, fwd + bwd + Adam",
+            "dtype": "bf16x3", "samples_per_step": n, "ms_per_step": round(dt * 1e3, 2), "Msamples_s": round(n / dt / 1e6, 2),
+            "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
+
+
 def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
     """BASELINE configs 1, 3, 4 and 5 (both SDF networks) through the model layer on a fixed 200 x 800 x 128 slab: whole
     forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
@@ -366,6 +400,7 @@ def main():
                                        "roofline": roofline(fourth, kern4_ms)}
         if world == 1 and not args.no_other_configs:
             res["other_configs"], res["other_configs_s"] = other_configs(dev)
+            res["train_step"] = train_step(dev)
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, rays_cpu = cpu_baseline(model)
             res["cpu_baseline"] = cb
