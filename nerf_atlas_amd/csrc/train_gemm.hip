@@ -557,6 +557,7 @@ struct Src2 {
   int k0, k1;
 };
 constexpr uint32_t OOB = 0x78000000u;  // a byte offset past every tile buffer: the hardware drops the access
+constexpr int kNoScratch = 1;            // launch(): hipMallocAsync refused (returned to the dispatcher, never to the C ABI)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, int ld, int64_t m0, int64_t rows, const void* dummy) {
   int64_t bytes = base == nullptr ? 0 : (rows - m0) * ld * 4;
   if (bytes > 0x70000000ll) bytes = 0x70000000ll;
@@ -926,7 +927,7 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
   const size_t wbytes = (size_t)nrg * a.NCH * 2 * SEG;
   char* wp = nullptr;
   hipError_t e = hipMallocAsync((void**)&wp, wbytes, st);
-  if (e != hipSuccess) { set_error("%s: hipMallocAsync(%zu): %s", what, wbytes, hipGetErrorString(e)); return NA_EHIP; }
+  if (e != hipSuccess) { (void)hipGetLastError(); return kNoScratch; }  // no stream-ordered scratch here: the caller takes the K-staged kernel
   const int64_t nthr = (int64_t)nrg * a.NCH * 2 * 8 * 64;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.NCH, nrg, wp);
   a.wp = wp;
@@ -1200,7 +1201,7 @@ static int launch(const float* dY, int out, const float* x, int in, int act, int
   const size_t bytes = (size_t)grid * PART * sizeof(float);
   float* part = nullptr;
   hipError_t e = hipMallocAsync((void**)&part, bytes, st);
-  if (e != hipSuccess) { set_error("%s: hipMallocAsync(%zu): %s", what, bytes, hipGetErrorString(e)); return NA_EHIP; }
+  if (e != hipSuccess) { (void)hipGetLastError(); return lsnt::kNoScratch; }
   a.part = part;
   const bool ga = (out & 3) == 0, xa = (in & 3) == 0;
   auto k = ga ? (xa ? kernel<true, true> : kernel<true, false>) : (xa ? kernel<false, true> : kernel<false, false>);
@@ -1256,7 +1257,8 @@ int na_linear_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t
   if (lsnt_wanted(N, out)) {
     lsnt::Args l{};
     l.a = a.a; l.M = out; l.act = pre_act; l.bias = b; l.y0 = y; l.c0 = out;
-    return lsnt::launch<0>(l, W, in0 + in1, (hipStream_t)stream, "na_linear_bf16x3");
+    const int rc = lsnt::launch<0>(l, W, in0 + in1, (hipStream_t)stream, "na_linear_bf16x3");
+    if (rc != lsnt::kNoScratch) return rc;
   }
   return dispatch_nt<0>(a, out, (hipStream_t)stream, "na_linear_bf16x3");
 }
@@ -1282,7 +1284,8 @@ int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt,
   if (lsnt_wanted(N, in0 + in1)) {
     lsnt::Args l{};
     l.a = a.a; l.M = in0 + in1; l.act = pre_act; l.y0 = a.y0; l.y1 = a.y1; l.x0 = x0; l.x1 = x1; l.c0 = in0; l.c1 = in1;
-    return lsnt::launch<1>(l, Wt, out, (hipStream_t)stream, "na_linear_dgrad_bf16x3");
+    const int rc = lsnt::launch<1>(l, Wt, out, (hipStream_t)stream, "na_linear_dgrad_bf16x3");
+    if (rc != lsnt::kNoScratch) return rc;
   }
   return dispatch_nt<1>(a, in0 + in1, (hipStream_t)stream, "na_linear_dgrad_bf16x3");
 }
@@ -1299,8 +1302,14 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   const bool ls0 = lsnt_wanted(N, 4) && out <= 256 && in0 <= 256 && in1 <= 256;
   if (ls0) {
     int rc = lstn::launch(dY, out, x0, in0, pre_act, N, dW, in0 + in1, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
-    if (rc != NA_OK || in1 == 0) return rc;
-    return lstn::launch(dY, out, x1, in1, pre_act, N, dW + in0, in0 + in1, nullptr, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+    if (rc != lsnt::kNoScratch) {
+      if (rc != NA_OK || in1 == 0) return rc;
+      rc = lstn::launch(dY, out, x1, in1, pre_act, N, dW + in0, in0 + in1, nullptr, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+      if (rc != lsnt::kNoScratch) return rc;
+      // (no scratch for the second source only: the K-staged kernel below would add the first source's columns twice)
+      set_error("na_linear_wgrad_bf16x3: stream-ordered scratch allocation failed between the two sources");
+      return NA_EHIP;
+    }
   }
   constexpr int WM = 2, WN = 4, BM = 64 * WM, BN = 64 * WN;
   const int ldw = in0 + in1, in = in0 + in1, col0 = 0;

@@ -44,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
     n = a.crop * a.crop * a.steps
-    res = {"what": "PlainNeRF(view) training step: fwd + bwd (HIP fp32 path) + Adam", "samples_per_step": n,
+    res = {"what": "PlainNeRF(view) training step: fwd + bwd (HIP kernels, split-bf16 GEMMs) + Adam", "samples_per_step": n,
            "ms_per_step": round(dt * 1e3, 2), "Msamples_per_s": round(n / dt / 1e6, 3), "loss_first": losses[0], "loss_last": losses[-1]}
     if a.cpu_oracle:
         import oracle as O
