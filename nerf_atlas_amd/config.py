@@ -41,6 +41,21 @@ def set_train_precision(p: str):
     train_precision = p
 
 
+class train_precision_as:
+    """`with config.train_precision_as("fp32"): ...` -- the Linears recorded inside use that arithmetic (their backward too:
+    the choice is stored with the graph node)."""
+
+    def __init__(self, p: str):
+        self.p = p
+
+    def __enter__(self):
+        self.prev = train_precision
+        set_train_precision(self.p)
+
+    def __exit__(self, *exc):
+        set_train_precision(self.prev)
+
+
 # Fused PlainNeRF(view) renderer: "ls" = layer-synchronous engine (csrc/render_ls.hip: activations in LDS, weights
 # streamed into registers, two sample groups in antiphase), "reg" = register-resident engine (csrc/render_fused.hip).
 engine = "ls"

@@ -15,18 +15,22 @@ class SDFModel(nn.Module):
         raise NotImplementedError()
 
     def normals(self, pts, values=None):
-        """src/sdf.py:43-48: d sdf / d pts, [..., 3].  Forward-mode tangents through the MLP (one value row and three
-        tangent rows per point; SkipConnMLP.forward_with_input_tangents) instead of autograd(create_graph=True): the
-        result is differentiable w.r.t. the weights with first-order autograd, which is what the eikonal regulariser
-        needs (runner.py:685-692).  Always runs the fp32 / split-bf16 training GEMMs, also under no_grad."""
+        """src/sdf.py:43-48.  With `values=None` -- every call site of the reference -- the reference differentiates
+        `self(pts)`, the WHOLE output row (signed distance + the intermediate features), with `grad_outputs = ones`
+        (`utils.autograd`, src/utils.py:266-277): what it calls normals is d(sum_j out_j)/d pts, not d sdf/d pts.  The
+        regularisers built on it (`--sdf-eikonal`, `--smooth-normals`: runner.py:683-727) are reproduced as the reference
+        computes them (pinned by tests/golden/train_parity_volsdf_smooth.json, the reference's own training run).
+        Forward-mode tangents through the MLP (one value row and three tangent rows per point;
+        SkipConnMLP.forward_with_input_tangents) instead of autograd(create_graph=True): the result is differentiable
+        w.r.t. the weights with first-order autograd.  Always runs the fp32 / split-bf16 training GEMMs, also under no_grad.
+        `values="sdf"` selects the gradient of the signed distance alone (column 0)."""
         flat = pts.reshape(-1, 3)
-        _, t = self._net().forward_with_input_tangents(flat)
-        return t[..., 0].t().reshape(pts.shape)
+        return self.normals_tangent_major(flat, values).t().reshape(pts.shape)
 
-    def normals_tangent_major(self, pts):
+    def normals_tangent_major(self, pts, values=None):
         """[3, N] layout of the same normals (what ops.eikonal_loss consumes: no transposition in the graph)."""
         _, t = self._net().forward_with_input_tangents(pts.reshape(-1, 3))
-        return t[..., 0]
+        return t[..., 0] if values == "sdf" else t.sum(-1)
 
 
 class MLP(SDFModel):

@@ -2,8 +2,9 @@
 :1221-1322 main), restricted to what the five hot-path configs use: l2/l1/rmse loss in RGB, Adam(eps 1e-7) with the
 cosine schedule, random crops/views from Python's `random`, pixel jitter 0.1, stratified sampling and density noise
 in training mode, `--volsdf-scale-decay`, `--delta-x-decay`, `--offset-decay`, `--sdf-eikonal` (SDF normals by forward-mode
-tangents through the MLP), `--ffjord-div-decay` (forward-mode divergence estimate); the smooth-normals and
-`--dyn-diverge-decay` terms raise.
+tangents through the MLP), `--smooth-normals` in the reference's default epsilon-perturbation form (`--smooth-eps`,
+`--smooth-eps-rng`, `--smooth-n-ord`), `--ffjord-div-decay` (forward-mode divergence estimate); `--dyn-diverge-decay` and
+`--smooth-normals --smooth-eps 0` (double backward) raise.
 
 Every forward and backward is a HIP kernel (nerf_atlas_amd/autograd.py); torch.optim owns the parameter update, like
 in the reference.  With `replay_reference_rng=True` the stochastic tensors come from torch's CPU generator in the
@@ -21,7 +22,7 @@ import torch.nn.functional as F
 
 from . import autograd as ag
 from . import dist as na_dist
-from . import loaders, nerf, refl, utils
+from . import config, loaders, nerf, refl, utils
 from .render import render, render_frame
 
 # the reference's CLI defaults for the fields used here (runner.py:38-424)
@@ -33,7 +34,8 @@ DEFAULTS = dict(
     refl_bidirectional=True, sdf_kind="mlp", near=2.0, far=6.0, spline=0, dyn_refl_latent=0, time_gamma=False,
     volsdf_scale_decay=0.0, delta_x_decay=0.0, opt_step=1, clip_gradients=0.0, train_imgs=-1, serial_idxs=False,
     higher_end_chance=0, opt_kind="adam", light_kind=None, occ_kind=None, volsdf_alternate=False, test_white_bg=False,
-    sdf_eikonal=0.0, ffjord_div_decay=0.0, offset_decay=0.0, dyn_diverge_decay=0.0, smooth_normals=0.0,
+    sdf_eikonal=0.0, ffjord_div_decay=0.0, offset_decay=0.0, dyn_diverge_decay=0.0, smooth_normals=0.0, smooth_eps=1e-3,
+    smooth_eps_rng=False, smooth_n_ord=[2],
     neural_upsample=False, quiet=False,
 )
 
@@ -73,7 +75,7 @@ def args_from_argv(argv) -> SimpleNamespace:
         elif isinstance(v, bool):
             p.add_argument(flag, action="store_true", default=False)
         elif isinstance(v, list):
-            p.add_argument(flag, nargs="+", default=v)
+            p.add_argument(flag, nargs="+", default=v, type=type(v[0]))
         elif v is None:
             p.add_argument(flag, default=None, type=(int if k == "spline" else str))
         else:
@@ -139,10 +141,14 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
     optimiser step (dist.allreduce_gradients); the reference's own --data-parallel is broken (SURVEY header table)."""
     if args.epochs == 0:
         return []
-    for k in ("dyn_diverge_decay", "smooth_normals"):
-        if getattr(args, k, 0) > 0:
-            raise NotImplementedError(f"--{k.replace('_', '-')} needs input Jacobians of the deformation / normal "
-                                      "networks (hash-encoder and spline tangents are not implemented: DESIGN.md 9a)")
+    if getattr(args, "dyn_diverge_decay", 0) > 0:
+        raise NotImplementedError("--dyn-diverge-decay needs the exact divergence of the deformation by double backward "
+                                  "(hash-encoder and spline second derivatives are not implemented: DESIGN.md 9a)")
+    if args.smooth_normals > 0 and args.smooth_eps <= 0:
+        raise NotImplementedError("--smooth-normals with --smooth-eps 0 differentiates the normals again (double backward); "
+                                  "the epsilon-perturbation form (--smooth-eps > 0, the reference's default) is implemented")
+    if args.smooth_normals > 0 and not hasattr(model, "sdf"):
+        raise ValueError("--smooth-normals needs an SDF model (--model volsdf)")
     if args.ffjord_div_decay and not hasattr(model, "ffjord_div"):
         raise ValueError("--ffjord-div-decay needs a dynamic model (--data-kind dnerf --dyn-model plain --spline N): the "
                          "reference reads model.pts / model.rigid_dp (runner.py:698-699)")
@@ -189,10 +195,20 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
             loss = loss + args.delta_x_decay * model.dp.norm(dim=-1).mean()
         if args.offset_decay > 0:
             loss = loss + offset_decay_term(model, i / args.epochs) * args.offset_decay
+        reg_pts = reg_n = None
+        if args.sdf_eikonal > 0 or args.smooth_normals > 0:
+            # runner.py:683-689: one set of 10240 points 5 * randn for both SDF regularisers; normals by forward-mode
+            # tangents ([3, N], differentiable w.r.t. the weights with first-order autograd)
+            reg_pts = 5 * utils.randn(((1 << 13) * 5 // 4, 3), device)
+            # The smoothing term is a DIFFERENCE of two normals <= eps = 1e-3 apart: |delta n| ~ 1e-2 against |n| ~ 4, so the
+            # 2^-16 relative error of the split-bf16 GEMMs is 400x larger relative to it (measured against the reference's
+            # run: per-view PSNR 0.22 dB off instead of 0.1).  Its two tangent sweeps run in exact fp32 (10 240 points:
+            # 0.1 ms), like the FFJORD tangent; the eikonal term alone keeps the configured arithmetic.
+            with config.train_precision_as("fp32" if args.smooth_normals > 0 else config.train_precision):
+                reg_n = model.sdf.underlying.normals_tangent_major(reg_pts)
         if args.sdf_eikonal > 0:
-            # runner.py:683-692: E[|d sdf/dx|] = 1 on 10240 points 5*randn; normals by forward-mode tangents
-            pts = 5 * utils.randn(((1 << 13) * 5 // 4, 3), device)
-            loss = loss + args.sdf_eikonal * ag.EikonalFn.apply(model.sdf.underlying.normals_tangent_major(pts))
+            # runner.py:691-692: E[|d sdf/dx|] = 1
+            loss = loss + args.sdf_eikonal * ag.EikonalFn.apply(reg_n)
         if args.ffjord_div_decay:
             # runner.py:697-700: FFJORD divergence estimate of the rigid deformation, e = randn_like(rigid_dp).  The
             # reference's div_approx builds no graph (src/utils.py:471-477: autograd.grad without create_graph), so the
@@ -201,6 +217,20 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
             exp_ratio = (1 / 100) ** (1 - i / args.epochs)
             div = model.ffjord_div(e).abs().square()
             loss = loss + exp_ratio * args.ffjord_div_decay * (model.canonical.alpha.detach() * div).mean()
+        if args.smooth_normals > 0:
+            # runner.py:711-727, the epsilon-perturbation form "from unisurf": normals at the points and at points a random
+            # direction of length eps away should agree.  Draw order of the reference: random.random() (with
+            # --smooth-eps-rng), then randn_like(pts).
+            s_eps = args.smooth_eps
+            if args.smooth_eps_rng:
+                s_eps = random.random() * s_eps
+            perturb = F.normalize(utils.randn(tuple(reg_pts.shape), device), dim=-1) * s_eps
+            with config.train_precision_as("fp32"):
+                delta_n = reg_n - model.sdf.underlying.normals_tangent_major(reg_pts + perturb)  # [3, N]
+            smoothness = 0
+            for o in args.smooth_n_ord:
+                smoothness = smoothness + torch.linalg.norm(delta_n, ord=int(o), dim=0).sum()
+            loss = loss + args.smooth_normals * smoothness
         if args.opt_step != 1:
             loss = loss / args.opt_step
         loss.backward()

@@ -427,7 +427,9 @@ def test_backward_and_march_edge_cases(ops):
 def test_sdf_normals_and_eikonal_gradients(ops, kind, train_prec):
     """N1 remainder: SDF normals (src/sdf.py:43-48) and the eikonal regulariser (runner.py:685-692, src/utils.py:31).
     Normals by forward-mode tangents vs torch.autograd.grad of the CPU oracle; d(eikonal)/d(every weight) vs the
-    oracle's double backward.  Points 5*randn like the reference's get_pts()."""
+    oracle's double backward.  Points 5*randn like the reference's get_pts().  The reference differentiates the whole output
+    row with grad_outputs = ones (src/sdf.py:43-48 with values=None, src/utils.py:266-277), i.e. the SUM of the signed
+    distance and the 64 intermediate features: that is what `normals()` returns; `values="sdf"` = column 0 alone."""
     import nerf_atlas_amd.sdf as sdf
     from nerf_atlas_amd import autograd as ag
     h = load_golden(f"g10_volsdf_{kind}")
@@ -446,7 +448,8 @@ def test_sdf_normals_and_eikonal_gradients(ops, kind, train_prec):
         raw = O.skip_mlp(ref_p, prefix, x, enc=lambda q: O.fourier_encode(q, ref_p[prefix + "enc.basis"]))
     else:
         raw = O.skip_mlp(ref_p, prefix, x, act="sin")
-    n_ref, = torch.autograd.grad(raw[..., 0].sum(), x, create_graph=True)
+    n_sdf_ref, = torch.autograd.grad(raw[..., 0].sum(), x, retain_graph=True)
+    n_ref, = torch.autograd.grad(raw.sum(), x, create_graph=True)
     loss_ref = (torch.linalg.norm(n_ref, dim=-1) - 1).square().mean()
     loss_ref.backward()
     # ---- HIP
@@ -454,6 +457,8 @@ def test_sdf_normals_and_eikonal_gradients(ops, kind, train_prec):
     tol_n = 2e-5 if train_prec == "fp32" else 2e-3
     scale = float(n_ref.abs().max())
     assert float((n.detach().cpu() - n_ref.detach()).abs().max()) <= tol_n * scale, float((n.detach().cpu() - n_ref.detach()).abs().max())
+    n_sdf = m.normals(pts.cuda(), values="sdf")
+    assert float((n_sdf.detach().cpu() - n_sdf_ref).abs().max()) <= tol_n * float(n_sdf_ref.abs().max())
     loss = ag.EikonalFn.apply(m.normals_tangent_major(pts.cuda()))
     assert abs(float(loss.detach()) - float(loss_ref.detach())) <= (1e-5 if train_prec == "fp32" else 1e-3) * max(1.0, float(loss_ref.detach()))
     loss.backward()

@@ -39,7 +39,8 @@ def procedural_init(model):
 
 @pytest.mark.parametrize("name,train_prec", [("plain", "fp32"), ("plain", "bf16x3"), ("dnerf", "bf16x3"),
                                              ("volsdf", "bf16x3"), ("dnerf", "fp32"), ("volsdf", "fp32"),
-                                             ("dnerf_make", "bf16x3"), ("dnerf_make", "fp32")])
+                                             ("dnerf_make", "bf16x3"), ("dnerf_make", "fp32"),
+                                             ("volsdf_smooth", "bf16x3"), ("volsdf_smooth", "fp32")])
 def test_training_tracks_the_reference(name, train_prec, tmp_path):
     path = os.path.join(GOLDEN, f"train_parity_{name}.json")
     if not os.path.exists(path):
@@ -87,6 +88,12 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
         # chaotic but deterministic trajectory (see above): measured 0.08 dB per view / 0.04 dB mean in bf16x3 and
         # 0.35 / 0.20 dB in fp32 (an untrained model is > 8 dB away); the bars leave ~1.5x for a different toolchain
         assert d.max() <= 0.5 and abs(res["test_psnr_mean"] - fx["test_psnr_mean"]) <= 0.3, (res["test_psnr"], fx["test_psnr"])
+    elif name == "volsdf_smooth":
+        # eikonal + normal smoothing (the reference's VolSDF regularisers, makefile:85-95): the smoothing term is a difference
+        # of normals <= 1e-3 apart, which amplifies rounding-order differences over the 200 iterations; its tangent sweeps
+        # run in exact fp32 in both modes (train.py).  Measured: loss within 2.7e-5 over the first 10 iterations, per-view
+        # PSNR within 0.10 dB of the reference's run (north_star's bar); 1.5x for another toolchain
+        assert d.max() <= 0.15, (res["test_psnr"], fx["test_psnr"])
     else:
         assert d.max() <= (0.01 if train_prec == "fp32" else 0.1), (res["test_psnr"], fx["test_psnr"])
     # the fast renderer on the trained model
@@ -139,6 +146,11 @@ def test_unsupported_regularisers_raise_and_eikonal_trains(tmp_path):
         T.fit(T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, ffjord_div_decay=0.1))
     with pytest.raises(ValueError):  # the eikonal term needs an SDF model
         T.fit(T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, sdf_eikonal=0.1))
+    with pytest.raises(ValueError):  # so does the normal smoothing
+        T.fit(T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, smooth_normals=0.1))
+    with pytest.raises(NotImplementedError):  # its double-backward form (eps = 0) is not implemented; the default form is
+        T.fit(T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=1, model="volsdf", sdf_kind="siren",
+                          smooth_normals=0.1, smooth_eps=0.0))
     # `make dtu`-style recipe: VolSDF + --sdf-eikonal runs and lowers E[(|n|-1)^2] of the SDF
     args = T.make_args(data=data, size=16, crop_size=8, batch_size=1, steps=8, epochs=25, model="volsdf", sdf_kind="siren",
                        near=0.3, far=1.8, sdf_eikonal=0.5, learning_rate=2e-4)

@@ -46,6 +46,10 @@ RECIPES = {
                           "plain", "--spline", "6", "--higher-end-chance", "1", "--offset-decay", "60",
                           "--ffjord-div-decay", "0.5", "--sigmoid-kind", "upshifted", "--opt-step", "3"]),
     "volsdf": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6"]),
+    # the SDF regularisers of the reference's VolSDF recipes (makefile:85-95): eikonal + normal smoothing by the unisurf
+    # epsilon perturbation with a random radius (one random.random() and two randn draws per iteration in the RNG streams)
+    "volsdf_smooth": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6",
+                              "--sdf-eikonal", "1e-2", "--smooth-normals", "1e-2", "--smooth-eps-rng"]),
 }
 
 
