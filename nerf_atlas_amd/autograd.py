@@ -73,6 +73,24 @@ class HashEncodeFn(Function):
         return gx, gt, None
 
 
+class HashJvpFn(Function):
+    """d hash_encode(x)/dx . tangent (rows [tangent | per-level features]: na_hash_encode_jvp) as a graph node: the gradient
+    w.r.t. the tables is the adjoint scatter na_hash_encode_jvp_backward (the features are linear in the tables); positions
+    and tangent carry no gradient (floor() has none, and the callers' directions are constants)."""
+
+    @staticmethod
+    def forward(ctx, x, tables, tangent, include_input):
+        ctx.save_for_backward(x, tangent)
+        ctx.include_input = include_input
+        return ops.hash_encode_jvp(x, tables, tangent, include_input)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, tangent = ctx.saved_tensors
+        gt = ops.hash_encode_jvp_backward(x, tangent, g.contiguous(), ctx.include_input) if ctx.needs_input_grad[1] else None
+        return None, gt, None, None
+
+
 class LaplaceDensityFn(Function):
     """VolSDF density 1/beta * laplace_cdf(-sdf, beta) (src/nerf.py:985-990, src/utils.py:50-58)."""
 

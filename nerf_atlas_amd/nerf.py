@@ -385,6 +385,24 @@ class DynamicNeRF(nn.Module):
         est, dest = self.delta_estim.forward_with_direction_tangent(self.pts, e)
         return ops.ffjord_div(est, dest, self._tt, e.contiguous(), self.spline_n).reshape(self.pts.shape[:-1])
 
+    def sum_jacobian_div(self):
+        """`utils.divergence(model.pts, model.dp)` of runner.py:694-696 at the samples of the last forward, with its graph.  What
+        the reference computes: `autograd(x, field)` differentiates the SUM of the field's three components
+        (grad_outputs = ones, src/utils.py:266-277, 461-464) and the result is summed over the coordinates, i.e.
+        sum_ij d dp_j / d x_i = sum_j (J . (1,1,1))_j -- the sum of all Jacobian entries, not its trace.  One direction
+        tangent with e = (1,1,1) through the hash encoder and the deformation MLP (first-order graph nodes), then the
+        spline, which is linear in its control points (the Bezier combination of the control points' tangents, by the warp
+        kernel's own differentiable dp output).  The sweep runs in exact fp32 like the FFJORD tangent: the hash features'
+        derivatives scale with the grid resolutions and largely cancel in the sum (split-bf16 GEMMs: 3 % of the result).
+        [T,B,H,W,1]"""
+        from . import config
+        e = torch.ones_like(self.pts)
+        with config.train_precision_as("fp32"):
+            _, dest = self.delta_estim.forward_with_direction_tangent_graph(self.pts, e)
+        dest = dest.reshape(*self.pts.shape[:-1], -1)
+        _, ddp, _ = ag.BezierWarpFn.apply(dest.contiguous(), self.pts, self._tt, self.spline_n)
+        return ddp.sum(dim=-1, keepdim=True)
+
     def forward(self, rays_t):
         rays, t = rays_t
         c = self.canonical

@@ -389,6 +389,35 @@ class SkipConnMLP(nn.Module):
             t = ops.linear_f32(mt, lin.weight.data, None)
         return z, t
 
+    def forward_with_direction_tangent_graph(self, p, e):
+        """The same (y, dy = (d y / d p) . e) as forward_with_direction_tangent, but every node a first-order autograd Function
+        (LinearFn in the configured training arithmetic, ActDerivFn, MulBcastFn, HashEncodeFn, HashJvpFn): a loss on dy
+        back-propagates to the weights and the hash tables without double backward -- what `--dyn-diverge-decay`
+        (runner.py:694-696: autograd of model.dp w.r.t. model.pts with create_graph) needs.  Encoders: none, HashEncoder."""
+        assert self.latent_size == 0 and p.shape[-1] == self.in_size == 3 and e.shape == p.shape
+        p, e = p.reshape(-1, 3).contiguous(), e.reshape(-1, 3).contiguous()
+        N = p.shape[0]
+        init, dinit = p, e
+        if isinstance(self.enc, HashEncoder):
+            tables = torch.stack([t.weight for t in self.enc.embs])  # differentiable view of the 8 parameters
+            init = torch.cat([p, ag.HashEncodeFn.apply(p, tables, self.enc.include_input)], dim=-1)
+            dinit = torch.cat([e, ag.HashJvpFn.apply(p, tables, e, self.enc.include_input)], dim=-1)
+        elif self.enc is not None:
+            raise NotImplementedError("differentiable direction tangents through " + type(self.enc).__name__)
+        init, dinit = init.contiguous(), dinit.contiguous()
+        z = ag.LinearFn.apply(init, None, self.init.weight, self.init.bias, "none")
+        t = ag.LinearFn.apply(dinit, None, self.init.weight, None, "none")
+        n = len(self.layers)
+        lins = [(l, i != n - 1 and (i % self.skip) == 0) for i, l in enumerate(self.layers)] + [(self.out, False)]
+        for lin, skip in lins:
+            x_in = torch.cat([z, init], dim=-1).contiguous() if skip else z
+            t_in = torch.cat([t, dinit], dim=-1).contiguous() if skip else t
+            m = ag.ActDerivFn.apply(x_in, self.act_name)
+            mt = ag.MulBcastFn.apply(m, t_in[None])[0]
+            z = ag.LinearFn.apply(z, init if skip else None, lin.weight, lin.bias, self.act_name)
+            t = ag.LinearFn.apply(mt.contiguous(), None, lin.weight, None, "none")
+        return z, t
+
     def zero_last_layer(self):
         nn.init.zeros_(self.out.weight)
         nn.init.zeros_(self.out.bias)

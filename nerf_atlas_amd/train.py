@@ -3,8 +3,8 @@
 cosine schedule, random crops/views from Python's `random`, pixel jitter 0.1, stratified sampling and density noise
 in training mode, `--volsdf-scale-decay`, `--delta-x-decay`, `--offset-decay`, `--sdf-eikonal` (SDF normals by forward-mode
 tangents through the MLP), `--smooth-normals` in the reference's default epsilon-perturbation form (`--smooth-eps`,
-`--smooth-eps-rng`, `--smooth-n-ord`), `--ffjord-div-decay` (forward-mode divergence estimate); `--dyn-diverge-decay` and
-`--smooth-normals --smooth-eps 0` (double backward) raise.
+`--smooth-eps-rng`, `--smooth-n-ord`), `--dyn-diverge-decay` (one differentiable direction tangent), `--ffjord-div-decay`
+(forward-mode divergence estimate); `--smooth-normals --smooth-eps 0` (double backward) raises.
 
 Every forward and backward is a HIP kernel (nerf_atlas_amd/autograd.py); torch.optim owns the parameter update, like
 in the reference.  With `replay_reference_rng=True` the stochastic tensors come from torch's CPU generator in the
@@ -141,9 +141,9 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
     optimiser step (dist.allreduce_gradients); the reference's own --data-parallel is broken (SURVEY header table)."""
     if args.epochs == 0:
         return []
-    if getattr(args, "dyn_diverge_decay", 0) > 0:
-        raise NotImplementedError("--dyn-diverge-decay needs the exact divergence of the deformation by double backward "
-                                  "(hash-encoder and spline second derivatives are not implemented: DESIGN.md 9a)")
+    if getattr(args, "dyn_diverge_decay", 0) > 0 and not hasattr(model, "sum_jacobian_div"):
+        raise ValueError("--dyn-diverge-decay needs a dynamic model (--data-kind dnerf --dyn-model plain --spline N): the "
+                         "reference reads model.pts / model.dp (runner.py:694-696)")
     if args.smooth_normals > 0 and args.smooth_eps <= 0:
         raise NotImplementedError("--smooth-normals with --smooth-eps 0 differentiates the normals again (double backward); "
                                   "the epsilon-perturbation form (--smooth-eps > 0, the reference's default) is implemented")
@@ -209,6 +209,9 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
         if args.sdf_eikonal > 0:
             # runner.py:691-692: E[|d sdf/dx|] = 1
             loss = loss + args.sdf_eikonal * ag.EikonalFn.apply(reg_n)
+        if args.dyn_diverge_decay > 0:
+            # runner.py:694-696: utils.divergence(model.pts, model.dp).mean(), with its graph (forward-mode tangent nodes)
+            loss = loss + args.dyn_diverge_decay * model.sum_jacobian_div().mean()
         if args.ffjord_div_decay:
             # runner.py:697-700: FFJORD divergence estimate of the rigid deformation, e = randn_like(rigid_dp).  The
             # reference's div_approx builds no graph (src/utils.py:471-477: autograd.grad without create_graph), so the

@@ -513,3 +513,66 @@ def test_hash_jvp_ffjord_divergence_and_adjoint():
     term = float((g["alpha"] * div.abs().square()).mean())
     assert abs(term - float(g["term"])) <= 2e-4 * float(g["term"])
     assert not div.requires_grad
+
+
+@pytest.mark.parametrize("train_prec", ["fp32", "bf16x3"])
+def test_dyn_diverge_term_and_its_gradients(train_prec):
+    """`--dyn-diverge-decay` (runner.py:694-696, src/utils.py:266-277,461-464): utils.divergence(model.pts, model.dp) =
+    autograd of the SUM of dp's components w.r.t. the sample positions, summed over the coordinates (the sum of all Jacobian
+    entries), with create_graph.  Value per sample and d(mean)/d(every deformation weight and hash table) of the forward-mode
+    graph (DynamicNeRF.sum_jacobian_div) against the double backward of the CPU oracle, on the reference's g17 state."""
+    import oracle as O
+    import oracle.nerf_oracle as NO
+    from conftest import load_golden, golden_params
+    from nerf_atlas_amd import nerf, config
+    g = load_golden("g17_ffjord")
+    p = golden_params(g)
+    spline = 6
+    # the golden's deformation head is freshly initialised (zero last layer): give it procedural weights so that dp depends on x
+    from oracle.procedural import proc_param
+    for k in list(p):
+        if k.startswith("delta_estim.out."):
+            p[k] = torch.from_numpy(proc_param(k, tuple(p[k].shape))) * 0.5
+    canon = nerf.PlainNeRF(steps=int(g["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = nerf.DynamicNeRF(canonical=canon, spline=spline).cuda()
+    sd = m.state_dict()
+    for k, v in p.items():
+        sd[k].copy_(v)
+    pts = g["pts"][:, :, :4, :4].contiguous()  # [T,B,4,4,3]
+    times = g["times"]
+    # ---- oracle: double backward
+    rp = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k.startswith("delta_estim.") and not k.endswith("primes"))
+          for k, v in p.items()}
+    x = pts.clone().requires_grad_()
+    t = times[None, :, None, None, None].expand(*x.shape[:-1], 1)
+    est = NO.skip_mlp(rp, "delta_estim.", x, enc=NO._hash_enc_from(rp, "delta_estim.enc."))
+    ps = torch.stack(est[..., 1:1 + 3 * spline].split([3] * spline, dim=-1), dim=0)
+    dp = NO.de_casteljau(ps, t, spline)
+    v, = torch.autograd.grad(dp, x, grad_outputs=torch.ones_like(dp), create_graph=True)
+    div_ref = v.sum(dim=-1, keepdim=True)
+    div_ref.mean().backward()
+    # ---- HIP
+    prev = config.train_precision
+    config.set_train_precision(train_prec)
+    try:
+        m.pts = pts.cuda()
+        m._tt = times.cuda()[None, :, None, None].expand(*m.pts.shape[:-1]).contiguous()
+        div = m.sum_jacobian_div()
+        div.mean().backward()
+    finally:
+        config.set_train_precision(prev)
+    scale = float(div_ref.abs().max())
+    err = float((div.detach().cpu() - div_ref.detach()).abs().max())
+    # (the sweep runs in exact fp32 whatever the configured training arithmetic: cancellation, see sum_jacobian_div)
+    assert div.shape == div_ref.shape and err <= 2e-5 * scale, (err, scale)
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, r in rp.items():
+        if r.grad is None or float(r.grad.abs().max()) == 0:
+            continue
+        gp = named[k].grad
+        assert gp is not None, k
+        e = float((gp.cpu() - r.grad).norm() / r.grad.norm())
+        assert e <= 2e-3, (k, e)
+        checked += 1
+    assert checked >= 12, checked  # 7 Linears (weights, some biases) + the 8 hash tables

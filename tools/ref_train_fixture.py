@@ -45,6 +45,10 @@ RECIPES = {
     "dnerf_make": (True, ["--model", "plain", "--refl-kind", "pos-linear-view", "--data-kind", "dnerf", "--dyn-model",
                           "plain", "--spline", "6", "--higher-end-chance", "1", "--offset-decay", "60",
                           "--ffjord-div-decay", "0.5", "--sigmoid-kind", "upshifted", "--opt-step", "3"]),
+    # the "exact divergence" regulariser of the deformation field (runner.py:694-696): autograd of model.dp w.r.t. model.pts with
+    # create_graph -- a double backward through the hash encoder, the deformation MLP and the spline in the reference
+    "dnerf_div": (True, ["--model", "plain", "--refl-kind", "view", "--data-kind", "dnerf", "--dyn-model", "plain",
+                         "--spline", "4", "--dyn-diverge-decay", "0.05"]),
     "volsdf": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6"]),
     # the SDF regularisers of the reference's VolSDF recipes (makefile:85-95): eikonal + normal smoothing by the unisurf
     # epsilon perturbation with a random radius (one random.random() and two randn draws per iteration in the RNG streams)
