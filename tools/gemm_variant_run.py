@@ -10,7 +10,8 @@ if sys.argv[1] in ("fwd", "dgrad", "wgrad"):
 dWb = torch.zeros(256, 256, device="cuda"); dbb = torch.zeros(256, device="cuda")
 gy = torch.randn(N, 256, device="cuda"); Wt = W.t().contiguous(); gx = torch.empty(N, 256, device="cuda")
 for name in sys.argv[1:]:
-    path = os.path.join("nerf_atlas_amd", "libnerf_atlas_amd.so") if name == "shipped" else os.path.join("gpurun_ablate", f"lib_var_{name}.so")
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(REPO, "nerf_atlas_amd", "libnerf_atlas_amd.so") if name == "shipped" else os.path.join(REPO, "gpurun_ablate", f"lib_var_{name}.so")
     lib = C.CDLL(path)
     fn = lib.na_linear_bf16x3
     fn.argtypes = _lib.SIGNATURES["na_linear_bf16x3"][1]; fn.restype = C.c_int
