@@ -1299,7 +1299,7 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_wgrad_bf16x3: activation %d", pre_act);
   // The layer-synchronous kernel, one launch per source of the concatenation (dY is read again for the second: the sources of
   // a skip layer are [hidden 256 | encoding 38 or 69]); wider shapes and small batches stay on the K-staged kernel.
-  const bool ls0 = lsnt_wanted(N, 4) && out <= 256 && in0 <= 256 && in1 <= 256;
+  const bool ls0 = lsnt_wanted(N, out) && out <= 256 && in0 <= 256 && in1 <= 256;
   if (ls0) {
     int rc = lstn::launch(dY, out, x0, in0, pre_act, N, dW, in0 + in1, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
     if (rc != lsnt::kNoScratch) {
