@@ -197,10 +197,17 @@ __global__ void hash_encode_kernel(const float* __restrict__ x, int64_t N, const
                                    HashRes res, int include_input, float* __restrict__ out,
                                    int64_t* __restrict__ idx_out) {
   const int odim = 32 + 3 * include_input;
-  int64_t total = N * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int lvl = (int)(i & 7);
-    int64_t n = i >> 3;
+  // A wave = 64 CONSECUTIVE SAMPLES at ONE level (8 waves of a 512-thread workgroup = the 8 levels of the same 64 samples):
+  // neighbouring samples of a ray share grid cells on the coarse levels, so a gather instruction's lanes fall into few cache
+  // lines (with the 8 levels of one sample in adjacent lanes every lane of an instruction hit a different table).
+  // The rows of the 64 samples (64 x 35 floats, contiguous in memory) are assembled in LDS and leave as one coalesced sweep:
+  // 4-byte pieces 140 bytes apart, straight from the registers, cost as much as the gathers.
+  __shared__ float rows[64 * 35];
+  const int lvl = (int)(threadIdx.x >> 6);
+  const int64_t nblocks = (N + 63) >> 6;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t n_raw = blk * 64 + (threadIdx.x & 63);
+    const int64_t n = n_raw < N ? n_raw : N - 1;  // (tail lanes repeat the last sample: every thread reaches the barriers)
     float px = x[n * 3 + 0], py = x[n * 3 + 1], pz = x[n * 3 + 2];
     float Nl = res.n[lvl];
     float vx = px * Nl, vy = py * Nl, vz = pz * Nl;
@@ -215,7 +222,7 @@ __global__ void hash_encode_kernel(const float* __restrict__ x, int64_t N, const
       // corner order of the reference: bit2 = x high, bit1 = y high, bit0 = z high
       int cx = lx + ((c >> 2) & 1), cy = ly + ((c >> 1) & 1), cz = lz + (c & 1);
       uint32_t id = hash_index(cx, cy, cz);
-      if (idx_out != nullptr) idx_out[((int64_t)lvl * 8 + c) * N + n] = (int64_t)id;
+      if (idx_out != nullptr && n_raw < N) idx_out[((int64_t)lvl * 8 + c) * N + n] = (int64_t)id;
       float w = (((c >> 2) & 1) ? wx : iwx) * (((c >> 1) & 1) ? wy : iwy) * ((c & 1) ? wz : iwz);
       float4 e = tab[id];
       if (c == 0) {
@@ -224,43 +231,101 @@ __global__ void hash_encode_kernel(const float* __restrict__ x, int64_t N, const
         acc.x = acc.x + e.x * w; acc.y = acc.y + e.y * w; acc.z = acc.z + e.z * w; acc.w = acc.w + e.w * w;
       }
     }
-    float* o = out + n * odim + 3 * include_input + lvl * 4;
+    float* o = rows + (threadIdx.x & 63) * odim + 3 * include_input + lvl * 4;
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
     if (include_input && lvl == 0) {
-      out[n * odim + 0] = px; out[n * odim + 1] = py; out[n * odim + 2] = pz;
+      float* r = rows + (threadIdx.x & 63) * odim;
+      r[0] = px; r[1] = py; r[2] = pz;
     }
+    __syncthreads();
+    const int64_t left = N - blk * 64;
+    const int nval = (int)(left < 64 ? left : 64) * odim;
+    float* dst = out + blk * 64 * odim;
+    for (int i = threadIdx.x; i < nval; i += 512) dst[i] = rows[i];
+    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------ fourier / positional
 // src/utils.py:14-17: [sin(x@B) | cos(x@B)], accurate sinf/cosf (arguments reach 1e3).
+__device__ __forceinline__ void fourier_sincos(float m, float& sn, float& cs) {
+  // Cody-Waite reduction + polynomials (common.h: 1.6e-7 / 5e-7 for |m| <= 3e3, the same pair the fused prologues use in the
+  // parity mode); larger arguments (a basis far beyond the reference's sigma 16 / 32) take libm's large-argument path
+  if (fabsf(m) <= 3.0e3f) sincos_cw(m, sn, cs);
+  else { sn = sinf(m); cs = cosf(m); }
+}
+// VEC: F is a multiple of 4 -- a thread owns 4 consecutive frequencies of one sample: 16-byte stores, a quarter of the store
+// instructions (the one-frequency-per-thread form ran at 30 % of the HBM rate whatever the sine cost)
+template <bool VEC>
 __global__ void fourier_kernel(const float* __restrict__ x, int64_t N, int D, const float* __restrict__ basis, int F,
                                float scale, float* __restrict__ out) {
-  int64_t total = N * F;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int j = (int)(i % F);
-    int64_t n = i / F;
-    float m = 0.f;
-    for (int d = 0; d < D; ++d) {
-      float b = scale == 1.0f ? basis[d * F + j] : scale * basis[d * F + j];
-      m = d == 0 ? x[n * D + d] * b : fmaf(x[n * D + d], b, m);
+  if constexpr (VEC) {
+    const int F4 = F >> 2;
+    const int64_t total = N * F4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int j = (int)(i % F4) * 4;
+      const int64_t n = i / F4;
+      float m[4];
+      for (int d = 0; d < D; ++d) {
+        const float xd = x[n * D + d];
+        const float4 bv = *(const float4*)(basis + d * F + j);
+        const float b[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float be = scale == 1.0f ? b[e] : scale * b[e];
+          m[e] = d == 0 ? xd * be : fmaf(xd, be, m[e]);
+        }
+      }
+      float sn[4], cs[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fourier_sincos(m[e], sn[e], cs[e]);
+      *(float4*)(out + n * 2 * F + j) = make_float4(sn[0], sn[1], sn[2], sn[3]);
+      *(float4*)(out + n * 2 * F + F + j) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
-    out[n * 2 * F + j] = sinf(m);
-    out[n * 2 * F + F + j] = cosf(m);
+  } else {
+    int64_t total = N * F;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int j = (int)(i % F);
+      int64_t n = i / F;
+      float m = 0.f;
+      for (int d = 0; d < D; ++d) {
+        float b = scale == 1.0f ? basis[d * F + j] : scale * basis[d * F + j];
+        m = d == 0 ? x[n * D + d] * b : fmaf(x[n * D + d], b, m);
+      }
+      float sn, cs;
+      fourier_sincos(m, sn, cs);
+      out[n * 2 * F + j] = sn;
+      out[n * 2 * F + F + j] = cs;
+    }
   }
 }
 
 // src/neural_blocks.py:30-34: raw[n, d*NB + k] = x[n,d]*bands[k]; out = [sin(raw) | cos(raw)]
+template <bool VEC>
 __global__ void positional_kernel(const float* __restrict__ x, int64_t N, int D, const float* __restrict__ bands, int NB,
                                   float* __restrict__ out) {
   int W = D * NB;
-  int64_t total = N * W;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int j = (int)(i % W);
-    int64_t n = i / W;
-    float raw = x[n * D + j / NB] * bands[j % NB];
-    out[n * 2 * W + j] = sinf(raw);
-    out[n * 2 * W + W + j] = cosf(raw);
+  if constexpr (VEC) {  // NB a multiple of 4: a thread owns 4 consecutive bands of one input dimension, 16-byte stores
+    const int W4 = W >> 2;
+    const int64_t total = N * W4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int j = (int)(i % W4) * 4;
+      const int64_t n = i / W4;
+      const float xv = x[n * D + j / NB];
+      const float4 bv = *(const float4*)(bands + j % NB);
+      const float raw[4] = {xv * bv.x, xv * bv.y, xv * bv.z, xv * bv.w};
+      *(float4*)(out + n * 2 * W + j) = make_float4(sinf(raw[0]), sinf(raw[1]), sinf(raw[2]), sinf(raw[3]));
+      *(float4*)(out + n * 2 * W + W + j) = make_float4(cosf(raw[0]), cosf(raw[1]), cosf(raw[2]), cosf(raw[3]));
+    }
+  } else {
+    int64_t total = N * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int j = (int)(i % W);
+      int64_t n = i / W;
+      float raw = x[n * D + j / NB] * bands[j % NB];
+      out[n * 2 * W + j] = sinf(raw);
+      out[n * 2 * W + W + j] = cosf(raw);
+    }
   }
 }
 
@@ -528,7 +593,7 @@ int na_hash_encode(const float* x, int64_t N, const float* tables, int include_i
   NA_REQUIRE(x && tables && out, NA_ENULL, "na_hash_encode: null pointer");
   NA_REQUIRE(N >= 0, NA_EINVAL, "na_hash_encode: N=%lld", (long long)N);
   if (N == 0) return NA_OK;
-  hipLaunchKernelGGL(hash_encode_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
+  hipLaunchKernelGGL(hash_encode_kernel, dim3(grid_for((N + 63) / 64 * 512, 512, 16384)), dim3(512), 0, (hipStream_t)stream, x, N,
                      (const float4*)tables, hash_resolutions(), include_input ? 1 : 0, out, idx_out);
   return check_launch("na_hash_encode");
 }
@@ -538,8 +603,12 @@ int na_fourier_encode(const float* x, int64_t N, int D, const float* basis, int 
   NA_REQUIRE(x && basis && out, NA_ENULL, "na_fourier_encode: null pointer");
   NA_REQUIRE(N >= 0 && D >= 1 && F >= 1, NA_EINVAL, "na_fourier_encode: bad shape");
   if (N == 0) return NA_OK;
-  hipLaunchKernelGGL(fourier_kernel, dim3(grid_for(N * F, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D, basis,
-                     F, scale, out);
+  if ((F & 3) == 0 && ((uintptr_t)basis & 15) == 0 && ((uintptr_t)out & 15) == 0)
+    hipLaunchKernelGGL(fourier_kernel<true>, dim3(grid_for(N * (F / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
+                       D, basis, F, scale, out);
+  else
+    hipLaunchKernelGGL(fourier_kernel<false>, dim3(grid_for(N * F, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
+                       basis, F, scale, out);
   return check_launch("na_fourier_encode");
 }
 
@@ -547,8 +616,12 @@ int na_positional_encode(const float* x, int64_t N, int D, const float* bands, i
   NA_REQUIRE(x && bands && out, NA_ENULL, "na_positional_encode: null pointer");
   NA_REQUIRE(N >= 0 && D >= 1 && NB >= 1, NA_EINVAL, "na_positional_encode: bad shape");
   if (N == 0) return NA_OK;
-  hipLaunchKernelGGL(positional_kernel, dim3(grid_for(N * D * NB, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N,
-                     D, bands, NB, out);
+  if ((NB & 3) == 0 && ((uintptr_t)bands & 15) == 0 && ((uintptr_t)out & 15) == 0)
+    hipLaunchKernelGGL(positional_kernel<true>, dim3(grid_for(N * (D * NB / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       x, N, D, bands, NB, out);
+  else
+    hipLaunchKernelGGL(positional_kernel<false>, dim3(grid_for(N * D * NB, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       N, D, bands, NB, out);
   return check_launch("na_positional_encode");
 }
 
