@@ -96,7 +96,8 @@ constexpr int kPartialFloats = 8;
 #define NA_LSX_PRIO 0  // experiments: 0 the MFMA phases run at s_setprio 1 (like the other precisions), 1 no priorities, 2 the epilogues
 #endif
 #ifndef NA_LSX_EXP
-#define NA_LSX_EXP 0  // timing experiments (tools/ls_variant.py): 1 two of three fp6 parts, 2 no fp6 loads, 4 no f16 refills
+#define NA_LSX_EXP 0  // timing experiments (tools/ls_variant.py): 1 two of three fp6 parts, 2 no fp6 loads, 4 no f16 refills,
+                     // 8 no LDS reads of the T plane, 16 no LDS writes of the T plane
 #endif
 namespace x {
 constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
@@ -590,7 +591,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
       }
       if (c == 1) {  // this group's fp6 B operands: two chunks of lead
 #pragma unroll
-        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = b6(b, Q, 1); }
+        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = (NA_LSX_EXP & 8) ? B6[b][0] : b6(b, Q, 1); }
       }
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 A0 = R.a16[c][0], A1 = R.a16[c][1];
@@ -679,8 +680,10 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
   char* p = kq + 4096 + lane * 16;
   *(u32x4*)p = u32x4{(uint32_t)Rr[0], (uint32_t)Rr[1], (uint32_t)Rr[2], (uint32_t)Rr[3]};
   *(u32x4*)(p + 1024) = u32x4{(uint32_t)Rr[4], (uint32_t)Rr[5], (uint32_t)eR, 0u};
-  *(u32x4*)(p + 2048) = u32x4{(uint32_t)Tt[0], (uint32_t)Tt[1], (uint32_t)Tt[2], (uint32_t)Tt[3]};
-  *(u32x4*)(p + 3072) = u32x4{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT, 0u};
+  if (!(NA_LSX_EXP & 16)) {
+    *(u32x4*)(p + 2048) = u32x4{(uint32_t)Tt[0], (uint32_t)Tt[1], (uint32_t)Tt[2], (uint32_t)Tt[3]};
+    *(u32x4*)(p + 3072) = u32x4{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT, 0u};
+  }
 }
 template <int ACT, int NB, int T0 = 0, int T1 = 2>
 __device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane) {
