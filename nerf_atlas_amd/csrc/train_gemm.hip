@@ -44,12 +44,20 @@ __device__ __forceinline__ float tact_grad(float v, int act) {
   return 1.f;
 }
 
+// v = hi + lo + O(2^-17 |v|), both halves rounded to nearest even.  Pairwise, so that each pair costs v_cvt_pk_bf16_f32, a shift,
+// a mask, v_pk_add_f32 and v_cvt_pk_bf16_f32 (element by element the compiler converted every high half twice)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+  for (int p = 0; p < 2; ++p) {
+    const f32x2 w = {v[2 * p], v[2 * p + 1]};
+    const bf16x2 h = __builtin_convertvector(w, bf16x2);
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    const f32x2 f = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+    const bf16x2 l = __builtin_convertvector(w - f, bf16x2);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
   }
 }
 
@@ -477,23 +485,30 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 // ================================================================================ layer-synchronous NT kernel (round 3)
 // The same GEMM  C[samples, M] = A[samples, K] . B[M, K]^T  organised like the renderer (render_ls.hip) instead of a
 // K-staged tile pair: a workgroup keeps a 64-sample tile of A in LDS as split bf16 planes, 128 k at a time, and streams the
-// pre-packed bf16 hi/lo fragments of B from L2 straight into registers (an 8-deep fragment ring refilled in place), so B never
+// pre-packed bf16 hi/lo fragments of B from L2 straight into registers (a fragment ring refilled in place), so B never
 // passes through LDS or the split arithmetic again and A is read from HBM as whole contiguous rows (the K-staged kernel
 // moved 48 KiB through the vector memory path per 24 MFMAs and was bound by that path).
-// Two roles of four waves.  PRODUCERS (waves 4-7) fetch the rows two units ahead into registers, activate + split them and
-// fill the other LDS buffer; for the input gradient with an activation they also bring the tile of forward inputs into LDS.
-// CONSUMERS (waves 0-3, one 64-column group of C each) run the MFMAs and the epilogue and never load from HBM: loads of one
-// wave return in order, so a row fetch (HBM latency) in front of a weight fragment (L2) would stall the matrix pipe.
+// Three roles of four waves (twelve waves, three per SIMD, 168 registers each).  LOADERS (waves 4-7) fetch the rows three units
+// ahead into registers -- hand-issued buffer loads with hand-counted waits, see the kernel -- activate + split them and fill
+// the other LDS buffer.  MOVERS (waves 8-11) carry the finished output tile from LDS to HBM, in parts spread over the units
+// of the next tile, and for the input gradient with an activation bring the tile of forward inputs into LDS.  CONSUMERS
+// (waves 0-3, one 64-column group of C each) run the MFMAs and the epilogue and touch HBM never: loads and stores of one wave
+// retire in order, so a row fetch (HBM latency) or a tile store in front of a weight fragment (L2) would stall the matrix
+// pipe; and a wave that mixes kinds of memory work loses the compiler its exact wait counts (two roles in one wave: vmcnt(0)
+// in front of every conversion, the prefetch one unit deep whatever the code said).
 // A unit = (tile, pass over 256 columns of C, k chunk), one barrier per unit.  Inside a unit a consumer finishes its column tile
-// t = 0 before it starts t = 1: the stores of tile 0 drain under the MFMAs of tile 1, those of tile 1 under the next unit's.
+// t = 0 before it starts t = 1.
 #ifndef TGL_ABLATE
-#define TGL_ABLATE 0  // timing experiments: 1 no row fetches, 2 no epilogue stores, 4 no MFMAs, 8 no weight refills, 16 no LDS fill
+#define TGL_ABLATE 0  // timing experiments: 1 no row fetches, 2 no epilogue stores, 4 no MFMAs, 8 no weight refills, 16 no LDS fill, 32 fill from constants, 64 conversion without its LDS writes
 #endif
 #ifndef TGL_TRACE
-#define TGL_TRACE 0  // experiment builds (tools/ls_variant.py): s_memtime stamps of workgroup 0, waves 0 (consumer) and 4 (producer)
+#define TGL_TRACE 0  // experiment builds (tools/ls_variant.py): s_memtime stamps of workgroup 0, waves 0 (consumer) and 4 (loader)
 #endif
 #ifndef TGL_PRIO
-#define TGL_PRIO 0   // s_setprio of the producer waves
+#define TGL_PRIO 0   // s_setprio of the loader and mover waves
+#endif
+#ifndef TGL_RD
+#define TGL_RD 4     // weight fragment ring of a consumer wave, in k steps (8 = a whole segment, or 4)
 #endif
 namespace lsnt {
 #if TGL_TRACE
@@ -508,10 +523,12 @@ constexpr int PITCH = KC * 2 + 16;  // row pitch of a plane: 68 dwords = 4 mod 6
 constexpr int PLANE = TS * PITCH;
 constexpr int BUF = 2 * PLANE;      // hi | lo
 constexpr int LDS = 2 * BUF;        // two buffers: 68 KiB
-constexpr int NPF = TS * (KC / 4) / 256;  // 16-byte pieces per producer thread and unit (8)
+constexpr int PT = 256;             // threads of a role
+constexpr int NTHR = 256 + 2 * PT;
+constexpr int NPF = TS * (KC / 4) / PT;  // 16-byte pieces per loader thread and unit (8)
 constexpr int XP = 260;             // float pitch of the output tile (= the forward-input tile of an input gradient with an activation)
 constexpr int XB = TS * XP * 4;     // 65 KiB behind the buffers
-constexpr int NXF = TS * 64 / 256;  // its 16-byte pieces per producer thread (16)
+constexpr int NXF = TS * 64 / PT;   // its 16-byte pieces per mover thread (16)
 constexpr int SEG = 8 * 2048;       // stream bytes of one (column group, chunk, column tile): 8 k steps x (hi | lo) fragments
 
 struct Args {
@@ -564,13 +581,32 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, i
   if (bytes < 0) bytes = 0;
   return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)dummy : base + m0 * ld), 0, (int)bytes, 0x00020000);
 }
-// WHICH: 0 both sources, 1 the first only, 2 the second only (a caller that knows where its columns lie -- a whole k chunk
-// inside one source -- issues a fifth of the loads a skip layer's unaligned second source would otherwise add to every piece)
+// the same descriptor as four plain words, for the hand-issued loads below
+__device__ __forceinline__ u32x4 tile_desc(const float* base, int ld, int64_t m0, int64_t rows) {
+  int64_t bytes = base == nullptr ? 0 : (rows - m0) * ld * 4;
+  if (bytes > 0x70000000ll) bytes = 0x70000000ll;
+  if (bytes < 0) bytes = 0;
+  const uint64_t a = base == nullptr ? 0 : (uint64_t)(base + m0 * ld);
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+}
+// WHICH: 1 the first source only, 2 the second only -- a caller that knows where its columns lie (a whole k chunk inside one
+// source): ONE 16-byte load per piece whatever the row length.  Raw-buffer loads of 16 bytes need only 4-byte alignment and
+// are range-checked per dword (profiles/r03/unaligned_probe.log), so a 38-column source takes them too; a piece that crosses
+// the end of its row brings the first elements of the NEXT row along, which the caller zeroes when it USES the piece (zeroing
+// here would wait for the load).  WHICH 0: both sources, summed element by element on the spot: exact zeros outside, but it
+// waits for its loads (only the STRADDLE instantiation uses it).
 template <int WHICH = 0>
 __device__ __forceinline__ f32x4 load_piece(const Src2& s, int row, int col) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (WHICH == 1) {
+    const uint32_t o = col < s.k0 ? (uint32_t)((row * s.k0 + col) * 4) : OOB;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r0, o, 0, 0));
+  }
   if (WHICH == 2) {
-  } else if ((s.k0 & 3) == 0) {
+    const uint32_t o = (col >= s.k0 && col < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + col - s.k0) * 4) : OOB;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r1, o, 0, 0));
+  }
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if ((s.k0 & 3) == 0) {
     const uint32_t o = col < s.k0 ? (uint32_t)((row * s.k0 + col) * 4) : OOB;
     v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r0, o, 0, 0));
   } else {
@@ -580,26 +616,25 @@ __device__ __forceinline__ f32x4 load_piece(const Src2& s, int row, int col) {
       v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.r0, o, 0, 0));
     }
   }
-  if (WHICH != 1 && s.k1 > 0) {
-    if (((s.k0 | s.k1) & 3) == 0) {
-      const uint32_t o = (col >= s.k0 && col < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + col - s.k0) * 4) : OOB;
-      v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r1, o, 0, 0));
-    } else {
+  if (s.k1 > 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ce = col + e;
-        const uint32_t o = (ce >= s.k0 && ce < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + ce - s.k0) * 4) : OOB;
-        v[e] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.r1, o, 0, 0));
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int ce = col + e;
+      const uint32_t o = (ce >= s.k0 && ce < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + ce - s.k0) * 4) : OOB;
+      v[e] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.r1, o, 0, 0));
     }
   }
   return v;
 }
 
-// MODE 0 forward, 1 input gradient; DACT: the input gradient is scaled by act'(forward input) in the epilogue
-template <int MODE, bool DACT>
-__global__ __launch_bounds__(512) void kernel(Args g) {
-  constexpr int RD = 8;  // depth of the weight fragment ring = the k steps of one segment
+// MODE 0 forward, 1 input gradient; DACT: the input gradient is scaled by act'(forward input) in the epilogue; STRADDLE: a
+// 128-wide chunk of k may hold columns of BOTH concatenated sources (first source not a multiple of 128 wide).  That loader
+// adds two fetches per element on the spot, and one copy of it inside the unit loop is enough for the compiler's wait-count
+// pass to give up on the whole loop (vmcnt(0) in front of every conversion): it gets its own instantiation.
+template <int MODE, bool DACT, bool STRADDLE>
+__global__ __launch_bounds__(NTHR) void kernel(Args g) {
+  constexpr int RD = TGL_RD;  // depth of the weight fragment ring (8 = the k steps of one segment)
+  constexpr int KS = 8;       // k steps of a segment
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NCH = g.NCH;
@@ -609,28 +644,32 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   const int my_tiles = (int)((g.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   const int nunits = my_tiles * UPT;
   const int K = g.a.k0 + g.a.k1;
-  // x goes through LDS (any column layout: the producers' loader handles unaligned rows); that needs a unit in which the
+  // x goes through LDS (any column layout: the movers' loader handles unaligned rows); that needs a unit in which the
   // consumers do not read it, so the launcher gives a DACT launch at least two chunks (a zero chunk if K <= 128)
   constexpr bool xlds = DACT;
   // The output tile of a (tile, pass): [64 samples][256 columns] fp32.  The consumers write it in the last chunk's unit, the
-  // PRODUCERS store it to HBM during the next unit: loads of a wave return in order behind its older stores, so a consumer
+  // MOVERS store it to HBM during the next tile's units: loads of a wave return in order behind its older stores, so a consumer
   // that stored its own results waited ~3 k cycles per column tile for the stores to complete before its next weight
-  // fragments counted as arrived; the producers' queue holds only long-latency work anyway.  For an input gradient with an
-  // activation the same memory first holds the forward inputs x (parked by the producers one unit earlier): a consumer reads
-  // x, scales its accumulators and overwrites x with the result in place.
+  // fragments counted as arrived.  For an input gradient with an activation the same memory first holds the forward inputs x
+  // (parked by the movers one unit earlier): a consumer reads x, scales its accumulators and overwrites x with the result.
   float* xbuf = (float*)(smem + LDS);
   // the bias vector (zero padded to whole column groups) lives in LDS: the epilogue reads it with LDS loads, which do not queue
   // behind the wave's outstanding stores the way a global load would
   float* lbias = (float*)(smem + LDS + XB);
   if (MODE == 0) {
-    for (int i = tid; i < nrg * 64; i += 512) lbias[i] = (g.bias != nullptr && i < g.M) ? g.bias[i] : 0.f;
+    for (int i = tid; i < nrg * 64; i += NTHR) lbias[i] = (g.bias != nullptr && i < g.M) ? g.bias[i] : 0.f;
   }
 
   if (wave >= 4) {
-    // ------------------------------------------------------------------------------------------------ producers
+    // ------------------------------------------------------------------------------------- loaders (4-7) and movers (8-11)
     if (TGL_PRIO) __builtin_amdgcn_s_setprio(TGL_PRIO);
-    const int ptid = tid - 256, c4 = ptid & 31, r0 = ptid >> 5;  // piece c4 (4 k) of rows r0 + 8 j
-    const int xc4 = ptid & 63, xr0 = ptid >> 6;                  // x tile: piece xc4 (4 columns) of rows xr0 + 4 j
+    // Two roles of four waves each, so that every wave's vector memory queue holds ONE kind of long-latency work and the
+    // compiler's s_waitcnt counts stay exact: vmcnt counts loads and stores in order, and with the tile's stores, the x fetches
+    // and the row fetches of several uniform branches in one wave the pass fell back to vmcnt(0) in front of the conversion --
+    // every unit waited for the rows it had just requested AND for the tile it had just stored (45 of 150 us at 256 -> 256).
+    const int ptid = (tid - 256) & 255, c4 = ptid & 31, r0 = ptid >> 5;  // loader: piece c4 (4 k) of rows r0 + RS j
+    constexpr int RS = PT / 32, XS = PT / 64;
+    const int xc4 = ptid & 63, xr0 = ptid >> 6;                          // mover: piece xc4 (4 columns) of rows xr0 + XS j
     f32x4 pf0[NPF], pf1[NPF], xs[NXF];
     auto tile_of = [&](int u) __attribute__((always_inline)) -> int64_t { return u < nunits ? blockIdx.x + (int64_t)(u / UPT) * gridDim.x : g.ntiles; };
     // With two chunks per tile both stay in the two LDS buffers, at the same buffer parity, for every further pass over the
@@ -645,36 +684,54 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       const int k_lo = (u % NCH) * KC;
       if (k_lo + KC <= g.a.k0 || g.a.k1 == 0) {  // (uniform) the chunk lies inside the first source
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<1>(src, r0 + 8 * j, k);
-      } else if (k_lo >= g.a.k0) {               // inside the second
+        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<1>(src, r0 + RS * j, k);
+      } else if (!STRADDLE || k_lo >= g.a.k0) {  // inside the second
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<2>(src, r0 + 8 * j, k);
+        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<2>(src, r0 + RS * j, k);
       } else {
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<0>(src, r0 + 8 * j, k);
+        for (int j = 0; j < NPF; ++j) pf[j] = load_piece<0>(src, r0 + RS * j, k);
       }
     };
     // (the activation is a runtime argument: one specialised copy of the loop per kind, chosen once per unit -- with the switch
     // inside, every element carried the sine polynomial next to the LeakyReLU select: 180 instructions per 4 values)
-    auto convert_as = [&](const f32x4 (&pf)[NPF], char* buf, auto actc) {
+    // (kq: the first k of the thread's pieces in the unit being converted; with a row length that is not a multiple of four,
+    // elements at k >= K came along from the next row.  One copy of the loop per (activation, ragged): decided once per unit)
+    const bool ragged = (K & 3) != 0;
+    auto convert_as = [&](const f32x4 (&pf)[NPF], char* buf, int kq, auto actc, auto raggedc) __attribute__((always_inline)) {
       constexpr int ACT = decltype(actc)::value;
+      constexpr bool RAGGED = decltype(raggedc)::value;
+      char* d = buf + r0 * PITCH + c4 * 8;
 #pragma unroll
       for (int j = 0; j < NPF; ++j) {
         f32x4 v = pf[j];
+        if (TGL_ABLATE & 32) v = f32x4{(float)c4, (float)(r0 + j), 1.5f, 2.5f};  // (no wait for the rows)
+        if (RAGGED) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = kq + e < K ? v[e] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = tact(v[e], ACT);
         bf16x4 hi, lo;
         split4(v, hi, lo);
-        char* d = buf + (r0 + 8 * j) * PITCH + c4 * 8;
-        *(bf16x4*)d = hi;
-        *(bf16x4*)(d + PLANE) = lo;
+        if (TGL_ABLATE & 64) { asm volatile("" ::"v"(hi), "v"(lo)); continue; }  // (no LDS writes)
+        *(bf16x4*)(d + RS * j * PITCH) = hi;
+        *(bf16x4*)(d + RS * j * PITCH + PLANE) = lo;
       }
     };
-    auto convert = [&](const f32x4 (&pf)[NPF], char* buf) {
+    auto convert = [&](const f32x4 (&pf)[NPF], char* buf, int u) __attribute__((always_inline)) {
       if (TGL_ABLATE & 16) return;
-      if (MODE == 0 && g.act == NA_ACT_LEAKY_RELU) convert_as(pf, buf, std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
-      else if (MODE == 0 && g.act == NA_ACT_SIN) convert_as(pf, buf, std::integral_constant<int, NA_ACT_SIN>{});
-      else convert_as(pf, buf, std::integral_constant<int, NA_ACT_NONE>{});
+      const int kq = (u % NCH) * KC + c4 * 4;
+      const int act = MODE == 0 ? g.act : NA_ACT_NONE;
+      if (ragged) {
+        if (act == NA_ACT_LEAKY_RELU) convert_as(pf, buf, kq, std::integral_constant<int, NA_ACT_LEAKY_RELU>{}, std::true_type{});
+        else if (act == NA_ACT_SIN) convert_as(pf, buf, kq, std::integral_constant<int, NA_ACT_SIN>{}, std::true_type{});
+        else convert_as(pf, buf, kq, std::integral_constant<int, NA_ACT_NONE>{}, std::true_type{});
+      } else {
+        if (act == NA_ACT_LEAKY_RELU) convert_as(pf, buf, kq, std::integral_constant<int, NA_ACT_LEAKY_RELU>{}, std::false_type{});
+        else if (act == NA_ACT_SIN) convert_as(pf, buf, kq, std::integral_constant<int, NA_ACT_SIN>{}, std::false_type{});
+        else convert_as(pf, buf, kq, std::integral_constant<int, NA_ACT_NONE>{}, std::false_type{});
+      }
     };
     // forward inputs of (tile, pass) = unit u's: columns 256 pass + 4 xc4 .. + 3 of the concatenated [x0 | x1]
     auto xload = [&](int u) __attribute__((always_inline)) {
@@ -684,23 +741,31 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       const int c_lo = 256 * ((u / NCH) % NP);
       if (c_lo + 256 <= g.c0 || g.c1 == 0) {
 #pragma unroll
-        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<1>(src, xr0 + 4 * j, col);
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<1>(src, xr0 + XS * j, col);
       } else if (c_lo >= g.c0) {
 #pragma unroll
-        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<2>(src, xr0 + 4 * j, col);
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<2>(src, xr0 + XS * j, col);
       } else {
 #pragma unroll
-        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<0>(src, xr0 + 4 * j, col);
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<0>(src, xr0 + XS * j, col);
       }
     };
     auto xstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < NXF; ++j) *(f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4) = xs[j];
+      for (int j = 0; j < NXF; ++j) *(f32x4*)(xbuf + (xr0 + XS * j) * XP + 4 * xc4) = xs[j];
     };
     // the finished output tile of unit u's (tile, pass), from LDS to HBM: whole rows, 16 bytes per lane (the thread's pieces are the
     // ones it parks x in, so its own program order is all the synchronisation the shared buffer needs)
     const int ncols = g.c0 + g.c1;
-    auto store_out = [&](int u) __attribute__((always_inline)) {
+    // (two steps: the tile leaves LDS for registers at once, then goes out in NCH parts, one per unit of the next (tile, pass) --
+    // 64 KB in one burst kept every wave of the CU, the loaders' fetches and the consumers' weight refills included, queued
+    // behind it for ~9 k cycles of every other unit)
+    f32x4 ot[NXF];
+    auto take_out = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NXF; ++j) ot[j] = *(const f32x4*)(xbuf + (xr0 + XS * j) * XP + 4 * xc4);
+    };
+    auto store_out = [&](int u, int part) __attribute__((always_inline)) {  // part < 0: all of it
       if (TGL_ABLATE & 2) return;
       const int64_t m0 = tile_of(u) * TS;
       const int c_lo = 256 * ((u / NCH) % NP);
@@ -712,72 +777,138 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       const bool vec0 = (g.c0 & 3) == 0, vec1 = ((g.c0 | g.c1) & 3) == 0;
 #pragma unroll
       for (int j = 0; j < NXF; ++j) {
-        const f32x4 v = *(const f32x4*)(xbuf + (xr0 + 4 * j) * XP + 4 * xc4);
+        if (part >= 0 && j * NCH / NXF != part) continue;  // (uniform)
+        const f32x4 v = ot[j];
         if (side0) {
           if (vec0) {
             const uint32_t o0 = col < g.c0 ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, 4 * j * g.c0 * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, XS * j * g.c0 * 4, 0);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const uint32_t p0 = col + e < g.c0 ? (uint32_t)((xr0 * g.c0 + col + e) * 4) : OOB;
               const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, 4 * j * g.c0 * 4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, XS * j * g.c0 * 4, 0);
             }
           }
         }
         if (side1) {
           if (vec1) {
             const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, 4 * j * g.c1 * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, XS * j * g.c1 * 4, 0);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ce = col + e;
               const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
               const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, 4 * j * g.c1 * 4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, XS * j * g.c1 * 4, 0);
             }
           }
         }
       }
     };
-    // producer step during unit u: first the previous (tile, pass)'s finished output if this unit opens a new one; then fill the
-    // other buffer with unit u + 1, fetch unit u + 3; x of the (tile, pass) whose last chunk comes next is parked in LDS one unit
-    // before the consumers read it (behind the store of the old tile in the same buffer), and the following one's is requested
-    auto step = [&](f32x4 (&pf)[NPF], int u, char* other) __attribute__((always_inline)) {
-      if (wave == 4) TGL_STAMP(1, u, 0);
-      if (u % NCH == 0 && u > 0) store_out(u - 1);
-      // (no conditions around the fetches: units past the end read rows past the batch = zeros; conditional fetches made the
-      // compiler's wait-count pass wait with vmcnt(0), i.e. for the rows just requested)
-      if (!resident(u + 1)) convert(pf, other);
-      if (wave == 4) TGL_STAMP(1, u, 1);
-      load(pf, u + 3);
-      if (xlds && u % NCH == NCH - 2) {
-        xstore();
-        xload(u + NCH);
-      }
-      if (wave == 4) TGL_STAMP(1, u, 2);
+    if (wave >= 8) {
+      // movers, during unit u: the previous (tile, pass)'s finished output from LDS to HBM if this unit opens a new one; x of the
+      // (tile, pass) whose last chunk comes next is parked in the same memory one unit before the consumers read it (its
+      // registers are waited for BEFORE the stores are issued: behind them the in-order count would wait for the stores too),
+      // and the following one's is requested
+      if (xlds) xload(0);
       __syncthreads();
-      if (wave == 4) TGL_STAMP(1, u, 3);
-    };
-    load(pf0, 0);
-    if (xlds) xload(0);
-    load(pf1, 1);
-    convert(pf0, smem);
-    load(pf0, 2);
-    __syncthreads();
-    for (int u = 0; u < nunits; u += 2) {
-      step(pf1, u, smem + BUF);
-      if (u + 1 < nunits) step(pf0, u + 1, smem);
+      for (int u = 0; u < nunits; ++u) {
+        const int i = u % NCH;
+        const bool park = xlds && i == NCH - 2;
+        if (park) {
+#pragma unroll
+          for (int j = 0; j < NXF; ++j) asm volatile("" ::"v"(xs[j]));
+        }
+        if (u >= NCH) {
+          if (i == 0) take_out();
+          store_out(u - 1 - i, i);
+        }
+        if (park) {
+          xstore();
+          xload(u + NCH);
+        }
+        __syncthreads();
+      }
+      take_out();
+      store_out(nunits - 1, -1);  // (behind the last unit's barrier)
+      return;
     }
-    store_out(nunits - 1);  // (behind the last unit's barrier)
+    // loaders, during unit u: fill the other buffer with unit u + 1, fetch unit u + 1 + PD into the registers this frees.
+    // (no conditions around the fetches: units past the end read rows past the batch = zeros)
+    if constexpr (STRADDLE) {
+      auto step = [&](f32x4 (&pf)[NPF], int u, char* other) __attribute__((always_inline)) {
+        if (!resident(u + 1)) convert(pf, other, u + 1);
+        load(pf, u + 3);
+        __syncthreads();
+      };
+      load(pf0, 0);
+      load(pf1, 1);
+      convert(pf0, smem, 0);
+      load(pf0, 2);
+      __syncthreads();
+      for (int u = 0; u < nunits; u += 2) {
+        step(pf1, u, smem + BUF);
+        if (u + 1 < nunits) step(pf0, u + 1, smem);
+      }
+    } else {
+      // The fetches are issued by hand and waited for by hand.  A loader's vector memory queue holds nothing but these fetches,
+      // NPF per unit, in order: when unit u + 1's rows are needed exactly (PD - 1) NPF younger fetches are outstanding, so
+      // `s_waitcnt vmcnt((PD - 1) NPF)` is the exact wait.  The compiler's own counts were not: with the loop's uniform
+      // branches (which source, which activation, resident chunks) it waited with vmcnt(7) .. vmcnt(0) through a conversion,
+      // i.e. for the rows requested one unit ago as well -- the prefetch was one unit deep whatever the code said, and at
+      // 4 TB/s with 32 MB in flight a fetch takes a whole unit to come back.
+      constexpr int PD = 3;
+      f32x4 pf2[NPF];
+      auto issue = [&](f32x4 (&pf)[NPF], int u) __attribute__((always_inline)) {
+        const int64_t m0 = ((TGL_ABLATE & 1) || resident(u) ? g.ntiles : tile_of(u)) * TS;
+        const int k_lo = (u % NCH) * KC, k = k_lo + c4 * 4;
+        const bool first = k_lo + KC <= g.a.k0 || g.a.k1 == 0;  // (uniform) the chunk lies inside the first source, or the second
+        const u32x4 d = first ? tile_desc(g.a.p0, g.a.k0, m0, g.a.rows) : tile_desc(g.a.p1, g.a.k1, m0, g.a.rows);
+        const int ld = first ? g.a.k0 : g.a.k1, col = first ? k : k - g.a.k0;
+        const uint32_t o0 = col < ld ? (uint32_t)((r0 * ld + col) * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+          const uint32_t o = o0 + (uint32_t)(RS * j * ld * 4);  // (OOB + a tile's worth of bytes is still out of range)
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(pf[j]) : "v"(o), "s"(d));
+        }
+      };
+      auto await = [&](f32x4 (&pf)[NPF]) __attribute__((always_inline)) {
+        static_assert(NPF == 8, "operand list below");
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]), "+v"(pf[7])
+                     : "n"((PD - 1) * NPF));
+      };
+      auto step = [&](f32x4 (&pf)[NPF], int u, char* other) __attribute__((always_inline)) {
+        if (wave == 4) TGL_STAMP(1, u, 0);
+        await(pf);
+        if (!resident(u + 1)) convert(pf, other, u + 1);
+        if (wave == 4) TGL_STAMP(1, u, 1);
+        issue(pf, u + 1 + PD);
+        if (wave == 4) TGL_STAMP(1, u, 2);
+        __syncthreads();
+        if (wave == 4) TGL_STAMP(1, u, 3);
+      };
+      issue(pf0, 0);
+      issue(pf1, 1);
+      issue(pf2, 2);
+      await(pf0);
+      convert(pf0, smem, 0);
+      issue(pf0, 3);
+      __syncthreads();
+      for (int u = 0; u < nunits; u += 3) {
+        step(pf1, u, smem + ((u + 1) & 1) * BUF);
+        if (u + 1 < nunits) step(pf2, u + 1, smem + (u & 1) * BUF);
+        if (u + 2 < nunits) step(pf0, u + 2, smem + ((u + 1) & 1) * BUF);
+      }
+    }
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- consumers
   const int ncols = g.c0 + g.c1;
-  f32x16 acc[2][2];      // [column tile][32-sample block]: rows = 32 columns of C, columns = samples
   bf16x8 ring[RD][2];    // [k step of the segment][plane]
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.wp, 0, nrg * NCH * 2 * SEG, 0x00020000);
   // Work of this wave in pass p (ng = column groups of the pass, 1..4): with 3 or 4 groups a wave owns a whole group (2 column
@@ -806,104 +937,139 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     }
     return -1;
   };
-  {
-    const int so = first_seg(0);
-    if (so >= 0) {
+  int cso = __builtin_amdgcn_readfirstlane(first_seg(0));  // the segment the ring's oldest entries belong to
+  if (cso >= 0) {
 #pragma unroll
-      for (int i = 0; i < RD; ++i) { ring[i][0] = wfrag(so, i, 0); ring[i][1] = wfrag(so, i, 1); }
-    }
+    for (int i = 0; i < RD; ++i) { ring[i][0] = wfrag(cso, i, 0); ring[i][1] = wfrag(cso, i, 1); }
   }
   constexpr bool dact = DACT;
   __syncthreads();
-  for (int u = 0; u < nunits; ++u) {
+  // Two copies of the unit loop: every pass with four whole column groups (C a multiple of 256 columns wide: the masks of
+  // work_of() are constants), and the general case.  With the wave-uniform branches of the general case around every fragment
+  // read and MFMA group, the compiler's s_waitcnt placement turns conservative at each join -- lgkmcnt(0) in front of the MFMAs,
+  // i.e. the NEXT k step's LDS reads waited for at once: 54 instead of 32 cycles per MFMA.
+  // One unit's work of a wave, NT column tiles x NB sample blocks of its group R: (2, 2) a whole group, (2, 1) both tiles of
+  // block `bsel`, (1, 1) tile `tsel` of block `bsel` -- straight-line code each, accumulators acc[tt][bb] with constant indices;
+  // which tile / block they stand for only moves addresses.  (Runtime masks around every fragment read and MFMA group, the
+  // first version, cost the compiler's s_waitcnt placement its precision at each join -- lgkmcnt(0) in front of the MFMAs, i.e.
+  // the NEXT k step's LDS reads waited for at once: 54 instead of 32 cycles per MFMA -- and spilled.)
+  auto unit_body = [&](auto ntc, auto nbc, auto& acc, int u, int R, int tsel, int bsel) __attribute__((always_inline)) {
+    constexpr int NT = decltype(ntc)::value, NB = decltype(nbc)::value;
     const int ch = u % NCH, pass = (u / NCH) % NP;
-    const char* buf = smem + (u & 1) * BUF;
-    const Work wk = work_of(pass);
-    const int R = wk.R;
-    if (wave == 0) TGL_STAMP(0, u, 0);
-    if (R >= 0) {
-      const char* brow = buf + (lane & 31) * PITCH + (lane >> 5) * 16;
-      const bool last = ch == NCH - 1;
+    const char* brow = smem + (u & 1) * BUF + (lane & 31) * PITCH + (lane >> 5) * 16 + (NB == 2 ? 0 : bsel * 32 * PITCH);
+    const bool last = ch == NCH - 1;
+    const int t_first = NT == 2 ? 0 : tsel;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (!((wk.tmask >> t) & 1)) continue;
-        if (ch == 0) {
+    for (int tt = 0; tt < NT; ++tt) {
+      const int t = NT == 2 ? tt : tsel;
+      // the segment after this one: the wave's other column tile, the next chunk, the next pass it works in, the next tile
+      int nso;
+      if (NT == 2 && tt == 0) nso = seg_off(R, ch, 1);
+      else if (!last) nso = seg_off(R, ch + 1, t_first);
+      else nso = first_seg(pass + 1 == NP ? 0 : pass + 1);
+      nso = __builtin_amdgcn_readfirstlane(nso);
+      bf16x8 xh[2][NB], xl[2][NB];  // [buffer][block]
+      auto xfrag = [&](int ks, int slot) __attribute__((always_inline)) {
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
+        for (int bb = 0; bb < NB; ++bb) {
+          const char* p = brow + bb * 32 * PITCH + ks * 32;
+          xh[slot][bb] = *(const bf16x8*)p;
+          xl[slot][bb] = *(const bf16x8*)(p + PLANE);
         }
-        // the segment after this one: the wave's other column tile, the next chunk, the next pass it works in, the next tile
-        int nso;
-        if (t == 0 && (wk.tmask & 2)) nso = seg_off(R, ch, 1);
-        else if (!last) nso = seg_off(R, ch + 1, (wk.tmask & 1) ? 0 : 1);
-        else nso = first_seg(pass + 1 == NP ? 0 : pass + 1);
-        nso = __builtin_amdgcn_readfirstlane(nso);
-        bf16x8 xh[2][2], xl[2][2];  // [buffer][block]
-        auto xfrag = [&](int ks, int slot) __attribute__((always_inline)) {
+      };
+      xfrag(0, 0);
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            if (!((wk.bmask >> b) & 1)) continue;
-            const char* p = brow + b * 32 * PITCH + ks * 32;
-            xh[slot][b] = *(const bf16x8*)p;
-            xl[slot][b] = *(const bf16x8*)(p + PLANE);
-          }
-        };
-        xfrag(0, 0);
+      for (int i = 0; i < KS; ++i) {
+        const int cur = i & 1, sl = i % RD;
+        if (i + 1 < KS) xfrag(i + 1, cur ^ 1);  // the next k step's fragments under this one's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 wh = ring[sl][0], wl = ring[sl][1];
 #pragma unroll
-        for (int i = 0; i < RD; ++i) {
-          const int cur = i & 1;
-          if (i + 1 < RD) xfrag(i + 1, cur ^ 1);  // the next k step's fragments under this one's MFMAs
-          __builtin_amdgcn_sched_barrier(0);
-          const bf16x8 wh = ring[i][0], wl = ring[i][1];
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            if (!((wk.bmask >> b) & 1)) continue;
-            if (TGL_ABLATE & 4) { acc[t][b][0] += (float)wl[0] + (float)xh[cur][b][0] + (float)wh[1] + (float)xl[cur][b][1]; continue; }
-            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[cur][b], acc[t][b], 0, 0, 0);
-            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[cur][b], acc[t][b], 0, 0, 0);
-            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[cur][b], acc[t][b], 0, 0, 0);
-          }
-          // refill in place, behind the slot's MFMAs: needed one segment (8 k steps) from now
-          if (!(TGL_ABLATE & 8)) { ring[i][0] = wfrag(nso, i, 0); ring[i][1] = wfrag(nso, i, 1); }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int bb = 0; bb < NB; ++bb) {
+          if (TGL_ABLATE & 4) { acc[tt][bb][0] += (float)wl[0] + (float)xh[cur][bb][0] + (float)wh[1] + (float)xl[cur][bb][1]; continue; }
+          acc[tt][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[cur][bb], acc[tt][bb], 0, 0, 0);
+          acc[tt][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[cur][bb], acc[tt][bb], 0, 0, 0);
+          acc[tt][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[cur][bb], acc[tt][bb], 0, 0, 0);
         }
-        if (wave == 0 && t == 1) TGL_STAMP(0, u, 1);
-        if (last) {
-          // Epilogue of column tile t: bias / activation derivative in the accumulator layout -- register 4 q + e of acc[t][b] =
-          // column 64 R + 32 t + 8 q + 4 (lane >> 5) + e, sample 32 b + (lane & 31) -- then the quads go to the output tile in
-          // LDS (row-major; x, where it is needed, sits at the very same places and is overwritten by the result).
+        // refill in place, behind the slot's MFMAs: needed RD k steps from now
+        if (!(TGL_ABLATE & 8)) {
+          const int so = i + RD < KS ? cso : nso, j = (i + RD) % KS;
+          ring[sl][0] = wfrag(so, j, 0); ring[sl][1] = wfrag(so, j, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cso = nso;
+      if (wave == 0 && tt == NT - 1) TGL_STAMP(0, u, 1);
+      if (last) {
+        // Epilogue of column tile t: bias / activation derivative in the accumulator layout -- register 4 q + e of acc[.][.] =
+        // column 64 R + 32 t + 8 q + 4 (lane >> 5) + e, sample 32 b + (lane & 31) -- then the quads go to the output tile in
+        // LDS (row-major; x, where it is needed, sits at the very same places and is overwritten by the result).
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cl = 64 * (R & 3) + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
-            f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == 0) bj = *(const f32x4*)(lbias + 256 * pass + cl);
+        for (int q = 0; q < 4; ++q) {
+          const int cl = 64 * (R & 3) + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
+          f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+          if (MODE == 0) bj = *(const f32x4*)(lbias + 256 * pass + cl);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              if (!((wk.bmask >> b) & 1)) continue;
-              float* o = xbuf + (32 * b + (lane & 31)) * XP + cl;
-              f32x4 v = {acc[t][b][4 * q], acc[t][b][4 * q + 1], acc[t][b][4 * q + 2], acc[t][b][4 * q + 3]};
-              if (MODE == 0) v += bj;
-              if (dact) {
-                const f32x4 xv = *(const f32x4*)o;
-                if (g.act == NA_ACT_SIN) {
+          for (int bb = 0; bb < NB; ++bb) {
+            const int bk = NB == 2 ? bb : bsel;
+            float* o = xbuf + (32 * bk + (lane & 31)) * XP + cl;
+            f32x4 v = {acc[tt][bb][4 * q], acc[tt][bb][4 * q + 1], acc[tt][bb][4 * q + 2], acc[tt][bb][4 * q + 3]};
+            if (MODE == 0) v += bj;
+            if (dact) {
+              const f32x4 xv = *(const f32x4*)o;
+              if (g.act == NA_ACT_SIN) {
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
-                } else {
+                for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
+              } else {
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
-                }
+                for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
               }
-              *(f32x4*)o = v;
             }
+            *(f32x4*)o = v;
           }
         }
       }
     }
-    if (wave == 0) TGL_STAMP(0, u, 2);
-    __syncthreads();
-    if (wave == 0) TGL_STAMP(0, u, 3);
-  }
+  };
+  // The chunks of one (tile, pass), with accumulators of their own: the three shapes of work never meet in one live range
+  auto chunks = [&](auto ntc, auto nbc, int u0, int R, int tsel, int bsel) __attribute__((always_inline)) {
+    constexpr int NT = decltype(ntc)::value, NB = decltype(nbc)::value;
+    f32x16 acc[NT][NB];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][bb][r] = 0.f;
+    for (int u = u0; u < u0 + NCH; ++u) {
+      if (wave == 0) TGL_STAMP(0, u, 0);
+      unit_body(ntc, nbc, acc, u, R, tsel, bsel);
+      if (wave == 0) TGL_STAMP(0, u, 2);
+      __syncthreads();
+      if (wave == 0) TGL_STAMP(0, u, 3);
+    }
+  };
+  // Two copies of the loop: every pass with four whole column groups (C a multiple of 256 columns wide), and the general case
+  auto units = [&](auto full) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full)::value;
+    constexpr std::integral_constant<int, 1> one{};
+    constexpr std::integral_constant<int, 2> two{};
+    for (int u0 = 0; u0 < nunits; u0 += NCH) {
+      const int pass = (u0 / NCH) % NP;
+      if (FULL) {
+        chunks(two, two, u0, 4 * pass + wave_s, 0, 0);
+      } else {
+        const Work wk = work_of(pass);
+        if (wk.R < 0) {
+          for (int ch = 0; ch < NCH; ++ch) __syncthreads();
+        } else if (wk.bmask == 3) chunks(two, two, u0, wk.R, 0, 0);
+        else if (wk.tmask == 3) chunks(two, one, u0, wk.R, 0, wk.bmask >> 1);
+        else chunks(one, one, u0, wk.R, wk.tmask >> 1, wk.bmask >> 1);
+      }
+    }
+  };
+  if ((nrg & 3) == 0) units(std::true_type{});
+  else units(std::false_type{});
 }
 
 static int cu_count() {
@@ -933,20 +1099,22 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
   a.wp = wp;
   a.ntiles = (a.a.rows + TS - 1) / TS;
   const int grid = a.ntiles < cu_count() ? (int)a.ntiles : cu_count();
-  auto k = kernel<MODE, false>;
-  if constexpr (MODE == 1) { if (dact) k = kernel<MODE, true>; }
+  const bool straddle = a.a.k1 > 0 && a.a.k0 % KC != 0;  // (forward only: the gradient's A operand is a single matrix)
+  auto k = kernel<MODE, false, false>;
+  if constexpr (MODE == 0) { if (straddle) k = kernel<MODE, false, true>; }
+  else { if (straddle) { set_error("%s: two-source A operand", what); return NA_EUNSUPPORTED; } if (dact) k = kernel<MODE, true, false>; }
   const int lds = LDS + XB + nrg * 256;
-  static std::atomic<uint64_t> done[2];
+  static std::atomic<uint64_t> done[4];
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   int rc = NA_OK;
-  if (!(done[dact].load(std::memory_order_acquire) & bit)) {
+  if (!(done[2 * dact + straddle].load(std::memory_order_acquire) & bit)) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + XB + 4096);
     if (e2 != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e2)); rc = NA_EHIP; }
-    else done[dact].fetch_or(bit, std::memory_order_release);
+    else done[2 * dact + straddle].fetch_or(bit, std::memory_order_release);
   }
-  if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+  if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, st, a);
   (void)hipFreeAsync(wp, st);
   if (rc != NA_OK) return rc;
   return check_launch(what);

@@ -16,7 +16,10 @@ ACTS = {"none": (lambda v: v, lambda v: torch.ones_like(v)),
 SHAPES = [(4096, 256, 0, 256), (2048 + 37, 256, 0, 256), (8192 + 5, 38, 0, 256), (4096, 256, 38, 256), (4096 + 63, 256, 69, 256),
           (4096, 69, 0, 256), (4096 + 1, 256, 0, 65), (4096, 256, 0, 3), (16384 + 64 * 256 + 9, 256, 0, 64), (40000, 16, 0, 256),
           # beyond the five configs: four passes over 1000 output columns, eight k chunks, an aligned second source, 512 x 512
-          (4096, 512, 0, 512), (5000, 100, 0, 1000), (3000, 1000, 24, 72), (2048, 128, 128, 128)]
+          (4096, 512, 0, 512), (5000, 100, 0, 1000), (3000, 1000, 24, 72), (2048, 128, 128, 128),
+          # a k chunk that holds columns of both sources (the loader's own instantiation), rows of 38 and 63 floats (16-byte
+          # fetches at 4-byte alignment, tails zeroed at conversion), 6 and 7 column groups (a pair / three waves in the last pass)
+          (4096 + 3, 64, 38, 64), (4096, 63, 0, 128), (4096 + 17, 256, 0, 325), (2048 + 5, 128, 0, 448)]
 
 
 @pytest.fixture(scope="module")

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--kernel", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--cus", type=int, default=256)
+    ap.add_argument("--extra-pass", action="append", default=[], help="NAME:CTR1,CTR2,... one more counter pass (raw values only)")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -63,7 +64,11 @@ def main():
     work = tempfile.mkdtemp(prefix="pmc_")
     res = {"kernel": a.kernel, "command": " ".join(cmd), "per_launch": {}}
     try:
-        for name, counters in PASSES.items():
+        passes = dict(PASSES)
+        for spec in a.extra_pass:
+            nm, ctrs = spec.split(":", 1)
+            passes[nm] = ctrs.split(",")
+        for name, counters in passes.items():
             vals, n, dispatch = run_pass(name, counters, cmd, a.kernel, work)
             res["per_launch"][name] = vals
             res["launches_profiled"] = n
