@@ -177,14 +177,28 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 // The grids are coarse (16 ... 6.3 cells per unit) and consecutive samples are neighbouring pixels at one depth, so
 // most of a wave lands in the same few cells: plain per-lane atomics serialise on a handful of addresses (measured
 // 10.2 ms for 262 144 samples).  One wave handles 64 consecutive samples of ONE level; per corner the lanes that share
-// a table row are combined first (leader loop: readfirstlane -> match mask -> wave reduction) and only the leader
-// issues the 4 atomics.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
+// a table row are combined first (leader loop: readfirstlane -> match mask -> wave reduction) and one lane adds the
+// 4 sums.
+// wave total on DPP (row shifts inside rows of 16, row_bcast:15 / :31 across them): 6 VALU instructions instead of the 6
+// dependent ds_bpermute round trips of a __shfl_xor butterfly (402 -> 170 us for the kernel below); the total arrives in lane 63 only
+#define NA_DPP_ADD(X, CTRL, ROWS) \
+  X += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, ROWS, 0xF, false))
+__device__ __forceinline__ float wave_total_lane63(float x) {
+  NA_DPP_ADD(x, 0x111, 0xF);
+  NA_DPP_ADD(x, 0x112, 0xF);
+  NA_DPP_ADD(x, 0x114, 0xF);
+  NA_DPP_ADD(x, 0x118, 0xF);
+  NA_DPP_ADD(x, 0x142, 0xA);
+  NA_DPP_ADD(x, 0x143, 0xC);
+  return x;
 }
 
+// Round 3: the wave leaders no longer go to memory.  A workgroup takes a CONTIGUOUS run of samples of one level and sums
+// into a small table in LDS (1024 direct-mapped rows keyed by the table index; a row taken by another index falls through
+// to the global atomic), flushed once at the end: the 4096 waves of a coarse level used to queue on the same few dozen
+// addresses in L2 (613 us for 262 144 samples; per-lane atomics 8.9 ms).  In deterministic mode the LDS rows hold the
+// same 2^-40 fixed-point integers as the global accumulator, so the result stays independent of the order.
+constexpr int HB_ROWS = 1024;
 __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restrict__ x, int64_t N,
                                                             const float* __restrict__ g_out, int include_input,
                                                             HashRes res, float* __restrict__ tables_grad,
@@ -192,16 +206,38 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
                                                             const float* __restrict__ tangent) {
   // tangent != nullptr: g_out is the gradient of the directional derivative J(x).e of hash_jvp_kernel, whose corner
   // weights are N_l * <grad w_corner, e> instead of w_corner
+  __shared__ uint32_t tags[HB_ROWS];
+  __shared__ unsigned long long vals[HB_ROWS * 4];  // fp32 sums (low word) or fixed-point sums
   const int odim = 32 + 3 * include_input;
   const int lvl = blockIdx.y;
   const float Nl = res.n[lvl];
   float* tab = tables_grad + (int64_t)lvl * 65536 * 4;
   long long* ftab = fix != nullptr ? fix + (int64_t)lvl * 65536 * 4 : nullptr;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t rounds = (N + stride - 1) / stride;
-  for (int64_t it = 0; it < rounds; ++it) {
-    const int64_t n = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const bool live = n < N;
+  for (int i = threadIdx.x; i < HB_ROWS; i += 256) tags[i] = 0xffffffffu;
+  for (int i = threadIdx.x; i < HB_ROWS * 4; i += 256) vals[i] = 0ull;
+  __syncthreads();
+  // one row of four sums; `who` is the only lane of its wave that calls this for the row right now
+  auto add_row = [&](uint32_t id, float s0, float s1, float s2, float s3) {
+    const uint32_t row = id & (HB_ROWS - 1);
+    const uint32_t old = atomicCAS(&tags[row], 0xffffffffu, id);
+    const float sv[4] = {s0, s1, s2, s3};
+    if (old == 0xffffffffu || old == id) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ftab == nullptr) atomicAdd((float*)&vals[row * 4 + e], sv[e]);
+        else if (fabsf(sv[e]) < 1048576.0f) atomicAdd(&vals[row * 4 + e], (unsigned long long)__float2ll_rn(sv[e] * kFixScale));
+        else accumulate(tab, ftab, (int64_t)id * 4 + e, sv[e]);  // (out of the fixed-point range, NaN: the fp32 path, as accumulate() does)
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accumulate(tab, ftab, (int64_t)id * 4 + e, sv[e]);
+    }
+  };
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;  // samples of this workgroup: whole rounds
+  const int64_t n_lo = blockIdx.x * per, n_hi = n_lo + per < N ? n_lo + per : N;
+  for (int64_t base = n_lo; base < n_hi; base += 256) {
+    const int64_t n = base + threadIdx.x;
+    const bool live = n < n_hi;
     float wx = 0.f, wy = 0.f, wz = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
     float ex = 0.f, ey = 0.f, ez = 0.f;
     int lx = 0, ly = 0, lz = 0;
@@ -228,27 +264,30 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
       }
       const float a0 = w * g0, a1 = w * g1, a2 = w * g2, a3 = w * g3;
       bool todo = live;
-      // at most 4 leader rounds (covers the common case of a wave straddling a cell face), then per-lane atomics
+      // at most 4 leader rounds (covers the common case of a wave straddling a cell face), then lane by lane
       for (int round = 0; round < 4; ++round) {
         const uint64_t pending = __ballot(todo);
         if (pending == 0) break;
         const int leader = __ffsll((unsigned long long)pending) - 1;
         const uint32_t lid = __shfl(id, leader);
         const bool mine = todo && id == lid;
-        const float s0 = wave_sum(mine ? a0 : 0.f), s1 = wave_sum(mine ? a1 : 0.f);
-        const float s2 = wave_sum(mine ? a2 : 0.f), s3 = wave_sum(mine ? a3 : 0.f);
-        if ((int)(threadIdx.x & 63) == leader) {
-          const int64_t t = (int64_t)lid * 4;
-          accumulate(tab, ftab, t + 0, s0); accumulate(tab, ftab, t + 1, s1);
-          accumulate(tab, ftab, t + 2, s2); accumulate(tab, ftab, t + 3, s3);
-        }
+        const float s0 = wave_total_lane63(mine ? a0 : 0.f), s1 = wave_total_lane63(mine ? a1 : 0.f);
+        const float s2 = wave_total_lane63(mine ? a2 : 0.f), s3 = wave_total_lane63(mine ? a3 : 0.f);
+        if ((threadIdx.x & 63) == 63) add_row(lid, s0, s1, s2, s3);
         todo = todo && !mine;
       }
-      if (todo) {
-        const int64_t t = (int64_t)id * 4;
-        accumulate(tab, ftab, t + 0, a0); accumulate(tab, ftab, t + 1, a1);
-        accumulate(tab, ftab, t + 2, a2); accumulate(tab, ftab, t + 3, a3);
-      }
+      if (todo) add_row(id, a0, a1, a2, a3);
+    }
+  }
+  __syncthreads();
+  for (int row = threadIdx.x; row < HB_ROWS; row += 256) {
+    const uint32_t id = tags[row];
+    if (id == 0xffffffffu) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned long long v = vals[row * 4 + e];
+      if (ftab == nullptr) atomicAdd(tab + (int64_t)id * 4 + e, __uint_as_float((uint32_t)v));
+      else atomicAdd((unsigned long long*)(ftab + (int64_t)id * 4 + e), v);
     }
   }
 }
@@ -637,7 +676,7 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
   const size_t ntab = (size_t)8 * 65536 * 4;
   long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_backward", &rc);
   if (rc != NA_OK) return rc;
-  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 128), 8), dim3(256), 0, (hipStream_t)stream, x, N,
                      g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, (const float*)nullptr);
   if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_backward");
   return check_launch("na_hash_encode_backward");
@@ -672,7 +711,7 @@ int na_hash_encode_jvp_backward(const float* x, const float* tangent, int64_t N,
   int rc;
   long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_jvp_backward", &rc);
   if (rc != NA_OK) return rc;
-  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 2048), 8), dim3(256), 0, (hipStream_t)stream, x, N,
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 128), 8), dim3(256), 0, (hipStream_t)stream, x, N,
                      g_t, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, tangent);
   if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_jvp_backward");
   return check_launch("na_hash_encode_jvp_backward");
