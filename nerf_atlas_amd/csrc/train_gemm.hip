@@ -507,6 +507,12 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #ifndef TGL_PRIO
 #define TGL_PRIO 0   // s_setprio of the loader and mover waves
 #endif
+#ifndef TGL_P0F
+#define TGL_P0F 6   // of the 16 pieces a mover thread stores per tile, those that go out in the first of the tile's two units: forward
+#endif
+#ifndef TGL_P0D
+#define TGL_P0D 2   // ... input gradient with an activation (the first unit also parks x: 8 / 8 -> 2 / 14: 210 -> 189 us)
+#endif
 #ifndef TGL_RD
 #define TGL_RD 4     // weight fragment ring of a consumer wave, in k steps (8 = a whole segment, or 4)
 #endif
@@ -761,6 +767,7 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
     // 64 KB in one burst kept every wave of the CU, the loaders' fetches and the consumers' weight refills included, queued
     // behind it for ~9 k cycles of every other unit)
     f32x4 ot[NXF];
+    constexpr int P0 = DACT ? TGL_P0D : TGL_P0F;  // pieces stored in the first of a tile's two units, the rest in the second
     auto take_out = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < NXF; ++j) ot[j] = *(const f32x4*)(xbuf + (xr0 + XS * j) * XP + 4 * xc4);
@@ -777,7 +784,7 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
       const bool vec0 = (g.c0 & 3) == 0, vec1 = ((g.c0 | g.c1) & 3) == 0;
 #pragma unroll
       for (int j = 0; j < NXF; ++j) {
-        if (part >= 0 && j * NCH / NXF != part) continue;  // (uniform)
+        if (part >= 0 && (NCH == 2 ? (j < P0 ? 0 : 1) : j * NCH / NXF) != part) continue;  // (uniform)
         const f32x4 v = ot[j];
         if (side0) {
           if (vec0) {

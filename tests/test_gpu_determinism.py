@@ -12,9 +12,19 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _keep(name, r):
+    """a failing guard leaves its whole output under gpurun_out/ (merged back from the GPU box), whatever the caller's `tail`"""
+    if r.returncode != 0 or "0 nondeterministic runs" not in r.stdout and "\n0 irreproducible runs" not in r.stdout:
+        d = os.path.join(REPO, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"determinism_failure_{name}.log"), "w") as f:
+            f.write(f"rc {r.returncode}\n--- stdout\n{r.stdout}\n--- stderr\n{r.stderr}\n")
+
+
 def test_repeated_calls_are_bit_identical():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "ls_determinism.py"), "30"], capture_output=True, text=True,
                        timeout=900)
+    _keep("repeated_calls", r)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 nondeterministic runs" in r.stdout
 
@@ -23,5 +33,6 @@ def test_full_grid_slab_is_reproducible_over_many_runs():
     """The slab that fills all 256 workgroups, 150 runs per precision, every output element against the per-element
     median (tools/ls_repeat.py; DESIGN 3b "reproducibility": before the fix a few hundred elements per ~20..1000 runs)."""
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "ls_repeat.py"), "150"], capture_output=True, text=True, timeout=900)
+    _keep("full_grid_slab", r)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "\n0 irreproducible runs" in r.stdout
