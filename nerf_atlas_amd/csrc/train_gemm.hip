@@ -513,6 +513,10 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #ifndef TGL_P0D
 #define TGL_P0D 2   // ... input gradient with an activation (the first unit also parks x: 8 / 8 -> 2 / 14: 210 -> 189 us)
 #endif
+#ifndef TGL_RIDE
+#define TGL_RIDE 0   // 1: the first column tile's epilogue rides under the second one's MFMAs, an item per k step (measured SLOWER:
+                     // forward 151 -> 154 us, input gradient 191 -> 206: its LDS traffic and waits land inside the k steps)
+#endif
 #ifndef TGL_RD
 #define TGL_RD 4     // weight fragment ring of a consumer wave, in k steps (8 = a whole segment, or 4)
 #endif
@@ -960,12 +964,35 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
   // which tile / block they stand for only moves addresses.  (Runtime masks around every fragment read and MFMA group, the
   // first version, cost the compiler's s_waitcnt placement its precision at each join -- lgkmcnt(0) in front of the MFMAs, i.e.
   // the NEXT k step's LDS reads waited for at once: 54 instead of 32 cycles per MFMA -- and spilled.)
-  auto unit_body = [&](auto ntc, auto nbc, auto& acc, int u, int R, int tsel, int bsel) __attribute__((always_inline)) {
+  auto unit_body = [&](auto ntc, auto nbc, auto lastc, auto& acc, int u, int R, int tsel, int bsel) __attribute__((always_inline)) {
     constexpr int NT = decltype(ntc)::value, NB = decltype(nbc)::value;
+    constexpr bool last = decltype(lastc)::value;  // the (tile, pass)'s last chunk: its own copy of the code, with the epilogue
     const int ch = u % NCH, pass = (u / NCH) % NP;
     const char* brow = smem + (u & 1) * BUF + (lane & 31) * PITCH + (lane >> 5) * 16 + (NB == 2 ? 0 : bsel * 32 * PITCH);
-    const bool last = ch == NCH - 1;
     const int t_first = NT == 2 ? 0 : tsel;
+    // Epilogue of column tile t, one quad of columns of one sample block at a time: bias / activation derivative in the
+    // accumulator layout -- register 4 q + e of acc[.][.] = column 64 R + 32 t + 8 q + 4 (lane >> 5) + e, sample 32 b +
+    // (lane & 31) -- then the quad goes to the output tile in LDS (row-major; x, where it is needed, sits at the very same
+    // place and is overwritten by the result).  (TGL_RIDE: with two column tiles the first one's eight items under the second
+    // one's k steps, one per step.)
+    auto epi_item = [&](const f32x16& a, int t, int q, int bk) __attribute__((always_inline)) {
+      const int cl = 64 * (R & 3) + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
+      float* o = xbuf + (32 * bk + (lane & 31)) * XP + cl;
+      f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+      if (MODE == 0) v += *(const f32x4*)(lbias + 256 * pass + cl);
+      if (dact) {
+        const f32x4 xv = *(const f32x4*)o;
+        if (g.act == NA_ACT_SIN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
+        }
+      }
+      *(f32x4*)o = v;
+    };
+    constexpr bool ride = last && NT == 2 && TGL_RIDE;  // tile 0's epilogue under tile 1's MFMAs
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int t = NT == 2 ? tt : tsel;
@@ -1003,38 +1030,16 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
           const int so = i + RD < KS ? cso : nso, j = (i + RD) % KS;
           ring[sl][0] = wfrag(so, j, 0); ring[sl][1] = wfrag(so, j, 1);
         }
+        if (ride && tt == 1 && i < 4 * NB) epi_item(acc[0][NB == 2 ? (i & 1) : 0], 0, NB == 2 ? (i >> 1) : i, NB == 2 ? (i & 1) : bsel);
         __builtin_amdgcn_sched_barrier(0);
       }
       cso = nso;
       if (wave == 0 && tt == NT - 1) TGL_STAMP(0, u, 1);
-      if (last) {
-        // Epilogue of column tile t: bias / activation derivative in the accumulator layout -- register 4 q + e of acc[.][.] =
-        // column 64 R + 32 t + 8 q + 4 (lane >> 5) + e, sample 32 b + (lane & 31) -- then the quads go to the output tile in
-        // LDS (row-major; x, where it is needed, sits at the very same places and is overwritten by the result).
+      if (last && !(ride && tt == 0)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cl = 64 * (R & 3) + 32 * t + 8 * q + 4 * (lane >> 5);  // column inside the pass
-          f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-          if (MODE == 0) bj = *(const f32x4*)(lbias + 256 * pass + cl);
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int bb = 0; bb < NB; ++bb) {
-            const int bk = NB == 2 ? bb : bsel;
-            float* o = xbuf + (32 * bk + (lane & 31)) * XP + cl;
-            f32x4 v = {acc[tt][bb][4 * q], acc[tt][bb][4 * q + 1], acc[tt][bb][4 * q + 2], acc[tt][bb][4 * q + 3]};
-            if (MODE == 0) v += bj;
-            if (dact) {
-              const f32x4 xv = *(const f32x4*)o;
-              if (g.act == NA_ACT_SIN) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_SIN);
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= tact_grad(xv[e], NA_ACT_LEAKY_RELU);
-              }
-            }
-            *(f32x4*)o = v;
-          }
-        }
+          for (int bb = 0; bb < NB; ++bb) epi_item(acc[tt][bb], t, q, NB == 2 ? bb : bsel);
       }
     }
   };
@@ -1048,9 +1053,17 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
       for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][bb][r] = 0.f;
-    for (int u = u0; u < u0 + NCH; ++u) {
+    for (int u = u0; u < u0 + NCH - 1; ++u) {
       if (wave == 0) TGL_STAMP(0, u, 0);
-      unit_body(ntc, nbc, acc, u, R, tsel, bsel);
+      unit_body(ntc, nbc, std::false_type{}, acc, u, R, tsel, bsel);
+      if (wave == 0) TGL_STAMP(0, u, 2);
+      __syncthreads();
+      if (wave == 0) TGL_STAMP(0, u, 3);
+    }
+    {
+      const int u = u0 + NCH - 1;
+      if (wave == 0) TGL_STAMP(0, u, 0);
+      unit_body(ntc, nbc, std::true_type{}, acc, u, R, tsel, bsel);
       if (wave == 0) TGL_STAMP(0, u, 2);
       __syncthreads();
       if (wave == 0) TGL_STAMP(0, u, 3);
