@@ -513,6 +513,32 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #ifndef TGL_P0D
 #define TGL_P0D 2   // ... input gradient with an activation (the first unit also parks x: 8 / 8 -> 2 / 14: 210 -> 189 us)
 #endif
+// Cache policies (gfx950 buffer aux bits: 2 = nt), experiment switches.  Timed alone in a loop, non-temporal stores of the
+// output tile take the forward from 151-156 to 136-137 us and, with the parked x fetched non-temporal too, the input gradient
+// from 200-205 to 177-180 -- but that is the loop: the same 268-MB inputs are read again by the next iteration and survive in
+// the 256-MB memory-side cache when the outputs do not pass through it.  In the training step, where every tensor is
+// written once and read by the next kernel, the three policies give 7.49 / 7.56 / 7.45 ms (tools/train_bench_ab.py): nothing.
+#ifndef TGL_ST_AUX
+#define TGL_ST_AUX 0     // the output tile's stores
+#endif
+#ifndef TGL_X_AUX
+#define TGL_X_AUX 0      // the fetches of the forward inputs x an input gradient parks
+#endif
+#ifndef TGL_LD_NT_FWD
+#define TGL_LD_NT_FWD 0
+#endif
+#ifndef TGL_LD_NT
+#define TGL_LD_NT 0      // cache policy of the row fetches (experiments): 1 nt, 2 sc1, 3 sc0 sc1
+#endif
+#if TGL_LD_NT == 1
+#define TGL_LD_POLICY " nt"
+#elif TGL_LD_NT == 2
+#define TGL_LD_POLICY " sc1"
+#elif TGL_LD_NT == 3
+#define TGL_LD_POLICY " sc0 sc1"
+#else
+#define TGL_LD_POLICY ""
+#endif
 #ifndef TGL_RIDE
 #define TGL_RIDE 0   // 1: the first column tile's epilogue rides under the second one's MFMAs, an item per k step (measured SLOWER:
                      // forward 151 -> 154 us, input gradient 191 -> 206: its LDS traffic and waits land inside the k steps)
@@ -605,15 +631,15 @@ __device__ __forceinline__ u32x4 tile_desc(const float* base, int ld, int64_t m0
 // the end of its row brings the first elements of the NEXT row along, which the caller zeroes when it USES the piece (zeroing
 // here would wait for the load).  WHICH 0: both sources, summed element by element on the spot: exact zeros outside, but it
 // waits for its loads (only the STRADDLE instantiation uses it).
-template <int WHICH = 0>
+template <int WHICH = 0, int AUX = 0>
 __device__ __forceinline__ f32x4 load_piece(const Src2& s, int row, int col) {
   if (WHICH == 1) {
     const uint32_t o = col < s.k0 ? (uint32_t)((row * s.k0 + col) * 4) : OOB;
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r0, o, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r0, o, 0, AUX));
   }
   if (WHICH == 2) {
     const uint32_t o = (col >= s.k0 && col < s.k0 + s.k1) ? (uint32_t)((row * s.k1 + col - s.k0) * 4) : OOB;
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r1, o, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r1, o, 0, AUX));
   }
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if ((s.k0 & 3) == 0) {
@@ -751,10 +777,10 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
       const int c_lo = 256 * ((u / NCH) % NP);
       if (c_lo + 256 <= g.c0 || g.c1 == 0) {
 #pragma unroll
-        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<1>(src, xr0 + XS * j, col);
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<1, TGL_X_AUX>(src, xr0 + XS * j, col);
       } else if (c_lo >= g.c0) {
 #pragma unroll
-        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<2>(src, xr0 + XS * j, col);
+        for (int j = 0; j < NXF; ++j) xs[j] = load_piece<2, TGL_X_AUX>(src, xr0 + XS * j, col);
       } else {
 #pragma unroll
         for (int j = 0; j < NXF; ++j) xs[j] = load_piece<0>(src, xr0 + XS * j, col);
@@ -793,27 +819,27 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
         if (side0) {
           if (vec0) {
             const uint32_t o0 = col < g.c0 ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, XS * j * g.c0 * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, XS * j * g.c0 * 4, TGL_ST_AUX);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const uint32_t p0 = col + e < g.c0 ? (uint32_t)((xr0 * g.c0 + col + e) * 4) : OOB;
               const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, XS * j * g.c0 * 4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, XS * j * g.c0 * 4, TGL_ST_AUX);
             }
           }
         }
         if (side1) {
           if (vec1) {
             const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, XS * j * g.c1 * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, XS * j * g.c1 * 4, TGL_ST_AUX);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ce = col + e;
               const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
               const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, XS * j * g.c1 * 4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, XS * j * g.c1 * 4, TGL_ST_AUX);
             }
           }
         }
@@ -883,7 +909,8 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
           const uint32_t o = o0 + (uint32_t)(RS * j * ld * 4);  // (OOB + a tile's worth of bytes is still out of range)
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(pf[j]) : "v"(o), "s"(d));
+          if (MODE == 1 || TGL_LD_NT_FWD) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" TGL_LD_POLICY : "=&v"(pf[j]) : "v"(o), "s"(d));
+          else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(pf[j]) : "v"(o), "s"(d));
         }
       };
       auto await = [&](f32x4 (&pf)[NPF]) __attribute__((always_inline)) {
@@ -1162,6 +1189,12 @@ extern "C" int na_debug_tgl_trace(unsigned long long* host_out) {
 #ifndef TGW_ABLATE
 #define TGW_ABLATE 0  // timing experiments: 1 no row fetches, 2 no convert / LDS fill, 4 no MFMAs, 8 no fragment reads, 16 no partials
 #endif
+#ifndef TGW_G_AUX
+#define TGW_G_AUX 0  // cache policy of the dY fetches
+#endif
+#ifndef TGW_X_AUX
+#define TGW_X_AUX 0  // ... of the x fetches
+#endif
 namespace lstn {
 constexpr int SS = 32;                // samples per stage
 constexpr int PW = 576;               // row pitch of a plane: 144 dwords = 16 mod 64 -> the 4 rows of a transposing read do not collide
@@ -1228,15 +1261,15 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const __amdgpu_buffer_rsrc_t rg = lsnt::tile_rsrc(g.dY, g.out, m0, g.N, g.part), rx = lsnt::tile_rsrc(g.x, g.in, m0, g.N, g.part);
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {  // rows r0 + 8 j: one lane offset, the row step in the scalar offset
-      if constexpr (GA) gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, 0));
+      if constexpr (GA) gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, TGW_G_AUX));
       else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, og[e & (GA ? 0 : 3)], 8 * j * g.out * 4, 0));
+        for (int e = 0; e < 4; ++e) gs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, og[e & (GA ? 0 : 3)], 8 * j * g.out * 4, TGW_G_AUX));
       }
-      if constexpr (XA) xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox[0], 8 * j * g.in * 4, 0));
+      if constexpr (XA) xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox[0], 8 * j * g.in * 4, TGW_X_AUX));
       else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ox[e & (XA ? 0 : 3)], 8 * j * g.in * 4, 0));
+        for (int e = 0; e < 4; ++e) xs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ox[e & (XA ? 0 : 3)], 8 * j * g.in * 4, TGW_X_AUX));
       }
     }
   };
