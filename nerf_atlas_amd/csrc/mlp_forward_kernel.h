@@ -2,6 +2,10 @@
 #pragma once
 #include "mlp_layout.h"
 #include "encoders.h"
+#ifndef NA_MLP_OUT_NT
+#define NA_MLP_OUT_NT 0  // 1: the network's output rows leave with non-temporal stores (measured: the chains of configs 3 / 4 / 5m,
+                         // whose next kernel reads them at once, get 1-4 % SLOWER: 594 -> 568, 575 -> 568, 554 -> 542 Msamples/s in bf16)
+#endif
 
 namespace na {
 
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_forward_kernel(MlpArgs a, Til
           const int f0 = 32 * j + acc_row(4 * q, lane);
           if (f0 + 4 <= a.d.out_size) {
             const f32x4u v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            *(f32x4u*)(yrow + f0) = v;
+            if (NA_MLP_OUT_NT) __builtin_nontemporal_store(v, (f32x4u*)(yrow + f0)); else *(f32x4u*)(yrow + f0) = v;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
