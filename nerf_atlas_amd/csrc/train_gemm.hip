@@ -13,6 +13,9 @@
 // double-buffered LDS tile pair [rows][32 k] of hi and lo bf16 with an 80-byte row pitch (conflict-free ds_read_b128
 // fragments), global loads for stage k+1 in flight under the MFMAs of stage k, one barrier per stage.  The activation
 // (and the split) is applied once per element by the loader; with BN = 256 a sample's row is activated exactly once.
+// These K-staged kernels serve small batches and very wide layers; since round 3 every launch with N >= 2048 and at most 1024
+// output columns goes to the layer-synchronous kernels in the second half of this file (`lsnt`, `lstn`), which keep the
+// arithmetic (same products, same order per output) and reorganise the data flow.
 #include <atomic>
 #include <type_traits>
 #include <stdlib.h>
@@ -524,9 +527,6 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #ifndef TGL_X_AUX
 #define TGL_X_AUX 0      // the fetches of the forward inputs x an input gradient parks
 #endif
-#ifndef TGL_LD_NT_FWD
-#define TGL_LD_NT_FWD 0
-#endif
 #ifndef TGL_LD_NT
 #define TGL_LD_NT 0      // cache policy of the row fetches (experiments): 1 nt, 2 sc1, 3 sc0 sc1
 #endif
@@ -909,8 +909,7 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
           const uint32_t o = o0 + (uint32_t)(RS * j * ld * 4);  // (OOB + a tile's worth of bytes is still out of range)
-          if (MODE == 1 || TGL_LD_NT_FWD) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" TGL_LD_POLICY : "=&v"(pf[j]) : "v"(o), "s"(d));
-          else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(pf[j]) : "v"(o), "s"(d));
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" TGL_LD_POLICY : "=&v"(pf[j]) : "v"(o), "s"(d));
         }
       };
       auto await = [&](f32x4 (&pf)[NPF]) __attribute__((always_inline)) {
