@@ -548,7 +548,7 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #endif
 namespace lsnt {
 #if TGL_TRACE
-__device__ unsigned long long tgl_trace[2][32][4];
+__device__ unsigned long long tgl_trace[3][32][4];
 #define TGL_STAMP(role, u, slot) do { if (blockIdx.x == 0 && lane == 0 && (u) < 32) tgl_trace[role][(u)][slot] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TGL_STAMP(role, u, slot) do {} while (0)
@@ -821,9 +821,15 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
             const uint32_t o0 = col < g.c0 ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, XS * j * g.c0 * 4, TGL_ST_AUX);
           } else {
+            // rows of a length that is no multiple of four: a piece that lies inside its row still leaves as ONE 16-byte store
+            // (4-byte aligned: tools/hw/unaligned_probe.hip), only the piece across the row's end element by element --
+            // 38 four-byte stores per row of a skip layer's second gradient kept the mover's queue busy for 10 k cycles
+            const bool whole = col + 3 < g.c0;
+            const uint32_t o0 = whole ? (uint32_t)((xr0 * g.c0 + col) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry0, o0, XS * j * g.c0 * 4, TGL_ST_AUX);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const uint32_t p0 = col + e < g.c0 ? (uint32_t)((xr0 * g.c0 + col + e) * 4) : OOB;
+              const uint32_t p0 = (!whole && col + e < g.c0) ? (uint32_t)((xr0 * g.c0 + col + e) * 4) : OOB;
               const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry0, p0, XS * j * g.c0 * 4, TGL_ST_AUX);
             }
@@ -834,10 +840,13 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
             const uint32_t o1 = (col >= g.c0 && col < ncols) ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, XS * j * g.c1 * 4, TGL_ST_AUX);
           } else {
+            const bool whole = col >= g.c0 && col + 3 < ncols;
+            const uint32_t o1 = whole ? (uint32_t)((xr0 * g.c1 + col - g.c0) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry1, o1, XS * j * g.c1 * 4, TGL_ST_AUX);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ce = col + e;
-              const uint32_t p1 = (ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
+              const uint32_t p1 = (!whole && ce >= g.c0 && ce < ncols) ? (uint32_t)((xr0 * g.c1 + ce - g.c0) * 4) : OOB;
               const float w = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), ry1, p1, XS * j * g.c1 * 4, TGL_ST_AUX);
             }
@@ -855,18 +864,22 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
       for (int u = 0; u < nunits; ++u) {
         const int i = u % NCH;
         const bool park = xlds && i == NCH - 2;
+        if (wave == 8) TGL_STAMP(2, u, 0);
         if (park) {
 #pragma unroll
           for (int j = 0; j < NXF; ++j) asm volatile("" ::"v"(xs[j]));
         }
+        if (wave == 8) TGL_STAMP(2, u, 1);
         if (u >= NCH) {
           if (i == 0) take_out();
           store_out(u - 1 - i, i);
         }
+        if (wave == 8) TGL_STAMP(2, u, 2);
         if (park) {
           xstore();
           xload(u + NCH);
         }
+        if (wave == 8) TGL_STAMP(2, u, 3);
         __syncthreads();
       }
       take_out();
