@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training GEMMs (csrc/train_gemm.hip) against an fp64 torch reference over the shapes the five configs use, and their times.
 
-  python tools/gemm_check.py [--time]
+  python tools/gemm_check.py [--time [--cold]]
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,8 +13,25 @@ ACTS = {"none": (lambda v: v, lambda v: torch.ones_like(v)),
         "sin": (torch.sin, torch.cos)}
 
 
+_flush = None
+
+
 def t_us(f, n=10):
+    """--time: back-to-back calls on the same buffers (their inputs partly survive in the 256-MB memory-side cache from one call
+    to the next: up to ~10 % optimistic against the same kernel inside a training step); --time --cold: a 1-GiB fill between the
+    calls, each call timed on its own with events."""
+    global _flush
     for _ in range(2): f()
+    if "--cold" in sys.argv:
+        if _flush is None:
+            _flush = torch.empty(1 << 28, device="cuda")
+        tot = 0.0
+        for _ in range(n):
+            _flush.fill_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); f(); b.record(); torch.cuda.synchronize()
+            tot += a.elapsed_time(b)
+        return tot / n * 1e3
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
