@@ -410,8 +410,12 @@ def linear_wgrad(x0: torch.Tensor, dY: torch.Tensor, pre_act: str = "none", x1: 
         x1 = _f32(x1, "x1")
         in1 = x1.shape[1]
     out = dY.shape[1]
-    dW = torch.zeros(out, in0 + in1, device=x0.device, dtype=torch.float32)
-    db = torch.zeros(out, device=x0.device, dtype=torch.float32) if want_bias else None
+    # (one zero fill for both accumulators: db sits behind dW, on a 16-byte boundary)
+    nW = out * (in0 + in1)
+    pad = (-nW) % 4
+    acc = torch.zeros(nW + pad + (out if want_bias else 0), device=x0.device, dtype=torch.float32)
+    dW = acc[:nW].view(out, in0 + in1)
+    db = acc[nW + pad:] if want_bias else None
     fn = lib.na_linear_wgrad_bf16x3 if split_bf16 else lib.na_linear_wgrad
     check(fn(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(dY), out, ACT[pre_act], _ptr(dW), _ptr(db), _stream()))
     return dW, db
