@@ -510,6 +510,9 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #ifndef TGL_PRIO
 #define TGL_PRIO 0   // s_setprio of the loader and mover waves
 #endif
+#ifndef TGL_CPRIO
+#define TGL_CPRIO 0  // s_setprio of the consumer waves (1, 3: 147-151 against 153-160 us forward alone, 7.5-7.9 ms in the step either way)
+#endif
 #ifndef TGL_P0F
 #define TGL_P0F 6   // of the 16 pieces a mover thread stores per tile, those that go out in the first of the tile's two units: forward
 #endif
@@ -958,6 +961,7 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
   }
 
   // -------------------------------------------------------------------------------------------------- consumers
+  if (TGL_CPRIO) __builtin_amdgcn_s_setprio(TGL_CPRIO);
   const int ncols = g.c0 + g.c1;
   bf16x8 ring[RD][2];    // [k step of the segment][plane]
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.wp, 0, nrg * NCH * 2 * SEG, 0x00020000);
