@@ -15,7 +15,8 @@
 // (and the split) is applied once per element by the loader; with BN = 256 a sample's row is activated exactly once.
 // These K-staged kernels serve small batches and very wide layers; since round 3 every launch with N >= 2048 and at most 1024
 // output columns goes to the layer-synchronous kernels in the second half of this file (`lsnt`, `lstn`), which keep the
-// arithmetic (same products, same order per output) and reorganise the data flow.
+// arithmetic (the same three products per k, fp32 accumulation; the order of the additions differs: last-bit differences) and
+// reorganise the data flow.
 #include <atomic>
 #include <type_traits>
 #include <stdlib.h>
