@@ -79,3 +79,33 @@ def test_only_requested_gradient_halves_are_written(ops):
     none0, only1 = ops.linear_dgrad(gy, W, x0, "leaky_relu", x1=x1, want0=False)
     assert none1 is None and none0 is None
     assert torch.equal(only0, full0) and torch.equal(only1, full1)
+
+
+def test_layer_synchronous_and_k_staged_kernels_agree(tmp_path):
+    """The two implementations of the forward / input gradient (the choice is made once per process: two subprocesses) form the
+    same three bf16 products per k in fp32 and add them in another order: equal to a few units in the last place of the O(1)
+    values (measured 2e-7 .. 1e-6 absolute), not bit for bit."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm_ls_vs_tiled.py")
+    files = {}
+    for mode in ("ls", "tiled"):
+        env = dict(os.environ)
+        env.pop("NA_TRAIN_GEMM", None)
+        if mode == "tiled":
+            env["NA_TRAIN_GEMM"] = "tiled"
+        files[mode] = str(tmp_path / f"{mode}.pt")
+        r = subprocess.run([sys.executable, tool, files[mode]], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    a, b = torch.load(files["ls"]), torch.load(files["tiled"])
+    worst = 0.0
+    for k in a:
+        for ta, tb in zip(a[k], b[k]):
+            if ta is None:
+                assert tb is None
+                continue
+            assert ta.shape == tb.shape
+            worst = max(worst, float((ta - tb).abs().max() / tb.abs().max()))
+    print(f"layer-synchronous vs K-staged: worst relative difference {worst:.2e}")
+    assert worst <= 2e-6, worst
