@@ -879,10 +879,10 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
           store_out(u - 1 - i, i);
         }
         if (wave == 8) TGL_STAMP(2, u, 2);
-        if (park) {
-          xstore();
-          xload(u + NCH);
-        }
+        if (park) xstore();
+        // the next (tile, pass)'s x is requested one unit later, behind the last stores of the tile in flight: with both the tile
+        // (16 registers x 4) and the parked x (another 64) alive through every unit the movers spilled
+        if (xlds && i == NCH - 1) xload(u + 1);
         if (wave == 8) TGL_STAMP(2, u, 3);
         __syncthreads();
       }
