@@ -19,7 +19,9 @@ SHAPES = [(4096, 256, 0, 256), (2048 + 37, 256, 0, 256), (8192 + 5, 38, 0, 256),
           (4096, 512, 0, 512), (5000, 100, 0, 1000), (3000, 1000, 24, 72), (2048, 128, 128, 128),
           # a k chunk that holds columns of both sources (the loader's own instantiation), rows of 38 and 63 floats (16-byte
           # fetches at 4-byte alignment, tails zeroed at conversion), 6 and 7 column groups (a pair / three waves in the last pass)
-          (4096 + 3, 64, 38, 64), (4096, 63, 0, 128), (4096 + 17, 256, 0, 325), (2048 + 5, 128, 0, 448)]
+          (4096 + 3, 64, 38, 64), (4096, 63, 0, 128), (4096 + 17, 256, 0, 325), (2048 + 5, 128, 0, 448),
+          # both sources ragged: 16-byte pieces of the gradient straddle the boundary between the two outputs at column 38
+          (4096 + 1, 38, 69, 128)]
 
 
 @pytest.fixture(scope="module")
