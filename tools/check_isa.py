@@ -8,6 +8,12 @@ for: `nerf_atlas_amd/build.py` compiles the three render_ls units with -save-tem
 contains `render_ls_kernel` holds one of those instructions.  This script runs the same check on the listings of the last
 build (or on listings given on the command line) and prints what it scanned.
 
+Second check (round 3): `v_cvt_scalef32_2xpk16_{fp6,bf6}_f32` writes its six destination registers while it still reads its
+scale and the tails of its sources; the compiler does not mark the destination early-clobber, so a register allocation can
+overlap them and the instruction then packs wrong values (tools/hw/cvt_fp6_overlap.hip; found through an
+`-mllvm -amdgpu-sched-strategy=...` build whose fp6 weight pack differed).  Every instance of every function of the listing is
+checked (`build.check_cvt_overlap`); the build fails on an offender.
+
     python tools/check_isa.py [listing.s ...]
 """
 import os
@@ -29,7 +35,11 @@ def main(argv):
         print(f"{name}: {len(seen)} {B.ISA_KERNEL} instantiation(s) scanned, {nbad} packed-fp32 instruction(s)")
         for k, v in bad.items():
             print(f"  {k}: " + ", ".join(f"{m}@{n}" for n, m in v[:8]))
-        if not seen or nbad:
+        cbad, ncvt = B.check_cvt_overlap(path)
+        print(f"  {ncvt} multi-pass fp6 conversion(s) scanned, {len(cbad)} with an operand overlapping the destination")
+        for n, text in cbad[:8]:
+            print(f"    line {n}: {text}")
+        if not seen or nbad or cbad:
             rc = 1
     return rc
 
