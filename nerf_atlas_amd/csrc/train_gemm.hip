@@ -492,9 +492,8 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 // pre-packed bf16 hi/lo fragments of B from L2 straight into registers (a fragment ring refilled in place), so B never
 // passes through LDS or the split arithmetic again and A is read from HBM as whole contiguous rows (the K-staged kernel
 // moved 48 KiB through the vector memory path per 24 MFMAs and was bound by that path).
-// Three roles of four waves (twelve waves, three per SIMD, 168 registers each).  LOADERS (waves 4-7) fetch the rows three units
-// ahead into registers -- hand-issued buffer loads with hand-counted waits, see the kernel -- activate + split them and fill
-// the other LDS buffer.  MOVERS (waves 8-11) carry the finished output tile from LDS to HBM, in parts spread over the units
+// Three roles of four waves (twelve waves, three per SIMD, 168 registers each).  LOADERS (waves 4-7) fetch the rows two units
+// ahead into registers, activate + split them and fill the other LDS buffer.  MOVERS (waves 8-11) carry the finished output tile from LDS to HBM, in parts spread over the units
 // of the next tile, and for the input gradient with an activation bring the tile of forward inputs into LDS.  CONSUMERS
 // (waves 0-3, one 64-column group of C each) run the MFMAs and the epilogue and touch HBM never: loads and stores of one wave
 // retire in order, so a row fetch (HBM latency) or a tile store in front of a weight fragment (L2) would stall the matrix
@@ -530,18 +529,6 @@ static int dispatch_nt(const NtArgs& a, int ncols, hipStream_t st, const char* w
 #endif
 #ifndef TGL_X_AUX
 #define TGL_X_AUX 0      // the fetches of the forward inputs x an input gradient parks
-#endif
-#ifndef TGL_LD_NT
-#define TGL_LD_NT 0      // cache policy of the row fetches (experiments): 1 nt, 2 sc1, 3 sc0 sc1
-#endif
-#if TGL_LD_NT == 1
-#define TGL_LD_POLICY " nt"
-#elif TGL_LD_NT == 2
-#define TGL_LD_POLICY " sc1"
-#elif TGL_LD_NT == 3
-#define TGL_LD_POLICY " sc0 sc1"
-#else
-#define TGL_LD_POLICY ""
 #endif
 #ifndef TGL_RIDE
 #define TGL_RIDE 0   // 1: the first column tile's epilogue rides under the second one's MFMAs, an item per k step (measured SLOWER:
@@ -620,14 +607,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, i
   if (bytes > 0x70000000ll) bytes = 0x70000000ll;
   if (bytes < 0) bytes = 0;
   return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)dummy : base + m0 * ld), 0, (int)bytes, 0x00020000);
-}
-// the same descriptor as four plain words, for the hand-issued loads below
-__device__ __forceinline__ u32x4 tile_desc(const float* base, int ld, int64_t m0, int64_t rows) {
-  int64_t bytes = base == nullptr ? 0 : (rows - m0) * ld * 4;
-  if (bytes > 0x70000000ll) bytes = 0x70000000ll;
-  if (bytes < 0) bytes = 0;
-  const uint64_t a = base == nullptr ? 0 : (uint64_t)(base + m0 * ld);
-  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
 }
 // WHICH: 1 the first source only, 2 the second only -- a caller that knows where its columns lie (a whole k chunk inside one
 // source): ONE 16-byte load per piece whatever the row length.  Raw-buffer loads of 16 bytes need only 4-byte alignment and
@@ -892,11 +871,20 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
     }
     // loaders, during unit u: fill the other buffer with unit u + 1, fetch unit u + 1 + PD into the registers this frees.
     // (no conditions around the fetches: units past the end read rows past the batch = zeros)
-    if constexpr (STRADDLE) {
+    // (The wait counts are the compiler's.  A version of this loop issued the fetches by inline asm and waited for them with a
+    // hand-counted `s_waitcnt vmcnt(16)`, three units in flight: not faster in the final structure (151-154 against 154-155 us
+    // forward, 185-188 against 191 input gradient) and WRONG under another instruction scheduler -- registers the compiler does
+    // not know to be in flight get copied: `-mllvm -amdgpu-sched-strategy=max-ilp` produced 1e34.  With the fetches visible to
+    // the compiler the three schedulers give the same bits.)
+    {
       auto step = [&](f32x4 (&pf)[NPF], int u, char* other) __attribute__((always_inline)) {
+        if (wave == 4) TGL_STAMP(1, u, 0);
         if (!resident(u + 1)) convert(pf, other, u + 1);
+        if (wave == 4) TGL_STAMP(1, u, 1);
         load(pf, u + 3);
+        if (wave == 4) TGL_STAMP(1, u, 2);
         __syncthreads();
+        if (wave == 4) TGL_STAMP(1, u, 3);
       };
       load(pf0, 0);
       load(pf1, 1);
@@ -906,56 +894,6 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
       for (int u = 0; u < nunits; u += 2) {
         step(pf1, u, smem + BUF);
         if (u + 1 < nunits) step(pf0, u + 1, smem);
-      }
-    } else {
-      // The fetches are issued by hand and waited for by hand.  A loader's vector memory queue holds nothing but these fetches,
-      // NPF per unit, in order: when unit u + 1's rows are needed exactly (PD - 1) NPF younger fetches are outstanding, so
-      // `s_waitcnt vmcnt((PD - 1) NPF)` is the exact wait.  The compiler's own counts were not: with the loop's uniform
-      // branches (which source, which activation, resident chunks) it waited with vmcnt(7) .. vmcnt(0) through a conversion,
-      // i.e. for the rows requested one unit ago as well -- the prefetch was one unit deep whatever the code said, and at
-      // 4 TB/s with 32 MB in flight a fetch takes a whole unit to come back.
-      constexpr int PD = 3;
-      f32x4 pf2[NPF];
-      auto issue = [&](f32x4 (&pf)[NPF], int u) __attribute__((always_inline)) {
-        const int64_t m0 = ((TGL_ABLATE & 1) || resident(u) ? g.ntiles : tile_of(u)) * TS;
-        const int k_lo = (u % NCH) * KC, k = k_lo + c4 * 4;
-        const bool first = k_lo + KC <= g.a.k0 || g.a.k1 == 0;  // (uniform) the chunk lies inside the first source, or the second
-        const u32x4 d = first ? tile_desc(g.a.p0, g.a.k0, m0, g.a.rows) : tile_desc(g.a.p1, g.a.k1, m0, g.a.rows);
-        const int ld = first ? g.a.k0 : g.a.k1, col = first ? k : k - g.a.k0;
-        const uint32_t o0 = col < ld ? (uint32_t)((r0 * ld + col) * 4) : OOB;
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-          const uint32_t o = o0 + (uint32_t)(RS * j * ld * 4);  // (OOB + a tile's worth of bytes is still out of range)
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" TGL_LD_POLICY : "=&v"(pf[j]) : "v"(o), "s"(d));
-        }
-      };
-      auto await = [&](f32x4 (&pf)[NPF]) __attribute__((always_inline)) {
-        static_assert(NPF == 8, "operand list below");
-        asm volatile("s_waitcnt vmcnt(%8)"
-                     : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]), "+v"(pf[7])
-                     : "n"((PD - 1) * NPF));
-      };
-      auto step = [&](f32x4 (&pf)[NPF], int u, char* other) __attribute__((always_inline)) {
-        if (wave == 4) TGL_STAMP(1, u, 0);
-        await(pf);
-        if (!resident(u + 1)) convert(pf, other, u + 1);
-        if (wave == 4) TGL_STAMP(1, u, 1);
-        issue(pf, u + 1 + PD);
-        if (wave == 4) TGL_STAMP(1, u, 2);
-        __syncthreads();
-        if (wave == 4) TGL_STAMP(1, u, 3);
-      };
-      issue(pf0, 0);
-      issue(pf1, 1);
-      issue(pf2, 2);
-      await(pf0);
-      convert(pf0, smem, 0);
-      issue(pf0, 3);
-      __syncthreads();
-      for (int u = 0; u < nunits; u += 3) {
-        step(pf1, u, smem + ((u + 1) & 1) * BUF);
-        if (u + 1 < nunits) step(pf2, u + 1, smem + (u & 1) * BUF);
-        if (u + 2 < nunits) step(pf0, u + 2, smem + ((u + 1) & 1) * BUF);
       }
     }
     return;
