@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnerf_atlas_amd.so")
+# NA_LIB_PATH: another build of the same library (experiments such as tools/sched_fuzz.py full: the whole GPU suite against it)
+LIB_PATH = os.environ.get("NA_LIB_PATH") or os.path.join(HERE, "libnerf_atlas_amd.so")
 
 c_f32p = C.c_void_p  # device pointers travel as integers
 c_i64 = C.c_int64

@@ -6,6 +6,10 @@ GEMMs whose in-flight registers the compiler copied.
 
     python tools/sched_fuzz.py build          # here (hipcc cross-compiles): gpurun_ablate/lib_var_<unit>_<strategy>.so
     python tools/sched_fuzz.py run            # on the GPU box: every variant against the shipped library, bit for bit
+
+The whole library under another scheduler (round 3: max-ilp, 248 GPU tests green; iterative-ilp fails to compile basic_ops.hip):
+    build it into a side directory (nerf_atlas_amd.build with OBJ / LIB / FLAGS pointed elsewhere) and run
+    NA_LIB_PATH=<that>/libnerf_atlas_amd.so python -m pytest tests -m gpu -q
 """
 import os
 import subprocess
