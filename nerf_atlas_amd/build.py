@@ -70,7 +70,7 @@ def _headers_digest() -> str:
 def _unit_digest(unit, headers: str) -> str:
     src, extra, suffix, isa = unit
     h = hashlib.sha256(headers.encode())
-    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v2"] if isa else [])).encode())
+    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v3"] if isa else [])).encode())
     with open(os.path.join(CSRC, src), "rb") as fh:
         h.update(fh.read())
     return h.hexdigest()
@@ -116,27 +116,53 @@ def check_isa(listing: str, kernel: str = ISA_KERNEL, forbidden=ISA_FORBIDDEN):
     return bad, seen
 
 
-_CVT_SCALE = re.compile(r"^\s*(v_cvt_scalef32_2xpk16_\w+)\s+v\[(\d+):(\d+)\],\s*v\[(\d+):(\d+)\],\s*v\[(\d+):(\d+)\],\s*v(\d+)")
+_CVT_MNEMONIC = re.compile(r"^\s*(v_cvt_scalef32_(?:2xpk16|pk32)_(?:fp6|bf6)_\w+)\s+(.*)$")
+_VREG = re.compile(r"^v\[(\d+):(\d+)\]$|^v(\d+)$")
+
+
+def _vrange(op):
+    """'v[4:9]' -> (4, 9), 'v7' -> (7, 7); anything else (an SGPR, a literal) -> None"""
+    m = _VREG.match(op.strip())
+    if not m:
+        return None
+    return (int(m.group(1)), int(m.group(2))) if m.group(1) is not None else (int(m.group(3)), int(m.group(3)))
 
 
 def check_cvt_overlap(listing: str):
-    """v_cvt_scalef32_2xpk16_{fp6,bf6}_f32 vdst[6], src0[16], src1[16], scale writes its destination while it still reads its
-    operands (hardware probe tools/hw/cvt_fp6_overlap.hip: a scale in vdst[1] corrupts destination dwords 2..5, a destination on
-    the LAST six registers of src1 dwords 3..5; a destination on the FIRST six registers of a source, or a scale in vdst[5], is
-    fine), and the compiler (ROCm 7.2) does not mark the destination early-clobber -- its register allocator produced
-    `v[0:5], v[32:47], v[48:63], v1` for the fp6 weight pack under another instruction scheduler.  Every instance in the whole
-    listing (all functions) must therefore keep the scale outside the destination and the destination either disjoint from a
-    source or on that source's first six registers.  Returns [(line number, text)] of the offenders and the number scanned."""
+    """The multi-pass fp6 conversions -- v_cvt_scalef32_2xpk16_{fp6,bf6}_f32 vdst[6], src0[16], src1[16], scale and
+    v_cvt_scalef32_pk32_{fp6,bf6}_{f16,bf16,f32} vdst[6], src[16|32], scale -- write their destination while they still read
+    their operands (hardware probe tools/hw/cvt_fp6_overlap.hip: a scale in vdst[1] corrupts destination dwords 2..5, a
+    destination on the LAST six registers of src1 dwords 3..5; a destination on the FIRST six registers of a source, or a scale
+    in vdst[5], is fine), and the compiler (ROCm 7.2) does not mark the destination early-clobber -- its register allocator
+    produced `v[0:5], v[32:47], v[48:63], v1` for the fp6 weight pack under another instruction scheduler.  Every instance in
+    the whole listing (all functions) must therefore keep a VGPR scale outside the destination and the destination either
+    disjoint from a source or on that source's first six registers.  The mnemonic is matched FIRST: an instance whose operand
+    list does not parse is an offender, not a silent pass (a scalar or literal scale is accepted and cannot overlap).
+    Returns [(line number, text)] of the offenders and the number scanned."""
     bad, n_seen = [], 0
     with open(listing) as fh:
         for n, line in enumerate(fh, 1):
-            m = _CVT_SCALE.match(line)
+            m = _CVT_MNEMONIC.match(line)
             if not m:
                 continue
             n_seen += 1
-            d0, d1, a0, a1, b0, b1, sc = (int(m.group(i)) for i in range(2, 9))
-            ok = not (d0 <= sc <= d1)
-            for s0, s1 in ((a0, a1), (b0, b1)):
+            ops = [o.strip() for o in m.group(2).split(";")[0].split(",")]
+            ops = [o for o in ops if o and not o.startswith(("op_sel", "clamp", "neg", "abs"))]
+            want = 4 if "2xpk16" in m.group(1) else 3
+            if len(ops) < want:
+                bad.append((n, line.strip()))
+                continue
+            dst = _vrange(ops[0])
+            srcs = [_vrange(o) for o in ops[1:want - 1]]
+            scale = _vrange(ops[want - 1])  # None: SGPR / literal scale
+            if dst is None or any(r is None for r in srcs):
+                bad.append((n, line.strip()))
+                continue
+            d0, d1 = dst
+            ok = True
+            if scale is not None and d0 <= scale[0] <= d1:
+                ok = False
+            for s0, s1 in srcs:
                 overlap = not (d1 < s0 or s1 < d0)
                 if overlap and d0 != s0:
                     ok = False

@@ -28,6 +28,17 @@ def kernel_precision(has_f16x: bool = False) -> str:
     return precision
 
 
+# Packed weight streams are cached per module and re-packed when a Parameter's version counter or address changes
+# (utils.invalidate_packed documents what that misses: writes through `.data`, out-of-band copies).  True = pack on every
+# forward instead (four small launches per model, ~30 us): for callers that update weights behind torch's back.
+repack_always = False
+
+
+def set_repack_always(on: bool):
+    global repack_always
+    repack_always = bool(on)
+
+
 # Training-step GEMMs (forward / input gradient / weight gradient of every Linear while gradients are recorded):
 # "bf16x3" = the same 2-way split on the bf16 matrix core (relative error ~2^-16 per GEMM, HBM-bound kernels);
 # "fp32" = exact fp32 on the f32 matrix core (gradient-parity mode, ~4x slower per step).

@@ -88,21 +88,25 @@ constexpr int kPartialFloats = 8;
 //   the producer's two tiles: the producing lane is the consuming lane (lane = (sample, k half)), as for the f16 fragments.
 //   Weight stream per row group: 16 init / geometry chunk PAIRS in the bf16x3 layout with f16 elements (f16 hi + f16 lo planes,
 //   three f16 products), then 40 uniform hidden RECORDS (one per (Linear, Q); the out Linears use tile 0 only):
-//   2 tiles x 4 f16 fragments (8 KiB) | 2 tiles x 48 bytes per lane {WL6 = fp6(W - f16 W) | WT6 = fp6(W)} as three lane-linear
-//   16-byte parts (3 KiB per tile: twelve consecutive registers hold both operands) | one dword per lane with the four E8M0
-//   scale bytes (WL6 t0, WT6 t0, WL6 t1, WT6 t1).  The MFMA phase is bound by the 64 B/clk the vector memory path delivers
-//   per CU (a record feeds 24 MFMAs = 768 cycles; four waves x 14.25 KiB = 912 cycles of that path), so every byte counts.
+//   2 tiles x 4 f16 fragments (8 KiB) | 48 bytes per lane {WL6 of tile 0 | WL6 of tile 1}, WL6 = fp6(W - f16 W), as three
+//   lane-linear 16-byte parts (3 KiB: twelve consecutive registers hold both operands) | one dword per lane with the four E8M0
+//   scale bytes (WL6 t0, WT6 t0, WL6 t1, WT6 t1).  The second correction operand WT6 = fp6(W) is NOT in the stream (round 4):
+//   the consuming wave derives it from the tile's four f16 fragments with ONE v_cvt_scalef32_pk32_fp6_f16 (the lane's 32
+//   halves of the K64 group sit in sixteen consecutive registers), so its slot order is the fragments' element order
+//   (slot 8 c + e <-> chunk c, element e) and the activation side packs the residual plane R in that order.  The MFMA phase
+//   is bound by the 64 B/clk the vector memory path delivers per CU (a record feeds 24 MFMAs = 768 cycles; four waves x
+//   14.25 KiB were 912 cycles of that path, 11.25 KiB are 720), so every byte counts.
 #ifndef NA_LSX_PRIO
 #define NA_LSX_PRIO 0  // experiments: 0 the MFMA phases run at s_setprio 1 (like the other precisions), 1 no priorities, 2 the epilogues
 #endif
 #ifndef NA_LSX_EXP
-#define NA_LSX_EXP 0  // timing experiments (tools/ls_variant.py): 1 two of three fp6 parts, 2 no fp6 loads, 4 no f16 refills,
-                     // 8 no LDS reads of the T plane, 16 no LDS writes of the T plane
+#define NA_LSX_EXP 0  // timing experiments (tools/ls_variant.py): 2 no fp6 loads, 4 no f16 refills,
+                     // 8 no LDS reads of the T plane, 16 no LDS writes of the T plane, 32 no WT6 derivation
 #endif
 namespace x {
 constexpr int KQ = 4096 + 2 * 2048;          // LDS bytes per (block, K64 group)
 constexpr int BLKH = 4 * KQ;                 // hidden activations of one block (32 KiB)
-constexpr int REC = 8192 + 2 * 3072 + 256;   // stream bytes per record (14.25 KiB)
+constexpr int REC = 8192 + 3072 + 256;       // stream bytes per record (11.25 KiB)
 constexpr int PAIRB = 4096;                  // stream bytes per init / geometry chunk pair
 // pairs / records per pass and row group of the four schedules (MODEL 0 PlainNeRF: first.init 3, first.L0 3, view.init 4 +
 // geometry, view.L0 4 + geometry | first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4;  1 TinyNeRF: init, two skip
@@ -464,14 +468,17 @@ __device__ __forceinline__ void mma6(f32x16& acc, const i32x8& A, int sa, const 
 struct PairR {  // one init / geometry chunk pair: tiles 0 and 1, f16 hi and lo planes
   Frag<NA_PREC_F16X> t0, t1;
 };
+typedef __attribute__((ext_vector_type(16))) uint32_t u32x16;
 struct Regs {   // weight registers that live across phases
   PairR pr[2];       // pair ring: slot i & 1 holds pair i
-  f16x8 a16[4][2];   // f16 fragments of the current record, refilled in place with the next record's
-  // fp6 operands (+ scale dword) of the current record; the next record's are requested right behind the group's scaled
-  // MFMAs and have the next group's sixteen f16 MFMAs to arrive (a second buffer costs 32 registers the kernel does not have).
-  // Clang vectors (one 12-dword vector per tile = both operands): as {u32x4, u32x2} structs the member stayed in scratch memory
-  u32x12 a6[2];
-  int asc;
+  // f16 fragments of the current record, one 16-dword vector per tile (chunk c = dwords 4 c .. 4 c + 3: the conversion that
+  // derives WT6 takes the tile's 32 halves from sixteen consecutive registers), refilled in place with the next record's
+  u32x16 a16[2];
+  // WL6 of both tiles (dwords 0..5 tile 0, 6..11 tile 1) of the current record; the next record's are requested right behind
+  // the group's scaled MFMAs and have the next group's sixteen f16 MFMAs to arrive (a second buffer costs registers the kernel
+  // does not have).  A clang vector: as a {u32x4, u32x2} struct member it stayed in scratch memory
+  u32x12 a6;
+  int asc[2];        // scale dwords: record i's in slot i & 1, requested a whole K64 group ahead (the WT6 conversion needs it early)
 };
 
 __device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int xbase, int i) {
@@ -481,25 +488,35 @@ __device__ __forceinline__ PairR wpair(__amdgpu_buffer_rsrc_t rs, int lane, int 
   return p;
 }
 // record loads: soff = a 4-KiB-aligned scalar base inside the record, the rest of the offset is an instruction immediate
-__device__ __forceinline__ f16x8 wload16(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t, int c) {
-  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + c * 1024, roff + t * 4096, 0));
+__device__ __forceinline__ u32x4 wload16(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t, int c) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + c * 1024, roff + t * 4096, 0);
 }
-// the two fp6 operands of tile t: dwords 0..5 WL6, 6..11 WT6
-__device__ __forceinline__ u32x12 wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff, int t) {
-  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + 8192 + t * 3072, 0);
-  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 1024, roff + 8192 + t * 3072, 0);
-#if NA_LSX_EXP & 1  // timing experiment: two of the three parts
-  const u32x4 c = b;
-#else
-  const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 2048, roff + 8192 + t * 3072, 0);
-#endif
+__device__ __forceinline__ f16x8 a16frag(const u32x16& v, int c) {
+  return __builtin_bit_cast(f16x8, u32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]});
+}
+__device__ __forceinline__ void a16set(u32x16& v, int c, const u32x4& q) {
+  v[4 * c] = q[0]; v[4 * c + 1] = q[1]; v[4 * c + 2] = q[2]; v[4 * c + 3] = q[3];
+}
+// WL6 of both tiles: dwords 0..5 tile 0, 6..11 tile 1
+__device__ __forceinline__ u32x12 wload6(__amdgpu_buffer_rsrc_t rs, int lane, int roff) {
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, roff + 8192, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 1024, roff + 8192, 0);
+  const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + 2048, roff + 8192, 0);
   return u32x12{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
 }
 __device__ __forceinline__ int wloadsc(__amdgpu_buffer_rsrc_t rs, int lane, int roff) {
-  return (int)__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, roff + 8192 + 6144, 0);
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, roff + 8192 + 3072, 0);
 }
 __device__ __forceinline__ i32x8 lo6(const u32x12& v) { return i32x8{(int)v[0], (int)v[1], (int)v[2], (int)v[3], (int)v[4], (int)v[5], 0, 0}; }
 __device__ __forceinline__ i32x8 hi6(const u32x12& v) { return i32x8{(int)v[6], (int)v[7], (int)v[8], (int)v[9], (int)v[10], (int)v[11], 0, 0}; }
+__device__ __forceinline__ i32x8 op6(const i32x6& v) { return i32x8{v[0], v[1], v[2], v[3], v[4], v[5], 0, 0}; }
+// 32 halves (sixteen consecutive registers) -> 32 fp6 e2m3 in element order, divided by the scale's power of two.  Early-clobber
+// like cvt_fp6_disjoint below: the multi-pass conversions write their destination while they still read their operands.
+__device__ __forceinline__ i32x6 cvt_fp6_f16_disjoint(const u32x16& h, float scale) {
+  i32x6 d;
+  asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(d) : "v"(h), "v"(scale));
+  return d;
+}
 
 // ---- N init chunk pairs (pairs I0 .. I0+N-1 of the pass) against the init chunks 0..N-1 of the NB blocks: three f16 products
 // (the phase's first products take the bias registers `cb` as their C operand: the accumulators are written, never initialised)
@@ -582,6 +599,10 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
     int nrc = rec0 + Q + 1;
     nrc = nrc >= NREC ? 0 : nrc;
     const int noff = __builtin_amdgcn_readfirstlane(xrec + nrc * REC);
+    // the NEXT record's scale bytes, a whole group ahead (its WT6 conversion runs behind the second chunk of its group)
+    if (!(NA_LSX_EXP & 2)) R.asc[(Q + 1) & 1] = wloadsc(rs, lane, noff);
+    const int asc = R.asc[Q & 1];
+    i32x6 wt[NT];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ci = Q * 4 + c;
@@ -594,15 +615,33 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
         for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = (NA_LSX_EXP & 8) ? B6[b][0] : b6(b, Q, 1); }
       }
       __builtin_amdgcn_sched_barrier(0);
-      const f16x8 A0 = R.a16[c][0], A1 = R.a16[c][1];
+      const f16x8 A0 = a16frag(R.a16[0], c), A1 = a16frag(R.a16[1], c);
 #pragma unroll
       for (int b = 0; b < NBk; ++b) {
         acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], (CB && ci == 0) ? cb[0] : acc[0][b], 0, 0, 0);
         if constexpr (NT == 2)
           acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], (CB && ci == 0) ? cb[NT - 1] : acc[1][b], 0, 0, 0);
-        if (b == 0 && !(NA_LSX_EXP & 4)) {
-          R.a16[c][0] = wload16(rs, lane, noff, 0, c);
-          R.a16[c][1] = wload16(rs, lane, noff, 1, c);
+        if (b == 0) {
+          if (c == 1) {
+            // WT6 = fp6(f16 W / 2^scale) of this record, from the fragments while all four chunks are still in place (the
+            // newest, chunk 3, was requested a group ago); then chunks 0 and 1 take the next record's
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float sc = __builtin_bit_cast(float, (((uint32_t)asc >> (8 * (2 * t + 1))) & 0xFFu) << 23);
+              wt[t] = (NA_LSX_EXP & 32) ? i32x6{(int)R.a16[t][0], (int)R.a16[t][1], (int)R.a16[t][2], (int)R.a16[t][3], (int)R.a16[t][4], (int)R.a16[t][5]}
+                                        : cvt_fp6_f16_disjoint(R.a16[t], sc);
+            }
+          }
+          if (!(NA_LSX_EXP & 4)) {
+            if (c == 1) {
+              a16set(R.a16[0], 0, wload16(rs, lane, noff, 0, 0));
+              a16set(R.a16[1], 0, wload16(rs, lane, noff, 1, 0));
+            }
+            if (c >= 1) {
+              a16set(R.a16[0], c, wload16(rs, lane, noff, 0, c));
+              a16set(R.a16[1], c, wload16(rs, lane, noff, 1, c));
+            }
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -610,19 +649,15 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
 #pragma unroll
     for (int b = 0; b < NBk; ++b) {
       // W_lo x T(x) and W_top x R(x)
-      mma6<0>(acc[0][b], lo6(R.a6[0]), R.asc, B6[b][1]);
-      mma6<1>(acc[0][b], hi6(R.a6[0]), R.asc, B6[b][0]);
+      mma6<0>(acc[0][b], lo6(R.a6), asc, B6[b][1]);
+      mma6<1>(acc[0][b], op6(wt[0]), asc, B6[b][0]);
       if constexpr (NT == 2) {
-        mma6<2>(acc[1][b], lo6(R.a6[1]), R.asc, B6[b][1]);
-        mma6<3>(acc[1][b], hi6(R.a6[1]), R.asc, B6[b][0]);
+        mma6<2>(acc[1][b], hi6(R.a6), asc, B6[b][1]);
+        mma6<3>(acc[1][b], op6(wt[NT - 1]), asc, B6[b][0]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!(NA_LSX_EXP & 2)) {
-      R.a6[0] = wload6(rs, lane, noff, 0);
-      R.a6[1] = wload6(rs, lane, noff, 1);
-      R.asc = wloadsc(rs, lane, noff);
-    }
+    if (!(NA_LSX_EXP & 2)) R.a6 = wload6(rs, lane, noff);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(0);
@@ -676,6 +711,10 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
   }
   const float sT = __builtin_bit_cast(float, (uint32_t)eT << 23);
   const float sR = __builtin_bit_cast(float, (uint32_t)eR << 23);
+  // The residual plane R pairs with WT6, which the consumer derives from its f16 weight fragments in THEIR element order: slot
+  // s = 8 c + e <-> chunk c, element e = value n[s] with n = (v0[0..15], v1[0..15]).  The conversion below puts a[i] into slot
+  // 2 i and b[i] into slot 2 i + 1, so a = the even-indexed n, b = the odd-indexed n (just which register each residual is
+  // written to).  The value plane T pairs with the streamed WL6 and keeps the interleaved order (v0[i], v1[i]).
   f32x16 r0, r1;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -685,7 +724,7 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(b) : "v"(v0[2 * u + 1]), "v"(pk[u]));
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(c) : "v"(v1[2 * u]), "v"(pk[8 + u]));
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v1[2 * u + 1]), "v"(pk[8 + u]));
-    r0[2 * u] = a; r0[2 * u + 1] = b; r1[2 * u] = c; r1[2 * u + 1] = d;
+    r0[u] = a; r1[u] = b; r0[8 + u] = c; r1[8 + u] = d;
   }
   // v_cvt_scalef32_2xpk16_fp6_f32 divides by the scale's power of two, rounds to nearest even, saturates, and puts a[i] into
   // slot 2 i, b[i] into slot 2 i + 1 (probed on the hardware: tools/proto/ls_f16x.py calibrate)
@@ -1062,10 +1101,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   constexpr int XNR = x::nrec(MODEL);
   if constexpr (PREC == NA_PREC_F16X) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { XR.a16[c][0] = x::wload16(wrs, lane, xrec, 0, c); XR.a16[c][1] = x::wload16(wrs, lane, xrec, 1, c); }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) XR.a6[t] = x::wload6(wrs, lane, xrec, t);
-    XR.asc = x::wloadsc(wrs, lane, xrec);
+    for (int c = 0; c < 4; ++c) { x::a16set(XR.a16[0], c, x::wload16(wrs, lane, xrec, 0, c)); x::a16set(XR.a16[1], c, x::wload16(wrs, lane, xrec, 1, c)); }
+    XR.a6 = x::wload6(wrs, lane, xrec);
+    XR.asc[0] = x::wloadsc(wrs, lane, xrec);
+    XR.asc[1] = 0;
   } else {
 #pragma unroll
     for (int p = 0; p < kPF; ++p) {
@@ -2345,9 +2384,10 @@ __global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
     }
   }
 }
-// one thread per (row group, record, tile, lane): the lane's 32 weights of the K64 group -> WL6, WT6 and their scale bytes.
-// Slot order = what v_cvt_scalef32_2xpk16_fp6_f32 gives the activations: slot 2 r <-> (producer tile 0, register r),
-// slot 2 r + 1 <-> (producer tile 1, register r), i.e. hidden feature 64 Q + 32 tt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// one thread per (row group, record, tile, lane): the lane's 32 weights of the K64 group -> WL6 and the scale bytes of WL6 and
+// of WT6 (which the render kernel derives from the f16 fragments with that scale).  WL6 pairs with the activations' T plane:
+// slot order = what v_cvt_scalef32_2xpk16_fp6_f32 gives it: slot 2 r <-> (producer tile 0, register r), slot 2 r + 1 <->
+// (producer tile 1, register r), i.e. hidden feature 64 Q + 32 tt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 __global__ void pack_lsx_fp6_kernel(XSched sc, char* __restrict__ dst) {
   const int srg = sc.npair * x::PAIRB + sc.nrec * x::REC;
   const int64_t n = 4ll * sc.nrec * 2 * 64;
@@ -2360,31 +2400,32 @@ __global__ void pack_lsx_fp6_kernel(XSched sc, char* __restrict__ dst) {
     int row;
     if (rd.out_mode == 0) row = 32 * (2 * rg + t) + (l & 31);
     else row = t == 0 ? out_row_map(sc.desc[L.desc], (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
-    f32x16 wt0, wt1, wl0, wl1;
+    f32x16 wl0, wl1;
     float mt = 0.f, ml = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c0 = 64 * rd.q + (r & 3) + 8 * (r >> 2) + 4 * h;
       float a = 0.f, b = 0.f;
       if (row >= 0 && row < L.out_dim) { a = L.W[(int64_t)row * L.in_dim + c0]; b = L.W[(int64_t)row * L.in_dim + c0 + 32]; }
-      wt0[r] = a; wt1[r] = b;
-      wl0[r] = a - from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(a));
-      wl1[r] = b - from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(b));
-      mt = fmaxf(mt, fmaxf(fabsf(a), fabsf(b)));
+      const float ah = from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(a)), bh = from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(b));
+      wl0[r] = a - ah;
+      wl1[r] = b - bh;
+      mt = fmaxf(mt, fmaxf(fabsf(ah), fabsf(bh)));  // (of the f16 values: that is what the kernel converts)
       ml = fmaxf(ml, fmaxf(fabsf(wl0[r]), fabsf(wl1[r])));
     }
     // block scale 2^(floor(log2 max) - 2): the largest element lands in [4, 8) (saturating at 7.5)
     auto scale_byte = [](float m) { const int ev = (int)(__builtin_bit_cast(uint32_t, m) >> 23); return ev > 3 ? ev - 2 : 1; };
     const int et = scale_byte(mt), el = scale_byte(ml);
     // (by construction here, where a few registers cost nothing: destination disjoint from every operand)
-    const x::i32x6 T6 = x::cvt_fp6_disjoint(wt0, wt1, __builtin_bit_cast(float, (uint32_t)et << 23));
     const x::i32x6 L6 = x::cvt_fp6_disjoint(wl0, wl1, __builtin_bit_cast(float, (uint32_t)el << 23));
     char* rec = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * srg + sc.npair * x::PAIRB + (int64_t)ri * x::REC;
-    char* pl = rec + 8192 + t * 3072 + l * 16;  // {WL6 | WT6} of tile t: three lane-linear 16-byte parts
-    *(u32x4*)pl = u32x4{(uint32_t)L6[0], (uint32_t)L6[1], (uint32_t)L6[2], (uint32_t)L6[3]};
-    *(u32x4*)(pl + 1024) = u32x4{(uint32_t)L6[4], (uint32_t)L6[5], (uint32_t)T6[0], (uint32_t)T6[1]};
-    *(u32x4*)(pl + 2048) = u32x4{(uint32_t)T6[2], (uint32_t)T6[3], (uint32_t)T6[4], (uint32_t)T6[5]};
-    uint8_t* scb = (uint8_t*)(rec + 8192 + 6144 + l * 4);
+    // {WL6 t0 | WL6 t1}: dword d of the lane's twelve sits in 16-byte part d >> 2 (three lane-linear parts)
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      const int dd = 6 * t + d;
+      *(uint32_t*)(rec + 8192 + (dd >> 2) * 1024 + l * 16 + (dd & 3) * 4) = (uint32_t)L6[d];
+    }
+    uint8_t* scb = (uint8_t*)(rec + 8192 + 3072 + l * 4);
     scb[2 * t] = (uint8_t)el;
     scb[2 * t + 1] = (uint8_t)et;
   }

@@ -62,7 +62,7 @@ def cat_not_none(a, b, dim=-1):
 
 
 # ------------------------------------------------------------------------------------------------- CommonNeRF
-class CommonNeRF(nn.Module):
+class CommonNeRF(utils.PackedCacheMixin, nn.Module):
     """src/nerf.py:147-276."""
 
     def __init__(self, r=None, steps: int = 64, fine_steps: int = 32, t_near: float = 0, t_far: float = 1,
@@ -79,6 +79,7 @@ class CommonNeRF(nn.Module):
         except AttributeError: ...
         self.alpha = self.weights = self.ts = None
         self.noise_std = 0.2
+        self._init_packed_hooks()
         self.set_bg(bg)
         if r is not None: self.refl = r(self.total_latent_size())
         self.set_sigmoid(sigmoid_kind)
@@ -145,10 +146,10 @@ class TinyNeRF(CommonNeRF):
     def packed_ls(self, precision: str):
         """Weight stream of the layer-synchronous renderer (cached, re-packed when any parameter changed)."""
         lin = self.estim._linears()
-        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        stamp = utils.pack_stamp(lin)
         cache = self.__dict__.setdefault("_packed_ls", {})
         hit = cache.get(precision)
-        if hit is None or hit[0] != stamp:
+        if hit is None or stamp is None or hit[0] != stamp:
             cache[precision] = (stamp, ops.render_tiny_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
         return cache[precision][1]
 
@@ -196,10 +197,10 @@ class PlainNeRF(CommonNeRF):
         """Weight stream of the layer-synchronous renderer (both MLPs in one buffer; cached, re-packed when any
         parameter changed)."""
         lin = self.first._linears() + self.refl.mlp._linears()
-        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        stamp = utils.pack_stamp(lin)
         cache = self.__dict__.setdefault("_packed_ls", {})
         hit = cache.get(precision)
-        if hit is None or hit[0] != stamp:
+        if hit is None or stamp is None or hit[0] != stamp:
             wb = lambda m: ([l.weight.data for l in m._linears()], [l.bias.data for l in m._linears()])
             cache[precision] = (stamp, ops.render_ls_pack(precision, wb(self.first), wb(self.refl.mlp)))
         return cache[precision][1]
@@ -280,19 +281,19 @@ class VolSDF(CommonNeRF):
 
     def packed_view_ls(self, precision: str):
         lin = self.sdf.refl.mlp._linears()
-        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        stamp = utils.pack_stamp(lin)
         cache = self.__dict__.setdefault("_packed_view_ls", {})
         hit = cache.get(precision)
-        if hit is None or hit[0] != stamp:
+        if hit is None or stamp is None or hit[0] != stamp:
             cache[precision] = (stamp, ops.render_view_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
         return cache[precision][1]
 
     def packed_siren_ls(self, precision: str):
         lin = self.sdf.underlying.siren._linears() + self.sdf.refl.mlp._linears()
-        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        stamp = utils.pack_stamp(lin)
         cache = self.__dict__.setdefault("_packed_siren_ls", {})
         hit = cache.get(precision)
-        if hit is None or hit[0] != stamp:
+        if hit is None or stamp is None or hit[0] != stamp:
             wb = lambda m: ([l.weight.data for l in m._linears()], [l.bias.data for l in m._linears()])
             cache[precision] = (stamp, ops.render_volsdf_siren_ls_pack(precision, wb(self.sdf.underlying.siren), wb(self.sdf.refl.mlp)))
         return cache[precision][1]

@@ -101,7 +101,7 @@ class NNEncoder(nn.Module):
         return ops.sigmoid(y, "sin").reshape(x.shape[:-1] + (self.fwd.out_features,))
 
 
-class HashEncoder(nn.Module):
+class HashEncoder(utils.PackedCacheMixin, nn.Module):
     """src/neural_blocks.py:92-193 (8 levels x 65536 x 4, resolutions 16 * 0.87497^l, Q8/Q9)."""
 
     def __init__(self, input_dims: int = 3, emb_size: int = 1 << 16, feat_size: int = 4, levels: int = 8,
@@ -118,14 +118,15 @@ class HashEncoder(nn.Module):
         self.scale = math.exp((math.log(self.high_reso) - math.log(self.low_reso)) / levels - 1)
         self._stacked = None
         self._stamp = None
+        self._init_packed_hooks()
 
     def output_dims(self):
         return self.levels * self.feat_size + self.include_input * self.in_features
 
     def tables(self) -> torch.Tensor:
         """[8,65536,4] contiguous copy of the embedding tables (rebuilt when a table changes)."""
-        stamp = tuple((e.weight._version, e.weight.data_ptr()) for e in self.embs)
-        if self._stacked is None or stamp != self._stamp:
+        stamp = None if config.repack_always else tuple((e.weight._version, e.weight.data_ptr()) for e in self.embs)
+        if self._stacked is None or stamp is None or stamp != self._stamp:
             self._stacked = torch.stack([e.weight.data for e in self.embs]).contiguous()
             self._stamp = stamp
         return self._stacked
@@ -147,7 +148,7 @@ class _Act:
         self.name = name
 
 
-class SkipConnMLP(nn.Module):
+class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
     """src/neural_blocks.py:204-311.  `activation`: nn.LeakyReLU (default) or torch.sin."""
 
     def __init__(self, num_layers=5, hidden_size=256, in_size=3, out=3, skip=3, activation=None, latent_size=0,
@@ -191,6 +192,7 @@ class SkipConnMLP(nn.Module):
         self.activation = activation
         self.last_layer_act = last_layer_act
         self._packed = {}
+        self._init_packed_hooks()
 
     # ---- HIP plumbing ------------------------------------------------------------------------
     def _linears(self):
@@ -219,10 +221,10 @@ class SkipConnMLP(nn.Module):
         if desc is None or ops.mlp_packed_bytes(desc, precision) == 0:
             return None, None
         lin = self._linears()
-        stamp = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in lin)
+        stamp = utils.pack_stamp(lin)
         key = (precision, layout)
         hit = self._packed.get(key)
-        if hit is None or hit[0] != stamp:
+        if hit is None or stamp is None or hit[0] != stamp:
             buf = ops.mlp_pack(desc, precision, [l.weight.data for l in lin], [l.bias.data for l in lin])
             self._packed[key] = (stamp, buf)
         return desc, self._packed[key][1]

@@ -150,10 +150,12 @@ PACK_CACHE_ATTRS = ("_packed", "_packed_ls", "_packed_view_ls", "_packed_siren_l
 
 def invalidate_packed(module) -> int:
     """Drop every cached packed weight stream under `module` (SkipConnMLP._packed, the layer-synchronous streams of the
-    models).  The caches are keyed on (Parameter._version, data_ptr): in-place ops on the Parameter under no_grad
-    (`p.copy_`, `p.mul_`, optimizer steps, load_state_dict) bump the version and re-pack on their own; writes THROUGH
-    `.data` (`p.data.copy_(...)`, `p.data *= ...`) do not, and the fused kernels would keep rendering the old weights.
-    Call this after such writes (runner --load does).  Returns the number of caches cleared."""
+    models, the stacked hash tables of HashEncoder).  The caches are keyed on (Parameter._version, data_ptr): in-place ops on
+    the Parameter under no_grad (`p.copy_`, `p.mul_`, optimizer steps) bump the version and re-pack on their own, and
+    `load_state_dict` / `.to()` / `.float()` ... invalidate through the hooks of `PackedCacheMixin`; writes THROUGH `.data`
+    (`p.data.copy_(...)`, `p.data *= ...`) or an out-of-band hipMemcpy into the parameter do neither, and the fused kernels
+    would keep rendering the old weights.  Call this (or `model.invalidate_packed()`) after such writes, or run with
+    `config.set_repack_always(True)`.  Returns the number of caches cleared."""
     n = 0
     for m in module.modules():
         for a in PACK_CACHE_ATTRS:
@@ -161,4 +163,36 @@ def invalidate_packed(module) -> int:
             if isinstance(c, dict) and c:
                 c.clear()
                 n += 1
+        if m.__dict__.get("_stacked") is not None and "_stamp" in m.__dict__:  # HashEncoder.tables()
+            m._stacked = None
+            m._stamp = None
+            n += 1
     return n
+
+
+class PackedCacheMixin:
+    """Modules that cache packed weight streams (CommonNeRF, SkipConnMLP, HashEncoder): `invalidate_packed()` as a method,
+    called automatically whenever torch replaces or rewrites the parameters wholesale -- `_apply` (`.to`, `.cuda`, `.float`,
+    `.half` ...) and `load_state_dict` (a post hook, which torch runs on every submodule of the module being loaded)."""
+
+    def _init_packed_hooks(self):
+        def _hook(mod, _incompatible_keys):
+            mod.invalidate_packed()  # (a post hook must return None)
+        self.register_load_state_dict_post_hook(_hook)
+
+    def invalidate_packed(self) -> int:
+        return invalidate_packed(self)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+
+def pack_stamp(linears):
+    """cache key of a packed stream: version counter + address of every weight / bias; None = never reuse
+    (config.repack_always: for callers that write parameters behind torch's back)"""
+    from . import config
+    if config.repack_always:
+        return None
+    return tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in linears)

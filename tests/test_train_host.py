@@ -60,3 +60,36 @@ def test_invalidate_packed_clears_every_stream_cache():
     assert invalidate_packed(root) == len(mods)
     assert all(not m.__dict__[PACK_CACHE_ATTRS[i % len(PACK_CACHE_ATTRS)]] for i, m in enumerate(mods))
     assert invalidate_packed(root) == 0
+
+
+def test_packed_caches_drop_on_load_state_dict_and_apply():
+    """`load_state_dict` (post hook on every caching submodule) and `_apply` (`.float()`, `.to()` ...) invalidate the packed
+    streams on their own; `config.repack_always` turns the version-counter stamp off altogether."""
+    import torch
+    from nerf_atlas_amd import config, nerf, utils
+    m = nerf.PlainNeRF(steps=8, intermediate_size=64)
+
+    def poison():
+        m.first._packed[("bf16x3", "generic")] = ("stamp", object())
+        m.refl.mlp._packed[("bf16x3", "generic")] = ("stamp", object())
+        m.__dict__.setdefault("_packed_ls", {})["f16x"] = ("stamp", object())
+        m.first.enc._stacked, m.first.enc._stamp = torch.zeros(1), ("stamp",)
+
+    def clean():
+        return (not m.first._packed and not m.refl.mlp._packed and not m.__dict__["_packed_ls"] and m.first.enc._stacked is None)
+
+    poison()
+    m.load_state_dict(m.state_dict())
+    assert clean()
+    poison()
+    m.float()
+    assert clean()
+    poison()
+    assert m.invalidate_packed() == 4 and clean()
+    lin = m.first._linears()
+    assert utils.pack_stamp(lin) is not None
+    config.set_repack_always(True)
+    try:
+        assert utils.pack_stamp(lin) is None
+    finally:
+        config.set_repack_always(False)

@@ -621,9 +621,72 @@ def g17():
          term=term, term_requires_grad=np.bool_(term.requires_grad), steps=T, near=2.0, far=6.0, **spec(names, shapes))
 
 
+# ------------------------------------------------------------------ G18 auxiliary maps (N3: runner.py:511-538, 894-913)
+def g18():
+    """The reference's OWN visualisation functions on the last forward of DynamicNeRF(spline 6): runner.depth_vis / flow_vis /
+    rigidity_vis (runner.py:511-538) and the raw maps of the test() loop (runner.py:894-913), utils.depth_to_normals
+    (src/utils.py:421-427).  `depth_vis` as written divides by `(args.far - args.near).clamp(min=0, max=1)` -- the clamp binds
+    to the denominator and only exists for tensors -- so it is called with tensor near / far chosen such that far - near = 1,
+    where the written expression and the evident intent ((raw - near) / (far - near), clamped to [0, 1]) coincide wherever
+    the result lies in [0, 1]; the fixture keeps the raw map too."""
+    import argparse
+    import runner as rrunner
+    size, T, spline = 6, 8, 6
+    canon = rnerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = rnerf.DynamicNeRF(canonical=canon, spline=spline)
+    m.eval()
+    names, shapes = fill_procedural(m)
+    c, focal = cam(POSES[:2], size)
+    rays = c.sample_positions(ref_pixel_grid(size, (0, 0, size, size)), size=size)
+    times = torch.tensor([0.25, 0.8])
+    out = m((rays, times))
+    w = canon.weights
+    raw_depth = rnerf.volumetric_integrate(w, canon.ts[:, None, None, None, None])
+    args = argparse.Namespace(near=torch.tensor(2.5), far=torch.tensor(3.5), normals_from_depth=True)
+    dvis = rrunner.depth_vis(m, args)
+    fvis = rrunner.flow_vis(m, args)
+    rvis = rrunner.rigidity_vis(m, args)
+    save("g18_aux_maps", rays=rays, times=times, out=out, steps=T, near=2.0, far=6.0, vis_near=2.5, vis_far=3.5,
+         weights=w, raw_depth=raw_depth, depth_vis=dvis[0], depth_normal_vis=dvis[1],
+         depth_normals=rutils.depth_to_normals(raw_depth[0]),
+         flow_raw=rnerf.volumetric_integrate(w, m.rigid_dp), flow_vis=fvis[0],
+         rigidity_raw=rnerf.volumetric_integrate(w, m.rigidity), rigidity_vis=rvis[0],
+         acc=w[:-1].sum(dim=0), **spec(names, shapes))
+
+
+# ------------------------------------------------------------------ G19 --bg random (src/nerf.py:99-103)
+def g19():
+    """PlainNeRF(view) with bg = "random": one uniform draw PER RAY (rand_like of the [..., 1] remainder), broadcast over the
+    colour channels, times 1 - sum(weights[:-1]).  The draw is replayed from the same seed and stored (the Q13 convention:
+    stochastic inputs are explicit tensors on the build's side)."""
+    size, T = 6, 8
+    m = rnerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted", bg="random")
+    m.eval()
+    names, shapes = fill_procedural(m)
+    c, focal = cam(POSES[:2], size)
+    rays = c.sample_positions(ref_pixel_grid(size, (0, 0, size, size)), size=size)
+    torch.manual_seed(19)
+    out = m(rays)
+    summed = 1 - m.weights[:-1].sum(dim=0).unsqueeze(-1)
+    torch.manual_seed(19)
+    rand = torch.rand_like(summed)
+    m.set_bg("black")
+    out_black = m(rays)
+    assert torch.allclose(out, out_black + rand * summed, atol=1e-6)
+    # the bare function on synthetic weights (g3's)
+    g3w = rnerf.alpha_from_density(torch.from_numpy(proc_uniform((16, 2, 3, 4), 101, 4.0)), torch.linspace(2, 6, 16),
+                                   torch.from_numpy(proc_uniform((2, 3, 4, 3), 103, 1.0)))[1]
+    torch.manual_seed(20)
+    sky = rnerf.random_color(None, g3w)
+    torch.manual_seed(20)
+    rand3 = torch.rand_like(sky)
+    save("g19_bg_random", rays=rays, out=out, out_black=out_black, rand=rand, steps=T, near=2.0, far=6.0,
+         fn_weights=g3w, fn_rand=rand3, fn_sky=sky, **spec(names, shapes))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for g in which:
         globals()[g]()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
