@@ -56,7 +56,7 @@ enum { NA_LAYOUT_GENERIC = 0, NA_LAYOUT_PLAIN_FIRST = 1, NA_LAYOUT_PLAIN_VIEW = 
 /* density -> sigma (src/nerf.py:64-65) */
 enum { NA_DENSITY_SOFTPLUS_M1 = 0, NA_DENSITY_RELU = 1 };
 /* background (src/nerf.py:96-109) */
-enum { NA_BG_BLACK = 0, NA_BG_WHITE = 1 };
+enum { NA_BG_BLACK = 0, NA_BG_WHITE = 1, NA_BG_RANDOM = 2 /* only through the *_random_bg entry points: needs the draw */ };
 /* colour-head activations, src/utils.py:484-518 sigmoid_kinds */
 enum {
   NA_SIG_NORMAL = 0, NA_SIG_THIN = 1, NA_SIG_FAT = 2, NA_SIG_TANH = 3, NA_SIG_UPSHIFTED = 4,
@@ -128,6 +128,15 @@ int na_mip_encode(const float* rays, int B, int H, int W, const float* ts, int T
 int na_composite(const float* density, const float* feat, const float* ts, const float* rays,
                  int T, int64_t R, int C, int density_kind, int bg_kind,
                  float* alpha, float* weights, float* out, void* stream);
+
+/* The same with `--bg random` (src/nerf.py:99-103 random_color): out += rand[r] * (1 - sum(weights[:-1])), ONE uniform draw
+ * per ray broadcast over the channels.  The draw is an explicit input rand [R] (the reference calls torch.rand_like inside).
+ * na_sky_random adds that term to the out [R,C] of a renderer that composited against black and kept weights [T,R]
+ * (the fused one-kernel renderers).                                                              */
+int na_composite_random_bg(const float* density, const float* feat, const float* ts, const float* rays,
+                           int T, int64_t R, int C, int density_kind, const float* rand,
+                           float* alpha, float* weights, float* out, void* stream);
+int na_sky_random(const float* weights, const float* rand, int T, int64_t R, int C, float* out, void* stream);
 
 /* volumetric_integrate(weights, other) alone (src/nerf.py:79-80; depth/flow maps,
  * runner.py:894-920): weights [T,R], other [T,R,C] -> out [R,C].                              */

@@ -489,7 +489,8 @@ template <int C>
 __global__ void composite_backward_kernel(const float* __restrict__ density, const float* __restrict__ feat,
                                           const float* __restrict__ ts, const float* __restrict__ rays, int T,
                                           int64_t R, int density_kind, int bg_kind, const float* __restrict__ g_out,
-                                          float* __restrict__ g_density, float* __restrict__ g_feat) {
+                                          float* __restrict__ g_density, float* __restrict__ g_feat,
+                                          const float* __restrict__ sky_rand = nullptr) {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
     const float* ry = rays + r * 6 + 3;
     const float nrm = sqrtf((ry[0] * ry[0] + ry[1] * ry[1]) + ry[2] * ry[2]);
@@ -497,6 +498,8 @@ __global__ void composite_backward_kernel(const float* __restrict__ density, con
     float gsum = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) { g[c] = g_out[r * C + c]; gsum += g[c]; }
+    // d sky / d w_t (t < T-1): -1 per channel for white, -rand[r] for the random background (src/nerf.py:98,101-103)
+    const float gsky = bg_kind == NA_BG_WHITE ? gsum : bg_kind == NA_BG_RANDOM ? gsum * sky_rand[r] : 0.f;
     float trans = 1.0f;
     for (int t = 0; t < T; ++t) {
       const float d = density[(int64_t)t * R + r];
@@ -525,7 +528,7 @@ __global__ void composite_backward_kernel(const float* __restrict__ density, con
         G += g[c] * ct[c];
         g_feat[((int64_t)t * R + r) * C + c] = w * g[c];
       }
-      if (bg_kind == NA_BG_WHITE && t < T - 1) G -= gsum;
+      if (t < T - 1) G -= gsky;
       const float dLda = G * Tt - suffix / f;
       suffix += G * w;
       const float dsig = density_kind == NA_DENSITY_SOFTPLUS_M1 ? sigmoidf_(d - 1.0f) : (d > 0.f ? 1.f : 0.f);
@@ -771,6 +774,24 @@ int na_composite_backward(const float* density, const float* feat, const float* 
     hipLaunchKernelGGL(composite_backward_kernel<1>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
                        density_kind, bg_kind, g_out, g_density, g_feat);
   return check_launch("na_composite_backward");
+}
+
+int na_composite_random_bg_backward(const float* density, const float* feat, const float* ts, const float* rays, int T,
+                                    int64_t R, int C, int density_kind, const float* rand, const float* g_out,
+                                    float* g_density, float* g_feat, void* stream) {
+  NA_REQUIRE(density && feat && ts && rays && rand && g_out && g_density && g_feat, NA_ENULL,
+             "na_composite_random_bg_backward: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_composite_random_bg_backward: bad shape");
+  NA_REQUIRE(C == 3 || C == 1, NA_EUNSUPPORTED, "na_composite_random_bg_backward: C=%d (1 or 3)", C);
+  if (R == 0) return NA_OK;
+  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
+  if (C == 3)
+    hipLaunchKernelGGL(composite_backward_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
+                       density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand);
+  else
+    hipLaunchKernelGGL(composite_backward_kernel<1>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
+                       density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand);
+  return check_launch("na_composite_random_bg_backward");
 }
 
 }  // extern "C"

@@ -406,7 +406,8 @@ template <int C>
 __global__ void composite_kernel(const float* __restrict__ density, const float* __restrict__ feat,
                                  const float* __restrict__ ts, const float* __restrict__ rays, int T, int64_t R,
                                  int density_kind, int bg_kind, float* __restrict__ alpha_out,
-                                 float* __restrict__ weights_out, float* __restrict__ out, int Crt) {
+                                 float* __restrict__ weights_out, float* __restrict__ out, int Crt,
+                                 const float* __restrict__ sky_rand = nullptr) {
   const int CC = C > 0 ? C : Crt;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
     const float* ry = rays + r * 6 + 3;
@@ -449,8 +450,21 @@ __global__ void composite_kernel(const float* __restrict__ density, const float*
         }
       }
     }
-    float sky = bg_kind == NA_BG_WHITE ? 1.0f - wsum_head : 0.f;
+    // white: the remainder 1 - sum(weights[:-1]) (src/nerf.py:98); random: one uniform draw per ray times it (src/nerf.py:101-103)
+    float sky = bg_kind == NA_BG_WHITE ? 1.0f - wsum_head : bg_kind == NA_BG_RANDOM ? sky_rand[r] * (1.0f - wsum_head) : 0.f;
     for (int c = 0; c < CC; ++c) out[r * CC + c] = acc[c] + sky;
+  }
+}
+
+// out[r, :] += rand[r] * (1 - sum_{t < T-1} weights[t, r]): the random background (src/nerf.py:101-103) behind a renderer that
+// composited against black and kept its weights (the fused one-kernel renderers)
+__global__ void sky_random_kernel(const float* __restrict__ weights, const float* __restrict__ rand, int T, int64_t R, int C,
+                                  float* __restrict__ out) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    float head = 0.f;
+    for (int t = 0; t < T - 1; ++t) head = head + weights[(int64_t)t * R + r];
+    const float sky = rand[r] * (1.0f - head);
+    for (int c = 0; c < C; ++c) out[r * C + c] = out[r * C + c] + sky;
   }
 }
 
@@ -695,6 +709,31 @@ int na_composite(const float* density, const float* feat, const float* ts, const
     hipLaunchKernelGGL(composite_kernel<0>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R, density_kind,
                        bg_kind, alpha, weights, out, C);
   return check_launch("na_composite");
+}
+
+int na_composite_random_bg(const float* density, const float* feat, const float* ts, const float* rays, int T, int64_t R, int C,
+                           int density_kind, const float* rand, float* alpha, float* weights, float* out, void* stream) {
+  NA_REQUIRE(density && feat && ts && rays && rand && out, NA_ENULL, "na_composite_random_bg: null pointer");
+  NA_REQUIRE(T >= 1 && R >= 0 && C >= 1 && C <= 8, NA_EINVAL, "na_composite_random_bg: bad shape T=%d R=%lld C=%d (C<=8)", T,
+             (long long)R, C);
+  NA_REQUIRE(density_kind == 0 || density_kind == 1, NA_EUNSUPPORTED, "na_composite_random_bg: density kind %d", density_kind);
+  if (R == 0) return NA_OK;
+  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
+  if (C == 3)
+    hipLaunchKernelGGL(composite_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R, density_kind,
+                       (int)NA_BG_RANDOM, alpha, weights, out, C, rand);
+  else
+    hipLaunchKernelGGL(composite_kernel<0>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R, density_kind,
+                       (int)NA_BG_RANDOM, alpha, weights, out, C, rand);
+  return check_launch("na_composite_random_bg");
+}
+
+int na_sky_random(const float* weights, const float* rand, int T, int64_t R, int C, float* out, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0 && C >= 1, NA_EINVAL, "na_sky_random: bad shape");
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(weights && rand && out, NA_ENULL, "na_sky_random: null pointer");
+  hipLaunchKernelGGL(sky_random_kernel, dim3(grid_for(R, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, weights, rand, T, R, C, out);
+  return check_launch("na_sky_random");
 }
 
 int na_integrate(const float* weights, const float* other, int T, int64_t R, int C, float* out, void* stream) {

@@ -619,29 +619,33 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
 #pragma unroll
       for (int b = 0; b < NBk; ++b) {
         acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], (CB && ci == 0) ? cb[0] : acc[0][b], 0, 0, 0);
-        if constexpr (NT == 2)
+        // WT6 = fp6(f16 W / 2^scale) of this record, from the fragments while all four chunks are still in place (the newest,
+        // chunk 3, was requested a group ago).  The conversion holds the wave's issue for ~46 cycles (measured: two of them
+        // behind the MFMAs of a chunk cost 2.9 % of the frame), so each one sits directly behind ONE MFMA and runs in its shadow
+        if (c == 1 && b == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          const float sc = __builtin_bit_cast(float, (((uint32_t)asc >> 8) & 0xFFu) << 23);
+          wt[0] = (NA_LSX_EXP & 32) ? i32x6{(int)R.a16[0][0], (int)R.a16[0][1], (int)R.a16[0][2], (int)R.a16[0][3], (int)R.a16[0][4], (int)R.a16[0][5]}
+                                    : cvt_fp6_f16_disjoint(R.a16[0], sc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NT == 2) {
           acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], (CB && ci == 0) ? cb[NT - 1] : acc[1][b], 0, 0, 0);
-        if (b == 0) {
+          if (c == 1 && b == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            const float sc = __builtin_bit_cast(float, (((uint32_t)asc >> 24) & 0xFFu) << 23);
+            wt[NT - 1] = (NA_LSX_EXP & 32) ? i32x6{(int)R.a16[1][0], (int)R.a16[1][1], (int)R.a16[1][2], (int)R.a16[1][3], (int)R.a16[1][4], (int)R.a16[1][5]}
+                                           : cvt_fp6_f16_disjoint(R.a16[1], sc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (b == NBk - 1 && c >= 1 && !(NA_LSX_EXP & 4)) {  // (behind the chunk's last MFMA: chunks 0 and 1 only once WT6 exists)
           if (c == 1) {
-            // WT6 = fp6(f16 W / 2^scale) of this record, from the fragments while all four chunks are still in place (the
-            // newest, chunk 3, was requested a group ago); then chunks 0 and 1 take the next record's
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const float sc = __builtin_bit_cast(float, (((uint32_t)asc >> (8 * (2 * t + 1))) & 0xFFu) << 23);
-              wt[t] = (NA_LSX_EXP & 32) ? i32x6{(int)R.a16[t][0], (int)R.a16[t][1], (int)R.a16[t][2], (int)R.a16[t][3], (int)R.a16[t][4], (int)R.a16[t][5]}
-                                        : cvt_fp6_f16_disjoint(R.a16[t], sc);
-            }
+            a16set(R.a16[0], 0, wload16(rs, lane, noff, 0, 0));
+            a16set(R.a16[1], 0, wload16(rs, lane, noff, 1, 0));
           }
-          if (!(NA_LSX_EXP & 4)) {
-            if (c == 1) {
-              a16set(R.a16[0], 0, wload16(rs, lane, noff, 0, 0));
-              a16set(R.a16[1], 0, wload16(rs, lane, noff, 1, 0));
-            }
-            if (c >= 1) {
-              a16set(R.a16[0], c, wload16(rs, lane, noff, 0, c));
-              a16set(R.a16[1], c, wload16(rs, lane, noff, 1, c));
-            }
-          }
+          a16set(R.a16[0], c, wload16(rs, lane, noff, 0, c));
+          a16set(R.a16[1], c, wload16(rs, lane, noff, 1, c));
         }
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -25,6 +25,7 @@ __all__ = [
     "view_refl", "positional_refl", "pos_linear_view_refl", "mse2psnr", "render_tiled",
     "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
     "point_light", "intersect_mask", "occlusion", "div_approx", "dnerf_rigid_dp", "ffjord_div",
+    "sky_random", "depth_to_normals", "depth_vis", "flow_vis", "rigidity_vis",
 ]
 
 # ----------------------------------------------------------------------------- A1 pixels
@@ -147,6 +148,12 @@ def volumetric_integrate(weights, other):
 def sky_white(weights):
     """src/nerf.py:98 (Q4)."""
     return 1 - weights[:-1].sum(dim=0).unsqueeze(-1)
+
+
+def sky_random(weights, rand):
+    """src/nerf.py:101-103 random_color: one uniform draw per ray (`rand_like` of the [..., 1] remainder, broadcast over the
+    colour channels) times the remainder.  `rand` is that draw, passed in (Q13: stochastic inputs are explicit)."""
+    return rand * (1 - weights[:-1].sum(dim=0).unsqueeze(-1))
 
 
 # ----------------------------------------------------------------------------- A5 hash encoder
@@ -447,6 +454,8 @@ def _sky(bg, weights):
         return 0
     if bg == "white":
         return sky_white(weights)
+    if isinstance(bg, tuple) and bg[0] == "random":  # ("random", rand [..., 1])
+        return sky_random(weights, bg[1])
     raise NotImplementedError(bg)
 
 
@@ -590,6 +599,42 @@ def render_tiled(model_fn, c2w, focal, size: int, crop_size: int):
             rays = nerf_camera_rays(pos, c2w, focal, size)
             got[c0:c0 + crop_size, c1:c1 + crop_size, :] = model_fn(rays).squeeze(0)
     return got
+
+
+# ----------------------------------------------------------------------------- N3 auxiliary maps (runner.py:511-538, 894-913)
+
+
+def depth_to_normals(depth_img):
+    """src/utils.py:421-427: forward differences of a depth image [H,W,1] -> unit normals [H-1,W-1,3]."""
+    dz_dx = depth_img[1:, 1:, ...] - depth_img[:-1, 1:, ...]
+    dz_dy = depth_img[1:, 1:, ...] - depth_img[1:, :-1, ...]
+    d = torch.cat([dz_dx / 2, dz_dy / 2, torch.ones_like(dz_dx)], dim=-1)
+    return F.normalize(d, dim=-1)
+
+
+def depth_vis(weights, ts, near: float, far: float, normals_from_depth: bool = False):
+    """runner.py:511-519 with the evident intent of its second line, ((raw - near) / (far - near)).clamp(0, 1): as written the
+    clamp binds to the denominator `(args.far - args.near)` and exists only for tensor arguments (tools/gen_golden.py g18 calls
+    it that way, with far - near = 1, where both readings agree on [0, 1]).  Returns [depth(, normal map)] of batch item 0."""
+    raw = volumetric_integrate(weights, ts[:, None, None, None, None])
+    depth = ((raw[0] - near) / (far - near)).clamp(min=0, max=1)
+    items = [depth]
+    if normals_from_depth:
+        items.append(((50 * depth_to_normals(depth) + 1) / 2).clamp(min=0, max=1))
+    return items
+
+
+def flow_vis(weights, rigid_dp):
+    """runner.py:521-526: integrated flow of batch item 0, normalised by its largest vector norm, signed square root, -> [0,1]."""
+    flow = volumetric_integrate(weights, rigid_dp)[0]
+    flow = flow / flow.norm(dim=-1).max()
+    flow = flow.abs().sqrt().copysign(flow)
+    return (flow + 1) / 2
+
+
+def rigidity_vis(weights, rigidity):
+    """runner.py:528-531."""
+    return volumetric_integrate(weights, rigidity)[0]
 
 
 # ----------------------------------------------------------------------------- N4 SDF marching (src/march.py)

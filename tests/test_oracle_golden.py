@@ -235,3 +235,44 @@ def test_ffjord_divergence_estimate_matches_reference():
     term = (g["alpha"] * div.abs().square()).mean()
     assert abs(float(term) - float(g["term"])) <= 1e-4 * float(g["term"])
     assert not bool(g["term_requires_grad"])  # the reference's term is a constant for the optimiser (no create_graph)
+
+
+def test_g18_aux_maps_match_the_references_own_functions():
+    """N3: runner.depth_vis / flow_vis / rigidity_vis (runner.py:511-538), the raw maps of the test() loop (runner.py:894-913)
+    and utils.depth_to_normals, produced by the reference itself on DynamicNeRF(spline 6)."""
+    g = load_golden("g18_aux_maps")
+    p = golden_params(g)
+    aux = {}
+    out = O.dynamic_nerf_spline(p, g["rays"], g["times"], 2.0, 6.0, int(g["steps"]), 6, act="upshifted", aux=aux)
+    close(out, g["out"], 2e-6, 1e-5)
+    w, ts = aux["weights"], aux["ts"]
+    close(w, g["weights"], 2e-6, 1e-5)
+    raw = O.volumetric_integrate(w, ts[:, None, None, None, None])
+    close(raw, g["raw_depth"], 1e-5, 1e-5)
+    close(O.depth_to_normals(g["raw_depth"][0]), g["depth_normals"], 1e-6, 1e-6)
+    close(O.volumetric_integrate(w, aux["rigid_dp"]), g["flow_raw"], 2e-6, 1e-5)
+    close(O.flow_vis(g["weights"], aux["rigid_dp"]), g["flow_vis"], 5e-6, 1e-5)
+    close(O.rigidity_vis(g["weights"], aux["rigidity"]), g["rigidity_vis"], 2e-6, 1e-5)
+    close(g["weights"][:-1].sum(dim=0), g["acc"], 1e-6, 1e-6)
+    # depth_vis: the reference's line as written (tensor near / far with far - near = 1) and the intended reading agree
+    # wherever the written result lies in [0, 1]; outside the intent clamps
+    dv, dn = O.depth_vis(g["weights"], ts, float(g["vis_near"]), float(g["vis_far"]), normals_from_depth=True)
+    written = g["depth_vis"]
+    inside = (written >= 0) & (written <= 1)
+    assert inside.any() and (~inside).any()
+    close(dv[inside], written[inside], 1e-5, 1e-5)
+    assert torch.equal(dv[~inside], written[~inside].clamp(0, 1))
+    same = inside[1:, 1:] & inside[:-1, 1:] & inside[1:, :-1]  # normals whose three depth samples were not clamped
+    assert same.any()
+    close(dn[same.expand_as(dn)], g["depth_normal_vis"][same.expand_as(dn)], 2e-4, 1e-4)
+
+
+def test_g19_bg_random():
+    """src/nerf.py:99-103: one draw per ray times the white-background remainder (PlainNeRF end to end + the bare function)."""
+    g = load_golden("g19_bg_random")
+    p = golden_params(g)
+    out = O.plain_nerf(p, g["rays"], 2.0, 6.0, int(g["steps"]), "view", act="upshifted", bg=("random", g["rand"]))
+    close(out, g["out"], 2e-6, 1e-5)
+    close(O.plain_nerf(p, g["rays"], 2.0, 6.0, int(g["steps"]), "view", act="upshifted"), g["out_black"], 2e-6, 1e-5)
+    assert torch.equal(O.sky_random(g["fn_weights"], g["fn_rand"]), g["fn_sky"])
+    assert g["rand"].shape[-1] == 1 and float((g["out"] - g["out_black"]).abs().max()) > 1e-3
