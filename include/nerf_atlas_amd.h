@@ -329,6 +329,10 @@ int na_bezier_warp_backward(const float* est, int est_stride, const float* t, in
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays,
                           int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
                           float* g_density, float* g_feat, void* stream);
+/* the same for na_composite_random_bg (src/nerf.py:99-103): d sky / d w_t = -rand[r] for t < T-1; rand carries no gradient */
+int na_composite_random_bg_backward(const float* density, const float* feat, const float* ts, const float* rays,
+                                    int T, int64_t R, int C, int density_kind, const float* rand, const float* g_out,
+                                    float* g_density, float* g_feat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layer-synchronous fused renderer (csrc/render_ls.hip): the same operator as na_render_plain_view

@@ -48,6 +48,11 @@ SIGNATURES = {
     "na_composite": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, c_f32p,
                                c_f32p, c_f32p, C.c_void_p]),
     "na_integrate": (C.c_int, [c_f32p, c_f32p, C.c_int, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_composite_random_bg": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, c_f32p, c_f32p,
+                                         c_f32p, c_f32p, C.c_void_p]),
+    "na_sky_random": (C.c_int, [c_f32p, c_f32p, C.c_int, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "na_composite_random_bg_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, c_f32p,
+                                                  c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_normalize3": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
     "na_pos_linear_combine": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_laplace_density": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),

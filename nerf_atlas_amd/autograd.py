@@ -207,15 +207,15 @@ class CompositeFn(Function):
     alpha/weights are auxiliary (non-differentiable) outputs."""
 
     @staticmethod
-    def forward(ctx, density, feat, ts, rays, softplus, bg):
-        out, alpha, weights = ops.composite(density, feat, ts, rays, softplus=softplus, bg=bg)
+    def forward(ctx, density, feat, ts, rays, softplus, bg, rand=None):
+        out, alpha, weights = ops.composite(density, feat, ts, rays, softplus=softplus, bg=bg, rand=rand)
         ctx.save_for_backward(density, feat, ts, rays)
-        ctx.softplus, ctx.bg = softplus, bg
+        ctx.softplus, ctx.bg, ctx.rand = softplus, bg, rand  # (rand: the per-ray draw of bg "random", a constant)
         ctx.mark_non_differentiable(alpha, weights)
         return out, alpha, weights
 
     @staticmethod
     def backward(ctx, g_out, _ga, _gw):
         density, feat, ts, rays = ctx.saved_tensors
-        gd, gf = ops.composite_backward(density, feat, ts, rays, g_out.contiguous(), ctx.softplus, ctx.bg)
-        return gd, gf, None, None, None, None
+        gd, gf = ops.composite_backward(density, feat, ts, rays, g_out.contiguous(), ctx.softplus, ctx.bg, rand=ctx.rand)
+        return gd, gf, None, None, None, None, None

@@ -51,8 +51,16 @@ def black(_elaz_r_d, _weights): return 0
 def white(_, weights): return 1 - weights[:-1].sum(dim=0).unsqueeze(-1)
 
 
-# src/nerf.py:104-109 (same keys; "mlp" and "random" are broken/stochastic in the reference: Q12)
-sky_kinds = {"black": black, "white": white, "mlp": "MLP_MARKER", "random": None}
+def random_color(_elaz_r_d, weights, rand=None):
+    """src/nerf.py:101-103: ONE uniform draw per ray (rand_like of the [..., 1] remainder) times the remainder; the draw is an
+    explicit tensor here (utils.rand: the replayable random source of Q13) and a kernel does the arithmetic."""
+    shape = tuple(weights.shape[1:]) + (1,)
+    if rand is None: rand = utils.rand(shape, weights.device)
+    return ops.sky_random(weights, rand, torch.zeros(shape, device=weights.device))
+
+
+# src/nerf.py:104-109 (same keys; "mlp" is broken in the reference: Q12)
+sky_kinds = {"black": black, "white": white, "mlp": "MLP_MARKER", "random": random_color}
 
 
 def cat_not_none(a, b, dim=-1):
@@ -86,10 +94,11 @@ class CommonNeRF(utils.PackedCacheMixin, nn.Module):
 
     def set_bg(self, bg="black"):
         if bg not in sky_kinds: raise NotImplementedError(bg)
-        if bg in ("mlp", "random"):
-            raise NotImplementedError(f"bg '{bg}' is broken/stochastic in the reference (SURVEY Q12); black|white")
+        if bg == "mlp":
+            raise NotImplementedError("bg 'mlp' is broken in the reference (SURVEY Q12); black|white|random")
         self.bg = bg
         self.sky_color = sky_kinds[bg]
+        self.bg_rand = None  # bg "random": the per-ray draw of the last forward ([..., 1])
 
     def set_sigmoid(self, kind="thin"):
         act = load_sigmoid(kind)
@@ -117,13 +126,27 @@ class CommonNeRF(utils.PackedCacheMixin, nn.Module):
 
     def _perturb(self): return 1 if self.training else 0
 
+    def _kernel_bg(self):
+        """what the fused one-kernel renderers composite against: the random background is added behind them (`_finish_sky`)"""
+        return "black" if self.bg == "random" else self.bg
+
+    def _finish_sky(self, out):
+        """bg "random" behind a fused renderer that composited against black and kept its weights (src/nerf.py:99-103)"""
+        if self.bg == "random":
+            self.bg_rand = utils.rand(tuple(out.shape[:-1]) + (1,), out.device)
+            ops.sky_random(self.weights, self.bg_rand, out)
+        return out
+
     def _composite(self, density, feat, ts, rays, softplus=True, with_sky=True):
         bg = self.bg if with_sky else "black"
+        rand = None
+        if bg == "random":
+            rand = self.bg_rand = utils.rand(tuple(rays.shape[:-1]) + (1,), rays.device)
         if torch.is_grad_enabled() and (density.requires_grad or feat.requires_grad):
             from .autograd import CompositeFn
-            out, self.alpha, self.weights = CompositeFn.apply(density.contiguous(), feat.contiguous(), ts, rays, softplus, bg)
+            out, self.alpha, self.weights = CompositeFn.apply(density.contiguous(), feat.contiguous(), ts, rays, softplus, bg, rand)
             return out
-        out, self.alpha, self.weights = ops.composite(density, feat, ts, rays, softplus=softplus, bg=bg)
+        out, self.alpha, self.weights = ops.composite(density, feat, ts, rays, softplus=softplus, bg=bg, rand=rand)
         return out
 
 
@@ -158,8 +181,8 @@ class TinyNeRF(CommonNeRF):
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
             prec = config.kernel_precision(has_f16x=True)
             out, self.alpha, self.weights = ops.render_tiny_ls(rays, self.ts, self.packed_ls(prec), prec, self.sigmoid_kind,
-                                                                self.bg, want_weights)
-            return out
+                                                                self._kernel_bg(), want_weights or self.bg == "random")
+            return self._finish_sky(out)
         pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb())
         return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
 
@@ -169,8 +192,8 @@ class TinyNeRF(CommonNeRF):
             # explicit sample positions (a deformation field in front of TinyNeRF) through the same kernel
             prec = config.kernel_precision(has_f16x=True)
             out, self.alpha, self.weights = ops.render_tiny_ls(rays.contiguous(), ts, self.packed_ls(prec), prec, self.sigmoid_kind,
-                                                                self.bg, True, pts=pts.contiguous())
-            return out
+                                                                self._kernel_bg(), True, pts=pts.contiguous())
+            return self._finish_sky(out)
         latent = self.mip_encoding(rays, ts)
         o = self.estim(pts, latent)
         density, feats = o[..., 0].contiguous(), o[..., 1:].contiguous()
@@ -209,19 +232,20 @@ class PlainNeRF(CommonNeRF):
         """sample -> hash -> first -> elaz -> View -> sigmoid -> composite in ONE kernel (config.engine picks the
         layer-synchronous engine or the register-resident one)."""
         prec = config.kernel_precision(has_f16x=True)
+        want_weights = want_weights or self.bg == "random"
         if config.engine == "ls":
             return ops.render_plain_view_ls(rays, ts, self.first.enc.tables(), self.packed_ls(prec), prec,
-                                            self.sigmoid_kind, self.bg, want_weights, pts=pts)
+                                            self.sigmoid_kind, self._kernel_bg(), want_weights, pts=pts)
         _, pf = self.first.packed(prec, "plain_first")
         _, pv = self.refl.mlp.packed(prec, "plain_view")
-        return ops.render_plain_view(rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self.bg,
+        return ops.render_plain_view(rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self._kernel_bg(),
                                      want_weights, pts=pts)
 
     def forward(self, rays, want_weights: bool = True):
         if self._fusable():
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
             out, self.alpha, self.weights = self._render_fused(rays, self.ts, want_weights)
-            return out
+            return self._finish_sky(out)
         rand = None
         pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb(),
                                                    rand=rand)
@@ -232,7 +256,7 @@ class PlainNeRF(CommonNeRF):
         if self._fusable(refl_latent) and not ag.needs_grad(pts):
             # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
             out, self.alpha, self.weights = self._render_fused(rays, ts, True, pts=pts.contiguous())
-            return out
+            return self._finish_sky(out)
         latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
         first_out = self.first(pts, latent)
         density = first_out[..., 0].contiguous()

@@ -164,22 +164,41 @@ def mip_encode(rays: torch.Tensor, ts: torch.Tensor, kind: str, t_end: float, mi
 
 # ------------------------------------------------------------------------------------------------- compositing
 def composite(density: torch.Tensor, feat: torch.Tensor, ts: torch.Tensor, rays: torch.Tensor, softplus: bool = True,
-              bg: str = "black", want_weights: bool = True):
-    """density [T,...], feat [T,...,C], rays [...,6] -> (out [...,C], alpha [T,...], weights [T,...])."""
+              bg: str = "black", want_weights: bool = True, rand: Optional[torch.Tensor] = None):
+    """density [T,...], feat [T,...,C], rays [...,6] -> (out [...,C], alpha [T,...], weights [T,...]).
+    bg "random" (src/nerf.py:99-103) takes the per-ray uniform draw `rand` [..., 1]."""
     lib = _lib.load()
     density, feat, ts, rays = _f32(density, "density"), _f32(feat, "feat"), _f32(ts, "ts"), _f32(rays, "rays")
     T = ts.shape[0]
     Cn = feat.shape[-1]
     R = rays.numel() // 6
     assert density.numel() == T * R and feat.numel() == T * R * Cn, (density.shape, feat.shape, rays.shape)
-    if bg not in BG:
+    if bg not in BG and bg != "random":
         raise NotImplementedError(bg)
     out = torch.empty(tuple(rays.shape[:-1]) + (Cn,), device=rays.device, dtype=torch.float32)
     alpha = torch.empty_like(density) if want_weights else None
     weights = torch.empty_like(density) if want_weights else None
+    if bg == "random":
+        rand = _f32(rand, "rand")
+        assert rand.numel() == R, (rand.shape, rays.shape)
+        check(lib.na_composite_random_bg(_ptr(density), _ptr(feat), _ptr(ts), _ptr(rays), T, R, Cn, 0 if softplus else 1,
+                                         _ptr(rand), _ptr(alpha), _ptr(weights), _ptr(out), _stream()))
+        return out, alpha, weights
     check(lib.na_composite(_ptr(density), _ptr(feat), _ptr(ts), _ptr(rays), T, R, Cn, 0 if softplus else 1, BG[bg],
                            _ptr(alpha), _ptr(weights), _ptr(out), _stream()))
     return out, alpha, weights
+
+
+def sky_random(weights: torch.Tensor, rand: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[..., :] += rand[..., 0] * (1 - sum(weights[:-1])) in place (src/nerf.py:101-103); weights [T,...], rand [...,1]."""
+    lib = _lib.load()
+    weights, rand = _f32(weights, "weights"), _f32(rand, "rand")
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.is_cuda
+    T = weights.shape[0]
+    R = weights.numel() // T
+    assert rand.numel() == R and out.numel() % R == 0, (weights.shape, rand.shape, out.shape)
+    check(lib.na_sky_random(_ptr(weights), _ptr(rand), T, R, out.numel() // R, _ptr(out), _stream()))
+    return out
 
 
 def integrate(weights: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
@@ -501,7 +520,7 @@ def bezier_warp_backward(est: torch.Tensor, t: torch.Tensor, n_ctrl: int, g_pts=
     return g_est
 
 
-def composite_backward(density, feat, ts, rays, g_out, softplus: bool = True, bg: str = "black"):
+def composite_backward(density, feat, ts, rays, g_out, softplus: bool = True, bg: str = "black", rand=None):
     lib = _lib.load()
     density, feat, ts, rays, g_out = (_f32(density, "density"), _f32(feat, "feat"), _f32(ts, "ts"), _f32(rays, "rays"),
                                       _f32(g_out, "g_out"))
@@ -510,6 +529,11 @@ def composite_backward(density, feat, ts, rays, g_out, softplus: bool = True, bg
     R = rays.numel() // 6
     gd = torch.empty_like(density)
     gf = torch.empty_like(feat)
+    if bg == "random":
+        rand = _f32(rand, "rand")
+        check(lib.na_composite_random_bg_backward(_ptr(density), _ptr(feat), _ptr(ts), _ptr(rays), T, R, Cn, 0 if softplus else 1,
+                                                  _ptr(rand), _ptr(g_out), _ptr(gd), _ptr(gf), _stream()))
+        return gd, gf
     check(lib.na_composite_backward(_ptr(density), _ptr(feat), _ptr(ts), _ptr(rays), T, R, Cn, 0 if softplus else 1, BG[bg],
                                     _ptr(g_out), _ptr(gd), _ptr(gf), _stream()))
     return gd, gf

@@ -79,6 +79,38 @@ def depth_to_normals(depth_img: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.normalize(d, dim=-1)
 
 
+def depth_vis(model, near: float, far: float, normals_from_depth: bool = False):
+    """runner.py:511-519 (`--visualize depth`): [normalised depth of batch item 0 (, its normal map)] of the last forward.
+    The reference line reads `(raw_depth[0]-args.near)/(args.far - args.near).clamp(min=0, max=1)`: the clamp binds to the
+    denominator and does not exist for the float arguments the CLI passes; this follows the evident intent
+    ((raw - near) / (far - near), clamped to [0, 1]) -- DESIGN section 8."""
+    depth = ((depth_map(model)[0] - near) / (far - near)).clamp(min=0, max=1)
+    items = [depth]
+    if normals_from_depth:
+        items.append(((50 * depth_to_normals(depth) + 1) / 2).clamp(min=0, max=1))
+    return items
+
+
+def flow_vis(model):
+    """runner.py:521-526 (`--visualize flow`): integrated rigid flow of batch item 0, normalised by its largest vector norm,
+    signed square root, mapped to [0, 1]."""
+    if not hasattr(model, "rigid_dp"): return []
+    flow = flow_map(model)[0]
+    flow = flow / flow.norm(dim=-1).max()
+    flow = flow.abs().sqrt().copysign(flow)
+    return [(flow + 1) / 2]
+
+
+def rigidity_vis(model):
+    """runner.py:528-531 (`--visualize rigidity`)."""
+    if not hasattr(model, "rigidity"): return []
+    return [rigidity_map(model)[0]]
+
+
+# runner.py:534-538
+visualizations = {"depth": depth_vis, "flow": flow_vis, "rigidity": rigidity_vis}
+
+
 def render_over_time(model, cam, size: int, crop_size: int, times, with_alpha: bool = False, rank: int = 0,
                      world: int = 1):
     """runner.py:998-1017: one camera, a sweep of times through a dynamic model; frame i is rendered in test()-style

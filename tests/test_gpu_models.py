@@ -429,3 +429,92 @@ def test_aux_render_outputs_and_extra_encoders(na):
     f = nb.LearnedFourierEncoder(3, 16, sigma=4).cuda()
     ref = O.fourier_encode(x, f.basis.detach().cpu(), 1.0)
     assert maxdiff(f(x.cuda()), ref) <= 5e-5 and f.output_dims() == 32
+
+
+def test_aux_maps_against_the_references_own_functions(na):
+    """N3 pinned by the reference (g18: runner.depth_vis / flow_vis / rigidity_vis, the raw maps of the test() loop and
+    utils.depth_to_normals, produced by /root/reference itself on DynamicNeRF(spline 6))."""
+    g = load_golden("g18_aux_maps")
+    canon = na.nerf.PlainNeRF(steps=int(g["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=6).cuda().eval()
+    load_params(m, golden_params(g))
+    out = m((g["rays"].cuda(), g["times"].cuda()))
+    # (1) end to end on the MFMA path: per-sample quantities inside the 1e-4 class, integrals scaled by what they sum
+    assert maxdiff(out, g["out"]) <= 1e-4
+    assert maxdiff(canon.weights, g["weights"]) <= 1e-4
+    assert maxdiff(na.render.depth_map(m), g["raw_depth"]) <= 6e-4      # sum of w t, t <= 6
+    assert maxdiff(na.render.alpha_map(m)[..., 0], g["acc"]) <= 4e-4
+    assert maxdiff(na.render.flow_map(m), g["flow_raw"]) <= 1e-4
+    assert maxdiff(na.render.rigidity_map(m), g["rigidity_raw"]) <= 1e-4
+    assert maxdiff(na.render.flow_vis(m)[0], g["flow_vis"]) <= 5e-3     # (x -> sqrt|x| amplifies near 0)
+    # (2) the map arithmetic alone, on the REFERENCE's weights: what runner.py:511-538 / 894-913 compute from them
+    canon.weights = g["weights"].cuda()
+    assert maxdiff(na.render.depth_map(m), g["raw_depth"]) <= 2e-6
+    assert maxdiff(na.render.alpha_map(m)[..., 0], g["acc"]) <= 1e-6
+    assert maxdiff(na.render.rigidity_vis(m)[0], g["rigidity_vis"]) <= 1e-4
+    assert maxdiff(na.render.depth_to_normals(g["raw_depth"][0].cuda()), g["depth_normals"]) <= 1e-6
+    # depth_vis: the written reference line (tensor args, far - near = 1) and the intended one agree inside [0, 1]
+    dv, dn = na.render.depth_vis(m, float(g["vis_near"]), float(g["vis_far"]), normals_from_depth=True)
+    written = g["depth_vis"]
+    inside = (written >= 0) & (written <= 1)
+    assert inside.any() and (~inside).any() and maxdiff(dv.cpu()[inside], written[inside]) <= 2e-6
+    assert torch.equal(dv.cpu()[~inside], written[~inside].clamp(0, 1))
+    same = (inside[1:, 1:] & inside[:-1, 1:] & inside[1:, :-1]).expand(-1, -1, 3)
+    assert same.any() and maxdiff(dn.cpu()[same], g["depth_normal_vis"][same]) <= 1e-4  # (50 x forward differences of 2e-6)
+    assert set(na.render.visualizations) == {"depth", "flow", "rigidity"}
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x"])
+def test_bg_random(na, prec):
+    """--bg random (src/nerf.py:99-103): one uniform draw per ray times the white-background remainder, behind the fused
+    renderer and in the operator chain, against the reference's own frame (g19) with its draw replayed."""
+    from nerf_atlas_amd import config, ops, utils
+    g = load_golden("g19_bg_random")
+    m = na.nerf.PlainNeRF(steps=int(g["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted", bg="random")
+    m = m.cuda().eval()
+    load_params(m, golden_params(g))
+
+    class Replay:
+        def rand(self, shape, device):
+            assert tuple(shape) == tuple(g["rand"].shape), shape
+            return g["rand"].to(device)
+        randn = None
+
+    utils.set_random_source(Replay())
+    config.set_precision(prec)
+    try:
+        out = m(g["rays"].cuda())  # fused renderer (black) + na_sky_random
+        assert maxdiff(out, g["out"]) <= 1e-4
+        assert torch.equal(m.bg_rand.cpu(), g["rand"])
+        # the bare sky function on the reference's weights: bit-exact sum order is not promised, 1e-6 is
+        sky = na.nerf.random_color(None, g["fn_weights"].cuda(), g["fn_rand"].cuda())
+        assert maxdiff(sky, g["fn_sky"]) <= 1e-6
+        # operator chain (what training uses): explicit composite kernel with the draw
+        with torch.enable_grad():
+            m.train()
+            m.noise_std = 0
+            ts = ops.compute_ts(2.0, 6.0, int(g["steps"]), "cuda")[0]
+            pts = ops.compute_pts(g["rays"].cuda(), ts)
+            r_o, r_d = g["rays"].cuda().split([3, 3], dim=-1)
+            out2 = m.from_pts(pts, ts, r_o, r_d, rays=g["rays"].cuda())
+            assert out2.requires_grad and maxdiff(out2, g["out"]) <= 1e-4
+            # gradient of the sky term: d out / d density through -rand * sum(weights[:-1]) (finite differences of the kernel pair)
+            dens = torch.randn(8, 1, 1, 5, device="cuda", requires_grad=True)  # [T,B,H,W] like the reference
+            feat = torch.rand(8, 1, 1, 5, 3, device="cuda", requires_grad=True)
+            rays = torch.randn(1, 1, 5, 6, device="cuda")
+            rnd = torch.rand(1, 1, 5, 1, device="cuda")
+            from nerf_atlas_amd.autograd import CompositeFn
+            o, _, _ = CompositeFn.apply(dens, feat, ts, rays, True, "random", rnd)
+            gout = torch.randn_like(o)
+            (o * gout).sum().backward()
+            import oracle as O
+            dc, fc = dens.detach().cpu().double().requires_grad_(), feat.detach().cpu().double().requires_grad_()
+            a, w = O.alpha_from_density(dc, ts.cpu().double(), rays.cpu().double()[..., 3:])
+            ref = O.volumetric_integrate(w, fc) + O.sky_random(w, rnd.cpu().double())
+            (ref * gout.cpu().double()).sum().backward()
+            assert maxdiff(o, ref.detach().float()) <= 2e-6
+            assert maxdiff(dens.grad, dc.grad.float()) <= 2e-5 * float(dc.grad.abs().max()) + 1e-7
+            assert maxdiff(feat.grad, fc.grad.float()) <= 1e-6
+    finally:
+        utils.set_random_source(None)
+        config.set_precision("bf16x3")
