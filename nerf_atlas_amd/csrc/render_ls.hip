@@ -160,9 +160,23 @@ struct Args {
   uint32_t packed_size;
   HashRes res;
   unsigned long long* trace;  // NA_LS_TRACE builds only: [2 groups][128] s_memtime stamps of workgroup 0, second pass
+  uint32_t sat_gen;           // NA_PREC_F16X: this launch's id for the saturation flag (g_lsx_saturated)
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// NA_PREC_F16X range guard.  IEEE half tops out at 65504; the LeakyReLU epilogue clamps there (act_apply) so that no inf / NaN
+// is manufactured -- but a clamped activation is a WRONG finite value, and f16x is the mode whose claim is parity.  Every
+// epilogue already has the block maximum in a register (it sets the fp6 scales): a maximum at the clamp, or a latent row beyond
+// it, writes the launch's id here, and a tiny kernel behind the renderer turns the WHOLE frame into NaN when it finds its id
+// (stream-ordered, no host synchronisation; ids instead of a reset: nothing to zero between launches).  Silence is never an
+// option for the parity mode: switch to bf16x3 (fp32 range) for such weights.  tests/test_gpu_range.py.
+static __device__ unsigned int g_lsx_saturated = 0;
+static __global__ void lsx_poison_kernel(uint32_t gen, float* __restrict__ out, int64_t n) {
+  if (g_lsx_saturated != gen) return;
+  const float nan = __builtin_nanf("");
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = nan;
+}
 
 // NA_PREC_F16X stream schedules (pack side): the Linears of the model and which of them every pair / record / bias block packs
 struct XLin { const float* W; const float* B; int in_dim, out_dim, desc; };  // nn.Linear layout [out,in]
@@ -684,7 +698,7 @@ __device__ __forceinline__ i32x6 cvt_fp6_disjoint(const f32x16& a, const f32x16&
 // ---- epilogue of a hidden Linear: the lane's 32 values of block b (accumulators of the row group's two tiles) -> the LDS
 // operands of K64 group rg: f16 fragments, fp6 residual plane R, fp6 value plane T, scale bytes
 template <int ACT>
-__device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f32x16& a1, int lane) {
+__device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f32x16& a1, int lane, uint32_t sat_gen) {
   constexpr int PREC = NA_PREC_F16X;
   f32x16 v0, v1;
 #pragma unroll
@@ -712,6 +726,7 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
     const int ev = (int)(__builtin_bit_cast(uint32_t, m) >> 23);
     eT = ev > 3 ? ev - 2 : 1;
     eR = ev > 14 ? ev - 13 : 1;
+    if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated = sat_gen;  // an activation sits at the half clamp (or is NaN)
   }
   const float sT = __builtin_bit_cast(float, (uint32_t)eT << 23);
   const float sR = __builtin_bit_cast(float, (uint32_t)eR << 23);
@@ -742,11 +757,18 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
     *(u32x4*)(p + 3072) = u32x4{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT, 0u};
   }
 }
+// the latent rows (no activation in front of them: to_elem clamps them to the half range) are checked the same way
+__device__ __forceinline__ void latent_range(const f32x16& v, uint32_t sat_gen) {
+  float m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v[r]), "v"(v[r + 1]));
+  if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated = sat_gen;
+}
 template <int ACT, int NB, int T0 = 0, int T1 = 2>
-__device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane) {
+__device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane, uint32_t sat_gen) {
   if (NA_LSX_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int b = 0; b < NB; ++b) store_block<ACT>(hb + b * BLKH + rg * KQ, acc[0][b], acc[1][b], lane);
+  for (int b = 0; b < NB; ++b) store_block<ACT>(hb + b * BLKH + rg * KQ, acc[0][b], acc[1][b], lane, sat_gen);
   if (NA_LSX_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 }
 }  // namespace x
@@ -1218,7 +1240,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::pairs<0, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
         SYNC();
         {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(1);
           if (owner) activate_init<PREC, NA_ACT_SIN, 1>(ib, blk, lane);
           x::pairs_prefetch(XR, wrs, xpair, lane, 1, 1);
@@ -1229,14 +1251,14 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(2 + i);
           SYNC();
           x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);             // L1, L2
           SYNC();
         }
         {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(4);
           x::pairs_prefetch(XR, wrs, xpair, lane, 2, 1);
         }
@@ -1245,7 +1267,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 12, hb, lane);                   // L3 (skip)
         SYNC();
         {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(5);
         }
         SYNC();
@@ -1254,7 +1276,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 oq[1][NB], bo[1];
         {
           bo[0] = bias_tile(wrs, bias_rg + 6 * 1024, rg < 2 ? rg : 2, lane);
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         }
         SYNC();
         x::recs<1, NB, true, XNR>(oq, bo, XR, wrs, xrec, 20, hb, lane);                       // sdf.out (row-major)
@@ -1267,6 +1289,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
             for (int b = 0; b < NB; ++b) {
               Frag<PREC> f0, f1;
               acc_to_frags<PREC, NA_ACT_NONE>(oq[0][b], f0, f1);
+            x::latent_range(oq[0][b], a.sat_gen);
               char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
               fwrite<PREC>(dst, f0);
               fwrite<PREC>(dst + FR, f1);
@@ -1294,7 +1317,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         }
         SYNC();
         {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(8);
           if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
           x::pairs_prefetch(XR, wrs, xpair, lane, 8);
@@ -1311,7 +1334,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(9 + i);
           SYNC();
           x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 28 + 4 * i, hb, lane);        // view.L1..L3
@@ -1320,7 +1343,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 ocx[1][1], bo1[1];
         {
           bo1[0] = bias_tile(wrs, bias_rg + 12 * 1024, 0, lane);
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         }
         SYNC();
         x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 40, hb + blk * x::BLKH, lane);   // view.out (block per wave)
@@ -1488,7 +1511,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         }
         SYNC();
         {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(1);
           if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
           x::pairs_prefetch(XR, wrs, xpair, lane, 5);
@@ -1505,7 +1528,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(2 + i);
           SYNC();
           x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);        // view.L1..L3
@@ -1514,7 +1537,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 ocx[1][1], bo1[1];
         {
           bo1[0] = bias_tile(wrs, bias_rg + 5 * 1024, 0, lane);
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         }
         SYNC();
         x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 16, hb + blk * x::BLKH, lane);   // view.out (block per wave)
@@ -1606,7 +1629,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::pairs<0, 1, NB>(acc, bvx, XR, wrs, xpair, ib, lane);
         SYNC();
         {
-          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(1);
           if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 1>(ib, blk, lane);
           x::pairs_prefetch(XR, wrs, xpair, lane, 1, 1);
@@ -1617,14 +1640,14 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
-          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(2 + i);
           SYNC();
           x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);             // L1, L2
           SYNC();
         }
         {
-          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(4);
           x::pairs_prefetch(XR, wrs, xpair, lane, 2, 1);
         }
@@ -1634,7 +1657,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
-          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(5 + i);
           SYNC();
           x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 16 + 4 * i, hb, lane);            // L4, L5
@@ -1643,7 +1666,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 ocx[1][1], bo1[1];
         {
           bo1[0] = bias_tile(wrs, bias_rg + 7 * 1024, 0, lane);
-          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
         }
         SYNC();
         x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 24, hb + blk * x::BLKH, lane);       // out
@@ -1766,7 +1789,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       x::pairs<0, 3, NB>(acc, bvx, XR, wrs, xpair, ib, lane);                              // first.init
       SYNC();
       {
-        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(1);
         if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
         x::pairs_prefetch(XR, wrs, xpair, lane, 3);
@@ -1777,7 +1800,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
-        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(2 + i);
         SYNC();
         x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);                // first.L1..L3
@@ -1787,7 +1810,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       f32x16 bo[1];
       {
         bo[0] = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? rg : 2, lane);
-        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane);
+        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
       }
       SYNC();
       x::recs<1, NB, true, XNR>(oq, bo, XR, wrs, xrec, 16, hb, lane);                            // first.out (row-major)
@@ -1800,6 +1823,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           for (int b = 0; b < NB; ++b) {
             Frag<PREC> f0, f1;
             acc_to_frags<PREC, NA_ACT_NONE>(oq[0][b], f0, f1);
+            x::latent_range(oq[0][b], a.sat_gen);
             char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
             fwrite<PREC>(dst, f0);
             fwrite<PREC>(dst + FR, f1);
@@ -1821,7 +1845,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       }
       SYNC();
       {
-        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(7);
         if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
         x::pairs_prefetch(XR, wrs, xpair, lane, 11);
@@ -1838,7 +1862,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
-        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(8 + i);
         SYNC();
         x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 24 + 4 * i, hb, lane);                // view.L1..L3
@@ -1847,7 +1871,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       f32x16 ocx[1][1];
       {
         bo[0] = bias_tile(wrs, bias_rg + 11 * 1024, 0, lane);
-        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane);
+        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
       }
       SYNC();
       x::recs<1, 1, true, XNR>(ocx, bo, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);             // view.out (block per wave)
@@ -2353,7 +2377,17 @@ static int launch(Args& a, hipStream_t stream) {
   a.npg = (int)((rays_per_group * a.nb + C::NBLK - 1) / C::NBLK);
   a.nb_magic = (1ull << 32) / (uint64_t)a.nb + 1;
   if ((int64_t)(a.npg + 1) * C::NBLK * a.nb >= (1ll << 32)) { set_error("na_render_plain_view_ls: batch too large"); return NA_EINVAL; }
+  if constexpr (PREC == NA_PREC_F16X) {
+    static std::atomic<uint32_t> gen{0};
+    uint32_t g = gen.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (g == 0) g = gen.fetch_add(1, std::memory_order_relaxed) + 1;  // (0 is the flag's initial value: never an id)
+    a.sat_gen = g;
+  } else {
+    a.sat_gen = 0;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * C::GROUP, stream, a);
+  if constexpr (PREC == NA_PREC_F16X)  // range guard: NaN frame if any activation of this launch sat at the half clamp
+    hipLaunchKernelGGL(lsx_poison_kernel, dim3(grid_for(a.R * 3, 256, 256)), dim3(256), 0, stream, a.sat_gen, a.out, a.R * 3);
   return check_launch("na_render_plain_view_ls");
 }
 
