@@ -304,6 +304,9 @@ def main():
         torch.cuda.synchronize()
 
     red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    # the group's first collective, with the rank / device / backend printed if it fails (the "nccl" = RCCL branch runs for the
+    # first time on the driver's multi-GPU node); the count it returns goes into the JSON line
+    rccl_ranks, backend = nd.first_collective(dev)
     gather = nd.BandGather(SIZE, 3, rank, world, dev)  # receive / send buffers of the frame gather, allocated once
 
     def rmax(x):
@@ -384,6 +387,10 @@ def main():
                        "parallelism": f"rays sharded in {world} row band(s) + 1 RCCL gather"},
             "roofline": roofline(prec, kern_ms),
             "per_rank_kernel_ms": [round(x, 3) for x in per_rank], "gather_ms": round(gath_ms, 3),
+            # torch.distributed backend of the run ("nccl" IS RCCL on ROCm; "none" for one process) and the ranks an
+            # all-reduce of ones on the device counted; the frame gather's implementation (dist.gather, or all_gather if the
+            # backend build lacks it)
+            "backend": backend, "rccl_ranks": rccl_ranks, "gather_impl": gather.impl if world > 1 else "none",
         }
         if checksum is not None:
             res["config"]["frame_checksum"] = checksum

@@ -59,6 +59,7 @@ class BandGather:
         self.recv = torch.empty(world, self.tall, size, channels, device=cdev, dtype=dtype) if rank == dst else None
         self.recv_list = list(self.recv.unbind(0)) if rank == dst else None
         self.frame = torch.empty(size, size, channels, device=self.device, dtype=dtype) if (rank == dst and (self.via_host or not self.even)) else None
+        self.impl = os.environ.get("NA_DIST_GATHER", "gather")  # "all_gather": skip dist.gather altogether
 
     def __call__(self, local: torch.Tensor) -> Optional[torch.Tensor]:
         if self.world == 1:
@@ -69,7 +70,22 @@ class BandGather:
         else:
             self.send[: self.nrows].copy_(local)
             send = self.send
-        dist.gather(send, self.recv_list, dst=self.dst)
+        if self.impl == "gather":
+            try:
+                dist.gather(send, self.recv_list, dst=self.dst)
+            except (RuntimeError, NotImplementedError) as e:
+                # a backend build without point-to-point gather: the same bytes with the collective every backend has.  Every
+                # rank takes this branch together (the failure is raised before any communication is enqueued).
+                import sys
+                print(f"[nerf_atlas_amd.dist] rank {self.rank}: dist.gather unavailable on backend {dist.get_backend()} "
+                      f"({type(e).__name__}: {e}); falling back to all_gather", file=sys.stderr, flush=True)
+                self.impl = "all_gather"
+        if self.impl == "all_gather":
+            if self.recv is None:
+                cdev = send.device
+                self.recv = torch.empty(self.world, self.tall, self.size, send.shape[-1], device=cdev, dtype=send.dtype)
+                self.recv_list = list(self.recv.unbind(0))
+            dist.all_gather(self.recv_list, send)
         if self.rank != self.dst:
             return None
         if self.even:
@@ -88,17 +104,27 @@ class BandGather:
 _band_plans = {}
 
 
-def gather_bands(local: torch.Tensor, size: int, rank: int, world: int, dst: int = 0) -> Optional[torch.Tensor]:
+def reset_plans():
+    """Drop the cached gather plans (their buffers belong to a process group: call after destroy_process_group)."""
+    _band_plans.clear()
+
+
+def gather_bands(local: torch.Tensor, size: int, rank: int, world: int, dst: int = 0, copy: bool = True) -> Optional[torch.Tensor]:
     """local: [nrows_rank, size, C] band of this rank.  Returns the [size,size,C] frame on `dst`, None elsewhere.
-    Bands may differ by one row; the buffers of the collective are allocated on the first call and reused (`BandGather`).
-    The returned frame is that persistent buffer: clone it to keep it across calls."""
+    Bands may differ by one row; the buffers of the collective are allocated on the first call and reused (`BandGather`,
+    one plan per process group and shape).  The frame is a COPY by default: the plan's receive buffer is overwritten by the
+    next call, so frames collected in a list would alias each other; `copy=False` (or a `BandGather` of your own, as
+    bench.py keeps) returns the persistent buffer itself."""
     if world == 1:
         return local
-    key = (size, local.shape[-1], rank, world, str(local.device), local.dtype, dst, dist.get_backend())
+    key = (size, local.shape[-1], rank, world, str(local.device), local.dtype, dst, dist.get_backend(), id(dist.group.WORLD))
     plan = _band_plans.get(key)
     if plan is None:
+        if len(_band_plans) >= 16:  # (plans of destroyed groups and of shapes no longer rendered)
+            _band_plans.clear()
         plan = _band_plans[key] = BandGather(size, local.shape[-1], rank, world, local.device, local.dtype, dst)
-    return plan(local)
+    frame = plan(local)
+    return frame.clone() if (copy and frame is not None) else frame
 
 
 def merge_tile_frames(frame: torch.Tensor, rank: int, world: int, dst: int = 0) -> Optional[torch.Tensor]:
@@ -113,10 +139,34 @@ def merge_tile_frames(frame: torch.Tensor, rank: int, world: int, dst: int = 0) 
     return buf.to(dev) if rank == dst else None
 
 
-def render_frame_sharded(render_rows: Callable[[int, int], torch.Tensor], size: int, rank: int, world: int):
-    """render_rows(row0, nrows) -> [nrows,size,3] on this rank's device; returns the frame on rank 0."""
+def render_frame_sharded(render_rows: Callable[[int, int], torch.Tensor], size: int, rank: int, world: int, copy: bool = True):
+    """render_rows(row0, nrows) -> [nrows,size,3] on this rank's device; returns the frame on rank 0 (a copy: see
+    `gather_bands`; `copy=False` hands out the gather's persistent receive buffer, valid until the next call)."""
     r0, n = row_bands(size, world)[rank]
-    return gather_bands(render_rows(r0, n), size, rank, world)
+    return gather_bands(render_rows(r0, n), size, rank, world, copy=copy)
+
+
+def first_collective(device) -> Tuple[int, str]:
+    """The process group's first collective, made diagnosable: an all-reduce of ones on `device` (RCCL over xGMI with backend
+    "nccl": communicator creation, IPC handle exchange and the first kernel all happen here).  Returns (ranks counted, backend).
+    A failure is re-raised after this rank has printed who and where it is -- on an 8-GPU node eight interleaved tracebacks
+    without that line say nothing about WHICH rank could not see its GPU or peer."""
+    if not dist.is_initialized():
+        return 1, "none"
+    backend = dist.get_backend()
+    try:
+        t = torch.ones(1, device=device if backend == "nccl" else "cpu", dtype=torch.float32)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(round(float(t))), backend
+    except Exception as e:  # noqa: BLE001 -- annotate and re-raise
+        import sys
+        vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "<unset>"))
+        print(f"[nerf_atlas_amd.dist] first collective FAILED on rank {dist.get_rank()}/{dist.get_world_size()} "
+              f"(local {os.environ.get('LOCAL_RANK')}), device {device}, backend {backend}, visible devices {vis}, "
+              f"cuda devices {torch.cuda.device_count()}, MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}, "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}: {type(e).__name__}: {e}",
+              file=sys.stderr, flush=True)
+        raise
 
 
 # ------------------------------------------------------------------------------------------------- training replicas

@@ -18,18 +18,29 @@ def _frame_fn(r0, n, size):
     return rows * 1000 + cols + ch * 0.25
 
 
-def _worker(rank, world, port, size, q):
+def _worker(rank, world, port, size, q, impl="gather"):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), NA_DIST_GATHER=impl)
     from nerf_atlas_amd import dist as nd
     r, w, _ = nd.init_from_env(backend="gloo")
+    n, backend = nd.first_collective("cpu")
+    ok = n == world and backend == "gloo"
     frame = nd.render_frame_sharded(lambda r0, n: _frame_fn(r0, n, size), size, r, w)
+    # a second frame through the convenience wrapper must not overwrite the first (the plan's receive buffer)
+    frame2 = nd.render_frame_sharded(lambda r0, n: _frame_fn(r0, n, size) + 1.0, size, r, w)
     if r == 0:
-        q.put(bool(torch.equal(frame, _frame_fn(0, size, size))))
+        ok &= bool(torch.equal(frame, _frame_fn(0, size, size))) and bool(torch.equal(frame2, _frame_fn(0, size, size) + 1.0))
+        raw = nd.render_frame_sharded(lambda r0, n: _frame_fn(r0, n, size), size, r, w, copy=False)
+        raw2 = nd.render_frame_sharded(lambda r0, n: _frame_fn(r0, n, size) + 2.0, size, r, w, copy=False)
+        ok &= raw.data_ptr() == raw2.data_ptr()  # (copy=False: the persistent buffer itself, documented to alias)
     else:
-        q.put(frame is None)
+        ok &= frame is None and frame2 is None
+        nd.render_frame_sharded(lambda r0, n: _frame_fn(r0, n, size), size, r, w, copy=False)
+        nd.render_frame_sharded(lambda r0, n: _frame_fn(r0, n, size) + 2.0, size, r, w, copy=False)
+    q.put(bool(ok))
     torch.distributed.destroy_process_group()
+    nd.reset_plans()
 
 
 def _free_port():
@@ -55,10 +66,10 @@ def test_row_bands_partition():
 
 def test_sharded_frame_gather_gloo_world2():
     ctx = mp.get_context("spawn")
-    for size in (16, 17):  # even and ragged split
+    for size, impl in ((16, "gather"), (17, "gather"), (17, "all_gather")):  # even and ragged split; the fallback collective
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, size, q)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, size, q, impl)) for r in range(2)]
         for p in procs: p.start()
         results = [q.get(timeout=120) for _ in procs]
         for p in procs: p.join(timeout=60)

@@ -33,3 +33,6 @@ def test_bench_spawns_its_own_ranks():
     assert (one["roofline"]["traffic"] is None) == (one["roofline"]["traffic_source"] is None)
     assert one["roofline"]["traffic_source"] is None or one["roofline"]["traffic_source"].startswith("profiles/")
     assert two["scaling"] == "strong" and two["gather_ms"] >= 0
+    # the process group's first collective counted the ranks on the backend the line names
+    assert (one["backend"], one["rccl_ranks"], one["gather_impl"]) == ("none", 1, "none")
+    assert (two["backend"], two["rccl_ranks"], two["gather_impl"]) == ("gloo", 2, "gather")

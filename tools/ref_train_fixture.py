@@ -100,6 +100,8 @@ def main():
     a.add_argument("--steps", type=int, default=48)
     a.add_argument("--seed", type=int, default=1337)
     a.add_argument("--threads", type=int, default=8)
+    a.add_argument("--out", default=None, help="write the fixture here instead of tests/golden/train_parity_<name>.json "
+                   "(sensitivity runs: the same recipe under another thread count = another summation order)")
     cfg = a.parse_args()
     torch.set_num_threads(cfg.threads)
     dynamic, model_argv = RECIPES[cfg.name]
@@ -159,7 +161,7 @@ def main():
         test_psnr=psnrs, test_psnr_mean=mean,
         torch=torch.__version__, threads=cfg.threads, wall_s=round(dt, 1),
     )
-    path = os.path.join(REPO, "tests", "golden", f"train_parity_{cfg.name}.json")
+    path = cfg.out or os.path.join(REPO, "tests", "golden", f"train_parity_{cfg.name}.json")
     with open(path, "w") as f:
         json.dump(fixture, f, indent=1)
     print(f"{path}: {len(fixture['losses'])} iterations in {dt:.0f} s, loss {fixture['losses'][0]:.4f} -> "
