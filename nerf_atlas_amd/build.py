@@ -43,6 +43,15 @@ UNITS = [
     ("render_ls.hip", ["-DNA_PREC_INST=3", "-fno-slp-vectorize"], "_f16x", True),
 ]
 UNITS = [u if len(u) == 4 else u + (False,) for u in UNITS]
+# The timing-stress build of the layer-synchronous renderer: sample group 1 runs THREE phases behind group 0 instead of one.
+# This is the configuration in which the unexplained round-2 events (DESIGN 3b "reproducibility": 16 samples of one block off
+# by 1e-3 in one run of 20 ... 10^3) were frequent enough to count -- 10^3 .. 10^5 differing elements per 200 runs without
+# the two fences (compositing in front of the gathers, no SLP-formed packed fp32).  It is built next to the product library
+# (same objects, the four render_ls units recompiled) so that tests/test_gpu_determinism.py exercises the fences on every
+# GPU run instead of only when somebody remembers tools/ls_repeat.py variants.
+STRESS_FLAGS = ["-DNA_LS_LAG_OVERRIDE=3"]
+STRESS_UNITS = [(u[0], u[1] + STRESS_FLAGS, u[2] + "_lag3", u[3]) for u in UNITS if u[0] == "render_ls.hip"]
+STRESS_LIB = os.path.join(HERE, "libnerf_atlas_amd_lag3.so")
 ISA_FORBIDDEN = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32)\b")
 ISA_KERNEL = "render_ls_kernel"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("NA_EXTRA_HIPCC_FLAGS", "").split()
@@ -216,7 +225,7 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     """Compile the units whose (source, headers, flags) digest changed since the object was built, then link.
     Up-to-date-ness is decided by content hashes recorded next to the objects (build/digests.json), never by mtime:
     a fresh checkout, an edited header and a changed flag all rebuild exactly what they touch."""
-    units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[0]))]
+    units = [u for u in UNITS + STRESS_UNITS if os.path.exists(os.path.join(CSRC, u[0]))]
     os.makedirs(OBJ, exist_ok=True)
     stamp = os.path.join(OBJ, "digests.json")
     try:
@@ -228,18 +237,22 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     new = {os.path.basename(_obj_path(u)): _unit_digest(u, headers) for u in units}
     stale = [u for u in units if force or not os.path.exists(_obj_path(u))
              or old.get(os.path.basename(_obj_path(u))) != new[os.path.basename(_obj_path(u))]]
-    if not stale and os.path.exists(LIB) and old.get("__lib__") == hashlib.sha256("".join(sorted(new.values())).encode()).hexdigest():
+    if (not stale and os.path.exists(LIB) and os.path.exists(STRESS_LIB)
+            and old.get("__lib__") == hashlib.sha256("".join(sorted(new.values())).encode()).hexdigest()):
         return LIB
     jobs = jobs or min(max(len(stale), 1), os.cpu_count() or 4)
     if verbose:
         print(f"[nerf_atlas_amd] compiling {len(stale)} of {len(units)} units for {ARCH} with {jobs} jobs", file=sys.stderr)
     with cf.ThreadPoolExecutor(jobs) as ex:
         list(ex.map(_compile, stale))
-    objs = [_obj_path(u) for u in units]
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    stress = {(u[0], u[2][:-len("_lag3")]): u for u in units if u in STRESS_UNITS}
+    for lib, pick in ((LIB, lambda u: u not in STRESS_UNITS),
+                      (STRESS_LIB, lambda u: u in STRESS_UNITS or (u not in STRESS_UNITS and (u[0], u[2]) not in stress))):
+        objs = [_obj_path(u) for u in units if pick(u)]
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     new["__lib__"] = hashlib.sha256("".join(sorted(v for k, v in new.items())).encode()).hexdigest()
     with open(stamp, "w") as fh:
         json.dump(new, fh, indent=1)

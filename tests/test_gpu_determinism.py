@@ -36,3 +36,37 @@ def test_full_grid_slab_is_reproducible_over_many_runs():
     _keep("full_grid_slab", r)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "\n0 irreproducible runs" in r.stdout
+
+
+def test_timing_stress_build_is_reproducible():
+    """The fence around the unexplained round-2 events, exercised on every GPU run: the library built
+    with sample group 1 THREE phases behind group 0 (nerf_atlas_amd/libnerf_atlas_amd_lag3.so, build.STRESS_UNITS) -- the
+    timing in which, without the two fences (compositing in front of the gathers, no SLP-formed packed fp32), 10^3 .. 10^5
+    elements differed per 200 runs -- renders the full-grid slab 120 times per parity precision with every output element
+    equal to the per-element median, and renders the same frame as the shipped library bit for bit."""
+    from nerf_atlas_amd import build as B
+    assert os.path.exists(B.STRESS_LIB), "python -m nerf_atlas_amd.build builds it next to the product library"
+    env = dict(os.environ, NA_LIB_PATH=B.STRESS_LIB)
+    for prec in ("bf16x3", "f16x"):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "ls_repeat.py"), prec, "120"], capture_output=True, text=True,
+                           timeout=900, env=env)
+        _keep(f"lag3_{prec}", r)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "\n0 irreproducible runs" in r.stdout
+    # same bits as the shipped schedule (a lag changes WHEN a group works, never what it computes)
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "import bench; from nerf_atlas_amd import ops, config, cameras\n"
+            "import math\n"
+            "torch.manual_seed(0); m = bench.build_model(torch.device('cuda', 0))\n"
+            "cam = cameras.NeRFCamera(cam_to_world=torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]), focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()\n"
+            "rays = cam.sample_positions((300, 0, 24, 800), size=800); ts, _ = ops.compute_ts(2.0, 6.0, 128, 'cuda')\n"
+            "for p in ('bf16x3', 'f16x', 'bf16'):\n"
+            "    config.set_precision(p)\n"
+            "    with torch.no_grad(): out = m._render_fused(rays, ts, True)\n"
+            "    print(p, float(out[0].double().sum()), float(out[2].double().sum()))\n") % REPO
+    outs = []
+    for e in (os.environ, env):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.split()[0] in ("bf16x3", "f16x", "bf16")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
