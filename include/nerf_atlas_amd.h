@@ -95,7 +95,8 @@ int na_compute_pts(const float* rays, const float* ts, int T, int64_t R, float* 
 /* ---------------------------------------------------------------------------------------------
  * A5 HashEncoder.forward (src/neural_blocks.py:139-193).  x [N,3]; tables [8,65536,4] fp32;
  * out [N, 32 + 3*include_input]; idx_out: NULL or int64 [8 levels, 8 corners, N] table rows
- * (bit-exact int64 hashing).                                                                  */
+ * (bit-exact int64 hashing).                                                                  
+ * `out` must be 16-byte aligned (the rows are written with 16-byte stores; NA_EINVAL otherwise). */
 int na_hash_encode(const float* x, int64_t N, const float* tables, int include_input,
                    float* out, int64_t* idx_out, void* stream);
 

@@ -629,6 +629,9 @@ int na_hash_encode(const float* x, int64_t N, const float* tables, int include_i
   NA_REQUIRE(x && tables && out, NA_ENULL, "na_hash_encode: null pointer");
   NA_REQUIRE(N >= 0, NA_EINVAL, "na_hash_encode: N=%lld", (long long)N);
   if (N == 0) return NA_OK;
+  // the rows leave the kernel as 16-byte non-temporal stores (a row is 35 or 32 floats: every 64-sample block starts on a
+  // 16-byte boundary of `out` exactly when `out` itself is aligned); torch allocations are 256-byte aligned
+  NA_REQUIRE(((uintptr_t)out & 15) == 0, NA_EINVAL, "na_hash_encode: out must be 16-byte aligned (got %p)", (void*)out);
   hipLaunchKernelGGL(hash_encode_kernel, dim3(grid_for((N + 63) / 64 * 512, 512, 16384)), dim3(512), 0, (hipStream_t)stream, x, N,
                      (const float4*)tables, hash_resolutions(), include_input ? 1 : 0, out, idx_out);
   return check_launch("na_hash_encode");

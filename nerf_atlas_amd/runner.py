@@ -28,9 +28,15 @@ def load_state(path, allow_pickled_module=False):
     torch.save(model, path); unpickling it runs arbitrary code from the file, so it must be a file you trust).  Anything
     exposing .state_dict() is accepted; parameter names are the reference's, so its tensors load into this package's modules
     unchanged."""
+    import pickle
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:  # noqa: BLE001  (pickle.UnpicklingError and friends: not a plain tensor dict)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        # not a plain tensor dict: weights_only refuses the file's globals (UnpicklingError; RuntimeError in older torch).
+        # I/O problems -- missing file, permissions, a truncated archive (EOFError / OSError / zipfile errors) -- are NOT caught:
+        # they say what is wrong themselves, and must never lead to the unsafe full unpickle below
+        if isinstance(e, RuntimeError) and not any(k in str(e) for k in ("Unsupported", "weights_only", "GLOBAL", "unpickl")):
+            raise
         if not allow_pickled_module:
             raise ValueError(f"{path} is not a plain state_dict ({type(e).__name__}: {str(e)[:120]}); a checkpoint that pickles "
                              f"a whole module executes code from the file when loaded: pass --load-pickled-module to accept it") from e

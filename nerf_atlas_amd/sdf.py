@@ -29,6 +29,12 @@ class SDFModel(nn.Module):
 
     def normals_tangent_major(self, pts, values=None):
         """[3, N] layout of the same normals (what ops.eikonal_loss consumes: no transposition in the graph)."""
+        if values is not None and not (isinstance(values, str) and values == "sdf"):
+            # the reference's `values` is a TENSOR to differentiate (src/sdf.py:43-48); forward-mode tangents cannot take an
+            # arbitrary graph output, and silently treating it as None would return a different quantity
+            raise NotImplementedError("SDFModel.normals: values must be None (the reference's call sites: gradient of the whole "
+                                      "output row) or \"sdf\" (gradient of the signed distance); a tensor to differentiate is "
+                                      "not supported by the forward-mode implementation")
         _, t = self._net().forward_with_input_tangents(pts.reshape(-1, 3))
         return t[..., 0] if values == "sdf" else t.sum(-1)
 

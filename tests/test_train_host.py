@@ -48,6 +48,14 @@ def test_load_state_executes_no_pickled_code_by_default(tmp_path):
     with pytest.raises(ValueError, match="load-pickled-module"):
         runner.load_state(str(p2))
     assert set(runner.load_state(str(p2), allow_pickled_module=True)) == {"weight", "bias"}
+    # I/O errors are not "a pickled module": they propagate as themselves and never reach the unsafe full unpickle
+    with pytest.raises(FileNotFoundError):
+        runner.load_state(str(tmp_path / "missing.pt"), allow_pickled_module=True)
+    p3 = tmp_path / "truncated.pt"
+    p3.write_bytes(p1.read_bytes()[:40])
+    with pytest.raises(Exception) as ei:
+        runner.load_state(str(p3))
+    assert not isinstance(ei.value, ValueError) or "load-pickled-module" not in str(ei.value)
 
 
 def test_invalidate_packed_clears_every_stream_cache():
