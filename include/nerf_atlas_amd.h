@@ -398,6 +398,11 @@ int na_render_volsdf_siren_ls(const float* rays, const float* pts, int64_t R, co
  * touch only the rays the reference's boolean-mask code would have touched.  `sdf` is column 0 of an [R, stride] MLP
  * output.  hits/rem/todo are 0/1 bytes.
  *
+ * Compacted iterations (src/march.py:37-45, 164-179: the reference evaluates the SDF only for the rays its boolean masks keep):
+ * na_compact_rays         idx[0..count) = the rays with live[r] != 0, ASCENDING (deterministic); *count = their number (device
+ *                         int32).  idx has room for R + 256 entries (the tail is scratch).
+ * na_ray_points_indexed / na_sphere_march_update_indexed / na_bisection_update_indexed: the kernels below on n compacted
+ *                         rows -- row i of pts / sdf belongs to ray idx[i]; per-ray state arrays stay full size.
  * na_ray_points           pts[R,3] = r_o + r_d * t, t per ray (t_ray[R]) or t_scalar when t_ray is NULL.
  * na_sphere_march_update  one iteration of sphere_march (src/march.py:39-45): for rem rays  hits |= (sdf < eps) &
  *                         (dist <= far);  dist += sdf;  rem &= !(hits | dist > far).
@@ -405,6 +410,13 @@ int na_render_volsdf_siren_ls(const float* rays, const float* pts, int64_t R, co
  *                         minimum + its step index, first sign change (last_pos / first_neg step indices, -1 = none).
  * na_bisection_update     bisection (src/march.py:159-179): sdf_mid NULL initialises todo and z = (low+high)/2 from
  *                         low/high/sdf_low/sdf_high; otherwise one iteration with the SDF at z.                        */
+int na_compact_rays(const uint8_t* live, int64_t R, int32_t* idx, int32_t* count, void* stream);
+int na_ray_points_indexed(const float* r_o, const float* r_d, const float* t_ray, const int32_t* idx, int64_t n, float* pts,
+                          void* stream);
+int na_sphere_march_update_indexed(const float* sdf, int stride, const int32_t* idx, int64_t n, float eps, float far,
+                                   float* dist, uint8_t* hits, uint8_t* rem, void* stream);
+int na_bisection_update_indexed(const float* sdf_mid, int stride, const int32_t* idx, int64_t n, float eps, float* low,
+                                float* high, float* sdf_low, float* sdf_high, float* z, uint8_t* todo, void* stream);
 int na_ray_points(const float* r_o, const float* r_d, const float* t_ray, float t_scalar, int64_t R, float* pts,
                   void* stream);
 int na_sphere_march_update(const float* sdf, int stride, int64_t R, float eps, float far, float* dist, uint8_t* hits,

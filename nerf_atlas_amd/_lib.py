@@ -70,6 +70,12 @@ SIGNATURES = {
     "na_mlp_forward_mip": (C.c_int, [C.POINTER(NaMlpDesc), C.c_int, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64, c_f32p,
                                      C.c_void_p, c_i64, c_f32p, C.c_void_p]),
     "na_ray_points": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_float, c_i64, c_f32p, C.c_void_p]),
+    "na_compact_rays": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "na_ray_points_indexed": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, c_i64, c_f32p, C.c_void_p]),
+    "na_sphere_march_update_indexed": (C.c_int, [c_f32p, C.c_int, C.c_void_p, c_i64, C.c_float, C.c_float, c_f32p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
+    "na_bisection_update_indexed": (C.c_int, [c_f32p, C.c_int, C.c_void_p, c_i64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
+                                              c_f32p, C.c_void_p, C.c_void_p]),
     "na_sphere_march_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_float, C.c_float, c_f32p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
     "na_sign_change_update": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -33,6 +33,81 @@ __global__ void sphere_march_update_kernel(const float* __restrict__ sdf, int st
   }
 }
 
+// ---- compaction of the live rays (src/march.py:37-45, :164-179: the reference indexes its state with boolean masks, so every
+// iteration evaluates the SDF network for the rays that are still marching only).  ORDERED and deterministic: block b owns the
+// contiguous segment [b * seg, (b + 1) * seg) of the rays; pass 1 counts its live rays, pass 2 places them behind the live rays
+// of the segments in front of it.  idx comes out ascending, so the gathers / scatters of the indexed kernels stay coalesced
+// where rays are live in runs (they are: neighbouring pixels).
+constexpr int kCompactBlocks = 256;
+__global__ __launch_bounds__(256) void compact_count_kernel(const uint8_t* __restrict__ live, int64_t R, int64_t seg,
+                                                            int32_t* __restrict__ counts) {
+  __shared__ int wsum[4];
+  const int64_t r0 = blockIdx.x * seg, r1 = r0 + seg < R ? r0 + seg : R;
+  int c = 0;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) c += live[r] != 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void compact_place_kernel(const uint8_t* __restrict__ live, int64_t R, int64_t seg,
+                                                            const int32_t* __restrict__ counts, int32_t* __restrict__ idx,
+                                                            int32_t* __restrict__ count) {
+  __shared__ int wsum[4];
+  __shared__ int base_s;
+  if (threadIdx.x == 0) {
+    int b = 0, total = 0;
+    for (int i = 0; i < kCompactBlocks; ++i) { if (i == (int)blockIdx.x) b = total; total += counts[i]; }
+    base_s = b;
+    if (blockIdx.x == 0) *count = total;
+  }
+  __syncthreads();
+  int base = base_s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r0 = blockIdx.x * seg, r1 = r0 + seg < R ? r0 + seg : R;
+  for (int64_t c0 = r0; c0 < r1; c0 += 256) {
+    const int64_t r = c0 + threadIdx.x;
+    const bool on = r < r1 && live[r] != 0;
+    const unsigned long long m = __ballot(on);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wv; ++w) off += wsum[w];
+    if (on) idx[off + before] = (int32_t)r;
+    base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+
+// pts[i] = r_o[idx[i]] + r_d[idx[i]] * t_ray[idx[i]] for the n compacted rays
+__global__ void ray_points_indexed_kernel(const float* __restrict__ r_o, const float* __restrict__ r_d,
+                                          const float* __restrict__ t_ray, const int32_t* __restrict__ idx, int64_t n,
+                                          float* __restrict__ pts) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * 3; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / 3, r = idx[k];
+    const int c = (int)(i - k * 3);
+    pts[i] = r_o[r * 3 + c] + r_d[r * 3 + c] * t_ray[r];
+  }
+}
+
+// sphere_march_update_kernel on compacted rows: row i of `sdf` belongs to ray idx[i] (all of them have rem != 0)
+__global__ void sphere_march_update_indexed_kernel(const float* __restrict__ sdf, int stride, const int32_t* __restrict__ idx,
+                                                   int64_t n, float eps, float far, float* __restrict__ dist,
+                                                   uint8_t* __restrict__ hits, uint8_t* __restrict__ rem) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx[i];
+    if (!rem[r]) continue;
+    const float d = sdf[i * stride];
+    float cd = dist[r];
+    uint8_t h = hits[r] | (uint8_t)((d < eps) && (cd <= far));
+    cd += d;
+    dist[r] = cd;
+    hits[r] = h;
+    if (h || cd > far) rem[r] = 0;
+  }
+}
+
 // src/march.py:96-103, one uniform step i (0-based)
 __global__ void sign_change_update_kernel(const float* __restrict__ sdf, int stride, int64_t R, int step,
                                           float* __restrict__ curr_min, int32_t* __restrict__ idxs,
@@ -70,6 +145,25 @@ __global__ void bisection_update_kernel(const float* __restrict__ sdf_mid, int s
       td = td && bisect_todo(lo, hi, sl, sh, eps);
       low[r] = lo; high[r] = hi; sdf_low[r] = sl; sdf_high[r] = sh;
     }
+    z[r] = (lo + hi) / 2.f;
+    todo[r] = td;
+  }
+}
+
+// bisection_update_kernel (one iteration) on compacted rows: row i of sdf_mid belongs to ray idx[i] (todo != 0)
+__global__ void bisection_update_indexed_kernel(const float* __restrict__ sdf_mid, int stride, const int32_t* __restrict__ idx,
+                                                int64_t n, float eps, float* __restrict__ low, float* __restrict__ high,
+                                                float* __restrict__ sdf_low, float* __restrict__ sdf_high, float* __restrict__ z,
+                                                uint8_t* __restrict__ todo) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx[i];
+    float lo = low[r], hi = high[r], sl = sdf_low[r], sh = sdf_high[r];
+    bool td = todo[r];
+    const float sm = sdf_mid[i * stride], zp = z[r];
+    if (sm > 0.f && td) { lo = zp; sl = sm; }
+    if (sm < 0.f && td) { hi = zp; sh = sm; }
+    td = td && bisect_todo(lo, hi, sl, sh, eps);
+    low[r] = lo; high[r] = hi; sdf_low[r] = sl; sdf_high[r] = sh;
     z[r] = (lo + hi) / 2.f;
     todo[r] = td;
   }
@@ -141,6 +235,48 @@ int na_sphere_march_update(const float* sdf, int stride, int64_t R, float eps, f
   hipLaunchKernelGGL(sphere_march_update_kernel, dim3(grid_for(R, 256, 8192)), dim3(256), 0, (hipStream_t)stream, sdf,
                      stride, R, eps, far, dist, hits, rem);
   return check_launch("na_sphere_march_update");
+}
+
+int na_compact_rays(const uint8_t* live, int64_t R, int32_t* idx, int32_t* count, void* stream) {
+  NA_REQUIRE(R >= 0 && R < (1ll << 31), NA_EINVAL, "na_compact_rays: R %lld", (long long)R);
+  NA_REQUIRE(idx && count, NA_ENULL, "na_compact_rays: null pointer");
+  if (R == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream); return check_launch("na_compact_rays"); }
+  NA_REQUIRE(live, NA_ENULL, "na_compact_rays: null pointer");
+  const int64_t seg = (R + kCompactBlocks - 1) / kCompactBlocks;
+  int32_t* counts = idx + R;  // scratch behind the indices: the caller allocates R + 256 entries
+  hipLaunchKernelGGL(compact_count_kernel, dim3(kCompactBlocks), dim3(256), 0, (hipStream_t)stream, live, R, seg, counts);
+  hipLaunchKernelGGL(compact_place_kernel, dim3(kCompactBlocks), dim3(256), 0, (hipStream_t)stream, live, R, seg, counts, idx, count);
+  return check_launch("na_compact_rays");
+}
+
+int na_ray_points_indexed(const float* r_o, const float* r_d, const float* t_ray, const int32_t* idx, int64_t n, float* pts,
+                          void* stream) {
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(n > 0, NA_EINVAL, "na_ray_points_indexed: n %lld", (long long)n);
+  NA_REQUIRE(r_o && r_d && t_ray && idx && pts, NA_ENULL, "na_ray_points_indexed: null pointer");
+  hipLaunchKernelGGL(ray_points_indexed_kernel, dim3(grid_for(n * 3, 256, 8192)), dim3(256), 0, (hipStream_t)stream, r_o, r_d,
+                     t_ray, idx, n, pts);
+  return check_launch("na_ray_points_indexed");
+}
+
+int na_sphere_march_update_indexed(const float* sdf, int stride, const int32_t* idx, int64_t n, float eps, float far, float* dist,
+                                   uint8_t* hits, uint8_t* rem, void* stream) {
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(n > 0 && stride >= 1, NA_EINVAL, "na_sphere_march_update_indexed: n %lld stride %d", (long long)n, stride);
+  NA_REQUIRE(sdf && idx && dist && hits && rem, NA_ENULL, "na_sphere_march_update_indexed: null pointer");
+  hipLaunchKernelGGL(sphere_march_update_indexed_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, sdf,
+                     stride, idx, n, eps, far, dist, hits, rem);
+  return check_launch("na_sphere_march_update_indexed");
+}
+
+int na_bisection_update_indexed(const float* sdf_mid, int stride, const int32_t* idx, int64_t n, float eps, float* low,
+                                float* high, float* sdf_low, float* sdf_high, float* z, uint8_t* todo, void* stream) {
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(n > 0 && stride >= 1, NA_EINVAL, "na_bisection_update_indexed: n %lld stride %d", (long long)n, stride);
+  NA_REQUIRE(sdf_mid && idx && low && high && sdf_low && sdf_high && z && todo, NA_ENULL, "na_bisection_update_indexed: null pointer");
+  hipLaunchKernelGGL(bisection_update_indexed_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, sdf_mid,
+                     stride, idx, n, eps, low, high, sdf_low, sdf_high, z, todo);
+  return check_launch("na_bisection_update_indexed");
 }
 
 int na_sign_change_update(const float* sdf, int stride, int64_t R, int step, float* curr_min, int32_t* idxs,

@@ -288,6 +288,37 @@ def ray_points(r_o: torch.Tensor, r_d: torch.Tensor, t) -> torch.Tensor:
     return pts
 
 
+def compact_rays(live: torch.Tensor, idx: torch.Tensor, count: torch.Tensor) -> int:
+    """idx[:n] = ascending indices of the rays with live != 0 (uint8 mask of any shape); returns n -- one host read of the
+    device counter (the reference's boolean-mask indexing synchronises at the same point).  idx: int32 [R + 256], count: int32 [1]."""
+    lib = _lib.load()
+    assert live.dtype == torch.uint8 and live.is_contiguous() and idx.dtype == torch.int32 and idx.numel() >= live.numel() + 256
+    check(lib.na_compact_rays(_ptr(live), live.numel(), _ptr(idx), _ptr(count), _stream()))
+    return int(count.item())
+
+
+def ray_points_indexed(r_o, r_d, t_ray, idx, n: int) -> torch.Tensor:
+    """[n,3] positions r_o + r_d * t of the compacted rays idx[:n]"""
+    lib = _lib.load()
+    pts = torch.empty(n, 3, device=r_o.device, dtype=torch.float32)
+    check(lib.na_ray_points_indexed(_ptr(r_o), _ptr(r_d), _ptr(t_ray), _ptr(idx), n, _ptr(pts), _stream()))
+    return pts
+
+
+def sphere_march_update_indexed(sdf, idx, n: int, eps: float, far: float, dist, hits, rem):
+    lib = _lib.load()
+    sdf, stride = _sdf_col(sdf)
+    check(lib.na_sphere_march_update_indexed(_ptr(sdf), stride, _ptr(idx), n, float(eps), float(far), _ptr(dist), _ptr(hits),
+                                             _ptr(rem), _stream()))
+
+
+def bisection_update_indexed(sdf_mid, idx, n: int, eps: float, low, high, sdf_low, sdf_high, z, todo):
+    lib = _lib.load()
+    sdf_mid, stride = _sdf_col(sdf_mid)
+    check(lib.na_bisection_update_indexed(_ptr(sdf_mid), stride, _ptr(idx), n, float(eps), _ptr(low), _ptr(high), _ptr(sdf_low),
+                                          _ptr(sdf_high), _ptr(z), _ptr(todo), _stream()))
+
+
 def _sdf_col(sdf: torch.Tensor):
     sdf = _f32(sdf, "sdf")
     return sdf, (sdf.shape[-1] if sdf.dim() > 1 else 1)

@@ -142,3 +142,65 @@ def test_hip_marching_disagreements_are_threshold_grazing():
     print(f"\n[march] fused-vs-fp32 SDF error {worst_sdf_err:.2e}; {int(grazing.sum())} grazing rays, "
           f"{int(final_differs.sum())} of {final_differs.numel()} final decisions differ from the golden")
     assert float(final_differs.float().mean()) <= 0.05
+
+
+@pytest.mark.gpu
+def test_compacted_marching_equals_dense_and_skips_finished_rays():
+    """the compacted path (na_compact_rays -> SDF on the live rays -> indexed update; what the reference's
+    boolean-mask indexing does, src/march.py:37-45, :164-179) gives the dense path's hits / distances / points BIT FOR BIT --
+    on the g15 fixture rays (analytic SDF: also equal to the reference's own outputs; SIREN SDF through the fused MLP) and on
+    a 160 x 160 frame -- and evaluates 2.5x fewer network rows on the fixture scene (printed; more on full frames)."""
+    from nerf_atlas_amd import march, ops, config
+    import nerf_atlas_amd.sdf as sdf
+    g = load_golden("g15_march")
+    config.set_precision("bf16x3")
+    m = sdf.SIREN(intermediate_size=0).cuda().eval()
+    sd = m.state_dict()
+    for k, v in golden_params(g).items():
+        sd[k].copy_(v)
+    jit = float(g["jitter"])
+    # ordered compaction: ascending indices, exact count, empty and full masks
+    for n, p in ((1, 0.5), (255, 0.3), (4097, 0.9), (100000, 0.02), (640000, 0.5)):
+        torch.manual_seed(n)
+        live = (torch.rand(n, device="cuda") < p).to(torch.uint8)
+        idx = torch.empty(n + 256, device="cuda", dtype=torch.int32)
+        cnt = torch.empty(1, device="cuda", dtype=torch.int32)
+        k = ops.compact_rays(live, idx, cnt)
+        assert k == int(live.sum()) and torch.equal(idx[:k].long(), live.nonzero().flatten())
+    z = torch.zeros(5000, device="cuda", dtype=torch.uint8)
+    assert ops.compact_rays(z, torch.empty(5256, device="cuda", dtype=torch.int32), torch.empty(1, device="cuda", dtype=torch.int32)) == 0
+    # (a) the fixture rays, both SDFs, compaction forced
+    for tag, fn in (("an", analytic), ("nn", m)):
+        r_o, r_d = g["r_o"].cuda(), g["r_d"].cuda()
+        near, far = float(g[f"{tag}_near"]), float(g[f"{tag}_far"])
+        dense = march.sphere_march(fn, r_o, r_d, iters=24, eps=1e-3, near=near, far=far, compact=False)
+        comp = march.sphere_march(fn, r_o, r_d, iters=24, eps=1e-3, near=near, far=far, compact=True)
+        st = dict(march.last_stats)
+        assert torch.equal(dense[0], comp[0]) and torch.equal(dense[1], comp[1]) and torch.equal(dense[2], comp[2])
+        print(f"\\n[march/{tag}] sphere_march: {st['mlp_rows']} network rows against {st['dense_rows']} dense "
+              f"({st['dense_rows'] / st['mlp_rows']:.1f}x fewer), {st['iters']} of 24 iterations ran")
+        # (measured: 2.5x on the analytic fixture -- a few grazing rays march through all 24 iterations -- and more on frames)
+        assert st["dense_rows"] >= 2 * st["mlp_rows"] if tag == "an" else st["mlp_rows"] < st["dense_rows"], st
+        if tag == "an":
+            assert torch.equal(comp[1].cpu(), g["an_sm_hits"])  # and it is the reference's answer
+        d2 = march.bisect(fn, r_o, r_d, iters=40, near=near, far=far, jitter=jit, compact=False)
+        c2 = march.bisect(fn, r_o, r_d, iters=40, near=near, far=far, jitter=jit, compact=True)
+        stb = dict(march.last_stats)
+        assert all(torch.equal(a, b) for a, b in zip(d2, c2))
+        print(f"[march/{tag}] bisection: {stb['mlp_rows']} network rows against {stb['dense_rows']} dense")
+        assert stb["mlp_rows"] < stb["dense_rows"]
+    # (b) a frame above COMPACT_MIN_RAYS: the default picks the compacted path and the answer is the dense one
+    import math
+    from nerf_atlas_amd import cameras
+    size = 160
+    cam = cameras.NeRFCamera(cam_to_world=torch.tensor([[[0.8, -0.36, 0.48, 1.9], [0.0, 0.8, 0.6, 2.4], [-0.6, -0.48, 0.64, 2.6]]]),
+                             focal=0.5 * size / math.tan(0.5 * 0.6911)).cuda()
+    rays = cam.sample_positions((0, 0, size, size), size=size, with_noise=False)[0]
+    r_o, r_d = rays[..., :3].contiguous(), torch.nn.functional.normalize(rays[..., 3:], dim=-1)
+    assert r_o.numel() // 3 >= march.COMPACT_MIN_RAYS
+    for fn in (analytic, m):
+        dense = march.sphere_march(fn, r_o, r_d, iters=32, eps=1e-3, near=1.0, far=6.0, compact=False)
+        auto = march.sphere_march(fn, r_o, r_d, iters=32, eps=1e-3, near=1.0, far=6.0)
+        st = dict(march.last_stats)
+        assert st["mlp_rows"] < st["dense_rows"] and all(torch.equal(a, b) for a, b in zip(dense[:3], auto[:3]))
+        print(f"[march/frame] {st['dense_rows'] / st['mlp_rows']:.1f}x fewer network rows, hit fraction {float(auto[1].float().mean()):.2f}")

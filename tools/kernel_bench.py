@@ -162,6 +162,43 @@ def main():
                              Msamples_per_s=round(n / dt / 1e6, 1), frac_of_mfma_peak=round(n * flop / dt / peak, 3)))
             print(f"model {name:30s} [{prec:6s}] {dt * 1e3:8.2f} ms  {n / dt / 1e6:8.1f} Msamples/s  ({n * flop / dt / peak:5.1%} of peak)")
     config.set_precision("bf16x3")
+    # ---- N4: SDF marching of an 800 x 800 frame (src/march.py:27-47, 147-180), dense vs compacted.
+    # "samples" = SDF network rows a DENSE march would evaluate (rays x iterations): the rate is per unit of the reference's
+    # nominal work, so the compacted path's gain shows as a higher rate.  SDF: the SIREN network (fused MLP kernel) shifted so
+    # that its zero level set is a blob in front of the camera, and the analytic two-sphere SDF of the fixtures.
+    from nerf_atlas_amd import march, cameras
+    cam = cameras.NeRFCamera(cam_to_world=torch.tensor([[[0.8, -0.36, 0.48, 1.9], [0.0, 0.8, 0.6, 2.4], [-0.6, -0.48, 0.64, 2.6]]]),
+                             focal=focal).to(dev)
+    fr = cam.sample_positions((0, 0, size, size), size=size, with_noise=False)[0]
+    r_o, r_d = fr[..., :3].contiguous(), torch.nn.functional.normalize(fr[..., 3:], dim=-1)
+
+    def analytic(p):
+        a_ = torch.linalg.norm(p - torch.tensor([0.1, -0.2, 0.0], device=p.device), dim=-1) - 1.1
+        b_ = torch.linalg.norm(p - torch.tensor([0.9, 0.6, 0.3], device=p.device), dim=-1) - 0.5
+        return torch.minimum(a_, b_).unsqueeze(-1)
+    torch.manual_seed(1)
+    siren = sdf.SIREN(intermediate_size=0).to(dev).eval()
+
+    def siren_blob(p):  # 0.4 * siren(p) + (|p| - 1): a perturbed unit sphere, evaluated by the fused MLP kernel
+        return (0.4 * siren(p)[..., :1] + (torch.linalg.norm(p, dim=-1, keepdim=True) - 1.0)) * 0.5
+    for name, fn in (("analytic two spheres", analytic), ("SIREN blob (fused MLP)", siren_blob)):
+        for iters_ in (32,):
+            res = {}
+            for mode, comp in (("dense", False), ("compacted", True)):
+                with torch.no_grad():
+                    dt = timed(lambda: march.sphere_march(fn, r_o, r_d, iters=iters_, eps=1e-3, near=1.0, far=6.0, compact=comp), iters=3, warm=1)
+                    out = march.sphere_march(fn, r_o, r_d, iters=iters_, eps=1e-3, near=1.0, far=6.0, compact=comp)
+                st = dict(march.last_stats)
+                res[mode] = (dt, st, out)
+                n = st["dense_rows"]
+                rows.append(dict(kernel=f"sphere_march {name} [{mode}]", units=n, unit="ray-iterations", us=round(dt * 1e6, 1),
+                                 Msamples_per_s=round(n / dt / 1e6, 1), mlp_rows=st["mlp_rows"], iters_run=st["iters"]))
+                print(f"sphere_march {name:24s} [{mode:9s}] {dt * 1e3:8.2f} ms  {n / dt / 1e6:8.1f} M ray-iterations/s  "
+                      f"network rows {st['mlp_rows']} of {n} ({n / max(st['mlp_rows'], 1):.1f}x fewer), hit fraction {float(out[1].float().mean()):.2f}")
+            same = all(torch.equal(x, y) for x, y in zip(res["dense"][2][:3], res["compacted"][2][:3]))
+            print(f"   compacted == dense bit for bit: {same}; speed-up {res['dense'][0] / res['compacted'][0]:.2f}x")
+            rows.append(dict(kernel=f"sphere_march {name} compacted == dense", identical=bool(same),
+                             speedup=round(res["dense"][0] / res["compacted"][0], 2)))
     if a.json:
         with open(a.json, "w") as f:
             json.dump(dict(rays=R, steps=T, samples=N, rows=rows), f, indent=1)
