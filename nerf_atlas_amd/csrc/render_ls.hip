@@ -112,8 +112,10 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // geometry, view.L0 4 + geometry | first.L0..L3 16, first.out 4, view.L0..L3 16, view.out 4;  1 TinyNeRF: init, two skip
 // chunks | six Linears + out;  2 View half: 4 + geometry twice | four Linears + out;  3 SIREN VolSDF: init, two skip chunks,
 // the View half's ten | five Linears + sdf.out + the View half's twenty)
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : 16; }
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : 40; }
+// (MODEL 0, round 4: the init / skip chunks of both MLPs are RECORDS too -- [hash | x] and the latent are one K64 group each,
+// f16 + 2 x fp6 like the hidden groups -- so only the two geometry chunk pairs of the View MLP are left as pairs)
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : 2; }
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -181,7 +183,10 @@ static __global__ void lsx_poison_kernel(uint32_t gen, float* __restrict__ out, 
 // NA_PREC_F16X stream schedules (pack side): the Linears of the model and which of them every pair / record / bias block packs
 struct XLin { const float* W; const float* B; int in_dim, out_dim, desc; };  // nn.Linear layout [out,in]
 struct XPairD { int8_t lin, q, skip; };      // init chunk q of Linear lin (skip: its columns sit behind the kHidden hidden ones)
-struct XRecD { int8_t lin, q, out_mode; };   // K64 group q of Linear lin; out_mode 0 hidden rows, 1 out row-major, 2 out, one tile
+// K64 group of Linear lin.  kind 0: hidden features 64 q .. 64 q + 63; kind 1 / 2: the init chunks 0..3 of the MLP (columns by
+// init_slot_feature; 2: behind the kHidden hidden columns of a skip layer).  out_mode 0 hidden rows, 1 out row-major (tile
+// min(rg, 2)), 2 out, one tile, 3 out split by block: row groups 0,1 hold tiles 0 and 1, row groups 2,3 tile 2
+struct XRecD { int8_t lin, q, out_mode, kind; };
 struct XSched {
   int npair, nrec, nphase, nlin, ndesc;
   XLin lin[13];
@@ -589,17 +594,24 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(0);
 }
 
-// ---- four records (one Linear, K = 256 hidden features) starting at record rec0 (a multiple of 4): per K64 group the four
-// f16 chunks, then the two fp6 correction products.  NT tiles (2: hidden Linear; 1: out Linear, tile 0 of the record) x NBk blocks
-// whose hidden activations start at hb0 + b * BLKH.
+// ---- NG records starting at record rec0: per K64 group the f16 chunks, then the two fp6 correction products.  NT tiles (2:
+// hidden Linear; 1: out Linear, tile 0 of the record) x NBk blocks.  The groups' B operands: with G0 = 1 the FIRST record is an
+// init group, read from the init region (block b at ib0 + b * KQ; NCH0 of its four f16 chunks carry data: 3 for [hash | x],
+// whose fourth chunk is padding that the fp6 operands hold as zeros and the f16 product skips); the others are the hidden
+// groups Q = 0, 1, ... of the blocks (hb0 + b * BLKH + Q * KQ).  PAR0 = parity of rec0 (which scale slot its dword sits in).
 // CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
-template <int NT, int NBk, bool CB, int NREC>
+template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4>
 __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
-                                     int rec0, const char* hb0, int lane) {
+                                     int rec0, const char* hb0, int lane, const char* ib0 = nullptr) {
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
-  auto b16 = [&](int b, int Q, int c) -> f16x8 { return *(const f16x8*)(hb0 + b * BLKH + Q * KQ + c * 1024 + lane * 16); };
-  auto b6 = [&](int b, int Q, int k) -> i32x8 {  // k: 0 R, 1 T
-    const char* p = hb0 + b * BLKH + Q * KQ + 4096 + k * 2048 + lane * 16;
+  auto gbase = [&](int gi, int b) -> const char* {  // K64 group gi of this call, block b
+    if (G0 != 0 && gi == 0) return ib0 + b * KQ;
+    return hb0 + b * BLKH + (gi - G0) * KQ;
+  };
+  auto nch = [&](int gi) -> int { return (G0 != 0 && gi == 0) ? NCH0 : 4; };
+  auto b16 = [&](int b, int gi, int c) -> f16x8 { return *(const f16x8*)(gbase(gi, b) + c * 1024 + lane * 16); };
+  auto b6 = [&](int b, int gi, int k) -> i32x8 {  // k: 0 R, 1 T
+    const char* p = gbase(gi, b) + 4096 + k * 2048 + lane * 16;
     const u32x4 a = *(const u32x4*)p, c = *(const u32x4*)(p + 1024);
     return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
   };
@@ -608,31 +620,36 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
 #pragma unroll
   for (int b = 0; b < NBk; ++b) Bq[0][b] = b16(b, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
+  bool first = true;  // (no MFMA of this call has issued yet: the next one takes the bias as its C operand)
+  int cur = 0;        // which half of Bq holds the chunk about to be consumed
 #pragma unroll
-  for (int Q = 0; Q < 4; ++Q) {
-    int nrc = rec0 + Q + 1;
+  for (int gi = 0; gi < NG; ++gi) {
+    int nrc = rec0 + gi + 1;
     nrc = nrc >= NREC ? 0 : nrc;
     const int noff = __builtin_amdgcn_readfirstlane(xrec + nrc * REC);
     // the NEXT record's scale bytes, a whole group ahead (its WT6 conversion runs behind the second chunk of its group)
-    if (!(NA_LSX_EXP & 2)) R.asc[(Q + 1) & 1] = wloadsc(rs, lane, noff);
-    const int asc = R.asc[Q & 1];
+    if (!(NA_LSX_EXP & 2)) R.asc[(PAR0 + gi + 1) & 1] = wloadsc(rs, lane, noff);
+    const int asc = R.asc[(PAR0 + gi) & 1];
     i32x6 wt[NT];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int ci = Q * 4 + c;
-      if (ci + 1 < 16) {
+      const bool live = c < nch(gi);  // (a padding chunk: no f16 product, its weight fragments are still streamed in step)
+      // the B fragments of the next chunk that carries data (this group's, or chunk 0 of the next group)
+      int ng = gi, nc = c + 1;
+      if (nc >= nch(gi)) { ng = gi + 1; nc = 0; }
+      if (live && ng < NG) {
 #pragma unroll
-        for (int b = 0; b < NBk; ++b) Bq[(ci + 1) & 1][b] = b16(b, (ci + 1) >> 2, (ci + 1) & 3);
+        for (int b = 0; b < NBk; ++b) Bq[cur ^ 1][b] = b16(b, ng, nc);
       }
       if (c == 1) {  // this group's fp6 B operands: two chunks of lead
 #pragma unroll
-        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, Q, 0); B6[b][1] = (NA_LSX_EXP & 8) ? B6[b][0] : b6(b, Q, 1); }
+        for (int b = 0; b < NBk; ++b) { B6[b][0] = b6(b, gi, 0); B6[b][1] = (NA_LSX_EXP & 8) ? B6[b][0] : b6(b, gi, 1); }
       }
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 A0 = a16frag(R.a16[0], c), A1 = a16frag(R.a16[1], c);
 #pragma unroll
       for (int b = 0; b < NBk; ++b) {
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[ci & 1][b], (CB && ci == 0) ? cb[0] : acc[0][b], 0, 0, 0);
+        if (live) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bq[cur][b], (CB && first) ? cb[0] : acc[0][b], 0, 0, 0);
         // WT6 = fp6(f16 W / 2^scale) of this record, from the fragments while all four chunks are still in place (the newest,
         // chunk 3, was requested a group ago).  The conversion holds the wave's issue for ~46 cycles (measured: two of them
         // behind the MFMAs of a chunk cost 2.9 % of the frame), so each one sits directly behind ONE MFMA and runs in its shadow
@@ -644,7 +661,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (NT == 2) {
-          acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[ci & 1][b], (CB && ci == 0) ? cb[NT - 1] : acc[1][b], 0, 0, 0);
+          if (live) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bq[cur][b], (CB && first) ? cb[NT - 1] : acc[1][b], 0, 0, 0);
           if (c == 1 && b == 0) {
             __builtin_amdgcn_sched_barrier(0);
             const float sc = __builtin_bit_cast(float, (((uint32_t)asc >> 24) & 0xFFu) << 23);
@@ -662,6 +679,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
           a16set(R.a16[1], c, wload16(rs, lane, noff, 1, c));
         }
       }
+      if (live) { first = false; cur ^= 1; }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -697,7 +715,8 @@ __device__ __forceinline__ i32x6 cvt_fp6_disjoint(const f32x16& a, const f32x16&
 
 // ---- epilogue of a hidden Linear: the lane's 32 values of block b (accumulators of the row group's two tiles) -> the LDS
 // operands of K64 group rg: f16 fragments, fp6 residual plane R, fp6 value plane T, scale bytes
-template <int ACT>
+// (NCHW: f16 chunks written -- the [hash | x] group leaves its padding chunk alone: the compositing partials live there)
+template <int ACT, int NCHW = 4>
 __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f32x16& a1, int lane, uint32_t sat_gen) {
   constexpr int PREC = NA_PREC_F16X;
   f32x16 v0, v1;
@@ -710,7 +729,7 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
     pk[8 + u] = __builtin_bit_cast(uint32_t, f16x2{(_Float16)v1[2 * u], (_Float16)v1[2 * u + 1]});
   }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) *(u32x4*)(kq + c * 1024 + lane * 16) = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
+  for (int c = 0; c < NCHW; ++c) *(u32x4*)(kq + c * 1024 + lane * 16) = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
   // E8M0 scales from the block maximum: T = v / 2^(e-2) lands in [4, 8) (fp6 e2m3 saturates at 7.5: 3 % at worst on a
   // correction operand), R = (v - f16 v) / 2^(e-13) in [-4, 4].  After a sine |v| <= 1: fixed scales, no maximum.
   int eT, eR;
@@ -1021,6 +1040,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   // of the block's fourth init chunk (the last latent chunk: dead once view.L0 has run, not written by EP, rewritten by the
   // epilogue of first.out).  The other schedules composite in the next pass's exposed phase, into the idle hidden region.
   auto part_of = [&](int b) -> float* {
+    if constexpr (MODEL == 0 && PREC == NA_PREC_F16X) return (float*)(ib + b * x::KQ + 3 * 1024);  // (f16 chunk 3 of the block's init group)
     return MODEL == 0 ? (float*)(ib + (b * 4 + 3) * FR) : (float*)hb + b * kPartialFloats;
   };
   // compositing of block rg of pass `pass` (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
@@ -1729,6 +1749,47 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     // wave stalls ~3k cycles per round and those epilogues have ~1.8k cycles of slack).
     STAMP(0);
     if (prev >= 0) combine(prev);  // (partials: written before the barrier that closed view.out; EP does not touch their chunk)
+    if constexpr (PREC == NA_PREC_F16X) {
+      // f16x (round 4): [hash | x] is ONE K64 group of the init region in the hidden format (f16 fragments | R | T), so the
+      // lane that converts must hold all 32 values of an MFMA lane (sample, k half h): h = 0 (levels 0..3 + x, y, z twice)
+      // comes from the block's owner wave, h = 1 (levels 4..7) from the helper wave rg + 2.  All 64 lanes gather -- lane
+      // (sample, j) the levels 4 h + 2 j, 4 h + 2 j + 1 -- then the j = 1 half hands its eight features to the j = 0 half
+      // (ds_bpermute: no memory), which converts and stores for MFMA lane (sample, h).  The raw values wait in the idle hidden
+      // region for the skip connection (E1 re-enters them through the activation).
+      const int part = owner ? 0 : 1;
+      const Geom q = geom(pass, blk, tnext);
+      float f8[8];
+      HashGather hg;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int lvl0 = 4 * part + k;                      // (j = 0) | + 2 (j = 1)
+        hash_level_issue(q.px, q.py, q.pz, a.tables, hi ? a.res.n[lvl0 + 2] : a.res.n[lvl0], lvl0 + 2 * hi, hg);
+        float f[4];
+        hash_level_finish(hg, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f8[4 * k + e] = f[e];
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(3 + k);
+      }
+      f32x16 n0, n1;  // the MFMA lane's 32 values in slot order: chunk 0 = n0[0..7], 1 = n0[8..15], 2 = n1[0..7], 3 = n1[8..15]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        n0[e] = f8[e];
+        n0[8 + e] = __shfl_down(f8[e], 32, 64);
+        n1[e] = 0.f; n1[8 + e] = 0.f;
+      }
+      if (part == 0) { n1[0] = q.px; n1[1] = q.py; n1[2] = q.pz; n1[3] = q.px; n1[4] = q.py; n1[5] = q.pz; }
+      if (hi == 0) {
+        const int ml = ln + 32 * part;  // the MFMA lane these values belong to
+        char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;   // raw values: this wave's own K64 region (idle until E1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f32x4*)(st + c * 1024) = f32x4{n0[4 * c], n0[4 * c + 1], n0[4 * c + 2], n0[4 * c + 3]};
+        *(f32x4*)(st + 4096) = f32x4{n1[0], n1[1], n1[2], n1[3]};
+        *(f32x4*)(st + 5120) = f32x4{n1[4], n1[5], n1[6], n1[7]};
+        x::store_block<NA_ACT_NONE, 3>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
+      }
+      STAMP(7);
+    } else
     if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
       STAMP(8);
       STAMP(9);
@@ -1768,7 +1829,6 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       f32x16 bv[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
-      if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0);
       SYNC();
       if constexpr (PREC == NA_PREC_F16X) {
         bvx[0] = bv[0]; bvx[1] = bv[1];  // (C operand of first.init's first products)
@@ -1786,78 +1846,111 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) bvx[t] = bias_tile(wrs, bias_rg + ph * 1024, t, lane);
       };
-      x::pairs<0, 3, NB>(acc, bvx, XR, wrs, xpair, ib, lane);                              // first.init
+      // records per pass (44, parity of the index = scale slot): 0 first.init | 1 skip group + 2..5 first.L0 | 6.. L1..L3 |
+      // 18..21 first.out | 22 view.init | 23 skip group + 24..27 view.L0 | 28.. L1..L3 | 40..43 view.out
+      // raw values of this wave's half of an init group (written by EP / E6 into the wave's own K64 region of the hidden
+      // space): read back before store_acts overwrites the region, re-entered through the activation (src/neural_blocks.py:291-293)
+      auto reenter_hash = [&]() {
+        if (hi == 0) {
+          const int part = owner ? 0 : 1, ml = ln + 32 * part;
+          const char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;
+          f32x16 n0, n1;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 v = *(const f32x4*)(st + c * 1024);
+            n0[4 * c] = v[0]; n0[4 * c + 1] = v[1]; n0[4 * c + 2] = v[2]; n0[4 * c + 3] = v[3];
+          }
+          const f32x4 u = *(const f32x4*)(st + 4096), w = *(const f32x4*)(st + 5120);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) n1[e] = 0.f;
+          n1[0] = u[0]; n1[1] = u[1]; n1[2] = u[2]; n1[3] = u[3]; n1[4] = w[0]; n1[5] = w[1]; n1[6] = w[2]; n1[7] = w[3];
+          x::store_block<NA_ACT_LEAKY_RELU, 3>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
+        }
+      };
+      x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);       // first.init: the [hash | x] group
       SYNC();
       {
+        reenter_hash();
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(1);
-        if (owner) activate_init<PREC, NA_ACT_LEAKY_RELU, 3>(ib, blk, lane);
-        x::pairs_prefetch(XR, wrs, xpair, lane, 3);
       }
       SYNC();
-      x::pairs<3, 3, NB>(acc, bvx, XR, wrs, xpair, ib, lane);                              // first.L0: skip chunks, then K = 256
-      x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
+      x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);       // first.L0: skip group, then K = 256
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(2 + i);
         SYNC();
-        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);                // first.L1..L3
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 6 + 4 * i, hb, lane);                  // first.L1..L3
         SYNC();
       }
-      f32x16 oq[1][NB];  // first.out: this row group's tile (0, 1: latent rows 0..63; 2: density row 64) for the NB blocks
-      f32x16 bo[1];
+      // first.out, split by BLOCK (NB = 2): every row group runs two tiles for ONE block, rg & 1 -- row groups 0, 1 the two
+      // latent tiles (rows 0..63: the 32 values of an MFMA lane of the View MLP's latent group end up in one lane, which converts
+      // them like a hidden epilogue), row groups 2, 3 the density tile (row 64) and an all-zero tile.  One code path for the
+      // four waves: a wave-dependent choice between two instantiations of the record loop made the compiler reconcile the
+      // weight registers at the join through scratch memory (165 spilled registers, every phase 30 % slower).
+      static_assert(NB == 2, "first.out by block");
+      f32x16 ol[2][1];
       {
-        bo[0] = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? rg : 2, lane);
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+        bvx[0] = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? 0 : 2, lane);
+        bvx[1] = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? 1 : 3, lane);  // (slot 3: zeros)
       }
       SYNC();
-      x::recs<1, NB, true, XNR>(oq, bo, XR, wrs, xrec, 16, hb, lane);                            // first.out (row-major)
+      x::recs<2, 1, true, XNR>(ol, bvx, XR, wrs, xrec, 18, hb + (rg & 1) * x::BLKH, lane);
       SYNC();
       {
         load_bias2(6);
         geo_setup(pass);
         if (rg < 2) {
+          // the latent group of block rg: raw rows into the wave's own (idle) K64 region for the skip connection, the group
+          // itself into the init region
+          char* st = hb + rg * x::BLKH + rg * x::KQ + lane * 16;
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            Frag<PREC> f0, f1;
-            acc_to_frags<PREC, NA_ACT_NONE>(oq[0][b], f0, f1);
-            x::latent_range(oq[0][b], a.sat_gen);
-            char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
-            fwrite<PREC>(dst, f0);
-            fwrite<PREC>(dst + FR, f1);
+          for (int c = 0; c < 4; ++c) {
+            *(f32x4*)(st + c * 1024) = f32x4{ol[0][0][4 * c], ol[0][0][4 * c + 1], ol[0][0][4 * c + 2], ol[0][0][4 * c + 3]};
+            *(f32x4*)(st + 4096 + c * 1024) = f32x4{ol[1][0][4 * c], ol[1][0][4 * c + 1], ol[1][0][4 * c + 2], ol[1][0][4 * c + 3]};
           }
-        } else if (rg == 2 && hi == 0) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[0][b][0];
+          x::store_block<NA_ACT_NONE>(ib + rg * x::KQ, ol[0][0], ol[1][0], lane, a.sat_gen);
+        } else if (hi == 0) {
+          ((float*)hb)[2048 + (rg & 1) * 32 + ln] = ol[0][0][0];  // density of block rg & 1 (behind the raw latent rows of block 0)
         }
-        x::pairs_prefetch(XR, wrs, xpair, lane, 6);
+        x::pairs_prefetch(XR, wrs, xpair, lane, 0, 1);
       }
       SYNC();
-      if (owner) density = ((const float*)hb)[blk * 32 + ln];
+      if (owner) density = ((const float*)hb)[2048 + blk * 32 + ln];
       {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::pairs<6, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                       // view.init: latent chunks + geometry
-        x::geo_pair<10, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
+        x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, 22, hb, lane, ib);    // view.init: latent group + geometry
+        x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
       }
       SYNC();
       {
+        if (rg < 2) {  // sin(latent) for the skip connection, from the raw rows (before store_acts overwrites their region)
+          const char* st = hb + rg * x::BLKH + rg * x::KQ + lane * 16;
+          f32x16 l0, l1;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 u = *(const f32x4*)(st + c * 1024), w = *(const f32x4*)(st + 4096 + c * 1024);
+            l0[4 * c] = u[0]; l0[4 * c + 1] = u[1]; l0[4 * c + 2] = u[2]; l0[4 * c + 3] = u[3];
+            l1[4 * c] = w[0]; l1[4 * c + 1] = w[1]; l1[4 * c + 2] = w[2]; l1[4 * c + 3] = w[3];
+          }
+          x::store_block<NA_ACT_SIN>(ib + rg * x::KQ, l0, l1, lane, a.sat_gen);
+        }
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(7);
-        if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
-        x::pairs_prefetch(XR, wrs, xpair, lane, 11);
+        XR.pr[0] = x::wpair(wrs, lane, xpair, 1);  // (the second geometry pair, into the same ring slot: the first one is spent)
       }
       SYNC();
       {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::pairs<11, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                      // view.L0: skip chunks, K = 256, geometry
-        x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 20, hb, lane);
-        x::geo_pair<15, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+        x::recs<2, NB, true, XNR, 5, 1, 1, 4>(acc, bvx, XR, wrs, xrec, 23, hb, lane, ib);    // view.L0: skip group, K = 256, geometry
+        x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       }
       SYNC();
 #pragma unroll 1
@@ -1865,16 +1958,17 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(8 + i);
         SYNC();
-        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 24 + 4 * i, hb, lane);                // view.L1..L3
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 28 + 4 * i, hb, lane);                // view.L1..L3
         SYNC();
       }
       f32x16 ocx[1][1];
+      f32x16 bo[1];
       {
         bo[0] = bias_tile(wrs, bias_rg + 11 * 1024, 0, lane);
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
       }
       SYNC();
-      x::recs<1, 1, true, XNR>(ocx, bo, XR, wrs, xrec, 36, hb + blk * x::BLKH, lane);             // view.out (block per wave)
+      x::recs<1, 1, true, XNR>(ocx, bo, XR, wrs, xrec, 40, hb + blk * x::BLKH, lane);             // view.out (block per wave)
       oc[0] = ocx[0][0];
       pass_tail(pass);
       SYNC();
@@ -2397,6 +2491,20 @@ static int launch(Args& a, hipStream_t stream) {
 namespace ls {
 // ---- NA_PREC_F16X weight streams (layout: namespace x above), built from a schedule table: which Linear every pair / record /
 // bias block belongs to.  One set of kernels for the four schedules.
+// column of Linear rd.lin's weight matrix that sits in k-slot kappa of chunk c of the record's K64 group; -1 = zero
+__device__ __forceinline__ int xrec_col(const XSched& sc, const XRecD& rd, int c, int kappa) {
+  if (rd.kind == 0) return 64 * rd.q + 16 * c + pi_perm(kappa);  // hidden feature (the skip layers store [hidden | init])
+  int col = init_slot_feature(sc.desc[sc.lin[rd.lin].desc], c, kappa);
+  if (col >= 0 && rd.kind == 2) col += kHidden;
+  return col;
+}
+// weight row held by lane l of tile t of row group rg; -1 = zero
+__device__ __forceinline__ int xrec_row(const XSched& sc, const XRecD& rd, int rg, int t, int l) {
+  const NaMlpDesc& d = sc.desc[sc.lin[rd.lin].desc];
+  if (rd.out_mode == 0) return 32 * (2 * rg + t) + (l & 31);
+  if (rd.out_mode == 3) return rg < 2 ? out_row_map(d, 32 * t + (l & 31)) : (t == 0 ? out_row_map(d, 64 + (l & 31)) : -1);
+  return t == 0 ? out_row_map(d, (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
+}
 __global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
   // one thread per 16-bit element of the f16 planes of the pairs and of the records' f16 fragments
   const int srg = sc.npair * x::PAIRB + sc.nrec * x::REC;
@@ -2425,12 +2533,10 @@ __global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
       const int t = f >> 2, c = f & 3;
       const XRecD rd = sc.rec[ri];
       const XLin L = sc.lin[rd.lin];
-      const int col = 64 * rd.q + 16 * c + pi_perm(8 * (l >> 5) + e);  // hidden feature (the skip layers store [hidden | init])
-      int row;
-      if (rd.out_mode == 0) row = 32 * (2 * rg + t) + (l & 31);
-      else row = t == 0 ? out_row_map(sc.desc[L.desc], (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
+      const int col = xrec_col(sc, rd, c, 8 * (l >> 5) + e);
+      const int row = xrec_row(sc, rd, rg, t, l);
       float v = 0.f;
-      if (row >= 0 && row < L.out_dim) v = L.W[(int64_t)row * L.in_dim + col];
+      if (row >= 0 && row < L.out_dim && col >= 0 && col < L.in_dim) v = L.W[(int64_t)row * L.in_dim + col];
       char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * srg + sc.npair * x::PAIRB + (int64_t)ri * x::REC + f * 1024 + l * 16 + e * 2;
       *(uint16_t*)o = __builtin_bit_cast(uint16_t, to_elem<NA_PREC_F16X>(v));
     }
@@ -2449,16 +2555,18 @@ __global__ void pack_lsx_fp6_kernel(XSched sc, char* __restrict__ dst) {
     const int h = l >> 5;
     const XRecD rd = sc.rec[ri];
     const XLin L = sc.lin[rd.lin];
-    int row;
-    if (rd.out_mode == 0) row = 32 * (2 * rg + t) + (l & 31);
-    else row = t == 0 ? out_row_map(sc.desc[L.desc], (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
+    const int row = xrec_row(sc, rd, rg, t, l);
     f32x16 wl0, wl1;
     float mt = 0.f, ml = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c0 = 64 * rd.q + (r & 3) + 8 * (r >> 2) + 4 * h;
+      // (hidden groups: columns 64 q + (r & 3) + 8 (r >> 2) + 4 h and + 32, the producer tiles' registers r)
+      const int ca = xrec_col(sc, rd, r >> 3, 8 * h + (r & 7)), cb = xrec_col(sc, rd, 2 + (r >> 3), 8 * h + (r & 7));
       float a = 0.f, b = 0.f;
-      if (row >= 0 && row < L.out_dim) { a = L.W[(int64_t)row * L.in_dim + c0]; b = L.W[(int64_t)row * L.in_dim + c0 + 32]; }
+      if (row >= 0 && row < L.out_dim) {
+        if (ca >= 0 && ca < L.in_dim) a = L.W[(int64_t)row * L.in_dim + ca];
+        if (cb >= 0 && cb < L.in_dim) b = L.W[(int64_t)row * L.in_dim + cb];
+      }
       const float ah = from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(a)), bh = from_elem<NA_PREC_F16X>(to_elem<NA_PREC_F16X>(b));
       wl0[r] = a - ah;
       wl1[r] = b - bh;
@@ -2492,11 +2600,11 @@ __global__ void pack_lsx_bias_kernel(XSched sc, char* __restrict__ dst) {
     float v = 0.f;
     if (p < sc.nphase) {
       const XLin L = sc.lin[sc.bias_lin[p]];
-      const int mode = sc.bias_mode[p];  // 0 hidden rows, 1 out Linear row-major (3 tiles), 2 out Linear, one tile
+      const int mode = sc.bias_mode[p];  // 0 hidden rows, 1 / 3 out Linear with 3 tiles, 2 out Linear, one tile
       if (L.B != nullptr) {
         if (mode == 0) { if (slot < 2) v = L.B[32 * (2 * rg + slot) + rin]; }
         else {
-          const int row = slot < (mode == 1 ? 3 : 1) ? out_row_map(sc.desc[L.desc], 32 * slot + rin) : -1;
+          const int row = slot < ((mode == 1 || mode == 3) ? 3 : 1) ? out_row_map(sc.desc[L.desc], 32 * slot + rin) : -1;
           if (row >= 0 && row < L.out_dim) v = L.B[row];
         }
       }
@@ -2511,7 +2619,7 @@ __global__ void pack_lsx_header_kernel(uint32_t* __restrict__ dst, uint32_t unit
 // `nl` Linears of one SkipConnMLP appended to the schedule: init (NI chunk pairs), hidden Linears (skip layers take the NI init
 // chunks again, + kHidden), out.  geo: the View MLP's fifth init chunk is its own pair behind the init / skip chunks.
 static void xs_add_mlp(XSched& sc, const NaMlpDesc& d, const float* const* w, const float* const* b, int nl, int ni, bool geo,
-                       int out_mode) {
+                       int out_mode, bool init_rec = false) {
   const int di = sc.ndesc++;
   sc.desc[di] = d;
   const int dim_p = d.in_size + d.enc_dims + d.latent_size;
@@ -2527,10 +2635,12 @@ static void xs_add_mlp(XSched& sc, const NaMlpDesc& d, const float* const* w, co
     sc.bias_lin[sc.nphase] = (int8_t)(l0 + i);
     sc.bias_mode[sc.nphase++] = (int8_t)(last ? out_mode : 0);
     if (first || skip) {
-      for (int q = 0; q < ni; ++q) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(skip ? 1 : 0)};
+      // init_rec: the (<= 4) init chunks as ONE record in front of the Linear's hidden records, consumed from the init region
+      if (init_rec) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), 0, 0, (int8_t)(skip ? 2 : 1)};
+      else for (int q = 0; q < ni; ++q) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(skip ? 1 : 0)};
     }
     if (!first) {
-      for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(last ? out_mode : 0)};
+      for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(last ? out_mode : 0), 0};
     }
     if ((first || skip) && geo) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), 4, (int8_t)(skip ? 1 : 0)};
   }
@@ -2543,8 +2653,8 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
   const NaMlpDesc view = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
   if (model == 0) {
     const NaMlpDesc first = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
-    xs_add_mlp(sc, first, w0, b0, 6, 3, false, 1);
-    xs_add_mlp(sc, view, w1, b1, 6, 4, true, 2);
+    xs_add_mlp(sc, first, w0, b0, 6, 3, false, 3, true);
+    xs_add_mlp(sc, view, w1, b1, 6, 4, true, 2, true);
   } else if (model == 1) {
     const NaMlpDesc tiny = {3, NA_ENC_NONE, 0, 0, 6, 256, 4, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
     xs_add_mlp(sc, tiny, w0, b0, 8, 1, false, 2);
