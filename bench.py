@@ -181,11 +181,16 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
             rows.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             continue
         inp = (rays, torch.tensor([0.5], device=dev)) if dyn else rays
-        for prec in precisions:
+        plist = list(precisions)
+        if name.split()[0] == "4" and "f16x" in plist:
+            plist.insert(plist.index("f16x") + 1, "f16x+ls-deformation")  # the deformation network on the LS engine too (opt-in)
+        for prec in plist:
             if prec == "f16x" and name.split()[0] == "3":
                 continue  # (config 3 has no one-kernel renderer: its f16x row would be the bf16x3 row)
+            lsdef = prec == "f16x+ls-deformation"
             try:
-                config.set_precision(prec)
+                config.set_precision("f16x" if lsdef else prec)
+                config.set_deformation_engine("ls" if lsdef else "generic")
                 with torch.no_grad():
                     m(inp)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -196,13 +201,17 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
                     torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / iters
                 rows.append({"config": name, "workload": f"{OTHER_SLAB[2]}x{OTHER_SLAB[3]} slab x {T} samples/ray ({n} samples)",
-                             "dtype": prec, "kernels": KERNELS_F16X.get(name.split()[0], "f16x") if prec == "f16x" else prec,
+                             "dtype": prec, "kernels": ("canonical model: one kernel, f16x; deformation MLP: ONE launch of the layer-synchronous engine, "
+                                                        "f16x (config.deformation_engine = 'ls', opt-in: its rows carry 3x the error of the split-bf16 "
+                                                        "rows -- reference golden 1.0-1.6e-4 end to end, trained model 2.4e-5)") if lsdef
+                             else KERNELS_F16X.get(name.split()[0], "f16x") if prec == "f16x" else prec,
                              "Msamples_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 3),
                              "flop_per_sample": flop, "frac": round(n * flop / (ms * 1e-3) / PEAK_BF16, 4)})
             except Exception as e:  # noqa: BLE001
                 rows.append({"config": name, "dtype": prec, "error": f"{type(e).__name__}: {e}"})
         del m
     config.set_precision(keep)
+    config.set_deformation_engine("generic")
     return rows, round(time.perf_counter() - t_all, 2)
 
 

@@ -79,6 +79,22 @@ def set_engine(e: str):
     engine = e
 
 
+# D-NeRF's deformation network under precision "f16x": "generic" = the register-engine fused MLP in the 3-product split (its rows
+# are 3x closer to fp32 than f16x rows: 1.3e-5 against 3.8e-5 relative on the reference's golden weights, and the canonical
+# model's hash grid amplifies position errors -- on that adversarial fixture the end-to-end RGB is 4.6e-5 with it and
+# 1.0-1.6e-4 with the f16x rows, i.e. over north_star's 1e-4); "ls" = ONE launch of the layer-synchronous engine in f16x
+# (csrc/render_ls.hip MODEL 4: +20 % on the config's sample rate; 2.4e-5 against the CPU oracle on the trained model of
+# tests/test_gpu_train.py).  The parity default is "generic".
+deformation_engine = "generic"
+
+
+def set_deformation_engine(e: str):
+    global deformation_engine
+    if e not in ("generic", "ls"):
+        raise ValueError(e)
+    deformation_engine = e
+
+
 # Reproducible training: gradients summed across workgroups (weight/bias gradients, hash-table scatter, d/dbeta)
 # accumulate in 64-bit fixed point instead of fp32 atomics (na_set_deterministic): bitwise run-to-run reproducibility
 # at ~the same speed.  Off by default (the fp32 atomics are the reference-like fast path).

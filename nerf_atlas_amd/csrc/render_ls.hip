@@ -114,8 +114,10 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // the View half's ten | five Linears + sdf.out + the View half's twenty)
 // (MODEL 0, round 4: the init / skip chunks of both MLPs are RECORDS too -- [hash | x] and the latent are one K64 group each,
 // f16 + 2 x fp6 like the hidden groups -- so only the two geometry chunk pairs of the View MLP are left as pairs)
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : 2; }
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : 44; }
+// MODEL 4 (round 4): a hash-encoded SkipConnMLP alone (D-NeRF's deformation network, src/nerf.py:1250-1257: 3 -> 5 x 256, skip 3,
+// out 3 n + 1 <= 32 rows), rows to HBM: init group | skip group + 4 (L0) | L1 | L2 | skip group + 4 (L3) | L4 | out = 27 records
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : model == 4 ? 0 : 2; }
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : model == 4 ? 27 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -132,6 +134,7 @@ struct Cfg {
   static constexpr int STREAM = kPairsPerPass * PAIR;           // weight stream of one row group
 };
 
+inline size_t packed_bytes_x(int model) { return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)x::stream_rg(model); }
 inline int model_of_pairs(int pairs) { return pairs == kTinyPairs ? 1 : pairs == kViewPairs ? 2 : pairs == kSirenPairs ? 3 : 0; }
 inline size_t packed_bytes(int precision, int pairs = kPairsPerPass) {
   if (precision == NA_PREC_F16X) return (size_t)kHeaderBytes + kBiasBytes + 4 * (size_t)x::stream_rg(model_of_pairs(pairs));
@@ -163,6 +166,8 @@ struct Args {
   HashRes res;
   unsigned long long* trace;  // NA_LS_TRACE builds only: [2 groups][128] s_memtime stamps of workgroup 0, second pass
   uint32_t sat_gen;           // NA_PREC_F16X: this launch's id for the saturation flag (g_lsx_saturated)
+  float* y;                   // MODEL 4: output rows [T * R, y_ld] (sample t * R + ray), n_out columns written
+  int y_ld, n_out;
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -198,7 +203,7 @@ struct XSched {
 // model: 0 PlainNeRF(view) (w0 = first, w1 = View), 1 TinyNeRF (w0), 2 View half (w0), 3 SIREN VolSDF (w0 = SDF net, w1 = View).
 // Defined in the NA_PREC_INST == 3 unit.
 int render_lsx_pack(int model, const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1,
-                    char* packed, hipStream_t stream);
+                    char* packed, hipStream_t stream, int n_out = 0);
 
 template <int PREC, int AUX = 0>
 __device__ __forceinline__ Frag<PREC> wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -600,7 +605,7 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
 // whose fourth chunk is padding that the fp6 operands hold as zeros and the f16 product skips); the others are the hidden
 // groups Q = 0, 1, ... of the blocks (hb0 + b * BLKH + Q * KQ).  PAR0 = parity of rec0 (which scale slot its dword sits in).
 // CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
-template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4>
+template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4, bool LAST0 = false>
 __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
                                      int rec0, const char* hb0, int lane, const char* ib0 = nullptr) {
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
@@ -628,8 +633,10 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
     nrc = nrc >= NREC ? 0 : nrc;
     const int noff = __builtin_amdgcn_readfirstlane(xrec + nrc * REC);
     // the NEXT record's scale bytes, a whole group ahead (its WT6 conversion runs behind the second chunk of its group)
-    if (!(NA_LSX_EXP & 2)) R.asc[(PAR0 + gi + 1) & 1] = wloadsc(rs, lane, noff);
     const int asc = R.asc[(PAR0 + gi) & 1];
+    // (LAST0: a schedule with an ODD number of records per pass -- the record behind this call's last one is record 0 of the next
+    // pass, whose scale belongs in slot 0 although the parity says 1; `asc` above was read first)
+    if (!(NA_LSX_EXP & 2)) R.asc[(LAST0 && gi == NG - 1) ? 0 : (PAR0 + gi + 1) & 1] = wloadsc(rs, lane, noff);
     i32x6 wt[NT];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1210,7 +1217,72 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       own_setup(pl + 1);
     }
   };
-  if constexpr (MODEL == 0) {
+  // ---- NA_PREC_F16X, schedules whose first MLP takes the hash encoder (MODEL 0, 4): the [hash | x] group
+  auto hash_group_ep = [&](int pass) {
+    if constexpr (PREC == NA_PREC_F16X) {
+      // f16x (round 4): [hash | x] is ONE K64 group of the init region in the hidden format (f16 fragments | R | T), so the
+      // lane that converts must hold all 32 values of an MFMA lane (sample, k half h): h = 0 (levels 0..3 + x, y, z twice)
+      // comes from the block's owner wave, h = 1 (levels 4..7) from the helper wave rg + 2.  All 64 lanes gather -- lane
+      // (sample, j) the levels 4 h + 2 j, 4 h + 2 j + 1 -- then the j = 1 half hands its eight features to the j = 0 half
+      // (ds_bpermute: no memory), which converts and stores for MFMA lane (sample, h).  The raw values wait in the idle hidden
+      // region for the skip connection (E1 re-enters them through the activation).
+      const int part = owner ? 0 : 1;
+      const Geom q = geom(pass, blk, tnext);
+      float f8[8];
+      HashGather hg;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int lvl0 = 4 * part + k;                      // (j = 0) | + 2 (j = 1)
+        hash_level_issue(q.px, q.py, q.pz, a.tables, hi ? a.res.n[lvl0 + 2] : a.res.n[lvl0], lvl0 + 2 * hi, hg);
+        float f[4];
+        hash_level_finish(hg, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f8[4 * k + e] = f[e];
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(3 + k);
+      }
+      f32x16 n0, n1;  // the MFMA lane's 32 values in slot order: chunk 0 = n0[0..7], 1 = n0[8..15], 2 = n1[0..7], 3 = n1[8..15]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        n0[e] = f8[e];
+        n0[8 + e] = __shfl_down(f8[e], 32, 64);
+        n1[e] = 0.f; n1[8 + e] = 0.f;
+      }
+      if (part == 0) { n1[0] = q.px; n1[1] = q.py; n1[2] = q.pz; n1[3] = q.px; n1[4] = q.py; n1[5] = q.pz; }
+      if (hi == 0) {
+        const int ml = ln + 32 * part;  // the MFMA lane these values belong to
+        char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;   // raw values: this wave's own K64 region (idle until E1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f32x4*)(st + c * 1024) = f32x4{n0[4 * c], n0[4 * c + 1], n0[4 * c + 2], n0[4 * c + 3]};
+        *(f32x4*)(st + 4096) = f32x4{n1[0], n1[1], n1[2], n1[3]};
+        *(f32x4*)(st + 5120) = f32x4{n1[4], n1[5], n1[6], n1[7]};
+        x::store_block<NA_ACT_NONE, 3>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
+      }
+      STAMP(7);
+    }
+  };
+      // raw values of this wave's half of an init group (written by EP / E6 into the wave's own K64 region of the hidden
+      // space): read back before store_acts overwrites the region, re-entered through the activation (src/neural_blocks.py:291-293)
+  auto reenter_hash = [&]() {
+    if constexpr (PREC == NA_PREC_F16X) {
+        if (hi == 0) {
+          const int part = owner ? 0 : 1, ml = ln + 32 * part;
+          const char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;
+          f32x16 n0, n1;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 v = *(const f32x4*)(st + c * 1024);
+            n0[4 * c] = v[0]; n0[4 * c + 1] = v[1]; n0[4 * c + 2] = v[2]; n0[4 * c + 3] = v[3];
+          }
+          const f32x4 u = *(const f32x4*)(st + 4096), w = *(const f32x4*)(st + 5120);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) n1[e] = 0.f;
+          n1[0] = u[0]; n1[1] = u[1]; n1[2] = u[2]; n1[3] = u[3]; n1[4] = w[0]; n1[5] = w[1]; n1[6] = w[2]; n1[7] = w[3];
+          x::store_block<NA_ACT_LEAKY_RELU, 3>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
+        }
+    }
+  };
+  if constexpr (MODEL == 0 || MODEL == 4) {
     tnext = ts_load(0);
     own_setup(0);
   }
@@ -1219,6 +1291,86 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #if NA_LS_TRACE
     ton = pass == 1;
 #endif
+    if constexpr (MODEL == 4) {
+      // ================= a hash-encoded SkipConnMLP alone, rows to HBM (NA_PREC_F16X; D-NeRF's deformation network): EP = the
+      // [hash | x] group; init | L0 (skip group + K = 256) | L1 | L2 | L3 (skip group + K = 256) | L4 | out (one tile, block per
+      // wave); 27 records per pass.  No compositing, nothing carried from pass to pass.
+      if constexpr (PREC == NA_PREC_F16X) {
+        static_assert(NB == 2, "MODEL 4: two blocks per group");
+        hash_group_ep(pass);
+        {
+          f32x16 bv[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
+          SYNC();
+          bvx[0] = bv[0]; bvx[1] = bv[1];
+        }
+        x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);          // init: record 0
+        SYNC();
+        {
+          reenter_hash();  // act(init) stays in the init region for both skip layers (src/neural_blocks.py:291-293)
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+          xbias(1);
+        }
+        SYNC();
+        x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);          // L0: records 1..5
+        SYNC();
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+          xbias(2 + i);
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 6 + 4 * i, hb, lane);                  // L1, L2: records 6..13
+          SYNC();
+        }
+        {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+          xbias(4);
+        }
+        SYNC();
+        x::recs<2, NB, true, XNR, 5, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 14, hb, lane, ib);         // L3: records 14..18
+        SYNC();
+        {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+          xbias(5);
+        }
+        SYNC();
+        x::recs<2, NB, true, XNR, 4, 0, 1>(acc, bvx, XR, wrs, xrec, 19, hb, lane);                  // L4: records 19..22
+        SYNC();
+        f32x16 ocx[1][1];
+        f32x16 bo1[1];
+        {
+          bo1[0] = bias_tile(wrs, bias_rg + 6 * 1024, 0, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+        }
+        SYNC();
+        x::recs<1, 1, true, XNR, 4, 0, 1, 4, true>(ocx, bo1, XR, wrs, xrec, 23, hb + blk * x::BLKH, lane);  // out: records 23..26
+        if (owner) {
+          // registers 4 q .. 4 q + 3 of a lane are the rows 8 q + 4 hi .. + 3 of its sample: 16-byte stores where the row allows
+          const Loc L = locate(pass, blk);
+          const int t = L.tb * 32 + ln;
+          if (L.ok && t < a.T) {
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            float* yrow = a.y + ((int64_t)t * a.R + L.ray) * a.y_ld;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int f0 = 8 * q + 4 * hi;
+              if (f0 + 4 <= a.n_out) *(f32x4u*)(yrow + f0) = f32x4u{ocx[0][0][4 * q], ocx[0][0][4 * q + 1], ocx[0][0][4 * q + 2], ocx[0][0][4 * q + 3]};
+              else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (f0 + i < a.n_out) yrow[f0 + i] = ocx[0][0][4 * q + i];
+              }
+            }
+          }
+        }
+        tnext = ts_load(pass + 1);
+        own_setup(pass + 1);
+        SYNC();
+      }
+      prev = pass;
+      continue;
+    }
     if constexpr (MODEL == 3) {
       // ================= VolSDF, SIREN SDF network + View head: EP = sample position + compositing of the previous pass
       auto none_l = [](int) { return 0; };
@@ -1750,45 +1902,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     STAMP(0);
     if (prev >= 0) combine(prev);  // (partials: written before the barrier that closed view.out; EP does not touch their chunk)
     if constexpr (PREC == NA_PREC_F16X) {
-      // f16x (round 4): [hash | x] is ONE K64 group of the init region in the hidden format (f16 fragments | R | T), so the
-      // lane that converts must hold all 32 values of an MFMA lane (sample, k half h): h = 0 (levels 0..3 + x, y, z twice)
-      // comes from the block's owner wave, h = 1 (levels 4..7) from the helper wave rg + 2.  All 64 lanes gather -- lane
-      // (sample, j) the levels 4 h + 2 j, 4 h + 2 j + 1 -- then the j = 1 half hands its eight features to the j = 0 half
-      // (ds_bpermute: no memory), which converts and stores for MFMA lane (sample, h).  The raw values wait in the idle hidden
-      // region for the skip connection (E1 re-enters them through the activation).
-      const int part = owner ? 0 : 1;
-      const Geom q = geom(pass, blk, tnext);
-      float f8[8];
-      HashGather hg;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int lvl0 = 4 * part + k;                      // (j = 0) | + 2 (j = 1)
-        hash_level_issue(q.px, q.py, q.pz, a.tables, hi ? a.res.n[lvl0 + 2] : a.res.n[lvl0], lvl0 + 2 * hi, hg);
-        float f[4];
-        hash_level_finish(hg, f);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f8[4 * k + e] = f[e];
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(3 + k);
-      }
-      f32x16 n0, n1;  // the MFMA lane's 32 values in slot order: chunk 0 = n0[0..7], 1 = n0[8..15], 2 = n1[0..7], 3 = n1[8..15]
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        n0[e] = f8[e];
-        n0[8 + e] = __shfl_down(f8[e], 32, 64);
-        n1[e] = 0.f; n1[8 + e] = 0.f;
-      }
-      if (part == 0) { n1[0] = q.px; n1[1] = q.py; n1[2] = q.pz; n1[3] = q.px; n1[4] = q.py; n1[5] = q.pz; }
-      if (hi == 0) {
-        const int ml = ln + 32 * part;  // the MFMA lane these values belong to
-        char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;   // raw values: this wave's own K64 region (idle until E1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) *(f32x4*)(st + c * 1024) = f32x4{n0[4 * c], n0[4 * c + 1], n0[4 * c + 2], n0[4 * c + 3]};
-        *(f32x4*)(st + 4096) = f32x4{n1[0], n1[1], n1[2], n1[3]};
-        *(f32x4*)(st + 5120) = f32x4{n1[4], n1[5], n1[6], n1[7]};
-        x::store_block<NA_ACT_NONE, 3>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
-      }
-      STAMP(7);
+      hash_group_ep(pass);
     } else
     if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
       STAMP(8);
@@ -1848,25 +1962,6 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       };
       // records per pass (44, parity of the index = scale slot): 0 first.init | 1 skip group + 2..5 first.L0 | 6.. L1..L3 |
       // 18..21 first.out | 22 view.init | 23 skip group + 24..27 view.L0 | 28.. L1..L3 | 40..43 view.out
-      // raw values of this wave's half of an init group (written by EP / E6 into the wave's own K64 region of the hidden
-      // space): read back before store_acts overwrites the region, re-entered through the activation (src/neural_blocks.py:291-293)
-      auto reenter_hash = [&]() {
-        if (hi == 0) {
-          const int part = owner ? 0 : 1, ml = ln + 32 * part;
-          const char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;
-          f32x16 n0, n1;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x4 v = *(const f32x4*)(st + c * 1024);
-            n0[4 * c] = v[0]; n0[4 * c + 1] = v[1]; n0[4 * c + 2] = v[2]; n0[4 * c + 3] = v[3];
-          }
-          const f32x4 u = *(const f32x4*)(st + 4096), w = *(const f32x4*)(st + 5120);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) n1[e] = 0.f;
-          n1[0] = u[0]; n1[1] = u[1]; n1[2] = u[2]; n1[3] = u[3]; n1[4] = w[0]; n1[5] = w[1]; n1[6] = w[2]; n1[7] = w[3];
-          x::store_block<NA_ACT_LEAKY_RELU, 3>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
-        }
-      };
       x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);       // first.init: the [hash | x] group
       SYNC();
       {
@@ -2095,7 +2190,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }  // (PREC != NA_PREC_F16X)
     prev = pass;
   }
-  if (MODEL != 0 && prev >= 0 && (NB == 4 || owner)) {  // (MODEL 0 composited its last pass in that pass's view.out phase)
+  if (MODEL != 0 && MODEL != 4 && prev >= 0 && (NB == 4 || owner)) {  // (MODEL 0 composited its last pass in that pass's view.out phase)
     prev_dn = own_dn;
     if constexpr (MODEL == 1) {
       f32x16 rgbv = oc[0];
@@ -2106,7 +2201,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
   }
   __syncthreads();
-  if (prev >= 0) combine(prev);
+  if (MODEL != 4 && prev >= 0) combine(prev);
   if (g == 0) {  // group 0 takes its extra barriers at the end
 #pragma unroll 1
     for (int i = 0; i < LAG; ++i) __syncthreads();
@@ -2480,8 +2575,13 @@ static int launch(Args& a, hipStream_t stream) {
     a.sat_gen = 0;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * C::GROUP, stream, a);
-  if constexpr (PREC == NA_PREC_F16X)  // range guard: NaN frame if any activation of this launch sat at the half clamp
-    hipLaunchKernelGGL(lsx_poison_kernel, dim3(grid_for(a.R * 3, 256, 256)), dim3(256), 0, stream, a.sat_gen, a.out, a.R * 3);
+  if constexpr (PREC == NA_PREC_F16X) {  // range guard: NaN output if any activation of this launch sat at the half clamp
+    if constexpr (MODEL == 4)
+      hipLaunchKernelGGL(lsx_poison_kernel, dim3(grid_for((int64_t)a.T * a.R * a.y_ld, 256, 1024)), dim3(256), 0, stream, a.sat_gen, a.y,
+                         (int64_t)a.T * a.R * a.y_ld);
+    else
+      hipLaunchKernelGGL(lsx_poison_kernel, dim3(grid_for(a.R * 3, 256, 256)), dim3(256), 0, stream, a.sat_gen, a.out, a.R * 3);
+  }
   return check_launch("na_render_plain_view_ls");
 }
 
@@ -2647,7 +2747,7 @@ static void xs_add_mlp(XSched& sc, const NaMlpDesc& d, const float* const* w, co
 }
 
 int render_lsx_pack(int model, const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1,
-                    char* packed, hipStream_t stream) {
+                    char* packed, hipStream_t stream, int n_out) {
   XSched sc;
   memset(&sc, 0, sizeof(sc));
   const NaMlpDesc view = {5, NA_ENC_NONE, 0, 64, 4, 256, 3, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_VIEW};
@@ -2660,6 +2760,9 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
     xs_add_mlp(sc, tiny, w0, b0, 8, 1, false, 2);
   } else if (model == 2) {
     xs_add_mlp(sc, view, w0, b0, 6, 4, true, 2);
+  } else if (model == 4) {
+    const NaMlpDesc hashmlp = {3, NA_ENC_HASH, 35, 0, 5, 256, n_out, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
+    xs_add_mlp(sc, hashmlp, w0, b0, 7, 3, false, 2, true);
   } else {
     const NaMlpDesc siren = {3, NA_ENC_NONE, 0, 0, 5, 256, 65, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_FIRST};
     xs_add_mlp(sc, siren, w0, b0, 7, 1, false, 1);
@@ -2680,7 +2783,10 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
 }  // namespace ls
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_F16X, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16X, 2>(a, s)
-         : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : ls::launch<NA_PREC_F16X>(a, s);
+         : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_F16X, 4>(a, s) : ls::launch<NA_PREC_F16X>(a, s);
+}
+int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream) {
+  return ls::render_lsx_pack(4, w, b, nullptr, nullptr, packed, stream, n_out);
 }
 #elif NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
@@ -2702,6 +2808,7 @@ int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model);
+int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream);
 
 }  // namespace na
 
@@ -2943,5 +3050,39 @@ extern "C" int na_render_volsdf_siren_ls(const float* rays, const float* pts, in
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 3);
   if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 3);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 3);
+}
+// ---- a hash-encoded SkipConnMLP on the layer-synchronous engine, rows to HBM (D-NeRF's deformation network, src/nerf.py:1250-1257,
+// 1267-1270): NA_PREC_F16X only -- the other precisions run it through na_mlp_forward
+extern "C" size_t na_mlp_hash_ls_packed_bytes(int precision) {
+  return precision == NA_PREC_F16X ? ls::packed_bytes_x(4) : 0;
+}
+
+extern "C" int na_mlp_hash_ls_pack(int precision, const float* const* w, const float* const* b, int n_out, void* packed, void* stream) {
+  NA_REQUIRE(w && b && packed, NA_ENULL, "na_mlp_hash_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: precision %d (f16x only)", precision);
+  NA_REQUIRE(n_out >= 1 && n_out <= 32, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: n_out %d (1..32: one output tile)", n_out);
+  for (int i = 0; i < 7; ++i) NA_REQUIRE(w[i], NA_ENULL, "na_mlp_hash_ls_pack: weights[%d] is null", i);
+  return render_lsx_pack_hashmlp(w, b, n_out, (char*)packed, (hipStream_t)stream);
+}
+
+extern "C" int na_mlp_hash_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                              const void* packed, int precision, int n_out, float* y, int64_t y_ld, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_mlp_hash_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && hash_tables && packed && y, NA_ENULL, "na_mlp_hash_ls: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_mlp_hash_ls: precision %d (f16x only)", precision);
+  NA_REQUIRE(n_out >= 1 && n_out <= 32 && y_ld >= n_out && y_ld < (1 << 20), NA_EINVAL, "na_mlp_hash_ls: n_out %d, y_ld %lld", n_out,
+             (long long)y_ld);
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
+  a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes_x(4);
+  a.alpha = nullptr; a.weights = nullptr; a.out = nullptr; a.bg_kind = NA_BG_BLACK;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.elaz = nullptr; a.sigmoid_kind = 0;
+  a.res = hash_resolutions();
+  a.trace = nullptr;
+  a.y = y; a.y_ld = (int)y_ld; a.n_out = n_out;
+  return render_ls_dispatch_f16x(a, (hipStream_t)stream, 4);
 }
 #endif

@@ -365,7 +365,7 @@ class VolSDF(CommonNeRF):
 
 
 # ------------------------------------------------------------------------------------------------- DynamicNeRF
-class DynamicNeRF(nn.Module):
+class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
     """src/nerf.py:1209-1303, Bezier-spline deformation (spline > 1, refl_latent = 0).  The delta path
     (spline = 0) raises at HEAD in the reference (SURVEY header table) and raises here too."""
 
@@ -383,6 +383,7 @@ class DynamicNeRF(nn.Module):
         self.delta_estim = SkipConnMLP(in_size=3, out=spline * 3 + 1, num_layers=5, hidden_size=256, init="xavier",
                                        enc=HashEncoder())
         self.delta_estim.zero_last_layer()
+        self._init_packed_hooks()
 
     @property
     def nerf(self): return self.canonical
@@ -428,6 +429,25 @@ class DynamicNeRF(nn.Module):
         _, ddp, _ = ag.BezierWarpFn.apply(dest.contiguous(), self.pts, self._tt, self.spline_n)
         return ddp.sum(dim=-1, keepdim=True)
 
+    def _fusable_deformation(self):
+        """the deformation network as ONE launch of the layer-synchronous engine in the 1.5-product parity mode (csrc/render_ls.hip,
+        MODEL 4): inference with `config.precision == "f16x"` and `config.deformation_engine == "ls"` (opt-in: config.py says
+        why); every other case runs the generic fused MLP / the training path"""
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        d = self.delta_estim
+        return (config.engine == "ls" and config.precision == "f16x" and config.deformation_engine == "ls"
+                and not self.training and not wants_grad and isinstance(d.enc, HashEncoder) and len(d.layers) == 5 and d.init.out_features == 256 and d.skip == 3
+                and d.out.out_features <= 32 and d.latent_size == 0 and d.act_name == "leaky_relu")
+
+    def packed_deformation_ls(self, precision: str):
+        lin = self.delta_estim._linears()
+        stamp = utils.pack_stamp(lin)
+        cache = self.__dict__.setdefault("_packed_ls", {})
+        hit = cache.get(precision)
+        if hit is None or stamp is None or hit[0] != stamp:
+            cache[precision] = (stamp, ops.mlp_hash_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
+        return cache[precision][1]
+
     def forward(self, rays_t):
         rays, t = rays_t
         c = self.canonical
@@ -435,7 +455,11 @@ class DynamicNeRF(nn.Module):
                                                         perturb=1 if self.training else 0)
         c.ts = self.ts
         tt = self._tt = t[None, :, None, None].expand(*self.pts.shape[:-1]).contiguous()
-        est = self.delta_estim(self.pts)
+        if self._fusable_deformation():
+            est = ops.mlp_hash_ls(rays, self.ts, self.delta_estim.enc.tables(), self.packed_deformation_ls("f16x"), "f16x",
+                                  self.delta_estim.out.out_features)
+        else:
+            est = self.delta_estim(self.pts)
         if ag.needs_grad(est):
             warped, self.dp, self.rigidity = ag.BezierWarpFn.apply(est.contiguous(), self.pts, tt, self.spline_n)
         else:

@@ -723,6 +723,44 @@ def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torc
     return out, alpha, weights
 
 
+def mlp_hash_ls_pack(precision: str, weights, biases) -> torch.Tensor:
+    """Pack a hash-encoded SkipConnMLP (in 3, HashEncoder, 5 x 256, skip 3, out <= 32: {init, layers.0..4, out}) into the weight
+    stream of the layer-synchronous engine (f16x only; D-NeRF's deformation network)."""
+    lib = _lib.load()
+    assert len(weights) == 7 and len(biases) == 7
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [None if b is None else _f32(b.detach(), "bias") for b in biases]
+    n_out = ws[-1].shape[0]
+    shapes = [(256, 38), (256, 294), (256, 256), (256, 256), (256, 294), (256, 256), (n_out, 256)]
+    for w, shp in zip(ws, shapes):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS hash MLP: weight shape {tuple(w.shape)} != {shp}")
+    nbytes = int(lib.na_mlp_hash_ls_packed_bytes(PREC[precision]))
+    if nbytes == 0 or not 1 <= n_out <= 32:
+        raise _lib.NaError(f"LS hash MLP: precision {precision} / {n_out} output rows not supported (f16x, <= 32 rows)")
+    wp = (C.c_void_p * 7)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * 7)(*[0 if b is None else b.data_ptr() for b in bs])
+    packed = torch.empty(nbytes, device=ws[0].device, dtype=torch.uint8)
+    check(lib.na_mlp_hash_ls_pack(PREC[precision], wp, bp, n_out, _ptr(packed), _stream()))
+    return packed
+
+
+def mlp_hash_ls(rays: torch.Tensor, ts: torch.Tensor, tables: torch.Tensor, packed: torch.Tensor, precision: str, n_out: int,
+                pts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The packed hash-encoded MLP at the samples of rays [..., 6] x ts [T] (or explicit pts [T, ..., 3]) -> [T, ..., n_out]."""
+    lib = _lib.load()
+    rays, ts, tables = _f32(rays, "rays"), _f32(ts, "ts"), _f32(tables, "tables")
+    T = ts.shape[0]
+    R = rays.numel() // 6
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3
+    y = torch.empty((T,) + tuple(rays.shape[:-1]) + (n_out,), device=rays.device, dtype=torch.float32)
+    check(lib.na_mlp_hash_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(tables), _ptr(packed), PREC[precision], n_out, _ptr(y),
+                             n_out, _stream()))
+    return y
+
+
 def render_tiny_ls_pack(precision: str, weights, biases) -> torch.Tensor:
     """Pack TinyNeRF.estim ({init, layers.0..5, out}) into the weight stream of the layer-synchronous renderer."""
     lib = _lib.load()

@@ -518,3 +518,55 @@ def test_bg_random(na, prec):
     finally:
         utils.set_random_source(None)
         config.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("spline", [6, 4])
+def test_dynamic_nerf_f16x_deformation_on_the_ls_engine(na, spline):
+    """Config 4 in the 1.5-product parity mode end to end: the deformation network runs as ONE launch of
+    the layer-synchronous engine (csrc/render_ls.hip MODEL 4, na_mlp_hash_ls) instead of falling back to the 3-product generic
+    kernel, then the Bezier warp, then the canonical model's one-kernel renderer on the warped positions -- against the
+    reference's own D-NeRF outputs (g9) and, row by row, against the CPU oracle's deformation MLP."""
+    import oracle as O
+    from nerf_atlas_amd import config, ops
+    h = load_golden(f"g9_dnerf_spline{spline}")
+    p = golden_params(h)
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=spline).cuda().eval()
+    load_params(m, p)
+    config.set_precision("f16x")
+    try:
+        assert not m._fusable_deformation()          # the parity default: generic 3-product deformation rows
+        out = m((h["rays"].cuda(), h["times"].cuda()))
+        assert maxdiff(out, h["out"]) <= 1e-4
+        config.set_deformation_engine("ls")
+        assert m._fusable_deformation()
+        out = m((h["rays"].cuda(), h["times"].cuda()))
+        # f16x rows carry 3x the error of the split-bf16 rows and the canonical hash grid amplifies position errors: on this
+        # fixture (procedural weights, |dp| up to 3.6) the end-to-end frame lands at 1.0e-4 (spline 6) / 1.6e-4 (spline 4) --
+        # why the engine is opt-in.  The trained model of tests/test_gpu_train.py is at 2.4e-5 with it.
+        assert maxdiff(out, h["out"]) <= 2e-4
+        assert maxdiff(m.rigidity, h["rigidity"]) <= 1e-4 and maxdiff(m.dp, h["dp"]) <= 1e-4
+        assert maxdiff(canon.weights, h["weights"]) <= 2e-4
+        # the network alone, on a slab that fills every workgroup and with a ragged step count (T = 130: 5 blocks, the last
+        # one with 2 live steps), rows against the oracle at 40 positions per ray
+        import math
+        for T, size in ((130, 40), (32, 8)):
+            cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]),
+                                        focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
+            rays = cam.sample_positions((380, 390, size, size), size=800, with_noise=False)
+            ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+            est = ops.mlp_hash_ls(rays, ts, m.delta_estim.enc.tables(), m.packed_deformation_ls("f16x"), "f16x", 3 * spline + 1)
+            assert est.shape == (T,) + tuple(rays.shape[:-1]) + (3 * spline + 1,) and torch.isfinite(est).all()
+            pts = ops.compute_pts(rays, ts)
+            sel = torch.arange(0, T, max(T // 40, 1))
+            ref = O.skip_mlp(p, "delta_estim.", pts[sel][:, :, ::7, ::5].cpu(), enc=O.nerf_oracle._hash_enc_from(p, "delta_estim.enc."))
+            assert maxdiff(est[sel][:, :, ::7, ::5], ref) <= 1e-4 * max(1.0, float(ref.abs().max()))
+            # explicit positions give the same rows bit for bit
+            est2 = ops.mlp_hash_ls(rays, ts, m.delta_estim.enc.tables(), m.packed_deformation_ls("f16x"), "f16x", 3 * spline + 1,
+                                   pts=pts)
+            assert torch.equal(est, est2)
+        config.set_precision("bf16x3")
+        assert not m._fusable_deformation()
+    finally:
+        config.set_precision("bf16x3")
+        config.set_deformation_engine("generic")

@@ -128,6 +128,17 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
               f"CPU oracle {err:.2e}")
         assert torch.isfinite(frames[0]).all() and err <= 1e-4, err
         assert dpx.max() <= 0.01, (px, res["test_psnr"])
+        if name == "dnerf":  # the deformation network on the layer-synchronous engine (opt-in, config.deformation_engine)
+            config.set_precision("f16x")
+            config.set_deformation_engine("ls")
+            try:
+                px2, frames2 = T.test(model, cam, labels, args)
+            finally:
+                config.set_precision("bf16x3")
+                config.set_deformation_engine("generic")
+            err2 = float((frames2[0].cpu() - ref[0]).abs().max())
+            print(f"[dnerf] f16x with the LS deformation kernel: view 0 L-inf vs the CPU oracle {err2:.2e}")
+            assert err2 <= 1e-4 and np.abs(np.array(px2) - np.array(res["test_psnr"])).max() <= 0.01
     # the fast renderer on the trained model
     if name == "plain":
         config.set_precision("bf16")
