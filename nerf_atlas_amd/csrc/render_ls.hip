@@ -723,7 +723,9 @@ __device__ __forceinline__ i32x6 cvt_fp6_disjoint(const f32x16& a, const f32x16&
 // ---- epilogue of a hidden Linear: the lane's 32 values of block b (accumulators of the row group's two tiles) -> the LDS
 // operands of K64 group rg: f16 fragments, fp6 residual plane R, fp6 value plane T, scale bytes
 // (NCHW: f16 chunks written -- the [hash | x] group leaves its padding chunk alone: the compositing partials live there)
-template <int ACT, int NCHW = 4>
+// KEEP7: the last dword of the lane's T operand (never read by the MFMA) is left alone -- the View MLP's latent group keeps the
+// block's density there from the epilogue of first.out to the compositing at the end of the pass
+template <int ACT, int NCHW = 4, bool KEEP7 = false>
 __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f32x16& a1, int lane, uint32_t sat_gen) {
   constexpr int PREC = NA_PREC_F16X;
   f32x16 v0, v1;
@@ -780,7 +782,12 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
   *(u32x4*)(p + 1024) = u32x4{(uint32_t)Rr[4], (uint32_t)Rr[5], (uint32_t)eR, 0u};
   if (!(NA_LSX_EXP & 16)) {
     *(u32x4*)(p + 2048) = u32x4{(uint32_t)Tt[0], (uint32_t)Tt[1], (uint32_t)Tt[2], (uint32_t)Tt[3]};
-    *(u32x4*)(p + 3072) = u32x4{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT, 0u};
+    if constexpr (KEEP7) {
+      typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
+      *(u32x3*)(p + 3072) = u32x3{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT};
+    } else {
+      *(u32x4*)(p + 3072) = u32x4{(uint32_t)Tt[4], (uint32_t)Tt[5], (uint32_t)eT, 0u};
+    }
   }
 }
 // the latent rows (no activation in front of them: to_elem clamps them to the half range) are checked the same way
@@ -790,11 +797,13 @@ __device__ __forceinline__ void latent_range(const f32x16& v, uint32_t sat_gen) 
   for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v[r]), "v"(v[r + 1]));
   if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated = sat_gen;
 }
-template <int ACT, int NB, int T0 = 0, int T1 = 2>
+// (blocks B0 .. B1 - 1: an epilogue that also re-enters an init group stores block 0, converts the group -- whose raw values
+// wait in the wave's K64 region of block 1 -- with half of the accumulators already dead, then stores block 1)
+template <int ACT, int NB, int B0 = 0, int B1 = NB>
 __device__ __forceinline__ void store_acts(const f32x16 (&acc)[2][NB], char* hb, int rg, int lane, uint32_t sat_gen) {
   if (NA_LSX_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int b = 0; b < NB; ++b) store_block<ACT>(hb + b * BLKH + rg * KQ, acc[0][b], acc[1][b], lane, sat_gen);
+  for (int b = B0; b < B1; ++b) store_block<ACT>(hb + b * BLKH + rg * KQ, acc[0][b], acc[1][b], lane, sat_gen);
   if (NA_LSX_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 }
 }  // namespace x
@@ -1074,8 +1083,11 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         o[0] = P; o[1] = sr; o[2] = sg; o[3] = sb; o[4] = wh;
       }
       if (q.ok && q.t_ok && a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
+      // MODEL 0 composites at the end of a pass and combines in the next pass's exposed phase: the block-local weight waits in
+      // the caller's weights array (scaled in place by `combine`) instead of in a register across the hash gathers
+      if (MODEL == 0 && q.ok && q.t_ok && a.weights != nullptr) a.weights[(int64_t)q.t * a.R + q.ray] = w;
     }
-    w_local = w;
+    if constexpr (MODEL != 0) w_local = w;
   };
   // Cross-block step of the compositing (the reference's cumprod runs over all T steps: src/nerf.py:22-27): every wave of
   // the group walks the NB blocks of pass `pl` in step order with the running transmittance / colour of the current ray
@@ -1112,7 +1124,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     if (a.weights != nullptr && owner && hi == 0) {
       const Loc L = locate(pl, blk);
       const int t = L.tb * 32 + ln;
-      if (L.ok && t < a.T) a.weights[(int64_t)t * a.R + L.ray] = w_local * mine;
+      if (L.ok && t < a.T) {
+        float* wp = a.weights + (int64_t)t * a.R + L.ray;
+        *wp = (MODEL == 0 ? *wp : w_local) * mine;
+      }
     }
   };
 
@@ -1209,6 +1224,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const TsPair tc = ts_load(pl);
       tnext = ts_load(pl + 1);
       prev_dn = own_dn;
+      if constexpr (PREC == NA_PREC_F16X) density = *(const float*)(ib + blk * x::KQ + 6144 + 1024 + ln * 16 + 12);
       composite(prev_geom(pl, tc), oc[0], density);
       __builtin_amdgcn_sched_barrier(0);
       own_setup(pl + 1);
@@ -1251,7 +1267,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       if (part == 0) { n1[0] = q.px; n1[1] = q.py; n1[2] = q.pz; n1[3] = q.px; n1[4] = q.py; n1[5] = q.pz; }
       if (hi == 0) {
         const int ml = ln + 32 * part;  // the MFMA lane these values belong to
-        char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;   // raw values: this wave's own K64 region (idle until E1)
+        char* st = hb + x::BLKH + rg * x::KQ + ml * 16;   // raw values: this wave's K64 region of block 1 (idle until E1 stores it LAST)
 #pragma unroll
         for (int c = 0; c < 4; ++c) *(f32x4*)(st + c * 1024) = f32x4{n0[4 * c], n0[4 * c + 1], n0[4 * c + 2], n0[4 * c + 3]};
         *(f32x4*)(st + 4096) = f32x4{n1[0], n1[1], n1[2], n1[3]};
@@ -1267,7 +1283,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     if constexpr (PREC == NA_PREC_F16X) {
         if (hi == 0) {
           const int part = owner ? 0 : 1, ml = ln + 32 * part;
-          const char* st = hb + blk * x::BLKH + rg * x::KQ + ml * 16;
+          const char* st = hb + x::BLKH + rg * x::KQ + ml * 16;
           f32x16 n0, n1;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -1308,8 +1324,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);          // init: record 0
         SYNC();
         {
+          x::store_acts<NA_ACT_LEAKY_RELU, NB, 0, 1>(acc, hb, rg, lane, a.sat_gen);
           reenter_hash();  // act(init) stays in the init region for both skip layers (src/neural_blocks.py:291-293)
-          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB, 1, 2>(acc, hb, rg, lane, a.sat_gen);
           xbias(1);
         }
         SYNC();
@@ -1965,8 +1982,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);       // first.init: the [hash | x] group
       SYNC();
       {
+        x::store_acts<NA_ACT_LEAKY_RELU, NB, 0, 1>(acc, hb, rg, lane, a.sat_gen);
         reenter_hash();
-        x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+        x::store_acts<NA_ACT_LEAKY_RELU, NB, 1, 2>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(1);
       }
       SYNC();
@@ -2001,20 +2019,21 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         if (rg < 2) {
           // the latent group of block rg: raw rows into the wave's own (idle) K64 region for the skip connection, the group
           // itself into the init region
-          char* st = hb + rg * x::BLKH + rg * x::KQ + lane * 16;
+          char* st = hb + x::BLKH + rg * x::KQ + lane * 16;  // (the wave's K64 region of block 1: E7 stores it last)
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             *(f32x4*)(st + c * 1024) = f32x4{ol[0][0][4 * c], ol[0][0][4 * c + 1], ol[0][0][4 * c + 2], ol[0][0][4 * c + 3]};
             *(f32x4*)(st + 4096 + c * 1024) = f32x4{ol[1][0][4 * c], ol[1][0][4 * c + 1], ol[1][0][4 * c + 2], ol[1][0][4 * c + 3]};
           }
-          x::store_block<NA_ACT_NONE>(ib + rg * x::KQ, ol[0][0], ol[1][0], lane, a.sat_gen);
+          x::store_block<NA_ACT_NONE, 4, true>(ib + rg * x::KQ, ol[0][0], ol[1][0], lane, a.sat_gen);
         } else if (hi == 0) {
-          ((float*)hb)[2048 + (rg & 1) * 32 + ln] = ol[0][0][0];  // density of block rg & 1 (behind the raw latent rows of block 0)
+          // density of block rg & 1 -> the spare dword of the latent group's T operand (lane = step), where it waits for the
+          // compositing at the end of the pass: carried in a register it was the one value spilled AND re-stored every pass
+          *(float*)(ib + (rg & 1) * x::KQ + 6144 + 1024 + ln * 16 + 12) = ol[0][0][0];
         }
         x::pairs_prefetch(XR, wrs, xpair, lane, 0, 1);
       }
       SYNC();
-      if (owner) density = ((const float*)hb)[2048 + blk * 32 + ln];
       {
         GeoRaw graw[NB];
 #pragma unroll
@@ -2024,8 +2043,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       }
       SYNC();
       {
-        if (rg < 2) {  // sin(latent) for the skip connection, from the raw rows (before store_acts overwrites their region)
-          const char* st = hb + rg * x::BLKH + rg * x::KQ + lane * 16;
+        x::store_acts<NA_ACT_SIN, NB, 0, 1>(acc, hb, rg, lane, a.sat_gen);
+        if (rg < 2) {  // sin(latent) for the skip connection, from the raw rows (before block 1's store overwrites their region)
+          const char* st = hb + x::BLKH + rg * x::KQ + lane * 16;
           f32x16 l0, l1;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -2033,9 +2053,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
             l0[4 * c] = u[0]; l0[4 * c + 1] = u[1]; l0[4 * c + 2] = u[2]; l0[4 * c + 3] = u[3];
             l1[4 * c] = w[0]; l1[4 * c + 1] = w[1]; l1[4 * c + 2] = w[2]; l1[4 * c + 3] = w[3];
           }
-          x::store_block<NA_ACT_SIN>(ib + rg * x::KQ, l0, l1, lane, a.sat_gen);
+          x::store_block<NA_ACT_SIN, 4, true>(ib + rg * x::KQ, l0, l1, lane, a.sat_gen);
         }
-        x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
+        x::store_acts<NA_ACT_SIN, NB, 1, 2>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(7);
         XR.pr[0] = x::wpair(wrs, lane, xpair, 1);  // (the second geometry pair, into the same ring slot: the first one is spent)
       }
