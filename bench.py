@@ -143,7 +143,8 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
                       f"torch-CPU fp32 oracle on {best} threads"}, out, rays
 
 
-KERNELS_F16X = {"4": "deformation MLP bf16x3 + canonical model f16x", "5m": "SDF MLP bf16x3 + View half f16x"}
+KERNELS_F16X = {"4": "deformation MLP bf16x3 + canonical model f16x",
+                "5m": "SDF MLP: ONE f16x launch of the layer-synchronous engine (Fourier features generated in the kernel) + View half f16x"}
 OTHER_SLAB = (300, 0, 200, SIZE)   # rows 300..499 of the 800-wide frame: 160 000 rays x 128 = 20.48 M samples
 
 
@@ -186,7 +187,7 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
     forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
     calls per (config, precision).  FLOP/sample = sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same
     numbers); `frac` is against the dense bf16 MFMA peak for every precision.  "f16x" rows: the one-kernel renderers run f16x, the
-    generic fused MLP launches of a config (mip: both MLPs; D-NeRF: the deformation network; VolSDF: the Fourier-MLP SDF network)
+    generic fused MLP launches of a config (mip: both MLPs; D-NeRF: the deformation network unless the opt-in LS kernel is on)
     stay in bf16x3 -- `kernels` says which."""
     import types
     import nerf_atlas_amd.nerf as nerf

@@ -451,6 +451,16 @@ int na_mlp_hash_ls_pack(int precision, const float* const* weights, const float*
 int na_mlp_hash_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
                    const void* packed, int precision, int n_out, float* y, int64_t y_ld, void* stream);
 
+/* The same for a Fourier-encoded SkipConnMLP: VolSDF's MLP SDF network (src/sdf.py:250-258: SkipConnMLP(in 3, FourierEncoder
+ * with 128 frequencies, 6 x 256, skip 3, out 1 + 64), evaluated at src/sdf.py:109-112).  weights / biases: init, layers.0..5,
+ * out; basis [3,128] fp32, 16-byte aligned, any extra_scale already multiplied in; rows y[(t * R + ray) * y_ld + 0..65) =
+ * (signed distance | 64 latent columns), the layout na_render_view_ls takes as `feat`.  The 256 Fourier features are generated
+ * inside the kernel wherever a Linear consumes them; they never exist in HBM.  NA_PREC_F16X only.                         */
+size_t na_mlp_fourier_ls_packed_bytes(int precision);
+int na_mlp_fourier_ls_pack(int precision, const float* const* weights, const float* const* biases, void* packed, void* stream);
+int na_mlp_fourier_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* basis,
+                      const void* packed, int precision, float* y, int64_t y_ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

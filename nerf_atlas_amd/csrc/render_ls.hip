@@ -28,6 +28,7 @@
 // Compiled once per precision (-DNA_PREC_INST=0|1|2).
 #include <atomic>
 #include <cstring>
+#include <type_traits>
 #include "mlp_layout.h"
 #include "encoders.h"
 
@@ -116,8 +117,12 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // f16 + 2 x fp6 like the hidden groups -- so only the two geometry chunk pairs of the View MLP are left as pairs)
 // MODEL 4 (round 4): a hash-encoded SkipConnMLP alone (D-NeRF's deformation network, src/nerf.py:1250-1257: 3 -> 5 x 256, skip 3,
 // out 3 n + 1 <= 32 rows), rows to HBM: init group | skip group + 4 (L0) | L1 | L2 | skip group + 4 (L3) | L4 | out = 27 records
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : model == 4 ? 0 : 2; }
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : model == 4 ? 27 : 44; }
+// MODEL 5 (round 4): a Fourier-encoded SkipConnMLP alone (VolSDF's MLP SDF network, src/sdf.py:250-258: 3 -> [p | sin, cos of 128
+// frequencies] -> 6 x 256, skip 3, out 65), rows to HBM.  The 256 Fourier features are K64 groups in the HIDDEN format, generated by
+// the row groups in a VALU phase wherever a Linear consumes them (init, L0, L3): init 4 | L0 4 + 4 | L1 | L2 | L3 4 + 4 | L4 | L5 |
+// out 4 = 40 records, and 3 pairs for the 3-wide position chunk
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : model == 4 ? 0 : model == 5 ? 3 : 2; }
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : model == 4 ? 27 : model == 5 ? 40 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -189,7 +194,8 @@ static __global__ void lsx_poison_kernel(uint32_t gen, float* __restrict__ out, 
 struct XLin { const float* W; const float* B; int in_dim, out_dim, desc; };  // nn.Linear layout [out,in]
 struct XPairD { int8_t lin, q, skip; };      // init chunk q of Linear lin (skip: its columns sit behind the kHidden hidden ones)
 // K64 group of Linear lin.  kind 0: hidden features 64 q .. 64 q + 63; kind 1 / 2: the init chunks 0..3 of the MLP (columns by
-// init_slot_feature; 2: behind the kHidden hidden columns of a skip layer).  out_mode 0 hidden rows, 1 out row-major (tile
+// init_slot_feature; 2: behind the kHidden hidden columns of a skip layer); kind 3 / 4: Fourier features 64 q .. 64 q + 63 in the
+// generator's slot order (fourier_slot_col; 4: behind the hidden columns of a skip layer).  out_mode 0 hidden rows, 1 out row-major (tile
 // min(rg, 2)), 2 out, one tile, 3 out split by block: row groups 0,1 hold tiles 0 and 1, row groups 2,3 tile 2
 struct XRecD { int8_t lin, q, out_mode, kind; };
 struct XSched {
@@ -1307,6 +1313,144 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #if NA_LS_TRACE
     ton = pass == 1;
 #endif
+    if constexpr (MODEL == 5) {
+      // ================= a Fourier-encoded SkipConnMLP alone, rows to HBM (NA_PREC_F16X; VolSDF's MLP SDF network).  The 256
+      // Fourier features never exist outside LDS: row group rg GENERATES the K64 group rg of every block of its sample group
+      // (16 frequencies per lane: three FMAs on the position, hardware sine / cosine on a two-constant reduction) straight into
+      // the hidden format, in a VALU phase in front of each Linear that consumes them -- init: [features | p]; the skip layers
+      // L0, L3: K = 256 hidden first, then (accumulators kept) the regenerated features through the activation + p.
+      if constexpr (PREC == NA_PREC_F16X) {
+        static_assert(NB == 2, "MODEL 5: two blocks per group");
+        const float* basis = (const float*)a.tables;  // [3][128] (frequencies contiguous), extra_scale folded in by the host
+        constexpr int F = 128;
+        geo_setup(pass);
+        auto gen = [&](auto act_tag) {
+          constexpr int ACT = decltype(act_tag)::value;
+          const int f0 = 32 * rg + 16 * hi;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const GeoRaw r = geo_load(b);
+            float px = r.x, py = r.y, pz = r.z;
+            if (a.pts == nullptr) { px = geo_u[b][0] + r.x * geo_u[b][3]; py = geo_u[b][1] + r.x * geo_u[b][4]; pz = geo_u[b][2] + r.x * geo_u[b][5]; }
+            f32x16 n0, n1;
+            // eight frequencies at a time (24 basis registers live, not 48: in the skip layers the 64 accumulator registers of the
+            // K = 256 part stay live across this phase -- with all of a lane's basis rows fetched at once 118 registers spilled)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              f32x4 bq[3][2];
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) bq[q][k] = *(const f32x4*)(basis + q * F + f0 + 8 * hf + 4 * k);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                // mapped = x @ basis in the generic kernel's order (one product, two fmas); sin / cos of it
+                float m = px * bq[0][j >> 2][j & 3];
+                m = fmaf(py, bq[1][j >> 2][j & 3], m);
+                m = fmaf(pz, bq[2][j >> 2][j & 3], m);
+                const float qr = rintf(m * 0.15915493667125702f);
+                float rv = fmaf(m, 0.15915493667125702f, -qr);
+                rv = fmaf(m, 6.4206382432985265e-09f, rv);
+                const float sn = __builtin_amdgcn_sinf(rv), cs = __builtin_amdgcn_cosf(rv);
+                if (hf == 0) { n0[2 * j] = sn; n0[2 * j + 1] = cs; } else { n1[2 * j] = sn; n1[2 * j + 1] = cs; }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            x::store_block<ACT>(hb + b * x::BLKH + rg * x::KQ, n0, n1, lane, a.sat_gen);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        auto p_make = [&](int b, const GeoRaw& r, bool act) -> Frag<PREC> {
+          float px = r.x, py = r.y, pz = r.z;
+          if (a.pts == nullptr) { px = geo_u[b][0] + r.x * geo_u[b][3]; py = geo_u[b][1] + r.x * geo_u[b][4]; pz = geo_u[b][2] + r.x * geo_u[b][5]; }
+          float v4[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v4[e] = 0.f;
+          if (hi == 0) { v4[0] = px; v4[1] = py; v4[2] = pz; }
+          Frag<PREC> f = make_frag<PREC>(v4);
+          if (act) frag_activate<PREC, NA_ACT_LEAKY_RELU>(f);
+          return f;
+        };
+        typedef std::integral_constant<int, NA_ACT_NONE> RawT;
+        typedef std::integral_constant<int, NA_ACT_LEAKY_RELU> LeakyT;
+        // ---- EP: the raw features; init = [features | p]
+        gen(RawT{});
+        xbias(0);
+        x::pairs_prefetch(XR, wrs, xpair, lane, 0, 1);
+        SYNC();
+        {
+          GeoRaw graw[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
+          x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, p_make, false);
+        }
+        SYNC();
+        // ---- L0 (skip), L1, L2, L3 (skip), L4, L5
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          const int r0 = half == 0 ? 4 : 20;  // first record of the skip layer
+          {
+            x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+            xbias(half == 0 ? 1 : 4);
+          }
+          SYNC();
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, r0, hb, lane);                       // K = 256 hidden
+          SYNC();
+          {
+            gen(LeakyT{});                                                                          // the features again, activated
+            XR.pr[0] = x::wpair(wrs, lane, xpair, 1 + half);  // (one ring slot for the three position pairs: one code path)
+          }
+          SYNC();
+          {
+            GeoRaw graw[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+            x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, r0 + 4, hb, lane);                  // + K = 256 features
+            x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, p_make, true);                      // + p
+          }
+          SYNC();
+#pragma unroll 1
+          for (int i = 0; i < 2; ++i) {
+            x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+            xbias((half == 0 ? 2 : 5) + i);
+            SYNC();
+            x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, r0 + 8 + 4 * i, hb, lane);           // L1, L2 | L4, L5
+            SYNC();
+          }
+        }
+        // ---- out: 65 rows, row-major (row group rg: tile min(rg, 2) for the NB blocks); rows to HBM
+        f32x16 oq[1][NB];
+        f32x16 bo1[1];
+        {
+          bo1[0] = bias_tile(wrs, bias_rg + 7 * 1024, rg < 2 ? rg : 2, lane);
+          x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
+        }
+        SYNC();
+        x::recs<1, NB, true, XNR>(oq, bo1, XR, wrs, xrec, 36, hb, lane);
+        if (rg < 3) {
+          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const Loc L = locate(pass, b);
+            const int t = L.tb * 32 + ln;
+            if (L.ok && t < a.T) {
+              float* yrow = a.y + ((int64_t)t * a.R + L.ray) * a.y_ld + 32 * rg;
+              if (rg < 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  *(f32x4u*)(yrow + 8 * q + 4 * hi) = f32x4u{oq[0][b][4 * q], oq[0][b][4 * q + 1], oq[0][b][4 * q + 2], oq[0][b][4 * q + 3]};
+              } else if (hi == 0) {
+                yrow[0] = oq[0][b][0];  // row 64
+              }
+            }
+          }
+        }
+        SYNC();
+      }
+      prev = pass;
+      continue;
+    }
     if constexpr (MODEL == 4) {
       // ================= a hash-encoded SkipConnMLP alone, rows to HBM (NA_PREC_F16X; D-NeRF's deformation network): EP = the
       // [hash | x] group; init | L0 (skip group + K = 256) | L1 | L2 | L3 (skip group + K = 256) | L4 | out (one tile, block per
@@ -2210,7 +2354,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }  // (PREC != NA_PREC_F16X)
     prev = pass;
   }
-  if (MODEL != 0 && MODEL != 4 && prev >= 0 && (NB == 4 || owner)) {  // (MODEL 0 composited its last pass in that pass's view.out phase)
+  if (MODEL != 0 && MODEL < 4 && prev >= 0 && (NB == 4 || owner)) {  // (MODEL 0 composited its last pass in that pass's view.out phase)
     prev_dn = own_dn;
     if constexpr (MODEL == 1) {
       f32x16 rgbv = oc[0];
@@ -2221,7 +2365,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
   }
   __syncthreads();
-  if (MODEL != 4 && prev >= 0) combine(prev);
+  if (MODEL < 4 && prev >= 0) combine(prev);
   if (g == 0) {  // group 0 takes its extra barriers at the end
 #pragma unroll 1
     for (int i = 0; i < LAG; ++i) __syncthreads();
@@ -2596,7 +2740,7 @@ static int launch(Args& a, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * C::GROUP, stream, a);
   if constexpr (PREC == NA_PREC_F16X) {  // range guard: NaN output if any activation of this launch sat at the half clamp
-    if constexpr (MODEL == 4)
+    if constexpr (MODEL == 4 || MODEL == 5)
       hipLaunchKernelGGL(lsx_poison_kernel, dim3(grid_for((int64_t)a.T * a.R * a.y_ld, 256, 1024)), dim3(256), 0, stream, a.sat_gen, a.y,
                          (int64_t)a.T * a.R * a.y_ld);
     else
@@ -2614,6 +2758,13 @@ namespace ls {
 // column of Linear rd.lin's weight matrix that sits in k-slot kappa of chunk c of the record's K64 group; -1 = zero
 __device__ __forceinline__ int xrec_col(const XSched& sc, const XRecD& rd, int c, int kappa) {
   if (rd.kind == 0) return 64 * rd.q + 16 * c + pi_perm(kappa);  // hidden feature (the skip layers store [hidden | init])
+  if (rd.kind >= 3) {
+    // Fourier group q as the MODEL 5 generator lays it out: slot s = 8 c + e of lane half h holds frequency f = 32 q + 16 h + s / 2,
+    // its sine (s even) or cosine (s odd).  Reference columns: [p | sin(128) | cos(128)] (src/neural_blocks.py:36-55, 283-287)
+    const NaMlpDesc& d = sc.desc[sc.lin[rd.lin].desc];
+    const int F = d.enc_dims / 2, s = 8 * c + (kappa & 7), f = 32 * rd.q + 16 * (kappa >> 3) + (s >> 1);
+    return (rd.kind == 4 ? kHidden : 0) + d.in_size + ((s & 1) ? F + f : f);
+  }
   int col = init_slot_feature(sc.desc[sc.lin[rd.lin].desc], c, kappa);
   if (col >= 0 && rd.kind == 2) col += kHidden;
   return col;
@@ -2780,6 +2931,25 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
     xs_add_mlp(sc, tiny, w0, b0, 8, 1, false, 2);
   } else if (model == 2) {
     xs_add_mlp(sc, view, w0, b0, 6, 4, true, 2);
+  } else if (model == 5) {
+    const NaMlpDesc fmlp = {3, NA_ENC_FOURIER, 256, 0, 6, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
+    sc.desc[sc.ndesc++] = fmlp;
+    const int dim_p = 3 + 256;
+    for (int i = 0; i < 8; ++i) {  // init, layers.0..5, out
+      const bool first = i == 0, last = i == 7, skip = i == 1 || i == 4;
+      XLin L;
+      L.W = w0[i]; L.B = b0[i]; L.desc = 0;
+      L.in_dim = first ? dim_p : skip ? kHidden + dim_p : kHidden;
+      L.out_dim = last ? 65 : kHidden;
+      sc.lin[sc.nlin++] = L;
+      sc.bias_lin[sc.nphase] = (int8_t)i;
+      sc.bias_mode[sc.nphase++] = (int8_t)(last ? 1 : 0);
+      if (!first) for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, (int8_t)(last ? 1 : 0), 0};
+      if (first || skip) {
+        for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, 0, (int8_t)(skip ? 4 : 3)};
+        sc.pair[sc.npair++] = XPairD{(int8_t)i, 16, (int8_t)(skip ? 1 : 0)};  // the position chunk: init chunk F / 8 of the Fourier layout
+      }
+    }
   } else if (model == 4) {
     const NaMlpDesc hashmlp = {3, NA_ENC_HASH, 35, 0, 5, 256, n_out, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
     xs_add_mlp(sc, hashmlp, w0, b0, 7, 3, false, 2, true);
@@ -2803,10 +2973,14 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
 }  // namespace ls
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_F16X, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16X, 2>(a, s)
-         : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_F16X, 4>(a, s) : ls::launch<NA_PREC_F16X>(a, s);
+         : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_F16X, 4>(a, s)
+         : model == 5 ? ls::launch<NA_PREC_F16X, 5>(a, s) : ls::launch<NA_PREC_F16X>(a, s);
 }
 int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream) {
   return ls::render_lsx_pack(4, w, b, nullptr, nullptr, packed, stream, n_out);
+}
+int render_lsx_pack_fouriermlp(const float* const* w, const float* const* b, char* packed, hipStream_t stream) {
+  return ls::render_lsx_pack(5, w, b, nullptr, nullptr, packed, stream);
 }
 #elif NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
@@ -2829,6 +3003,7 @@ int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model);
 int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream);
+int render_lsx_pack_fouriermlp(const float* const* w, const float* const* b, char* packed, hipStream_t stream);
 
 }  // namespace na
 
@@ -3104,5 +3279,39 @@ extern "C" int na_mlp_hash_ls(const float* rays, const float* pts, int64_t R, co
   a.trace = nullptr;
   a.y = y; a.y_ld = (int)y_ld; a.n_out = n_out;
   return render_ls_dispatch_f16x(a, (hipStream_t)stream, 4);
+}
+// ---- a Fourier-encoded SkipConnMLP on the layer-synchronous engine, rows to HBM (VolSDF's MLP SDF network, src/sdf.py:250-258):
+// NA_PREC_F16X only
+extern "C" size_t na_mlp_fourier_ls_packed_bytes(int precision) {
+  return precision == NA_PREC_F16X ? ls::packed_bytes_x(5) : 0;
+}
+
+extern "C" int na_mlp_fourier_ls_pack(int precision, const float* const* w, const float* const* b, void* packed, void* stream) {
+  NA_REQUIRE(w && b && packed, NA_ENULL, "na_mlp_fourier_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_mlp_fourier_ls_pack: precision %d (f16x only)", precision);
+  for (int i = 0; i < 8; ++i) NA_REQUIRE(w[i], NA_ENULL, "na_mlp_fourier_ls_pack: weights[%d] is null", i);
+  return render_lsx_pack_fouriermlp(w, b, (char*)packed, (hipStream_t)stream);
+}
+
+extern "C" int na_mlp_fourier_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* basis,
+                                 const void* packed, int precision, float* y, int64_t y_ld, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_mlp_fourier_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && basis && packed && y, NA_ENULL, "na_mlp_fourier_ls: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_mlp_fourier_ls: precision %d (f16x only)", precision);
+  NA_REQUIRE(y_ld >= 65 && y_ld < (1 << 20), NA_EINVAL, "na_mlp_fourier_ls: y_ld %lld < 65", (long long)y_ld);
+  NA_REQUIRE(((uintptr_t)basis & 15) == 0, NA_EINVAL, "na_mlp_fourier_ls: basis must be 16-byte aligned");
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)basis;
+  a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes_x(5);
+  a.alpha = nullptr; a.weights = nullptr; a.out = nullptr; a.bg_kind = NA_BG_BLACK;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.elaz = rays;  // (the group-wide ray table also fetches two floats per ray from here: any readable 8 R bytes)
+  a.sigmoid_kind = 0;
+  a.res = hash_resolutions();
+  a.trace = nullptr;
+  a.y = y; a.y_ld = (int)y_ld; a.n_out = 65;
+  return render_ls_dispatch_f16x(a, (hipStream_t)stream, 5);
 }
 #endif

@@ -303,6 +303,25 @@ class VolSDF(CommonNeRF):
                 and self.sdf.intermediate_size == 64 and getattr(r, "act_kind", None) in ops.SIGMOID and refl_latent is None
                 and not self.training and not wants_grad)
 
+    def _fusable_fourier_sdf(self):
+        from . import sdf as _sdf
+        from .neural_blocks import FourierEncoder
+        u = self.sdf.underlying
+        if type(u) is not _sdf.MLP or config.precision != "f16x" or config.engine != "ls":
+            return False
+        m = u.mlp
+        return (type(m.enc) is FourierEncoder and m.enc.freqs == 128 and m.enc.input_dims == 3 and len(m.layers) == 6 and m.skip == 3
+                and m.init.out_features == 256 and m.out.out_features == 65 and m.latent_size == 0 and m.act_name == "leaky_relu")
+
+    def packed_fourier_sdf_ls(self, precision: str):
+        lin = self.sdf.underlying.mlp._linears()
+        stamp = utils.pack_stamp(lin)
+        cache = self.__dict__.setdefault("_packed_fourier_ls", {})
+        hit = cache.get(precision)
+        if hit is None or stamp is None or hit[0] != stamp:
+            cache[precision] = (stamp, ops.mlp_fourier_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
+        return cache[precision][1]
+
     def packed_view_ls(self, precision: str):
         lin = self.sdf.refl.mlp._linears()
         stamp = utils.pack_stamp(lin)
@@ -336,7 +355,14 @@ class VolSDF(CommonNeRF):
         if self._fusable_view(refl_latent) and not ag.needs_grad(pts):
             # SDF network (fused MLP kernel) -> one kernel for Laplace density, View head and compositing: the colour,
             # density and [x | elev azim] tensors of the operator chain are never materialised
-            raw = self.sdf.underlying(pts)
+            if self._fusable_fourier_sdf():
+                # f16x: the Fourier-MLP SDF network as ONE launch of the layer-synchronous engine (MODEL 5) instead of the
+                # 3-product generic kernel; its 256 Fourier features are generated in the kernel
+                enc = self.sdf.underlying.mlp.enc
+                basis = (enc.basis.data * float(enc.extra_scale)).contiguous() if float(enc.extra_scale) != 1.0 else enc.basis.data
+                raw = ops.mlp_fourier_ls(rays.contiguous(), ts, basis, self.packed_fourier_sdf_ls("f16x"), "f16x", pts=pts.contiguous())
+            else:
+                raw = self.sdf.underlying(pts)
             scale = torch.nn.functional.softplus(self.scale.data) if self.scale_softplus else self.scale.data
             object.__setattr__(self, "scale_post_act", scale)
             prec = config.kernel_precision(has_f16x=True)

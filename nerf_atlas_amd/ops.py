@@ -761,6 +761,45 @@ def mlp_hash_ls(rays: torch.Tensor, ts: torch.Tensor, tables: torch.Tensor, pack
     return y
 
 
+def mlp_fourier_ls_pack(precision: str, weights, biases) -> torch.Tensor:
+    """Pack a Fourier-encoded SkipConnMLP (in 3, 128 frequencies, 6 x 256, skip 3, out 65: {init, layers.0..5, out}) into the weight
+    stream of the layer-synchronous engine (f16x only; VolSDF's MLP SDF network)."""
+    lib = _lib.load()
+    assert len(weights) == 8 and len(biases) == 8
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [None if b is None else _f32(b.detach(), "bias") for b in biases]
+    shapes = [(256, 259), (256, 515), (256, 256), (256, 256), (256, 515), (256, 256), (256, 256), (65, 256)]
+    for w, shp in zip(ws, shapes):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS Fourier MLP: weight shape {tuple(w.shape)} != {shp}")
+    nbytes = int(lib.na_mlp_fourier_ls_packed_bytes(PREC[precision]))
+    if nbytes == 0:
+        raise _lib.NaError(f"LS Fourier MLP: precision {precision} not supported (f16x only)")
+    wp = (C.c_void_p * 8)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * 8)(*[0 if b is None else b.data_ptr() for b in bs])
+    packed = torch.empty(nbytes, device=ws[0].device, dtype=torch.uint8)
+    check(lib.na_mlp_fourier_ls_pack(PREC[precision], wp, bp, _ptr(packed), _stream()))
+    return packed
+
+
+def mlp_fourier_ls(rays: torch.Tensor, ts: torch.Tensor, basis: torch.Tensor, packed: torch.Tensor, precision: str,
+                   pts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The packed Fourier-encoded MLP at the samples of rays [..., 6] x ts [T] (or explicit pts [T, ..., 3]) -> [T, ..., 65];
+    basis [3, 128] (FourierEncoder.basis x extra_scale)."""
+    lib = _lib.load()
+    rays, ts, basis = _f32(rays, "rays"), _f32(ts, "ts"), _f32(basis, "basis")
+    assert tuple(basis.shape) == (3, 128), basis.shape
+    T = ts.shape[0]
+    R = rays.numel() // 6
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3
+    y = torch.empty((T,) + tuple(rays.shape[:-1]) + (65,), device=rays.device, dtype=torch.float32)
+    check(lib.na_mlp_fourier_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(basis), _ptr(packed), PREC[precision], _ptr(y), 65,
+                                _stream()))
+    return y
+
+
 def render_tiny_ls_pack(precision: str, weights, biases) -> torch.Tensor:
     """Pack TinyNeRF.estim ({init, layers.0..5, out}) into the weight stream of the layer-synchronous renderer."""
     lib = _lib.load()

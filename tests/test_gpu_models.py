@@ -570,3 +570,50 @@ def test_dynamic_nerf_f16x_deformation_on_the_ls_engine(na, spline):
     finally:
         config.set_precision("bf16x3")
         config.set_deformation_engine("generic")
+
+
+def test_volsdf_mlp_f16x_sdf_network_on_the_ls_engine(na):
+    """Config 5 (Fourier-MLP SDF) in the 1.5-product parity mode end to end: the SDF network runs as ONE
+    launch of the layer-synchronous engine with its 256 Fourier features generated in the kernel (csrc/render_ls.hip MODEL 5,
+    na_mlp_fourier_ls) instead of the 3-product generic kernel, then the View-half kernel -- against the reference's own VolSDF
+    output (g10) and, row by row, against the CPU oracle's SDF MLP on 800²-geometry tiles with ragged step counts."""
+    import math
+    import oracle as O
+    from nerf_atlas_amd import config, ops
+    h = load_golden("g10_volsdf_mlp")
+    p = golden_params(h)
+    under = na.sdf.sdf_kinds["mlp"](intermediate_size=64)
+    r = na.refl.View(latent_size=64, act="upshifted", out_features=3)
+    m = na.nerf.VolSDF(sdf=na.sdf.SDF(under, r, isect=None, t_near=0.3, t_far=1.8), steps=int(h["steps"]), t_near=0.3, t_far=1.8,
+                       sigmoid_kind="upshifted").cuda().eval()
+    load_params(m, p)
+    config.set_precision("f16x")
+    try:
+        assert m._fusable_fourier_sdf()
+        out = m(h["rays"].cuda())
+        print(f"\\n[volsdf-mlp f16x] RGB vs the reference {maxdiff(out, h['out']):.2e}, weights {maxdiff(m.weights, h['weights']):.2e}")
+        assert maxdiff(out, h["out"]) <= 1e-4
+        assert maxdiff(m.weights, h["weights"]) <= 2e-4
+        basis = under.mlp.enc.basis.data
+        cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1.0]]]),
+                                    focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
+        for T, size in ((130, 40), (32, 8)):
+            rays = cam.sample_positions((380, 390, size, size), size=800, with_noise=False)
+            ts, _ = ops.compute_ts(0.3, 1.8, T, "cuda")
+            rows = ops.mlp_fourier_ls(rays, ts, basis, m.packed_fourier_sdf_ls("f16x"), "f16x")
+            assert rows.shape == (T,) + tuple(rays.shape[:-1]) + (65,) and torch.isfinite(rows).all()
+            pts = ops.compute_pts(rays, ts)
+            sel = torch.arange(0, T, max(T // 40, 1))
+            sub = pts[sel][:, :, ::7, ::5].cpu()
+            ref = O.skip_mlp(p, "sdf.underlying.mlp.", sub, enc=lambda x: O.fourier_encode(x, p["sdf.underlying.mlp.enc.basis"]))
+            err = maxdiff(rows[sel][:, :, ::7, ::5], ref)
+            generic = under(pts[sel][:, :, ::7, ::5].contiguous())
+            print(f"[volsdf-mlp f16x] T = {T}: SDF rows vs the oracle {err:.2e} (|ref| {float(ref.abs().max()):.2f}); the generic "
+                  f"kernel in bf16x3: {maxdiff(generic, ref):.2e}")
+            assert err <= 2e-4 * max(1.0, float(ref.abs().max()))
+            rows2 = ops.mlp_fourier_ls(rays, ts, basis, m.packed_fourier_sdf_ls("f16x"), "f16x", pts=pts)
+            assert torch.equal(rows, rows2)
+        config.set_precision("bf16x3")
+        assert not m._fusable_fourier_sdf()
+    finally:
+        config.set_precision("bf16x3")
