@@ -461,6 +461,21 @@ int na_mlp_fourier_ls_pack(int precision, const float* const* weights, const flo
 int na_mlp_fourier_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* basis,
                       const void* packed, int precision, float* y, int64_t y_ld, void* stream);
 
+/* PlainNeRF(view) with mip's integrated positional encoding (config 3: src/nerf.py:256-261 hook, :326-361 forward,
+ * src/utils.py:23-27, 60-140 cylinder / conic Gaussians) as ONE launch of the layer-synchronous engine, NA_PREC_F16X only.
+ * rays [B,H,W,6] of whole crops (pixel radii difference neighbouring rows: H >= 2); ts [T]; weights of `first`
+ * ([256,134], [256,390], 3 x [256,256], [65,256]) and of the View MLP ([256,165], [256,421], 3 x [256,256], [3,256]) in the
+ * reference's column order [p | enc(p) | IPE 96 | ...]; max_deg - min_deg must be 16.  The 96 IPE features of a sample are
+ * generated in the kernel for each of the four Linears that consume them (same arithmetic as na_mip_encode, intended
+ * layout; t_end as there).  Outputs, workspace (na_render_ls_workspace_bytes) and the range guard as na_render_plain_view_ls. */
+size_t na_render_plain_mip_ls_packed_bytes(int precision);
+int na_render_plain_mip_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                const float* const* w_view, const float* const* b_view, void* packed, void* stream);
+int na_render_plain_mip_ls(const float* rays, int B, int H, int W, const float* ts, int T, const float* hash_tables,
+                           const void* packed, int precision, int mip_kind, int min_deg, int max_deg, float t_end,
+                           int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,12 +117,15 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // f16 + 2 x fp6 like the hidden groups -- so only the two geometry chunk pairs of the View MLP are left as pairs)
 // MODEL 4 (round 4): a hash-encoded SkipConnMLP alone (D-NeRF's deformation network, src/nerf.py:1250-1257: 3 -> 5 x 256, skip 3,
 // out 3 n + 1 <= 32 rows), rows to HBM: init group | skip group + 4 (L0) | L1 | L2 | skip group + 4 (L3) | L4 | out = 27 records
+// MODEL 6 (round 4): PlainNeRF(view) + mip (src/nerf.py:256-261: the 96-wide integrated positional encoding as leading latent
+// columns of BOTH MLPs): MODEL 0's schedule with two IPE K64 groups generated in the kernel wherever a Linear consumes them
+// (first.init, first.L0, view.init, view.L0): 44 + 4 x 2 = 52 records, 2 geometry pairs
 // MODEL 5 (round 4): a Fourier-encoded SkipConnMLP alone (VolSDF's MLP SDF network, src/sdf.py:250-258: 3 -> [p | sin, cos of 128
 // frequencies] -> 6 x 256, skip 3, out 65), rows to HBM.  The 256 Fourier features are K64 groups in the HIDDEN format, generated by
 // the row groups in a VALU phase wherever a Linear consumes them (init, L0, L3): init 4 | L0 4 + 4 | L1 | L2 | L3 4 + 4 | L4 | L5 |
 // out 4 = 40 records, and 3 pairs for the 3-wide position chunk
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : model == 4 ? 0 : model == 5 ? 3 : 2; }
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : model == 4 ? 27 : model == 5 ? 40 : 44; }
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : model == 4 ? 0 : model == 5 ? 3 : 2; }  // (6: 2)
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -173,6 +176,9 @@ struct Args {
   uint32_t sat_gen;           // NA_PREC_F16X: this launch's id for the saturation flag (g_lsx_saturated)
   float* y;                   // MODEL 4: output rows [T * R, y_ld] (sample t * R + ray), n_out columns written
   int y_ld, n_out;
+  // MODEL 6 (mip): the crop's geometry (rays = [B,H,W,6]: the pixel radius is a difference of neighbouring rows) and the IPE's shape
+  int mip_H, mip_W, mip_kind, mip_min_deg, mip_nd;
+  float mip_t_end;
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -197,13 +203,13 @@ struct XPairD { int8_t lin, q, skip; };      // init chunk q of Linear lin (skip
 // init_slot_feature; 2: behind the kHidden hidden columns of a skip layer); kind 3 / 4: Fourier features 64 q .. 64 q + 63 in the
 // generator's slot order (fourier_slot_col; 4: behind the hidden columns of a skip layer).  out_mode 0 hidden rows, 1 out row-major (tile
 // min(rg, 2)), 2 out, one tile, 3 out split by block: row groups 0,1 hold tiles 0 and 1, row groups 2,3 tile 2
-struct XRecD { int8_t lin, q, out_mode, kind; };
+struct XRecD { int8_t lin, q, out_mode, kind; int16_t off; };  // off: added to the column (kinds 1, 2, 5: where the group's columns start)
 struct XSched {
   int npair, nrec, nphase, nlin, ndesc;
-  XLin lin[13];
+  XLin lin[13];  // (<= 13 Linears: SIREN VolSDF 7 + 6)
   NaMlpDesc desc[2];
   XPairD pair[16];
-  XRecD rec[44];
+  XRecD rec[56];
   int8_t bias_lin[16], bias_mode[16];
 };
 // model: 0 PlainNeRF(view) (w0 = first, w1 = View), 1 TinyNeRF (w0), 2 View half (w0), 3 SIREN VolSDF (w0 = SDF net, w1 = View).
@@ -611,13 +617,13 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
 // whose fourth chunk is padding that the fp6 operands hold as zeros and the f16 product skips); the others are the hidden
 // groups Q = 0, 1, ... of the blocks (hb0 + b * BLKH + Q * KQ).  PAR0 = parity of rec0 (which scale slot its dword sits in).
 // CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
-template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4, bool LAST0 = false>
+template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4, bool LAST0 = false, int BSTR = BLKH>
 __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
                                      int rec0, const char* hb0, int lane, const char* ib0 = nullptr) {
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
   auto gbase = [&](int gi, int b) -> const char* {  // K64 group gi of this call, block b
     if (G0 != 0 && gi == 0) return ib0 + b * KQ;
-    return hb0 + b * BLKH + (gi - G0) * KQ;
+    return hb0 + b * BSTR + (gi - G0) * KQ;  // (BSTR: MODEL 6 parks the two IPE groups of block b at groups 2 b, 2 b + 1 of block 0)
   };
   auto nch = [&](int gi) -> int { return (G0 != 0 && gi == 0) ? NCH0 : 4; };
   auto b16 = [&](int b, int gi, int c) -> f16x8 { return *(const f16x8*)(gbase(gi, b) + c * 1024 + lane * 16); };
@@ -850,6 +856,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
+  constexpr bool M0 = MODEL == 0 || MODEL == 6;  // the PlainNeRF(view) schedule (6: + mip)
+  constexpr bool MIP = MODEL == 6;
   constexpr int PPP = PREC == NA_PREC_F16X ? x::hdr_units(MODEL)
                       : MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
@@ -1062,8 +1070,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   // of the block's fourth init chunk (the last latent chunk: dead once view.L0 has run, not written by EP, rewritten by the
   // epilogue of first.out).  The other schedules composite in the next pass's exposed phase, into the idle hidden region.
   auto part_of = [&](int b) -> float* {
-    if constexpr (MODEL == 0 && PREC == NA_PREC_F16X) return (float*)(ib + b * x::KQ + 3 * 1024);  // (f16 chunk 3 of the block's init group)
-    return MODEL == 0 ? (float*)(ib + (b * 4 + 3) * FR) : (float*)hb + b * kPartialFloats;
+    if constexpr (M0 && PREC == NA_PREC_F16X) return (float*)(ib + b * x::KQ + 3 * 1024);  // (f16 chunk 3 of the block's init group)
+    return M0 ? (float*)(ib + (b * 4 + 3) * FR) : (float*)hb + b * kPartialFloats;
   };
   // compositing of block rg of pass `pass` (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
   auto composite = [&](const Prev& q, const f32x16& oc, float density) {
@@ -1071,7 +1079,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     const float cg = fast_sigmoid_kind(oc[1], a.sigmoid_kind);
     const float cb = fast_sigmoid_kind(oc[2], a.sigmoid_kind);
     // (MODEL 2: `density` is VolSDF's Laplace density, used as it is: src/nerf.py:1004-1006, softplus = False)
-    const float sigma = MODEL >= 2 ? fmaxf(density, 0.f) : fast_softplus(density - 1.0f);
+    const float sigma = (MODEL == 2 || MODEL == 3) ? fmaxf(density, 0.f) : fast_softplus(density - 1.0f);
     const float alpha = q.t_ok ? 1.0f - fast_exp(-sigma * q.dist) : 0.f;
     const float f = (1.0f - alpha) + 1e-10f;
     // exclusive product scan over the 32 steps of the block: shift by one lane (lane 0 of each half: 1), then scan
@@ -1091,9 +1099,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       if (q.ok && q.t_ok && a.alpha != nullptr) a.alpha[(int64_t)q.t * a.R + q.ray] = alpha;
       // MODEL 0 composites at the end of a pass and combines in the next pass's exposed phase: the block-local weight waits in
       // the caller's weights array (scaled in place by `combine`) instead of in a register across the hash gathers
-      if (MODEL == 0 && q.ok && q.t_ok && a.weights != nullptr) a.weights[(int64_t)q.t * a.R + q.ray] = w;
+      if (M0 && q.ok && q.t_ok && a.weights != nullptr) a.weights[(int64_t)q.t * a.R + q.ray] = w;
     }
-    if constexpr (MODEL != 0) w_local = w;
+    if constexpr (!M0) w_local = w;
   };
   // Cross-block step of the compositing (the reference's cumprod runs over all T steps: src/nerf.py:22-27): every wave of
   // the group walks the NB blocks of pass `pl` in step order with the running transmittance / colour of the current ray
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const int t = L.tb * 32 + ln;
       if (L.ok && t < a.T) {
         float* wp = a.weights + (int64_t)t * a.R + L.ray;
-        *wp = (MODEL == 0 ? *wp : w_local) * mine;
+        *wp = (M0 ? *wp : w_local) * mine;
       }
     }
   };
@@ -1239,6 +1247,73 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       own_setup(pl + 1);
     }
   };
+  // ---- MODEL 6 (mip, NA_PREC_F16X): the 96 IPE features of a sample (src/utils.py:23-27, 83-140; hook src/nerf.py:256-261) as two
+  // K64 groups in the hidden format.  Row group rg generates group rg & 1 of block rg >> 1: a lane (sample, k half h) computes
+  // its (degree, axis) pairs -- pidx = 16 h + j (group 0, j < 16) | 32 + 8 h + j (group 1, j < 8) -- sine and cosine feature
+  // of a pair from ONE reduced angle and one damping factor, into slots 2 j and 2 j + 1.  Block b's groups live at K64 groups
+  // 2 b, 2 b + 1 of block 0's hidden space (block 1's holds the raw [hash | x] / latent values that wait for the skip layer).
+  float rad_u[NB];  // pixel radius of block b's ray (uniform)
+  auto mip_setup = [&]() {
+    if constexpr (MIP) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int r = geo_ray[b];
+        const int W = a.mip_W, H = a.mip_H;
+        const int row = r / W, wq = r - row * W, bi = row / H, hq = row - bi * H;
+        rad_u[b] = uni(mip_radius(a.rays, H, W, bi, hq, wq));
+      }
+    }
+  };
+  auto gen_ipe = [&](auto act_tag) {
+    if constexpr (MIP && PREC == NA_PREC_F16X) {
+      constexpr int ACT = decltype(act_tag)::value;
+      const int g = rg & 1, b = rg >> 1;  // this wave's unit (NB = 2)
+      float ry[6], rad = 0.f;
+      int t0i = 0;
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb)
+        if (bb == b) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) ry[e] = geo_u[bb][e];
+          rad = rad_u[bb];
+          t0i = geo_t0[bb];
+        }
+      const int t = t0i + ln;
+      const int tc = t < a.T ? t : a.T - 1;
+      const float t0 = a.ts[tc];
+      const float t1 = tc < a.T - 1 ? a.ts[tc + 1] : mip_last_edge(a.ts, a.T, a.mip_t_end);
+      const MipGauss gs = mip_gaussian(ry, rad, t0, t1, a.mip_kind);
+      f32x16 n0, n1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { n0[e] = 0.f; n1[e] = 0.f; }
+      const int nd = a.mip_nd, nj = g == 0 ? 16 : 8;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < nj) {
+          const int pidx = g == 0 ? 16 * hi + j : 32 + 8 * hi + j;
+          const bool ok = pidx < 3 * nd;
+          const int k = (pidx * 43) >> 7, ax = pidx - 3 * k;  // pidx / 3 for pidx < 128
+          const float m = ax == 0 ? gs.m0 : (ax == 1 ? gs.m1 : gs.m2);
+          const float c = ax == 0 ? gs.c0 : (ax == 1 ? gs.c1 : gs.c2);
+          const int deg = a.mip_min_deg + k;
+          // mip_feature's angle (common.h): revolutions of y = m 2^deg with the product's rounding error recovered; the cosine
+          // half is sin(fl(y + pi/2)): the rounded sum differs from y by an exactly representable delta
+          const float chi = ldexpf(0.15915494309189535f, deg), clo = ldexpf(6.4206383e-9f, deg);
+          const float pr = m * chi;
+          const float er = fmaf(m, chi, -pr) + m * clo;
+          const float rev = (pr - rintf(pr)) + er;
+          const float y = ldexpf(m, deg);
+          const float yc = y + 1.5707963267948966f;
+          const float delta = yc - y;
+          const float damp = __builtin_amdgcn_exp2f(c * ldexpf(-0.7213475204444817f, 2 * deg));
+          const float sn = ok ? damp * __builtin_amdgcn_sinf(rev) : 0.f;
+          const float cs = ok ? damp * __builtin_amdgcn_sinf(rev + delta * 0.15915494309189535f) : 0.f;
+          if (j < 8) { n0[2 * j] = sn; n0[2 * j + 1] = cs; } else { n1[2 * (j - 8)] = sn; n1[2 * (j - 8) + 1] = cs; }
+        }
+      }
+      x::store_block<ACT>(hb + (2 * b + g) * x::KQ, n0, n1, lane, a.sat_gen);
+    }
+  };
   // ---- NA_PREC_F16X, schedules whose first MLP takes the hash encoder (MODEL 0, 4): the [hash | x] group
   auto hash_group_ep = [&](int pass) {
     if constexpr (PREC == NA_PREC_F16X) {
@@ -1304,7 +1379,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         }
     }
   };
-  if constexpr (MODEL == 0 || MODEL == 4) {
+  if constexpr (M0 || MODEL == 4) {
     tnext = ts_load(0);
     own_setup(0);
   }
@@ -2063,7 +2138,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     STAMP(0);
     if (prev >= 0) combine(prev);  // (partials: written before the barrier that closed view.out; EP does not touch their chunk)
     if constexpr (PREC == NA_PREC_F16X) {
+      if constexpr (MIP) { geo_setup(pass); mip_setup(); }
       hash_group_ep(pass);
+      if constexpr (MIP) gen_ipe(std::integral_constant<int, NA_ACT_NONE>{});
     } else
     if (NB == 4 || owner) {  // (bf16x3: row groups 2,3 own no block -- nothing to encode or composite)
       STAMP(8);
@@ -2123,7 +2200,15 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       };
       // records per pass (44, parity of the index = scale slot): 0 first.init | 1 skip group + 2..5 first.L0 | 6.. L1..L3 |
       // 18..21 first.out | 22 view.init | 23 skip group + 24..27 view.L0 | 28.. L1..L3 | 40..43 view.out
-      x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);       // first.init: the [hash | x] group
+      // MODEL 6 (mip): 52 records -- 0..2 first.init ([hash | x], IPE 0, IPE 1) | 3 skip group + 4..7 hidden + 8, 9 IPE (first.L0) |
+      // 10.. L1..L3 | 22..25 first.out | 26..28 view.init (latent, IPE 0, IPE 1) | 29 skip group + 30..33 + 34, 35 IPE (view.L0) |
+      // 36.. L1..L3 | 48..51 view.out; the IPE groups of a skip layer are regenerated (through the activation) between the
+      // layer's two MFMA phases, whose accumulators stay in registers
+      constexpr int IPS = 2 * x::KQ;  // block stride of the parked IPE groups
+      constexpr int RL1 = MIP ? 10 : 6, ROUT = MIP ? 22 : 18, RVI = MIP ? 26 : 22, RVL0 = MIP ? 29 : 23, RVL1 = MIP ? 36 : 28,
+                    RVO = MIP ? 48 : 40;
+      if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 3, false, IPS>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);
+      else x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);  // first.init: the [hash | x] group
       SYNC();
       {
         x::store_acts<NA_ACT_LEAKY_RELU, NB, 0, 1>(acc, hb, rg, lane, a.sat_gen);
@@ -2132,14 +2217,22 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         load_bias2(1);
       }
       SYNC();
-      x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);       // first.L0: skip group, then K = 256
+      if constexpr (MIP) {
+        x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 3, hb, lane, ib);     // first.L0: skip group + K = 256 ...
+        SYNC();
+        gen_ipe(std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
+        SYNC();
+        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS>(acc, bvx, XR, wrs, xrec, 8, hb, lane);  // ... + the IPE groups
+      } else {
+        x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);     // first.L0: skip group, then K = 256
+      }
       SYNC();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         x::store_acts<NA_ACT_LEAKY_RELU, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(2 + i);
         SYNC();
-        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 6 + 4 * i, hb, lane);                  // first.L1..L3
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, RL1 + 4 * i, hb, lane);                // first.L1..L3
         SYNC();
       }
       // first.out, split by BLOCK (NB = 2): every row group runs two tiles for ONE block, rg & 1 -- row groups 0, 1 the two
@@ -2155,7 +2248,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         bvx[1] = bias_tile(wrs, bias_rg + 5 * 1024, rg < 2 ? 1 : 3, lane);  // (slot 3: zeros)
       }
       SYNC();
-      x::recs<2, 1, true, XNR>(ol, bvx, XR, wrs, xrec, 18, hb + (rg & 1) * x::BLKH, lane);
+      x::recs<2, 1, true, XNR>(ol, bvx, XR, wrs, xrec, ROUT, hb + (rg & 1) * x::BLKH, lane);
       SYNC();
       {
         load_bias2(6);
@@ -2175,6 +2268,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           // compositing at the end of the pass: carried in a register it was the one value spilled AND re-stored every pass
           *(float*)(ib + (rg & 1) * x::KQ + 6144 + 1024 + ln * 16 + 12) = ol[0][0][0];
         }
+        if constexpr (MIP) { mip_setup(); gen_ipe(std::integral_constant<int, NA_ACT_NONE>{}); }
         x::pairs_prefetch(XR, wrs, xpair, lane, 0, 1);
       }
       SYNC();
@@ -2182,7 +2276,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, 22, hb, lane, ib);    // view.init: latent group + geometry
+        if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 4, false, IPS>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);
+        else x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);  // view.init: latent group + geometry
         x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
       }
       SYNC();
@@ -2201,14 +2296,25 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         }
         x::store_acts<NA_ACT_SIN, NB, 1, 2>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(7);
-        XR.pr[0] = x::wpair(wrs, lane, xpair, 1);  // (the second geometry pair, into the same ring slot: the first one is spent)
+        if constexpr (!MIP) XR.pr[0] = x::wpair(wrs, lane, xpair, 1);  // (the second geometry pair, into the same ring slot: the first one is spent)
       }
       SYNC();
-      {
+      if constexpr (MIP) {
+        x::recs<2, NB, true, XNR, 5, 1, 1, 4>(acc, bvx, XR, wrs, xrec, RVL0, hb, lane, ib);   // view.L0: skip group + K = 256 ...
+        SYNC();
+        gen_ipe(std::integral_constant<int, NA_ACT_SIN>{});
+        XR.pr[0] = x::wpair(wrs, lane, xpair, 1);
+        SYNC();
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::recs<2, NB, true, XNR, 5, 1, 1, 4>(acc, bvx, XR, wrs, xrec, 23, hb, lane, ib);    // view.L0: skip group, K = 256, geometry
+        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS>(acc, bvx, XR, wrs, xrec, RVL0 + 5, hb, lane);  // ... + IPE + geometry
+        x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+      } else {
+        GeoRaw graw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
+        x::recs<2, NB, true, XNR, 5, 1, 1, 4>(acc, bvx, XR, wrs, xrec, RVL0, hb, lane, ib);  // view.L0: skip group, K = 256, geometry
         x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       }
       SYNC();
@@ -2217,7 +2323,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         load_bias2(8 + i);
         SYNC();
-        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 28 + 4 * i, hb, lane);                // view.L1..L3
+        x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, RVL1 + 4 * i, hb, lane);              // view.L1..L3
         SYNC();
       }
       f32x16 ocx[1][1];
@@ -2227,7 +2333,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
       }
       SYNC();
-      x::recs<1, 1, true, XNR>(ocx, bo, XR, wrs, xrec, 40, hb + blk * x::BLKH, lane);             // view.out (block per wave)
+      x::recs<1, 1, true, XNR>(ocx, bo, XR, wrs, xrec, RVO, hb + blk * x::BLKH, lane);            // view.out (block per wave)
       oc[0] = ocx[0][0];
       pass_tail(pass);
       SYNC();
@@ -2354,7 +2460,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }  // (PREC != NA_PREC_F16X)
     prev = pass;
   }
-  if (MODEL != 0 && MODEL < 4 && prev >= 0 && (NB == 4 || owner)) {  // (MODEL 0 composited its last pass in that pass's view.out phase)
+  if (!M0 && MODEL < 4 && prev >= 0 && (NB == 4 || owner)) {  // (MODEL 0 composited its last pass in that pass's view.out phase)
     prev_dn = own_dn;
     if constexpr (MODEL == 1) {
       f32x16 rgbv = oc[0];
@@ -2365,7 +2471,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
   }
   __syncthreads();
-  if (MODEL < 4 && prev >= 0) combine(prev);
+  if ((MODEL < 4 || M0) && prev >= 0) combine(prev);
   if (g == 0) {  // group 0 takes its extra barriers at the end
 #pragma unroll 1
     for (int i = 0; i < LAG; ++i) __syncthreads();
@@ -2758,16 +2864,24 @@ namespace ls {
 // column of Linear rd.lin's weight matrix that sits in k-slot kappa of chunk c of the record's K64 group; -1 = zero
 __device__ __forceinline__ int xrec_col(const XSched& sc, const XRecD& rd, int c, int kappa) {
   if (rd.kind == 0) return 64 * rd.q + 16 * c + pi_perm(kappa);  // hidden feature (the skip layers store [hidden | init])
-  if (rd.kind >= 3) {
+  if (rd.kind == 3 || rd.kind == 4) {
     // Fourier group q as the MODEL 5 generator lays it out: slot s = 8 c + e of lane half h holds frequency f = 32 q + 16 h + s / 2,
     // its sine (s even) or cosine (s odd).  Reference columns: [p | sin(128) | cos(128)] (src/neural_blocks.py:36-55, 283-287)
     const NaMlpDesc& d = sc.desc[sc.lin[rd.lin].desc];
     const int F = d.enc_dims / 2, s = 8 * c + (kappa & 7), f = 32 * rd.q + 16 * (kappa >> 3) + (s >> 1);
     return (rd.kind == 4 ? kHidden : 0) + d.in_size + ((s & 1) ? F + f : f);
   }
+  if (rd.kind == 5) {
+    // IPE group q (0, 1) as the MODEL 6 generator lays it out: slot s = 8 c + e of lane half h holds the (degree, axis) pair
+    // pidx = 16 h + s / 2 (group 0) | 32 + 8 h + s / 2 for s < 16 (group 1; the rest is padding), its sine feature (s even:
+    // latent column pidx) or cosine feature (s odd: column 48 + pidx); src/utils.py:23-27 layout [sin | cos], degree-major
+    const int s = 8 * c + (kappa & 7), h = kappa >> 3;
+    const int pidx = rd.q == 0 ? 16 * h + (s >> 1) : (s < 16 ? 32 + 8 * h + (s >> 1) : -1);
+    return pidx < 0 ? -1 : rd.off + ((s & 1) ? 48 : 0) + pidx;
+  }
   int col = init_slot_feature(sc.desc[sc.lin[rd.lin].desc], c, kappa);
   if (col >= 0 && rd.kind == 2) col += kHidden;
-  return col;
+  return col < 0 ? col : col + rd.off;
 }
 // weight row held by lane l of tile t of row group rg; -1 = zero
 __device__ __forceinline__ int xrec_row(const XSched& sc, const XRecD& rd, int rg, int t, int l) {
@@ -2907,11 +3021,11 @@ static void xs_add_mlp(XSched& sc, const NaMlpDesc& d, const float* const* w, co
     sc.bias_mode[sc.nphase++] = (int8_t)(last ? out_mode : 0);
     if (first || skip) {
       // init_rec: the (<= 4) init chunks as ONE record in front of the Linear's hidden records, consumed from the init region
-      if (init_rec) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), 0, 0, (int8_t)(skip ? 2 : 1)};
+      if (init_rec) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), 0, 0, (int8_t)(skip ? 2 : 1), 0};
       else for (int q = 0; q < ni; ++q) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(skip ? 1 : 0)};
     }
     if (!first) {
-      for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(last ? out_mode : 0), 0};
+      for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)(l0 + i), (int8_t)q, (int8_t)(last ? out_mode : 0), 0, 0};
     }
     if ((first || skip) && geo) sc.pair[sc.npair++] = XPairD{(int8_t)(l0 + i), 4, (int8_t)(skip ? 1 : 0)};
   }
@@ -2931,6 +3045,39 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
     xs_add_mlp(sc, tiny, w0, b0, 8, 1, false, 2);
   } else if (model == 2) {
     xs_add_mlp(sc, view, w0, b0, 6, 4, true, 2);
+  } else if (model == 6) {
+    // PlainNeRF(view) + mip.  Column layouts (src/neural_blocks.py:283-287: [p | enc(p) | latent]): first [p 3 | x 3 + hash 32 |
+    // IPE 96] (134), skip layer [hidden 256 | the same]; View [x y z elev azim | IPE 96 | intermediate 64] (165)
+    // (src/nerf.py:352-358: latent = cat(mip, cat(intermediate, refl_latent))), skip layer [hidden 256 | the same].
+    // The slot maps of the [hash | x] and latent groups come from descs WITHOUT the IPE columns; `off` puts them in place.
+    const NaMlpDesc first = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+    sc.desc[0] = first; sc.desc[1] = view; sc.ndesc = 2;
+    for (int m = 0; m < 2; ++m) {
+      const float* const* w = m == 0 ? w0 : w1;
+      const float* const* b = m == 0 ? b0 : b1;
+      const int dim_p = m == 0 ? 134 : 165, ipe0 = m == 0 ? 38 : 5, grp_off = m == 0 ? 0 : 96;
+      for (int i = 0; i < 6; ++i) {  // init, layers.0..3, out
+        const bool fst = i == 0, last = i == 5, skip = i == 1;
+        XLin L;
+        L.W = w[i]; L.B = b[i]; L.desc = m;
+        L.in_dim = fst ? dim_p : skip ? kHidden + dim_p : kHidden;
+        L.out_dim = last ? (m == 0 ? 65 : 3) : kHidden;
+        const int li = sc.nlin;
+        sc.lin[sc.nlin++] = L;
+        sc.bias_lin[sc.nphase] = (int8_t)li;
+        sc.bias_mode[sc.nphase++] = (int8_t)(last ? (m == 0 ? 3 : 2) : 0);
+        if (fst || skip) {
+          const int so = skip ? kHidden : 0;
+          // consumption order: the [hash | x] / latent group (init region), then (skip layers) the four hidden groups, then the IPE groups
+          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)(skip ? 2 : 1), (int16_t)grp_off};
+          if (skip) for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, 0, 0, 0};
+          for (int q = 0; q < 2; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, 0, 5, (int16_t)(so + ipe0)};
+          if (m == 1) sc.pair[sc.npair++] = XPairD{(int8_t)li, 4, (int8_t)(skip ? 1 : 0)};
+        } else {
+          for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, (int8_t)(last ? (m == 0 ? 3 : 2) : 0), 0, 0};
+        }
+      }
+    }
   } else if (model == 5) {
     const NaMlpDesc fmlp = {3, NA_ENC_FOURIER, 256, 0, 6, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
     sc.desc[sc.ndesc++] = fmlp;
@@ -2944,9 +3091,9 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
       sc.lin[sc.nlin++] = L;
       sc.bias_lin[sc.nphase] = (int8_t)i;
       sc.bias_mode[sc.nphase++] = (int8_t)(last ? 1 : 0);
-      if (!first) for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, (int8_t)(last ? 1 : 0), 0};
+      if (!first) for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, (int8_t)(last ? 1 : 0), 0, 0};
       if (first || skip) {
-        for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, 0, (int8_t)(skip ? 4 : 3)};
+        for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, 0, (int8_t)(skip ? 4 : 3), 0};
         sc.pair[sc.npair++] = XPairD{(int8_t)i, 16, (int8_t)(skip ? 1 : 0)};  // the position chunk: init chunk F / 8 of the Fourier layout
       }
     }
@@ -2974,13 +3121,18 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_F16X, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16X, 2>(a, s)
          : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_F16X, 4>(a, s)
-         : model == 5 ? ls::launch<NA_PREC_F16X, 5>(a, s) : ls::launch<NA_PREC_F16X>(a, s);
+         : model == 5 ? ls::launch<NA_PREC_F16X, 5>(a, s) : model == 6 ? ls::launch<NA_PREC_F16X, 6>(a, s)
+         : ls::launch<NA_PREC_F16X>(a, s);
 }
 int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream) {
   return ls::render_lsx_pack(4, w, b, nullptr, nullptr, packed, stream, n_out);
 }
 int render_lsx_pack_fouriermlp(const float* const* w, const float* const* b, char* packed, hipStream_t stream) {
   return ls::render_lsx_pack(5, w, b, nullptr, nullptr, packed, stream);
+}
+int render_lsx_pack_mip(const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1, char* packed,
+                        hipStream_t stream) {
+  return ls::render_lsx_pack(6, w0, b0, w1, b1, packed, stream);
 }
 #elif NA_PREC_INST == 0
 int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
@@ -3004,6 +3156,8 @@ int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model);
 int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model);
 int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream);
 int render_lsx_pack_fouriermlp(const float* const* w, const float* const* b, char* packed, hipStream_t stream);
+int render_lsx_pack_mip(const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1, char* packed,
+                        hipStream_t stream);
 
 }  // namespace na
 
@@ -3077,6 +3231,54 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 0);
   if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 0);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 0);
+}
+
+// ---- PlainNeRF(view) + mip (config 3; src/nerf.py:256-261, 326-361, src/utils.py:23-140) as ONE launch, NA_PREC_F16X only:
+// the 96 IPE features of every sample are generated in the kernel (MODEL 6) for the init and skip Linears of both MLPs
+extern "C" size_t na_render_plain_mip_ls_packed_bytes(int precision) {
+  return precision == NA_PREC_F16X ? ls::packed_bytes_x(6) : 0;
+}
+
+extern "C" int na_render_plain_mip_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                           const float* const* w_view, const float* const* b_view, void* packed, void* stream) {
+  NA_REQUIRE(w_first && b_first && w_view && b_view && packed, NA_ENULL, "na_render_plain_mip_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_render_plain_mip_ls_pack: precision %d (f16x only)", precision);
+  for (int i = 0; i < 6; ++i)
+    NA_REQUIRE(w_first[i] && w_view[i] && b_first[i] && b_view[i], NA_ENULL, "na_render_plain_mip_ls_pack: Linear %d is null", i);
+  return render_lsx_pack_mip(w_first, b_first, w_view, b_view, (char*)packed, (hipStream_t)stream);
+}
+
+extern "C" int na_render_plain_mip_ls(const float* rays, int B, int H, int W, const float* ts, int T, const float* hash_tables,
+                                      const void* packed, int precision, int mip_kind, int min_deg, int max_deg, float t_end,
+                                      int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(T >= 1 && B >= 0 && H >= 0 && W >= 0, NA_EINVAL, "na_render_plain_mip_ls: bad shape T=%d B=%d H=%d W=%d", T, B, H, W);
+  const int64_t R = (int64_t)B * H * W;
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && hash_tables && packed && out && workspace, NA_ENULL, "na_render_plain_mip_ls: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_render_plain_mip_ls: precision %d (f16x only)", precision);
+  NA_REQUIRE(mip_kind == 0 || mip_kind == 1, NA_EUNSUPPORTED, "na_render_plain_mip_ls: mip kind %d", mip_kind);
+  NA_REQUIRE(max_deg - min_deg == 16, NA_EUNSUPPORTED, "na_render_plain_mip_ls: %d IPE degrees (the schedule is built for 16)",
+             max_deg - min_deg);
+  NA_REQUIRE(H >= 2, NA_EINVAL, "na_render_plain_mip_ls: pixel radii need H >= 2 rows per crop (H=%d)", H);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "na_render_plain_mip_ls: sigmoid %d", sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "na_render_plain_mip_ls: bg %d", bg_kind);
+  NA_REQUIRE(workspace_bytes >= na_render_ls_workspace_bytes(T, R), NA_EWORKSPACE,
+             "na_render_plain_mip_ls: workspace %zu < %zu bytes", workspace_bytes, na_render_ls_workspace_bytes(T, R));
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.pts = nullptr; a.tables = (const float4*)hash_tables;
+  a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes_x(6);
+  a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.mip_H = H; a.mip_W = W; a.mip_kind = mip_kind; a.mip_min_deg = min_deg; a.mip_nd = max_deg - min_deg; a.mip_t_end = t_end;
+  float* elaz = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.elaz = elaz;
+  hipLaunchKernelGGL(ls::ray_elaz_kernel, dim3(grid_for(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rays, R, elaz);
+  a.sigmoid_kind = sigmoid_kind;
+  a.res = hash_resolutions();
+  a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
+  return render_ls_dispatch_f16x(a, (hipStream_t)stream, 6);
 }
 
 // ---- TinyNeRF on the same engine (src/nerf.py:278-305)

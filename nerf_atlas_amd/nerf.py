@@ -216,6 +216,24 @@ class PlainNeRF(CommonNeRF):
                 and self.intermediate_size == 64 and self.refl.out_features == 3 and not self.training
                 and not wants_grad)
 
+    def _fusable_mip(self, rays):
+        """mip + f16x on the layer-synchronous engine (csrc/render_ls.hip MODEL 6): whole crops [B,H,W,6], 16 IPE degrees."""
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return (config.engine == "ls" and config.precision == "f16x" and self.mip is not None
+                and self.mip.max_deg - self.mip.min_deg == 16 and rays.dim() == 4 and rays.shape[1] >= 2
+                and isinstance(self.refl, refl.View) and self.intermediate_size == 64 and self.refl.out_features == 3
+                and self.total_latent_size() == 96 and not self.training and not wants_grad)
+
+    def packed_mip_ls(self, precision: str):
+        lin = self.first._linears() + self.refl.mlp._linears()
+        stamp = utils.pack_stamp(lin)
+        cache = self.__dict__.setdefault("_packed_mip_ls", {})
+        hit = cache.get(precision)
+        if hit is None or stamp is None or hit[0] != stamp:
+            wb = lambda m: ([l.weight.data for l in m._linears()], [l.bias.data for l in m._linears()])
+            cache[precision] = (stamp, ops.render_plain_mip_ls_pack(precision, wb(self.first), wb(self.refl.mlp)))
+        return cache[precision][1]
+
     def packed_ls(self, precision: str):
         """Weight stream of the layer-synchronous renderer (both MLPs in one buffer; cached, re-packed when any
         parameter changed)."""
@@ -245,6 +263,13 @@ class PlainNeRF(CommonNeRF):
         if self._fusable():
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
             out, self.alpha, self.weights = self._render_fused(rays, self.ts, want_weights)
+            return self._finish_sky(out)
+        if self._fusable_mip(rays):
+            # config 3 under f16x: sample -> hash -> IPE -> first -> View -> composite as ONE launch
+            _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
+            out, self.alpha, self.weights = ops.render_plain_mip_ls(
+                rays.contiguous(), self.ts, self.first.enc.tables(), self.packed_mip_ls("f16x"), "f16x", self.mip.kind, float("nan"),
+                self.mip.min_deg, self.mip.max_deg, self.sigmoid_kind, self._kernel_bg(), want_weights or self.bg == "random")
             return self._finish_sky(out)
         rand = None
         pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb(),

@@ -723,6 +723,49 @@ def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torc
     return out, alpha, weights
 
 
+def render_plain_mip_ls_pack(precision: str, first_wb, view_wb) -> torch.Tensor:
+    """PlainNeRF.first and View.mlp of a mip model (96 IPE latent columns in both) as one weight stream of the
+    layer-synchronous renderer (na_render_plain_mip_ls_pack; f16x only)."""
+    lib = _lib.load()
+    (w1, b1), (w2, b2) = first_wb, view_wb
+    assert len(w1) == 6 and len(w2) == 6, "the LS renderer is specialised for 4 hidden layers per MLP"
+    dev = w1[0].device
+    keep = [[_f32(w.detach(), "weight") for w in w1], [_f32(b.detach(), "bias") for b in b1],
+            [_f32(w.detach(), "weight") for w in w2], [_f32(b.detach(), "bias") for b in b2]]
+    shapes1 = [(256, 134), (256, 390), (256, 256), (256, 256), (256, 256), (65, 256)]
+    shapes2 = [(256, 165), (256, 421), (256, 256), (256, 256), (256, 256), (3, 256)]
+    for w, shp in zip(keep[0] + keep[2], shapes1 + shapes2):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS mip renderer: weight shape {tuple(w.shape)} != {shp}")
+    arrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in lst]) for lst in keep]
+    packed = torch.empty(int(lib.na_render_plain_mip_ls_packed_bytes(PREC[precision])), device=dev, dtype=torch.uint8)
+    check(lib.na_render_plain_mip_ls_pack(PREC[precision], arrs[0], arrs[1], arrs[2], arrs[3], _ptr(packed), _stream()))
+    return packed
+
+
+def render_plain_mip_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch.Tensor, packed: torch.Tensor, precision: str,
+                        kind: str, t_end: float, min_deg: int, max_deg: int, sigmoid_kind: str = "thin", bg: str = "black",
+                        want_weights: bool = False, workspace: Optional[torch.Tensor] = None):
+    """PlainNeRF(view) + mip forward as one launch (rays [B,H,W,6] of whole crops; same outputs as render_plain_view_ls)."""
+    lib = _lib.load()
+    rays, ts, hash_tables = _f32(rays, "rays"), _f32(ts, "ts"), _f32(hash_tables, "hash_tables")
+    assert rays.dim() == 4 and rays.shape[-1] == 6, rays.shape
+    B, H, W = rays.shape[:3]
+    R, T = B * H * W, ts.shape[0]
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    nbytes = int(lib.na_render_ls_workspace_bytes(T, R))
+    if workspace is None:
+        workspace = torch.empty(nbytes, device=rays.device, dtype=torch.uint8)
+    out = torch.empty((B, H, W, 3), device=rays.device, dtype=torch.float32)
+    alpha = torch.empty((T, B, H, W), device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty((T, B, H, W), device=rays.device, dtype=torch.float32) if want_weights else None
+    check(lib.na_render_plain_mip_ls(_ptr(rays), B, H, W, _ptr(ts), T, _ptr(hash_tables), _ptr(packed), PREC[precision],
+                                     MIP_KIND[kind], min_deg, max_deg, float(t_end), SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha),
+                                     _ptr(weights), _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
+    return out, alpha, weights
+
+
 def mlp_hash_ls_pack(precision: str, weights, biases) -> torch.Tensor:
     """Pack a hash-encoded SkipConnMLP (in 3, HashEncoder, 5 x 256, skip 3, out <= 32: {init, layers.0..4, out}) into the weight
     stream of the layer-synchronous engine (f16x only; D-NeRF's deformation network)."""

@@ -145,7 +145,7 @@ def rand(shape, device): return random_source.rand(tuple(shape), device)
 def randn(shape, device): return random_source.randn(tuple(shape), device)
 
 
-PACK_CACHE_ATTRS = ("_packed", "_packed_ls", "_packed_view_ls", "_packed_siren_ls", "_packed_fourier_ls")
+PACK_CACHE_ATTRS = ("_packed", "_packed_ls", "_packed_mip_ls", "_packed_view_ls", "_packed_siren_ls", "_packed_fourier_ls")
 
 
 def invalidate_packed(module) -> int:

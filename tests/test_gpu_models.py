@@ -337,6 +337,53 @@ def test_mip_plain_nerf_tile_800_geometry(na, kind):
     assert maxdiff(lat, ref_lat) <= 2e-5, kind
 
 
+@pytest.mark.parametrize("kind", ["cylinder", "cone"])
+def test_mip_plain_nerf_f16x_one_launch(na, kind):
+    """config 3 under f16x: the whole mip model is ONE launch of the layer-synchronous engine (render_ls.hip MODEL 6, the IPE
+    groups generated in the kernel); same tile, oracle and <= 1e-4 bar as the bf16x3 test above, plus a ragged crop
+    (rays not a multiple of anything, T not a multiple of 32) and agreement with the composed bf16x3 path."""
+    import math
+    import oracle as O
+    from oracle.procedural import proc_param
+    from nerf_atlas_amd import config, ops
+    from nerf_atlas_amd.utils import CylinderGaussian, ConicGaussian
+    size = 800
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]])
+    try:
+        for T, crop in ((128, (380, 390, 40, 40)), (45, (3, 700, 7, 5))):
+            mip = CylinderGaussian() if kind == "cylinder" else ConicGaussian()
+            m = na.nerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted", mip=mip).cuda().eval()
+            params = {}
+            for k, v in m.state_dict().items():
+                if k.endswith("primes") or v.numel() == 0:
+                    continue
+                params[k] = torch.from_numpy(proc_param(k, tuple(v.shape)))
+            load_params(m, params, strict=False)
+            rays = O.nerf_camera_rays(O.pixel_grid(size, crop), c2w, focal, size)
+            config.set_precision("bf16x3")
+            assert not m._fusable_mip(rays.cuda())
+            out3 = m(rays.cuda())
+            config.set_precision("f16x")
+            assert m._fusable_mip(rays.cuda())
+            calls = []
+            real = ops.render_plain_mip_ls
+            ops.render_plain_mip_ls = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            try:
+                out = m(rays.cuda())
+            finally:
+                ops.render_plain_mip_ls = real
+            assert calls == [1]
+            aux = {}
+            ref = O.plain_nerf(params, rays, 2.0, 6.0, T, "view", act="upshifted", mip=kind, aux=aux)
+            e, e3 = maxdiff(out, ref), maxdiff(out3, ref)
+            print(f"mip {kind} T={T} crop={crop}: f16x {e:.2e}  bf16x3 {e3:.2e}")
+            assert e <= 1e-4, (kind, T, e)
+            assert maxdiff(m.alpha, aux["alpha"]) <= 1e-4 and maxdiff(m.weights, aux["weights"]) <= 1e-4
+    finally:
+        config.set_precision("bf16x3")
+
+
 def test_bezier_keyframes_and_intersect_mask(na):
     """N3 tail (runner.py:1019-1039, src/nerf.py:1305-1319): one frame per Bezier control point, against the oracle's
     from_pts on pts + p_k * rigidity; N4 tail: SDF.intersect_mask (src/sdf.py:123-135) against the oracle's marching."""
