@@ -143,7 +143,8 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
                       f"torch-CPU fp32 oracle on {best} threads"}, out, rays
 
 
-KERNELS_F16X = {"4": "deformation MLP bf16x3 + canonical model f16x",
+KERNELS_F16X = {"3": "ONE f16x launch of the layer-synchronous engine (MODEL 6: IPE groups generated in the kernel for the four Linears that take them)",
+                "4": "deformation MLP bf16x3 + canonical model f16x",
                 "5m": "SDF MLP: ONE f16x launch of the layer-synchronous engine (Fourier features generated in the kernel) + View half f16x"}
 OTHER_SLAB = (300, 0, 200, SIZE)   # rows 300..499 of the 800-wide frame: 160 000 rays x 128 = 20.48 M samples
 
@@ -182,13 +183,12 @@ def train_step(dev, crop=64, steps_per_ray=64, iters=10):
             "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
 
 
-def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
+def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2, only=None):
     """BASELINE configs 1, 3, 4 and 5 (both SDF networks) through the model layer on a fixed 200 x 800 x 128 slab: whole
     forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
     calls per (config, precision).  FLOP/sample = sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same
     numbers); `frac` is against the dense bf16 MFMA peak for every precision.  "f16x" rows: the one-kernel renderers run f16x, the
-    generic fused MLP launches of a config (mip: both MLPs; D-NeRF: the deformation network unless the opt-in LS kernel is on)
-    stay in bf16x3 -- `kernels` says which."""
+    generic fused MLP launches of a config (D-NeRF: the deformation network unless the opt-in LS kernel is on) stay in bf16x3 -- `kernels` says which."""
     import types
     import nerf_atlas_amd.nerf as nerf
     import nerf_atlas_amd.refl as refl
@@ -217,6 +217,8 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
     keep = config.precision
     t_all = time.perf_counter()
     for name, cons, flop, dyn in models:
+        if only is not None and name.split()[0] not in only:
+            continue
         torch.manual_seed(2)
         try:
             m = cons().to(dev).eval()
@@ -228,8 +230,6 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2):
         if name.split()[0] == "4" and "f16x" in plist:
             plist.insert(plist.index("f16x") + 1, "f16x+ls-deformation")  # the deformation network on the LS engine too (opt-in)
         for prec in plist:
-            if prec == "f16x" and name.split()[0] == "3":
-                continue  # (config 3 has no one-kernel renderer: its f16x row would be the bf16x3 row)
             lsdef = prec == "f16x+ls-deformation"
             try:
                 config.set_precision("f16x" if lsdef else prec)

@@ -37,6 +37,9 @@
 #endif
 // NA_LS_TRACE: waves 0 and 4 of workgroup 0 stamp s_memtime before and after every barrier of their second pass
 // (tools/ls_trace.py).  Timing experiments only.
+#ifndef NA_LS_MIP_ABLATE
+#define NA_LS_MIP_ABLATE 0  // experiments (tools/ls_variant.py): 1 = MODEL 6 without its IPE generation (wrong output, timing only)
+#endif
 #ifndef NA_LS_TRACE
 #define NA_LS_TRACE 0
 #endif
@@ -1265,7 +1268,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
   };
   auto gen_ipe = [&](auto act_tag) {
-    if constexpr (MIP && PREC == NA_PREC_F16X) {
+    if constexpr (MIP && PREC == NA_PREC_F16X && !(NA_LS_MIP_ABLATE & 1)) {
       constexpr int ACT = decltype(act_tag)::value;
       const int g = rg & 1, b = rg >> 1;  // this wave's unit (NB = 2)
       float ry[6], rad = 0.f;
@@ -1283,34 +1286,44 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const float t0 = a.ts[tc];
       const float t1 = tc < a.T - 1 ? a.ts[tc + 1] : mip_last_edge(a.ts, a.T, a.mip_t_end);
       const MipGauss gs = mip_gaussian(ry, rad, t0, t1, a.mip_kind);
+      // mip_feature's arithmetic (common.h) with the powers of two pulled out of the products -- bit-identical: scaling by
+      // 2^deg commutes with every rounding here.  Per axis: the revolution count of the mean at degree 0 as a (rounded product,
+      // recovered error) pair and the damping exponent; per (degree, axis) pair four v_ldexp, one reduction, two v_sin, one v_exp.
+      float mm[3] = {gs.m0, gs.m1, gs.m2}, pr0[3], er0[3], ck[3];
+      const float cc[3] = {gs.c0, gs.c1, gs.c2};
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        pr0[ax] = mm[ax] * 0.15915494309189535f;
+        er0[ax] = fmaf(mm[ax], 0.15915494309189535f, -pr0[ax]) + mm[ax] * 6.4206383e-9f;
+        ck[ax] = cc[ax] * -0.7213475204444817f;
+      }
+      int min_deg = a.mip_min_deg;
+      asm volatile("" : "+s"(min_deg));  // (not loop-invariant for the optimiser: 90 hoisted per-pair constants were spilled)
       f32x16 n0, n1;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { n0[e] = 0.f; n1[e] = 0.f; }
-      const int nd = a.mip_nd, nj = g == 0 ? 16 : 8;
+      auto pairs = [&](auto g_tag) {
+        constexpr int G = decltype(g_tag)::value;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (j < nj) {
-          const int pidx = g == 0 ? 16 * hi + j : 32 + 8 * hi + j;
-          const bool ok = pidx < 3 * nd;
-          const int k = (pidx * 43) >> 7, ax = pidx - 3 * k;  // pidx / 3 for pidx < 128
-          const float m = ax == 0 ? gs.m0 : (ax == 1 ? gs.m1 : gs.m2);
-          const float c = ax == 0 ? gs.c0 : (ax == 1 ? gs.c1 : gs.c2);
-          const int deg = a.mip_min_deg + k;
-          // mip_feature's angle (common.h): revolutions of y = m 2^deg with the product's rounding error recovered; the cosine
-          // half is sin(fl(y + pi/2)): the rounded sum differs from y by an exactly representable delta
-          const float chi = ldexpf(0.15915494309189535f, deg), clo = ldexpf(6.4206383e-9f, deg);
-          const float pr = m * chi;
-          const float er = fmaf(m, chi, -pr) + m * clo;
-          const float rev = (pr - rintf(pr)) + er;
+        for (int j = 0; j < (G == 0 ? 16 : 8); ++j) {
+          // pair index of lane half 0 | 1 (compile-time: no per-lane division, one select per operand)
+          const int pl = G == 0 ? j : 32 + j, ph = G == 0 ? 16 + j : 40 + j;
+          const int kl = pl / 3, al = pl - 3 * kl, kh = ph / 3, ah = ph - 3 * kh;
+          const float m = hi ? mm[ah] : mm[al], p0 = hi ? pr0[ah] : pr0[al], e0 = hi ? er0[ah] : er0[al];
+          const float cK = hi ? ck[ah] : ck[al];
+          const int deg = min_deg + (hi ? kh : kl);
+          const float pr = ldexpf(p0, deg);
+          const float rev = (pr - rintf(pr)) + ldexpf(e0, deg);
           const float y = ldexpf(m, deg);
-          const float yc = y + 1.5707963267948966f;
-          const float delta = yc - y;
-          const float damp = __builtin_amdgcn_exp2f(c * ldexpf(-0.7213475204444817f, 2 * deg));
-          const float sn = ok ? damp * __builtin_amdgcn_sinf(rev) : 0.f;
-          const float cs = ok ? damp * __builtin_amdgcn_sinf(rev + delta * 0.15915494309189535f) : 0.f;
+          const float yc = y + 1.5707963267948966f;  // the cosine half is sin(fl(y + pi/2)): the rounded sum differs from y by an
+          const float delta = yc - y;                // exactly representable delta
+          const float damp = __builtin_amdgcn_exp2f(ldexpf(cK, 2 * deg));
+          const float sn = damp * __builtin_amdgcn_sinf(rev);
+          const float cs = damp * __builtin_amdgcn_sinf(fmaf(delta, 0.15915494309189535f, rev));
           if (j < 8) { n0[2 * j] = sn; n0[2 * j + 1] = cs; } else { n1[2 * (j - 8)] = sn; n1[2 * (j - 8) + 1] = cs; }
         }
-      }
+      };
+      if (g == 0) pairs(std::integral_constant<int, 0>{}); else pairs(std::integral_constant<int, 1>{});
       x::store_block<ACT>(hb + (2 * b + g) * x::KQ, n0, n1, lane, a.sat_gen);
     }
   };
