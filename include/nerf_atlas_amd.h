@@ -461,6 +461,19 @@ int na_mlp_fourier_ls_pack(int precision, const float* const* weights, const flo
 int na_mlp_fourier_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* basis,
                       const void* packed, int precision, float* y, int64_t y_ld, void* stream);
 
+/* Coarse -> fine rendering (BASELINE config 2 "64 + 128"; the reference's sample_pdf, src/nerf.py:1745-1779 with its call site
+ * :572-578, is dead code -- INTENDED reading, pinned against an fp64 restatement only: see csrc/basic_ops.hip).
+ * na_resample_ts: ts [T] shared coarse steps, weights [T,R] of the coarse pass (rows 0..T-2 are used: weights[:-1]),
+ * u NULL (linspace(0,1,N), the reference's `uniform`) or [N,R] draws in [0,1); fine [R,N] (nullable) = the N inverse-cdf
+ * positions per ray; merged [R,T+N] (nullable) = coarse and new positions of a ray in increasing order (stable).
+ * na_render_plain_view_ls_rayts: na_render_plain_view_ls with per-ray steps ts_ray [R,T] (e.g. `merged`).              */
+size_t na_resample_ts_lds_bytes(int T, int N, int with_u);
+int na_resample_ts(const float* ts, const float* weights, int64_t R, int T, const float* u, int N, float* fine, float* merged,
+                   void* stream);
+int na_render_plain_view_ls_rayts(const float* rays, int64_t R, const float* ts_ray, int T, const float* hash_tables,
+                                  const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
+                                  float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* PlainNeRF(view) with mip's integrated positional encoding (config 3: src/nerf.py:256-261 hook, :326-361 forward,
  * src/utils.py:23-27, 60-140 cylinder / conic Gaussians) as ONE launch of the layer-synchronous engine, NA_PREC_F16X only.
  * rays [B,H,W,6] of whole crops (pixel radii difference neighbouring rows: H >= 2); ts [T]; weights of `first`

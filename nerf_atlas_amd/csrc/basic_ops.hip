@@ -1,6 +1,7 @@
 // Memory-bound operators of the hot path (ray generation, sampling, encoders, compositing).
 // Built with -ffp-contract=off: every rounding matches the reference's separate fp32 ops unless a
 // fused multiply-add is written explicitly (torch's CPU linspace uses one).
+#include <atomic>
 #include "common.h"
 #include <math.h>
 #include <string.h>
@@ -551,6 +552,108 @@ __global__ void pos_linear_combine_kernel(const float* __restrict__ lin, const f
   }
 }
 
+
+// ---- coarse -> fine resampling (BASELINE config 2 "64 + 128").  The reference's sample_pdf (src/nerf.py:1745-1779, called at
+// :572-578 with (mids, weights[:-1], steps_fine)) is dead code: it prints, gathers bins with cdf indices (one too many for its
+// `mids`) and calls exit().  INTENDED reading, pinned only against an fp64 restatement (oracle.sample_pdf_intended): weight i of
+// the coarse pass is the mass of the interval [ts[i], ts[i + 1]] -- exactly how alpha_from_density defines it -- so the T - 1
+// weights weights[:-1] and the T bin edges `ts` (the call site's own "TODO see if ts works ok here?") give
+//     w' = w + 1e-5;  cdf = [0, cumsum(w' / sum w')]  (T entries);  u = linspace(0, 1, N) | rand(N, ...)
+//     inds = searchsorted(cdf, u, right=True);  below = max(inds - 1, 0);  above = min(inds, T - 1)
+//     denom = cdf[above] - cdf[below] (1 where < 1e-5);  sample = ts[below] + (u - cdf[below]) / denom * (ts[above] - ts[below])
+// and the fine pass evaluates the union of the coarse and the new positions in order (NeRF's z_vals = sort(cat(...))).
+// One workgroup = 64 consecutive rays (weight / u tiles read coalesced: lane = ray), then one wave per ray: cdf by a wave scan in
+// fp64, N binary searches in LDS, and a stable rank sort of the T + N positions (coarse before fine on ties), written as one
+// contiguous row per ray -- the layout the renderers take per-ray steps in.
+// (lanes of ONE wave exchange data through LDS: order the wave's own writes before its reads, for the compiler and the memory model)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void resample_ts_kernel(const float* __restrict__ ts, const float* __restrict__ w, int64_t R,
+                                                          int T, const float* __restrict__ u, int N, float* __restrict__ fine,
+                                                          float* __restrict__ merged) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t ray0 = (int64_t)blockIdx.x * 64;
+  const int M = T + N, Mp = (M + 3) & ~3;
+  float* wt = (float*)smem;                                  // [T - 1][64]
+  float* ut = wt + (size_t)(T - 1) * 64;                     // [N][64] (only with u)
+  char* pw = (char*)(ut + (u != nullptr ? (size_t)N * 64 : 0));
+  pw += (size_t)wave * ((size_t)T * 8 + (size_t)Mp * 4);
+  double* cdf = (double*)pw;                                 // [T]
+  float* vals = (float*)(pw + (size_t)T * 8);                // [T + N]: coarse steps, then the new ones
+  for (int i = tid; i < (T - 1) * 64; i += 256) {
+    const int64_t r = ray0 + (i & 63);
+    wt[i] = r < R ? w[(int64_t)(i >> 6) * R + r] : 0.f;
+  }
+  if (u != nullptr)
+    for (int i = tid; i < N * 64; i += 256) {
+      const int64_t r = ray0 + (i & 63);
+      ut[i] = r < R ? u[(int64_t)(i >> 6) * R + r] : 0.f;
+    }
+  __syncthreads();
+  for (int q = 0; q < 16; ++q) {
+    const int rl = wave * 16 + q;
+    const int64_t ray = ray0 + rl;
+    if (ray >= R) break;  // (wave-uniform)
+    // ---- cdf: inclusive scan of w' over the T - 1 intervals, 64 at a time
+    double total = 0.0;
+    for (int i0 = 0; i0 < T - 1; i0 += 64) {
+      const int i = i0 + lane;
+      double v = i < T - 1 ? (double)wt[i * 64 + rl] + 1e-5 : 0.0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+      }
+      if (i < T - 1) cdf[i + 1] = total + v;
+      total += __shfl(v, 63, 64);
+    }
+    if (lane == 0) cdf[0] = 0.0;
+    for (int i = lane; i < T; i += 64) vals[i] = ts[i];
+    wave_sync();
+    for (int i = 1 + lane; i < T; i += 64) cdf[i] = cdf[i] / total;
+    wave_sync();
+    // ---- N inverse-cdf samples
+    const float step = 1.0f / (float)(N > 1 ? N - 1 : 1);
+    for (int j = lane; j < N; j += 64) {
+      float uf;
+      if (u != nullptr) uf = ut[j * 64 + rl];
+      else uf = j < N / 2 ? step * (float)j : 1.0f - step * (float)(N - 1 - j);  // torch.linspace(0, 1, N) in fp32
+      const double uj = (double)uf;
+      int lo = 0, hi = T;  // first index with cdf > u
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+      }
+      const int below = lo - 1 > 0 ? lo - 1 : 0, above = lo < T - 1 ? lo : T - 1;
+      double den = cdf[above] - cdf[below];
+      if (den < 1e-5) den = 1.0;
+      const double tt = (uj - cdf[below]) / den;
+      const double b0 = (double)vals[below], b1 = (double)vals[above];
+      const float sj = (float)(b0 + tt * (b1 - b0));
+      vals[T + j] = sj;
+      if (fine != nullptr) fine[ray * N + j] = sj;
+    }
+    wave_sync();
+    // ---- stable rank sort of the T + N positions
+    if (merged != nullptr) {
+      for (int i = lane; i < M; i += 64) {
+        const float v = vals[i];
+        int rank = 0;
+        for (int k = 0; k < M; ++k) {
+          const float o = vals[k];
+          rank += (o < v || (o == v && k < i)) ? 1 : 0;
+        }
+        merged[ray * M + rank] = v;
+      }
+    }
+    wave_sync();
+  }
+}
+
 }  // namespace na
 
 // ================================================================================================ C ABI
@@ -783,6 +886,32 @@ int na_pos_linear_combine(const float* lin, const float* pos, int64_t pos_ld, in
   hipLaunchKernelGGL(pos_linear_combine_kernel, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, lin,
                      pos, pos_ld, N, C, out);
   return check_launch("na_pos_linear_combine");
+}
+
+size_t na_resample_ts_lds_bytes(int T, int N, int with_u) {
+  if (T < 2 || N < 1) return 0;
+  return (size_t)(T - 1) * 256 + (with_u ? (size_t)N * 256 : 0) + 4 * ((size_t)T * 8 + (size_t)((T + N + 3) & ~3) * 4);
+}
+
+int na_resample_ts(const float* ts, const float* weights, int64_t R, int T, const float* u, int N, float* fine, float* merged,
+                   void* stream) {
+  NA_REQUIRE(T >= 2 && N >= 1 && R >= 0, NA_EINVAL, "na_resample_ts: bad shape T=%d N=%d R=%lld", T, N, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(ts && weights && (fine || merged), NA_ENULL, "na_resample_ts: null pointer");
+  const size_t lds = na_resample_ts_lds_bytes(T, N, u != nullptr);
+  NA_REQUIRE(lds <= 160 * 1024, NA_EUNSUPPORTED, "na_resample_ts: T=%d, N=%d need %zu bytes of LDS (160 KiB per workgroup)", T, N, lds);
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  NA_REQUIRE(hipGetDevice(&dev) == hipSuccess, NA_EHIP, "na_resample_ts: hipGetDevice failed");
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)resample_ts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    NA_REQUIRE(e == hipSuccess, NA_EHIP, "na_resample_ts: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(resample_ts_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), lds, (hipStream_t)stream, ts, weights, R, T, u,
+                     N, fine, merged);
+  return check_launch("na_resample_ts");
 }
 
 }  // extern "C"

@@ -155,7 +155,8 @@ inline size_t packed_bytes(int precision, int pairs = kPairsPerPass) {
 
 struct Args {
   const float* rays;     // [R,6]
-  const float* ts;       // [T]
+  const float* ts;       // [T], or per-ray steps [R, ts_stride] (ts_stride = T: the fine pass of coarse -> fine rendering)
+  int64_t ts_stride = 0; // 0: every ray marches the same steps
   const float* pts;      // nullable [T,R,3]
   const float4* tables;  // [8,65536]
   const char* packed;    // LS stream (na_render_ls_pack)
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const float* p = a.pts + ((int64_t)tc * a.R + geo_ray[b]) * 3;
       r.x = p[0]; r.y = p[1]; r.z = p[2];
     } else {
-      r.x = a.ts[tc]; r.y = r.z = 0.f;
+      r.x = a.ts[(int64_t)geo_ray[b] * a.ts_stride + tc]; r.y = r.z = 0.f;
     }
     return r;
   };
@@ -1025,8 +1026,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     const int t = L.tb * 32 + ln;
     const int tc = t < a.T ? t : a.T - 1;
     TsPair r;
-    r.t0 = a.ts[tc];
-    r.t1 = a.ts[tc < a.T - 1 ? tc + 1 : tc];
+    const float* tsr = a.ts + (int64_t)L.ray * a.ts_stride;
+    r.t0 = tsr[tc];
+    r.t1 = tsr[tc < a.T - 1 ? tc + 1 : tc];
     return r;
   };
   auto geom = [&](int pass, int b, const TsPair& tp) {
@@ -3213,10 +3215,10 @@ extern "C" size_t na_render_ls_workspace_bytes(int T, int64_t R) {
   return (size_t)R * 2 * sizeof(float) + 256 + (NA_LS_TRACE ? 4096 + 256 : 0);
 }
 
-extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T,
-                                       const float* hash_tables, const void* packed, int precision, int sigmoid_kind,
-                                       int bg_kind, float* alpha, float* weights, float* out, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+static int render_plain_view_ls_impl(const float* rays, const float* pts, int64_t R, const float* ts, int64_t ts_stride, int T,
+                                     const float* hash_tables, const void* packed, int precision, int sigmoid_kind,
+                                     int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;  // empty batch: a no-op before any pointer check (zero-size tensors carry null pointers)
   NA_REQUIRE(rays && ts && hash_tables && packed && out && workspace, NA_ENULL, "na_render_plain_view_ls: null pointer");
@@ -3229,7 +3231,7 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
              "na_render_plain_view_ls: workspace %zu < %zu bytes", workspace_bytes, na_render_ls_workspace_bytes(T, R));
   if (R == 0) return NA_OK;
   ls::Args a;
-  a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
+  a.rays = rays; a.ts = ts; a.ts_stride = ts_stride; a.pts = pts; a.tables = (const float4*)hash_tables;
   a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
   a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes(precision);
   a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
@@ -3244,6 +3246,23 @@ extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int6
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 0);
   if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 0);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 0);
+}
+
+extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                                       const float* hash_tables, const void* packed, int precision, int sigmoid_kind,
+                                       int bg_kind, float* alpha, float* weights, float* out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  return render_plain_view_ls_impl(rays, pts, R, ts, 0, T, hash_tables, packed, precision, sigmoid_kind, bg_kind, alpha, weights, out,
+                                   workspace, workspace_bytes, stream);
+}
+
+// The same launch with PER-RAY steps ts_ray[R,T] (row r = the increasing sample distances of ray r): the fine pass of coarse ->
+// fine rendering, whose steps come from na_resample_ts.  Positions are o + t d, interval lengths t[i + 1] - t[i] of the ray's own row.
+extern "C" int na_render_plain_view_ls_rayts(const float* rays, int64_t R, const float* ts_ray, int T, const float* hash_tables,
+                                             const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
+                                             float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  return render_plain_view_ls_impl(rays, nullptr, R, ts_ray, T, T, hash_tables, packed, precision, sigmoid_kind, bg_kind, alpha, weights,
+                                   out, workspace, workspace_bytes, stream);
 }
 
 // ---- PlainNeRF(view) + mip (config 3; src/nerf.py:256-261, 326-361, src/utils.py:23-140) as ONE launch, NA_PREC_F16X only:

@@ -276,6 +276,25 @@ class PlainNeRF(CommonNeRF):
                                                    rand=rand)
         return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
 
+    def forward_coarse_fine(self, rays, steps_fine: int, u=None, want_weights: bool = True):
+        """Coarse -> fine rendering (BASELINE config 2 "64 + 128"; INTENDED reading of the reference's dead sample_pdf /
+        CoarseFineNeRF, src/nerf.py:548-580, 1745-1779 -- see csrc/basic_ops.hip resample_ts_kernel): a coarse pass over
+        `self.steps` shared steps, inverse-cdf resampling of `steps_fine` new positions per ray from its weights (u: None =
+        linspace, or [steps_fine, *rays.shape[:-1]] draws), and a fine pass over the union in order -- three launches of the
+        layer-synchronous engine's kernels, one network for both passes like the reference's class.  Inference only."""
+        if not (self._fusable() and config.engine == "ls"):
+            raise NotImplementedError("coarse -> fine rendering runs on the fused layer-synchronous renderer (eval mode, View head)")
+        rays = rays.contiguous()
+        _, _, ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
+        prec = config.kernel_precision(has_f16x=True)
+        tables, packed = self.first.enc.tables(), self.packed_ls(prec)
+        coarse, _, w = ops.render_plain_view_ls(rays, ts, tables, packed, prec, self.sigmoid_kind, self._kernel_bg(), True)
+        self.coarse = coarse
+        self.ts = ops.resample_ts(ts, w, steps_fine, u)
+        out, self.alpha, self.weights = ops.render_plain_view_ls_rayts(rays, self.ts, tables, packed, prec, self.sigmoid_kind,
+                                                                       self._kernel_bg(), want_weights or self.bg == "random")
+        return self._finish_sky(out)
+
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
         if self._fusable(refl_latent) and not ag.needs_grad(pts):

@@ -723,6 +723,49 @@ def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torc
     return out, alpha, weights
 
 
+def resample_ts(ts: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Optional[torch.Tensor] = None, want_fine: bool = False):
+    """Inverse-cdf resampling of a coarse pass (na_resample_ts): ts [T], weights [T, *batch] -> merged [*batch, T + n_fine] (the
+    coarse and the new positions of every ray in increasing order) and, with want_fine, fine [*batch, n_fine].  u: None
+    (linspace(0, 1, n_fine)) or [n_fine, *batch] draws."""
+    lib = _lib.load()
+    ts, weights = _f32(ts, "ts"), _f32(weights, "weights")
+    T = ts.shape[0]
+    assert weights.shape[0] == T, (weights.shape, T)
+    batch = tuple(weights.shape[1:])
+    R = weights.numel() // T
+    if u is not None:
+        u = _f32(u, "u")
+        assert tuple(u.shape) == (n_fine,) + batch, (u.shape, n_fine, batch)
+    merged = torch.empty(batch + (T + n_fine,), device=ts.device, dtype=torch.float32)
+    fine = torch.empty(batch + (n_fine,), device=ts.device, dtype=torch.float32) if want_fine else None
+    check(lib.na_resample_ts(_ptr(ts), _ptr(weights), R, T, _ptr(u), n_fine, _ptr(fine), _ptr(merged), _stream()))
+    return (merged, fine) if want_fine else merged
+
+
+def render_plain_view_ls_rayts(rays: torch.Tensor, ts_ray: torch.Tensor, hash_tables: torch.Tensor, packed: torch.Tensor,
+                               precision: str, sigmoid_kind: str = "thin", bg: str = "black", want_weights: bool = False,
+                               workspace: Optional[torch.Tensor] = None):
+    """render_plain_view_ls with per-ray steps ts_ray [*batch, T] (increasing along T)."""
+    lib = _lib.load()
+    rays, ts_ray, hash_tables = _f32(rays, "rays"), _f32(ts_ray, "ts_ray"), _f32(hash_tables, "hash_tables")
+    R = rays.numel() // 6
+    T = ts_ray.shape[-1]
+    assert ts_ray.numel() == R * T, (ts_ray.shape, R)
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    nbytes = int(lib.na_render_ls_workspace_bytes(T, R))
+    if workspace is None:
+        workspace = torch.empty(nbytes, device=rays.device, dtype=torch.uint8)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    check(lib.na_render_plain_view_ls_rayts(_ptr(rays), R, _ptr(ts_ray), T, _ptr(hash_tables), _ptr(packed), PREC[precision],
+                                            SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace),
+                                            workspace.numel(), _stream()))
+    return out, alpha, weights
+
+
 def render_plain_mip_ls_pack(precision: str, first_wb, view_wb) -> torch.Tensor:
     """PlainNeRF.first and View.mlp of a mip model (96 IPE latent columns in both) as one weight stream of the
     layer-synchronous renderer (na_render_plain_mip_ls_pack; f16x only)."""

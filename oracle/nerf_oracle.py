@@ -26,6 +26,7 @@ __all__ = [
     "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
     "point_light", "intersect_mask", "occlusion", "div_approx", "dnerf_rigid_dp", "ffjord_div",
     "sky_random", "depth_to_normals", "depth_vis", "flow_vis", "rigidity_vis",
+    "sample_pdf_intended", "merge_ts_intended", "plain_nerf_rayts",
 ]
 
 # ----------------------------------------------------------------------------- A1 pixels
@@ -509,6 +510,65 @@ def plain_nerf(params, rays, near, far, steps, refl_kind="view", act="thin", bg=
     pts = compute_pts(r_o, r_d, ts)
     mip_latent = None if mip is None else mip_latent_intended(r_o, r_d, ts, mip, end=(2 * ts[-1] - ts[-2]).item())
     return plain_nerf_from_pts(params, pts, ts, r_o, r_d, refl_kind, act, bg, mip_latent, aux=aux)
+
+
+# ----------------------------------------------------------------------------- coarse -> fine (parity unpinned: intended reading)
+def sample_pdf_intended(ts, weights, N: int, u=None):
+    """The reference's sample_pdf (src/nerf.py:1745-1779; call site :572-578 passes (mids, weights[:-1], steps_fine)) cannot run:
+    it gathers its bins with cdf indices (T entries against T - 1 mids) and calls exit().  INTENDED reading, in fp64: weight i of
+    weights[:-1] is the mass of [ts[i], ts[i + 1]] (alpha_from_density's own definition), the bins are `ts`.  PARITY UNPINNED --
+    there is no reference output to pin this against; csrc/basic_ops.hip `resample_ts_kernel` restates the same arithmetic.
+    ts [T]; weights [T, *batch] (the last row is dropped here); u None (linspace(0, 1, N), fp32 like the reference) or
+    [N, *batch].  Returns float64 [N, *batch]."""
+    w = weights[:-1].double() + 1e-5
+    pdf = w / w.sum(dim=0, keepdim=True)
+    cdf = torch.cumsum(pdf, dim=0)
+    cdf = torch.cat([torch.zeros_like(cdf[:1]), cdf], dim=0)                       # [T, *batch]
+    T = cdf.shape[0]
+    batch = cdf.shape[1:]
+    if u is None:
+        u = torch.linspace(0, 1, steps=N, dtype=torch.float).reshape((N,) + (1,) * len(batch)).expand((N,) + tuple(batch))
+    u = u.double().contiguous()
+    c2 = cdf.reshape(T, -1).t().contiguous()                                        # [rays, T]
+    u2 = u.reshape(N, -1).t().contiguous()                                          # [rays, N]
+    inds = torch.searchsorted(c2, u2, right=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=T - 1)
+    c0, c1 = torch.gather(c2, 1, below), torch.gather(c2, 1, above)
+    tsd = ts.double()
+    b0, b1 = tsd[below], tsd[above]
+    denom = c1 - c0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u2 - c0) / denom
+    samples = b0 + t * (b1 - b0)
+    return samples.t().reshape((N,) + tuple(batch))
+
+
+def merge_ts_intended(ts, fine):
+    """z_vals of the fine pass: the coarse steps ts [T] and the new positions fine [N, *batch] of every ray in increasing order
+    (stable, coarse first) -> [T + N, *batch]."""
+    batch = fine.shape[1:]
+    allv = torch.cat([ts.reshape((-1,) + (1,) * len(batch)).expand((ts.shape[0],) + tuple(batch)).to(fine.dtype), fine], dim=0)
+    return torch.sort(allv, dim=0, stable=True).values
+
+
+def plain_nerf_rayts(params, rays, ts_ray, refl_kind="view", act="thin", bg="black", aux=None):
+    """PlainNeRF.from_pts with PER-RAY steps ts_ray [T, *batch] (the fine pass): positions o + t d, interval lengths along the
+    step axis (the reference's alpha_from_density differences ts along its LAST axis: shared steps only), last interval 1e10."""
+    r_o, r_d = rays.split([3, 3], dim=-1)
+    pts = r_o.unsqueeze(0) + ts_ray.unsqueeze(-1) * r_d.unsqueeze(0)
+    first_out = skip_mlp(params, "first.", pts, None, enc=_hash_enc_from(params, "first.enc."))
+    density, intermediate = first_out[..., 0], first_out[..., 1:]
+    view = r_d.unsqueeze(0).expand_as(pts)
+    rgb = _refl_dispatch(params, refl_kind, pts, view, intermediate, act)
+    sigma_a = F.softplus(density - 1)
+    dists = torch.cat([ts_ray[1:] - ts_ray[:-1], torch.full_like(ts_ray[:1], 1e10)], dim=0).clamp(min=1e-5)
+    dists = dists * torch.linalg.norm(r_d, dim=-1)
+    alpha = 1 - torch.exp(-sigma_a * dists)
+    weights = alpha * cumuprod_exclusive(1.0 - alpha + 1e-10)
+    if aux is not None:
+        aux.update(alpha=alpha, weights=weights)
+    return volumetric_integrate(weights, rgb) + _sky(bg, weights)
 
 
 def volsdf(params, rays, near, far, steps, sdf_kind="mlp", refl_kind="view", act="thin", aux=None):
