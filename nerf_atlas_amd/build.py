@@ -79,7 +79,7 @@ def _headers_digest() -> str:
 def _unit_digest(unit, headers: str) -> str:
     src, extra, suffix, isa = unit
     h = hashlib.sha256(headers.encode())
-    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v3"] if isa else [])).encode())
+    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v4"] if isa else [])).encode())
     with open(os.path.join(CSRC, src), "rb") as fh:
         h.update(fh.read())
     return h.hexdigest()
@@ -180,6 +180,120 @@ def check_cvt_overlap(listing: str):
     return bad, n_seen
 
 
+# transcendental VALU ops (the "trans" unit): v_exp / v_log / v_rcp / v_rcp_iflag / v_rsq / v_sqrt / v_sin / v_cos, any float type
+_TRANS = re.compile(r"^\s*(v_(?:exp|log|rcp|rcp_iflag|rsq|sqrt|sin|cos)(?:_legacy)?_(?:f16|f32|f64|bf16)(?:_e32|_e64|_sdwa|_dpp)?)\s+(.*)$")
+_VALU = re.compile(r"^\s*(v_\w+)\s+(.*)$")
+_VTOK = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def check_trans_use(listing: str):
+    """CDNA3 / CDNA4 need ONE wait state between a transcendental VALU op and a non-transcendental VALU op that reads its result
+    (the "trans forwarding hazard").  LLVM inserts it for the instructions it selects (GCNHazardRecognizer) but does not look at
+    the operands of INLINE ASSEMBLY: an `asm("v_fma_mix_f32 ...")`, `asm("v_max3_f32 ...")` or asm fp6 conversion scheduled
+    directly behind the op that produces its operand reads the register's OLD contents in 30-50 % of the lanes, depending on how
+    the SIMD's waves interleave (hardware probe tools/hw/trans_use_hazard.hip).  Round 4: x::store_block<NA_ACT_SIN> of
+    csrc/render_ls.hip (v_sin_f32 activations -> asm residual / fp6 conversions) made the mip renderer differ from run to run in
+    the last bit of a few pixels.  Every trans op in the listing (all functions) must therefore NOT be followed immediately by a
+    VALU instruction that names one of its destination registers (the destination itself counts: conservative).  Since the
+    compiler keeps this invariant for its own instructions, an offender is an inline-asm consumer.
+    Returns [(line number, trans text, next text)] and the number of trans ops scanned."""
+    bad, n_seen = [], 0
+    prev = None  # (line number, text, (d0, d1)) of a trans op whose next instruction has not been seen yet
+    with open(listing) as fh:
+        for n, line in enumerate(fh, 1):
+            t = line.split(";")[0].rstrip()
+            if not t.strip() or t.lstrip().startswith((".", "//")) or re.match(r"^[\w.$]+:", t):
+                continue  # blank, directive, label (a fall-through into a label keeps the adjacency)
+            if prev is not None:
+                m = _VALU.match(t)
+                if m and not _TRANS.match(t):
+                    d0, d1 = prev[2]
+                    for a, b, c in _VTOK.findall(m.group(2)):
+                        lo, hi = (int(a), int(b)) if a else (int(c), int(c))
+                        if not (hi < d0 or d1 < lo):
+                            bad.append((prev[0], prev[1], t.strip()))
+                            break
+                prev = None
+            m = _TRANS.match(t)
+            if m:
+                n_seen += 1
+                dst = _vrange(m.group(2).split(",")[0])
+                if dst is not None:
+                    prev = (n, t.strip(), dst)
+    return bad, n_seen
+
+
+_MFMA = re.compile(r"^\s*(v_mfma_\w+)\s+(.*)$")
+
+
+def _mfma_passes(mnemonic: str, text: str) -> int:
+    """passes of an MFMA as far as the hazard rules need them (LLVM GCNHazardRecognizer, gfx950): 8 for the 32x32x16 f16 / bf16
+    ops and for the f8f6f4 ops with both operands in a 6- or 4-bit format (cbsz, blgp >= 2), 4 for their 16x16 forms, 16 for
+    everything else (conservative)."""
+    small = "16x16" in mnemonic
+    if re.search(r"_(?:f16|bf16)(?:_e64)?$", mnemonic) and re.search(r"32x32x16|16x16x32", mnemonic):
+        return 4 if small else 8
+    if "f8f6f4" in mnemonic:
+        c, b = re.search(r"cbsz:(\d)", text), re.search(r"blgp:(\d)", text)
+        narrow = c is not None and b is not None and int(c.group(1)) >= 2 and int(b.group(1)) >= 2
+        return (4 if narrow else 8) if small else (8 if narrow else 16)
+    return 16
+
+
+def check_mfma_use(listing: str):
+    """The matrix core writes its result several passes after issue and the hardware does NOT interlock a VALU instruction that
+    reads it early: the compiler inserts s_nop for the instructions it selects (passes + 4 wait states measured in every listing
+    of this library: 12 for the 8-pass ops) but is blind to INLINE ASSEMBLY, and a non-volatile asm statement may be scheduled
+    across a barrier right behind the MFMA that produces its operand.  Round 4: the asm v_max3_f32 / v_fma_mix_f32 / fp6
+    conversions of x::store_block on the accumulators of first.out ran 3 wait states behind the last MFMA in one instance of the
+    mip renderer -> R / T planes built from a partly written accumulator, last-bit run-to-run differences in a few pixels
+    (tools/mip_det_probe.py; the same class as tools/hw/trans_use_hazard.hip).  Every non-MFMA VALU instruction that names a
+    register of an MFMA's destination must be at least passes + 4 wait states behind it (s_nop N counts N + 1, any other
+    instruction 1); a later MFMA that overwrites the destination ends the window.  Returns [(line, mfma, consumer, waits)], n."""
+    bad, n_seen = [], 0
+    live = []  # [line, text, d0, d1, need, waits]
+    with open(listing) as fh:
+        for n, line in enumerate(fh, 1):
+            t = line.split(";")[0].rstrip()
+            if not t.strip() or t.lstrip().startswith((".", "//")):
+                continue
+            if re.match(r"^[\w.$]+:", t):
+                if not t.startswith(".L"):
+                    live = []  # a new function
+                continue
+            tt = t.strip()
+            m = _MFMA.match(t)
+            mn = tt.split()[0]
+            inc = 1
+            if mn == "s_nop":
+                try:
+                    inc = int(tt.split()[1]) + 1
+                except (IndexError, ValueError):
+                    inc = 1
+            if m:
+                dst = _vrange(m.group(2).split(",")[0])
+                if dst is not None:
+                    live = [e for e in live if e[3] < dst[0] or dst[1] < e[2]]  # (accumulating into the same registers: SrcC rule)
+                for e in live:
+                    e[5] += 1
+                n_seen += 1
+                if dst is not None:
+                    live.append([n, tt, dst[0], dst[1], _mfma_passes(m.group(1), t) + 4, 0])
+                continue
+            if mn.startswith("v_") and live:
+                ops = tt.split(None, 1)[1] if " " in tt else ""
+                for a, b, c in _VTOK.findall(ops):
+                    lo, hi = (int(a), int(b)) if a else (int(c), int(c))
+                    for e in live:
+                        if not (hi < e[2] or e[3] < lo) and e[5] < e[4]:
+                            bad.append((e[0], e[1], f"line {n}: {tt}", e[5]))
+                            e[5] = 1 << 20  # report an MFMA once
+            for e in live:
+                e[5] += inc
+            live = [e for e in live if e[5] < 24]
+    return bad, n_seen
+
+
 def _compile(unit):
     src, extra, suffix, isa = unit
     obj = _obj_path(unit)
@@ -210,6 +324,16 @@ def _compile(unit):
             raise RuntimeError(f"{src}{suffix}: a multi-pass fp6 conversion whose destination overlaps its scale or the tail of a source "
                                f"({cbad[0][1]} at line {cbad[0][0]} of {lst}): the hardware then packs wrong values (tools/hw/cvt_fp6_overlap.hip). "
                                "Change the surrounding code until the register allocator separates them.")
+        tbad, _ = check_trans_use(lst)
+        if tbad:
+            raise RuntimeError(f"{src}{suffix}: a transcendental result is read by the very next VALU instruction (line {tbad[0][0]} of {lst}: "
+                               f"{tbad[0][1]} -> {tbad[0][2]}): an inline-asm consumer the hazard recogniser cannot see; the hardware "
+                               "then reads the register's old contents (tools/hw/trans_use_hazard.hip).  Fence the asm's operands.")
+        mbad, _ = check_mfma_use(lst)
+        if mbad:
+            raise RuntimeError(f"{src}{suffix}: an MFMA result is read {mbad[0][3]} wait states after issue (line {mbad[0][0]} of {lst}: "
+                               f"{mbad[0][1][:60]} ... -> {mbad[0][2]}): an inline-asm consumer the hazard recogniser cannot see; the "
+                               "hardware then reads a partly written accumulator (tools/hw/mfma_use_hazard.hip).  Fence the asm's operands.")
         bad, seen = check_isa(lst)
         if not seen:
             raise RuntimeError(f"{src}{suffix}: no function named *{ISA_KERNEL}* in {lst}: the ISA check looked at nothing")

@@ -747,6 +747,16 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
   f32x16 v0, v1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { v0[r] = act_apply<ACT, PREC>(a0[r]); v1[r] = act_apply<ACT, PREC>(a1[r]); }
+  // The inline-asm consumers below (v_max3_f32, v_fma_mix_f32, the fp6 conversions) are INVISIBLE to the compiler's hazard
+  // recogniser, and being non-volatile they may be scheduled across a barrier right behind the instruction that produces their
+  // operand.  Two hardware rules then go unprotected (probes tools/hw/mfma_use_hazard.hip, trans_use_hazard.hip): an MFMA result
+  // is only complete passes + 4 = 12 wait states after issue (ACT = NONE passes accumulators straight through), a transcendental
+  // result (v_sin_f32) one wait state after.  A volatile fence that owns the 32 values and spends those wait states makes the
+  // consumers safe by construction; build.check_mfma_use / check_trans_use verify every listing.  (Round 4: the latent group of
+  // the mip renderer read first.out's accumulators 3 wait states behind the MFMA: run-to-run last-bit differences.)
+  if constexpr (ACT == NA_ACT_NONE) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(v0), "+v"(v1));
+  else if constexpr (ACT == NA_ACT_SIN) asm volatile("s_nop 0" : "+v"(v0), "+v"(v1));
+  else asm volatile("" : "+v"(v0), "+v"(v1));
   uint32_t pk[16];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -807,7 +817,9 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
   }
 }
 // the latent rows (no activation in front of them: to_elem clamps them to the half range) are checked the same way
-__device__ __forceinline__ void latent_range(const f32x16& v, uint32_t sat_gen) {
+__device__ __forceinline__ void latent_range(const f32x16& v_in, uint32_t sat_gen) {
+  f32x16 v = v_in;
+  asm volatile("s_nop 7\n\ts_nop 3" : "+v"(v));  // (accumulators read by inline asm: see store_block)
   float m = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v[r]), "v"(v[r + 1]));

@@ -26,7 +26,7 @@ __all__ = [
     "HASH_PRIMES", "sphere_march", "throughput_with_sign_change", "bisection", "bisect",
     "point_light", "intersect_mask", "occlusion", "div_approx", "dnerf_rigid_dp", "ffjord_div",
     "sky_random", "depth_to_normals", "depth_vis", "flow_vis", "rigidity_vis",
-    "sample_pdf_intended", "merge_ts_intended", "plain_nerf_rayts",
+    "sample_pdf_intended", "merge_ts_intended", "plain_nerf_rayts", "linspace01_f32",
 ]
 
 # ----------------------------------------------------------------------------- A1 pixels
@@ -513,6 +513,19 @@ def plain_nerf(params, rays, near, far, steps, refl_kind="view", act="thin", bg=
 
 
 # ----------------------------------------------------------------------------- coarse -> fine (parity unpinned: intended reading)
+def linspace01_f32(N: int):
+    """torch.linspace(0, 1, N) as ATen's scalar CPU kernel evaluates it in fp32 -- step = 1 / (N - 1); the lower half counts up
+    from 0, the upper half down from 1 -- with every operation rounded separately (numpy float32; torch's vectorised kernels may
+    fuse the multiply-add, a last-bit difference that an almost empty interval of the cdf amplifies to 1e-4 of a step: the
+    deterministic draw is therefore DEFINED by this formula, here and in csrc/basic_ops.hip)."""
+    import numpy as np
+    step = np.float32(1.0) / np.float32(max(N - 1, 1))
+    j = np.arange(N)
+    lo = step * j.astype(np.float32)
+    hi = np.float32(1.0) - step * (N - 1 - j).astype(np.float32)
+    return torch.from_numpy(np.where(j < N // 2, lo, hi).astype(np.float32))
+
+
 def sample_pdf_intended(ts, weights, N: int, u=None):
     """The reference's sample_pdf (src/nerf.py:1745-1779; call site :572-578 passes (mids, weights[:-1], steps_fine)) cannot run:
     it gathers its bins with cdf indices (T entries against T - 1 mids) and calls exit().  INTENDED reading, in fp64: weight i of
@@ -527,7 +540,7 @@ def sample_pdf_intended(ts, weights, N: int, u=None):
     T = cdf.shape[0]
     batch = cdf.shape[1:]
     if u is None:
-        u = torch.linspace(0, 1, steps=N, dtype=torch.float).reshape((N,) + (1,) * len(batch)).expand((N,) + tuple(batch))
+        u = linspace01_f32(N).reshape((N,) + (1,) * len(batch)).expand((N,) + tuple(batch))
     u = u.double().contiguous()
     c2 = cdf.reshape(T, -1).t().contiguous()                                        # [rays, T]
     u2 = u.reshape(N, -1).t().contiguous()                                          # [rays, N]

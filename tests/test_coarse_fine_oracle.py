@@ -13,7 +13,7 @@ def _scalar_loop(ts, w, N, u=None):
     """the same reading, one ray at a time in Python floats (fp64)"""
     T, R = w.shape
     out = np.zeros((N, R))
-    uu = torch.linspace(0, 1, N, dtype=torch.float).double().numpy() if u is None else None
+    uu = O.linspace01_f32(N).double().numpy() if u is None else None
     for r in range(R):
         wp = [float(w[i, r]) + 1e-5 for i in range(T - 1)]
         s = sum(wp)
@@ -43,6 +43,12 @@ def test_sample_pdf_intended_matches_a_scalar_loop():
         got = O.sample_pdf_intended(ts, w, 11, u).numpy()
         ref = _scalar_loop(ts.numpy(), w.numpy(), 11, None if u is None else u.numpy())
         assert np.abs(got - ref).max() <= 1e-12
+
+
+def test_linspace01_is_torchs_linspace_to_the_last_bit_or_one():
+    for N in (2, 5, 64, 128, 200):
+        a, b = O.linspace01_f32(N), torch.linspace(0, 1, N, dtype=torch.float)
+        assert float((a - b).abs().max()) <= 6e-8 and float(a[0]) == 0.0 and float(a[-1]) == 1.0
 
 
 def test_sample_pdf_intended_properties():

@@ -60,3 +60,60 @@ def test_check_cvt_overlap_flags_the_cases_the_hardware_gets_wrong(tmp_path):
     bad, n = B.check_cvt_overlap(str(lst))
     assert n == 6
     assert [b[0] for b in bad] == [4, 5, 6], bad
+
+
+def test_built_units_keep_inline_asm_behind_mfma_and_trans_results():
+    """The compiler's hazard recogniser does not see the operands of inline assembly: an asm v_max3_f32 / v_fma_mix_f32 / fp6
+    conversion scheduled right behind the MFMA or the transcendental op that produces its operand reads stale registers
+    (tools/hw/mfma_use_hazard.hip, trans_use_hazard.hip; round 4: last-bit run-to-run differences of the mip renderer).  Every
+    listing of the shipped and of the lag-3 stress build is scanned at build time; here once more, with the counts."""
+    import glob
+    from nerf_atlas_amd import build as B
+    B.build(verbose=False)
+    paths = [p for _, p in B.isa_listings()] + glob.glob(os.path.join(B.OBJ, "*_lag3.isa", "*.s"))
+    assert len(paths) >= 8, paths
+    n_mfma = n_trans = 0
+    for path in paths:
+        bad, n = B.check_mfma_use(path)
+        assert not bad, (path, bad[:2])
+        n_mfma += n
+        bad, n = B.check_trans_use(path)
+        assert not bad, (path, bad[:2])
+        n_trans += n
+    assert n_mfma >= 20000 and n_trans >= 10000, (n_mfma, n_trans)
+
+
+def test_check_mfma_use_and_trans_use_flag_what_the_hardware_gets_wrong(tmp_path):
+    from nerf_atlas_amd import build as B
+    lst = tmp_path / "fake.s"
+    lst.write_text(
+        "_Z1av:\n"
+        "\tv_mfma_f32_32x32x16_f16 v[64:79], v[0:3], v[4:7], v[64:79]\n"
+        "\tv_mov_b32_e32 v1, v2\n"
+        "\ts_nop 7\n"
+        "\tv_max3_f32 v0, v0, |v79|, |v3|\n"                                    # 10 wait states behind an 8-pass MFMA: stale
+        "\tv_mfma_scale_f32_32x32x64_f8f6f4 v[96:111], v[0:5], v[8:13], v[96:111], v20, v21 op_sel:[1,0,0] cbsz:2 blgp:2\n"
+        "\ts_nop 7\n"
+        "\ts_nop 3\n"
+        "\tv_fma_mix_f32 v5, v96, 1.0, -v6 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"   # 12: fine
+        "\tv_mfma_f32_32x32x16_f16 v[112:127], v[0:3], v[4:7], v[112:127]\n"
+        "\tv_mfma_f32_32x32x16_f16 v[112:127], v[0:3], v[4:7], v[112:127]\n"     # accumulation: SrcC, not this rule
+        "\ts_nop 1\n"
+        "\tv_add_f32_e32 v9, v8, v8\n"                                           # does not touch the accumulator
+        "\tv_mul_f32_e32 v9, v113, v8\n"                                         # 3 wait states: stale
+        ".Lfunc_end0:\n")
+    bad, n = B.check_mfma_use(str(lst))
+    assert n == 4 and [b[0] for b in bad] == [2, 11] and bad[0][3] == 9 and bad[1][3] == 3, bad
+    lst.write_text(
+        "\tv_sin_f32_e32 v5, v1\n"
+        "\tv_fma_mix_f32 v7, v5, 1.0, -v6 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"   # next instruction reads the result: stale
+        "\tv_exp_f32_e32 v8, v1\n"
+        "\ts_nop 0\n"
+        "\tv_max3_f32 v0, v0, |v8|, |v3|\n"                                      # one wait state: fine
+        "\tv_rcp_f32_e32 v9, v1\n"
+        "\tv_sin_f32_e32 v10, v9\n"                                              # trans -> trans: not this rule
+        "\tv_exp_f32_e32 v11, v1\n"
+        "\tv_mul_f32_e32 v12, v2, v3\n"
+        "\tv_mul_f32_e32 v13, v11, v3\n")                                        # second instruction behind: fine
+    bad, n = B.check_trans_use(str(lst))
+    assert n == 5 and [b[0] for b in bad] == [1], bad
