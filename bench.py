@@ -183,6 +183,38 @@ def train_step(dev, crop=64, steps_per_ray=64, iters=10):
             "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
 
 
+def coarse_fine(dev, rays, coarse=64, fine=128, iters=3):
+    """BASELINE config 2 as it is named ("64 + 128"): a coarse pass of 64 shared steps, inverse-cdf resampling of 128 new positions
+    per ray from its weights (na_resample_ts; the intended reading of the reference's dead sample_pdf), and a fine pass over
+    the 192 per-ray steps -- three launches, one network, f16x.  `Msamples_s` counts the 64 + 192 network evaluations per ray."""
+    import nerf_atlas_amd.nerf as nerf
+    from nerf_atlas_amd import config
+    torch.manual_seed(2)
+    m = nerf.PlainNeRF(steps=coarse, t_near=NEAR, t_far=FAR, intermediate_size=64, sigmoid_kind="upshifted", bg="black").to(dev).eval()
+    keep = config.precision
+    config.set_precision("f16x")
+    try:
+        with torch.no_grad():
+            m.forward_coarse_fine(rays, fine, want_weights=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                out = m.forward_coarse_fine(rays, fine, want_weights=False)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        R = rays.numel() // 6
+        n = R * (coarse + coarse + fine)
+        return {"workload": f"{SIZE}x{SIZE} frame: {coarse}-step pass (with weights) + resampling of {fine} positions per ray + "
+                            f"{coarse + fine}-step pass with per-ray steps", "dtype": "f16x", "ms_per_frame": round(ms, 3),
+                "evaluated_samples": n, "Msamples_s": round(n / ms / 1e3, 1), "finite": bool(torch.isfinite(out).all()),
+                "frac": round(n * FLOP_PER_SAMPLE / (ms * 1e-3) / PEAK_BF16, 4)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        config.set_precision(keep)
+
+
 def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2, only=None):
     """BASELINE configs 1, 3, 4 and 5 (both SDF networks) through the model layer on a fixed 200 x 800 x 128 slab: whole
     forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
@@ -469,6 +501,7 @@ def main():
         if world == 1 and not args.no_other_configs:
             res["other_configs"], res["other_configs_s"] = other_configs(dev)
             res["train_step"] = train_step(dev)
+            res["coarse_fine"] = coarse_fine(dev, ops.raygen(c2w, focal, SIZE, (0, 0, SIZE, SIZE)))
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, rays_cpu = cpu_baseline(model)
             res["cpu_baseline"] = cb
