@@ -127,8 +127,8 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // frequencies] -> 6 x 256, skip 3, out 65), rows to HBM.  The 256 Fourier features are K64 groups in the HIDDEN format, generated by
 // the row groups in a VALU phase wherever a Linear consumes them (init, L0, L3): init 4 | L0 4 + 4 | L1 | L2 | L3 4 + 4 | L4 | L5 |
 // out 4 = 40 records, and 3 pairs for the 3-wide position chunk
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 10 : model == 3 ? 13 : model == 4 ? 0 : model == 5 ? 3 : 2; }  // (6: 2)
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 20 : model == 3 ? 44 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : 44; }
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 2 : model == 3 ? 13 : model == 4 ? 0 : model == 5 ? 3 : 2; }  // (6: 2)
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 22 : model == 3 ? 44 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         f32x16 bv[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bv[t] = bias_tile(wrs, bias_rg + 0 * 1024, t, lane);
-        if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0, MODEL == 2 ? 2 : 1);
+        if constexpr (PREC == NA_PREC_F16X) x::pairs_prefetch(XR, wrs, xpair, lane, 0, 1);
         SYNC();
         if (prev >= 0) combine(prev);
         if constexpr (PREC == NA_PREC_F16X) {
@@ -1910,12 +1910,26 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           const float cdf = scaled <= 0.f ? fast_exp(fminf(scaled, 0.f)) * 0.5f : 1.f - fast_exp(-fmaxf(scaled, 0.f)) * 0.5f;
           density = (1.0f / sc) * cdf;
         }
+        if constexpr (PREC == NA_PREC_F16X) {
+          // the latent is ONE K64 group of the init region in the hidden format (f16 fragments | R | T), like the [hash | x] and
+          // latent groups of PlainNeRF: the lane (sample, k half hi) that loaded the 4 x 8 values of its slots converts them
+          f32x16 n0, n1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v8[8];
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v8[e] = lat[c][0][e]; v8[4 + e] = lat[c][1][e]; }
-          fwrite<PREC>(ib + (blk * 4 + c) * FR + lane * 16, make_frag<PREC>(v8));
+            for (int e = 0; e < 4; ++e) {
+              n0[8 * c + e] = lat[c][0][e]; n0[8 * c + 4 + e] = lat[c][1][e];
+              n1[8 * c + e] = lat[2 + c][0][e]; n1[8 * c + 4 + e] = lat[2 + c][1][e];
+            }
+          x::store_block<NA_ACT_NONE, 4>(ib + blk * x::KQ, n0, n1, lane, a.sat_gen);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = lat[c][0][e]; v8[4 + e] = lat[c][1][e]; }
+            fwrite<PREC>(ib + (blk * 4 + c) * FR + lane * 16, make_frag<PREC>(v8));
+          }
         }
       }
       geo_setup(pass);
@@ -1936,29 +1950,46 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         }
       }
       if constexpr (PREC == NA_PREC_F16X) {
-        // ---- NA_PREC_F16X: the View half (pairs 0..9, records 0..19)
+        // ---- NA_PREC_F16X: the View half -- records 0 view.init (the latent group) | 1 skip group + 2..5 (view.L0) | 6.. L1..L3 |
+        // 18..21 view.out; pairs 0, 1 = the 5-wide geometry chunk of init and skip layer
         {
           GeoRaw graw[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-          x::pairs<0, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                  // view.init: latent chunks + geometry
-          x::geo_pair<4, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
+          x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);      // view.init: latent group + geometry
+          x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
         }
         SYNC();
         {
           x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(1);
-          if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
-          x::pairs_prefetch(XR, wrs, xpair, lane, 5);
+          if (owner) {  // sin(latent) for the skip connection: the rows again (L2), through the activation, into the same group
+            const Loc L = locate(pass, blk);
+            const int t = L.tb * 32 + ln;
+            const float* row = a.feat + ((int64_t)(t < a.T ? t : a.T - 1) * a.R + L.ray) * a.feat_ld;
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            f32x16 n0, n1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const f32x4u p0 = *(const f32x4u*)(row + 1 + 16 * c + 4 * hi), p1 = *(const f32x4u*)(row + 1 + 16 * c + 8 + 4 * hi);
+              const f32x4u q0 = *(const f32x4u*)(row + 33 + 16 * c + 4 * hi), q1 = *(const f32x4u*)(row + 33 + 16 * c + 8 + 4 * hi);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                n0[8 * c + e] = p0[e]; n0[8 * c + 4 + e] = p1[e];
+                n1[8 * c + e] = q0[e]; n1[8 * c + 4 + e] = q1[e];
+              }
+            }
+            x::store_block<NA_ACT_SIN, 4>(ib + blk * x::KQ, n0, n1, lane, a.sat_gen);
+          }
+          XR.pr[0] = x::wpair(wrs, lane, xpair, 1);
         }
         SYNC();
         {
           GeoRaw graw[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-          x::pairs<5, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                // view.L0: skip chunks, K = 256, geometry
-          x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 0, hb, lane);
-          x::geo_pair<9, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+          x::recs<2, NB, true, XNR, 5, 1, 1, 4>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);      // view.L0: skip group, K = 256, geometry
+          x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
         }
         SYNC();
 #pragma unroll 1
@@ -1966,7 +1997,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(2 + i);
           SYNC();
-          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 4 + 4 * i, hb, lane);        // view.L1..L3
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 6 + 4 * i, hb, lane);        // view.L1..L3
           SYNC();
         }
         f32x16 ocx[1][1], bo1[1];
@@ -1975,7 +2006,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         }
         SYNC();
-        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 16, hb + blk * x::BLKH, lane);   // view.out (block per wave)
+        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 18, hb + blk * x::BLKH, lane);   // view.out (block per wave)
         oc[0] = ocx[0][0];
         SYNC();
         prev = pass;
@@ -3071,7 +3102,7 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
     const NaMlpDesc tiny = {3, NA_ENC_NONE, 0, 0, 6, 256, 4, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
     xs_add_mlp(sc, tiny, w0, b0, 8, 1, false, 2);
   } else if (model == 2) {
-    xs_add_mlp(sc, view, w0, b0, 6, 4, true, 2);
+    xs_add_mlp(sc, view, w0, b0, 6, 4, true, 2, true);
   } else if (model == 6) {
     // PlainNeRF(view) + mip.  Column layouts (src/neural_blocks.py:283-287: [p | enc(p) | latent]): first [p 3 | x 3 + hash 32 |
     // IPE 96] (134), skip layer [hidden 256 | the same]; View [x y z elev azim | IPE 96 | intermediate 64] (165)

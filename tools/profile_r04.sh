@@ -30,3 +30,9 @@ python tools/ls_trace.py run bf16x3 > $O/ls_trace_bf16x3.log 2>&1
 ls -la $O
 head -c 600 $O/bench_default.json
 bash tools/power_probe.sh f16x > $O/power_probe_f16x.log 2>&1
+# hardware probes behind the round's hazard finding + the reproducibility probe of the mip renderer
+for p in mfma_use_hazard trans_use_hazard pk_after_trans_mfma; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/hw/$p.hip -o /tmp/$p 2>/dev/null && /tmp/$p > $O/$p.log 2>&1
+done
+python tools/mip_det_probe.py 40 > $O/mip_det_probe.log 2>&1
+python tools/cfg_bench.py 1 3 4 5m 5 --iters 5 > $O/cfg_bench.log 2>&1
