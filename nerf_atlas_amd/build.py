@@ -42,7 +42,11 @@ UNITS = [
     ("render_ls.hip", ["-DNA_PREC_INST=2", "-fno-slp-vectorize"], "_f16", True),
     ("render_ls.hip", ["-DNA_PREC_INST=3", "-fno-slp-vectorize"], "_f16x", True),
 ]
-UNITS = [u if len(u) == 4 else u + (False,) for u in UNITS]
+# Fourth field: True = the full ISA check (render_ls_kernel: no packed fp32) + the hazard scans; "hazard" (every other unit) =
+# the hazard scans only -- fp6-conversion operand overlap, MFMA / transcendental results read early by inline asm
+# (check_cvt_overlap, check_mfma_use, check_trans_use): what the compiler's hazard recogniser cannot see is checked for the
+# whole library, not only where it was found.
+UNITS = [u if len(u) == 4 else u + ("hazard",) for u in UNITS]
 # The timing-stress build of the layer-synchronous renderer: sample group 1 runs THREE phases behind group 0 instead of one.
 # This is the configuration in which the unexplained round-2 events (DESIGN 3b "reproducibility": 16 samples of one block off
 # by 1e-3 in one run of 20 ... 10^3) were frequent enough to count -- 10^3 .. 10^5 differing elements per 200 runs without
@@ -79,7 +83,7 @@ def _headers_digest() -> str:
 def _unit_digest(unit, headers: str) -> str:
     src, extra, suffix, isa = unit
     h = hashlib.sha256(headers.encode())
-    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v4"] if isa else [])).encode())
+    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v5", str(isa)] if isa else [])).encode())
     with open(os.path.join(CSRC, src), "rb") as fh:
         h.update(fh.read())
     return h.hexdigest()
@@ -98,6 +102,16 @@ def isa_listings():
     """[(unit name, path of the device assembly listing)] of the units that are built with the ISA check"""
     out = []
     for u in UNITS:
+        if u[3] is True and os.path.isdir(_isa_dir(u)):
+            out += [(os.path.basename(_obj_path(u)), os.path.join(_isa_dir(u), f)) for f in sorted(os.listdir(_isa_dir(u)))
+                    if f.endswith(".s") and "amdgcn" in f]
+    return out
+
+
+def hazard_listings():
+    """[(unit name, listing path)] of EVERY unit of both libraries (the hazard scans run on all of them)"""
+    out = []
+    for u in UNITS + STRESS_UNITS:
         if u[3] and os.path.isdir(_isa_dir(u)):
             out += [(os.path.basename(_obj_path(u)), os.path.join(_isa_dir(u), f)) for f in sorted(os.listdir(_isa_dir(u)))
                     if f.endswith(".s") and "amdgcn" in f]
@@ -204,6 +218,9 @@ def check_trans_use(listing: str):
             t = line.split(";")[0].rstrip()
             if not t.strip() or t.lstrip().startswith((".", "//")) or re.match(r"^[\w.$]+:", t):
                 continue  # blank, directive, label (a fall-through into a label keeps the adjacency)
+            if t.strip().split()[0] in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                prev = None
+                continue
             if prev is not None:
                 m = _VALU.match(t)
                 if m and not _TRANS.match(t):
@@ -264,6 +281,9 @@ def check_mfma_use(listing: str):
             tt = t.strip()
             m = _MFMA.match(t)
             mn = tt.split()[0]
+            if mn in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                live = []  # no fall-through: what follows is reached by jumps only (the compiler's own cross-block care)
+                continue
             inc = 1
             if mn == "s_nop":
                 try:
@@ -334,6 +354,8 @@ def _compile(unit):
             raise RuntimeError(f"{src}{suffix}: an MFMA result is read {mbad[0][3]} wait states after issue (line {mbad[0][0]} of {lst}: "
                                f"{mbad[0][1][:60]} ... -> {mbad[0][2]}): an inline-asm consumer the hazard recogniser cannot see; the "
                                "hardware then reads a partly written accumulator (tools/hw/mfma_use_hazard.hip).  Fence the asm's operands.")
+        if isa is not True:
+            continue
         bad, seen = check_isa(lst)
         if not seen:
             raise RuntimeError(f"{src}{suffix}: no function named *{ISA_KERNEL}* in {lst}: the ISA check looked at nothing")

@@ -5,8 +5,8 @@ the analytic Blender-format scene of tools/make_scene.py: per-iteration losses a
 recipe runs through this repo's loaders, HIP forward/backward kernels and training loop on the GPU, replaying the
 reference's random stream.  Bars (written here): first 10 losses within 2e-4 absolute (same trajectory, rounding only);
 every test-view PSNR within 0.01 dB (exact-fp32 training GEMMs) / 0.1 dB (split-bf16 training GEMMs, the default) after
-the full budget (plain D-NeRF recipe, deterministic reductions: 1.3 dB per view, 0.9 dB on the mean -- its trajectory is
-chaotic, see below; `make dnerf`'s regularised recipe gets the strict bars), rendered by the
+the full budget (plain D-NeRF recipe: chaotic trajectory, its end point is checked against the reference's OWN end-point ensemble,
+tests/golden/train_spread.json, see below; `make dnerf`'s regularised recipe gets the strict bars), rendered by the
 fused bf16x3 kernel; the fast bf16 renderer within 0.1 dB of that mean as well."""
 import json
 import os
@@ -88,13 +88,34 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     # (dnerf_make steps the optimiser every third iteration: 67 updates in the 200 iterations)
     assert ref[-k:].mean() < (0.7 if name == "dnerf_make" else 0.5) * ref[:k].mean(), "the recipe must actually learn"
     if dyn:
-        # chaotic but deterministic trajectory (see above).  How far the end point moves under a last-bit change was measured
-        # in round 3, when the wave-level partial sums of the hash-table scatter went from a __shfl_xor butterfly to a DPP
-        # tree (same terms, another association): dnerf_div / bf16x3 moved from 0.18 dB per view of the reference's run to
-        # 0.85 dB (0.61 on the mean, ABOVE the reference) while its first 10 losses moved CLOSER to the reference's
-        # (2.3e-4 -> 4.6e-5).  The end-point bars are therefore 1.5x that spread; the loss bars above are the parity
-        # statement, this one says "same basin" (an untrained model is > 8 dB away)
-        assert d.max() <= 1.3 and abs(res["test_psnr_mean"] - fx["test_psnr_mean"]) <= 0.9, (res["test_psnr"], fx["test_psnr"])
+        # Chaotic recipe.  What is NOT chaotic is pinned strictly: the first losses above, and -- for the divergence recipe -- the
+        # regulariser's own effect on the trajectory: over the first 10 iterations the reference's `dnerf_div` losses differ from
+        # its plain `dnerf` losses by up to 6e-4 (same seed, same stream), and the build must reproduce the regularised trajectory
+        # to a small fraction of that effect (measured: 2 % with fp32 GEMMs, 8 % with split bf16).
+        if name == "dnerf_div":
+            plain = np.array(json.load(open(os.path.join(GOLDEN, "train_parity_dnerf.json")))["losses"][:10])
+            effect = np.abs(ref[:10] - plain).max()
+            frac = np.abs(got[:10] - ref[:10]).max() / effect
+            print(f"[{name}/{train_prec}] regulariser effect on the first 10 losses {effect:.2e}; build deviation = {frac:.3f} of it")
+            assert effect >= 3e-4 and frac <= (0.05 if train_prec == "fp32" else 0.15), (effect, frac)
+        # The END POINT is a distribution, on both sides.  tests/golden/train_spread.json holds the reference's own end points
+        # under a last-bit perturbation (same recipe, seed and random stream at several thread counts = another summation order
+        # in its CPU kernels) next to this build's (fp32-atomic accumulation; tools/train_spread.py).  The bars are DERIVED from
+        # the reference's spread, not chosen: 3 x the range its own runs span, per view and on the mean (a range of n runs
+        # underestimates the spread of the distribution; 3 x covers that for n = 3 .. 7), capped by round 3's 1.3 / 0.9 dB.
+        # NOTES "Round 4, second half" has the ensembles side by side (the build's dnerf_div ensemble sits 0.3-0.5 dB ABOVE the
+        # reference's; one of its 10 runs fell out of the basin altogether).
+        sp = json.load(open(os.path.join(GOLDEN, "train_spread.json")))[name]
+        ref_runs = np.array([r["test_psnr"] + [r["test_psnr_mean"]] for r in sp["reference_runs"]])
+        assert len(ref_runs) >= 3, len(ref_runs)
+        rng_ = ref_runs.max(axis=0) - ref_runs.min(axis=0)
+        bar_view, bar_mean = min(1.3, 3.0 * rng_[:-1].max()), min(0.9, 3.0 * rng_[-1])
+        dev_view = np.abs(np.array(res["test_psnr"]) - ref_runs[:, :-1].mean(axis=0)).max()
+        dev_mean = abs(res["test_psnr_mean"] - ref_runs[:, -1].mean())
+        print(f"[{name}/{train_prec}] end point vs the reference's own ensemble (n = {len(ref_runs)}): range per view "
+              f"{np.round(rng_[:-1], 3).tolist()}, of the mean {rng_[-1]:.3f} -> bars {bar_view:.3f} / {bar_mean:.3f} dB; this run "
+              f"{dev_view:.3f} / {dev_mean:.3f} dB from the ensemble mean")
+        assert dev_view <= bar_view and dev_mean <= bar_mean, (res["test_psnr"], ref_runs.tolist(), bar_view, bar_mean)
     elif name == "volsdf_smooth":
         # eikonal + normal smoothing (the reference's VolSDF regularisers, makefile:85-95): the smoothing term is a difference
         # of normals <= 1e-3 apart, which amplifies rounding-order differences over the 200 iterations; its tangent sweeps

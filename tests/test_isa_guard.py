@@ -67,11 +67,10 @@ def test_built_units_keep_inline_asm_behind_mfma_and_trans_results():
     conversion scheduled right behind the MFMA or the transcendental op that produces its operand reads stale registers
     (tools/hw/mfma_use_hazard.hip, trans_use_hazard.hip; round 4: last-bit run-to-run differences of the mip renderer).  Every
     listing of the shipped and of the lag-3 stress build is scanned at build time; here once more, with the counts."""
-    import glob
     from nerf_atlas_amd import build as B
     B.build(verbose=False)
-    paths = [p for _, p in B.isa_listings()] + glob.glob(os.path.join(B.OBJ, "*_lag3.isa", "*.s"))
-    assert len(paths) >= 8, paths
+    paths = [p for _, p in B.hazard_listings()]
+    assert len(paths) >= 19, paths  # the 15 units of the product library + the four lag-3 units
     n_mfma = n_trans = 0
     for path in paths:
         bad, n = B.check_mfma_use(path)
