@@ -2873,6 +2873,7 @@ __global__ void pack_ls_siren_kernel(SirenPackArgs w, int planes, int f16, char*
 
 #endif  // NA_PREC_INST == 0
 
+static std::atomic<uint32_t> g_lsx_launch_id{0};  // ids of the NA_PREC_F16X launches (range guard), shared by every schedule
 // per-device hipFuncSetAttribute bookkeeping (the attribute is per device, not per thread)
 template <int PREC, int MODEL = 0>
 static int launch(Args& a, hipStream_t stream) {
@@ -2895,9 +2896,11 @@ static int launch(Args& a, hipStream_t stream) {
   a.nb_magic = (1ull << 32) / (uint64_t)a.nb + 1;
   if ((int64_t)(a.npg + 1) * C::NBLK * a.nb >= (1ll << 32)) { set_error("na_render_plain_view_ls: batch too large"); return NA_EINVAL; }
   if constexpr (PREC == NA_PREC_F16X) {
-    static std::atomic<uint32_t> gen{0};
-    uint32_t g = gen.fetch_add(1, std::memory_order_relaxed) + 1;
-    if (g == 0) g = gen.fetch_add(1, std::memory_order_relaxed) + 1;  // (0 is the flag's initial value: never an id)
+    // ONE counter for all schedules: the flag is one device word, and a stale id left by a saturated launch of one schedule
+    // must never equal the id of a later launch of another (a per-instantiation counter did exactly that: the frame after
+    // tests/test_gpu_range.py's saturated PlainNeRF launch came out poisoned in whichever VolSDF kernel reached the same count)
+    uint32_t g = g_lsx_launch_id.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (g == 0) g = g_lsx_launch_id.fetch_add(1, std::memory_order_relaxed) + 1;  // (0 is the flag's initial value: never an id)
     a.sat_gen = g;
   } else {
     a.sat_gen = 0;

@@ -176,6 +176,7 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
         raise ValueError(f"--batch-size {batch_size} must be a multiple of the {world} training replicas "
                          f"(every replica renders batch_size / world views per step)")
     losses = []
+    reg_terms = train.last_reg_terms = []  # (the --dyn-diverge-decay term per iteration: a diagnostic next to the losses)
     model.train()
     opt.zero_grad()
     for i in range(args.epochs):
@@ -211,7 +212,9 @@ def train(model, cam, labels, opt, args, sched=None, on_iter=None, rank: int = 0
             loss = loss + args.sdf_eikonal * ag.EikonalFn.apply(reg_n)
         if args.dyn_diverge_decay > 0:
             # runner.py:694-696: utils.divergence(model.pts, model.dp).mean(), with its graph (forward-mode tangent nodes)
-            loss = loss + args.dyn_diverge_decay * model.sum_jacobian_div().mean()
+            div_term = model.sum_jacobian_div().mean()
+            reg_terms.append(float(div_term.detach()))
+            loss = loss + args.dyn_diverge_decay * div_term
         if args.ffjord_div_decay:
             # runner.py:697-700: FFJORD divergence estimate of the rigid deformation, e = randn_like(rigid_dp).  The
             # reference's div_approx builds no graph (src/utils.py:471-477: autograd.grad without create_graph), so the
@@ -307,5 +310,5 @@ def fit(args, device="cuda", replay_reference_rng=False, init=None, on_iter=None
     if args.test_white_bg:
         model.set_bg("white")
     psnrs, gots = test(model, test_cam, test_labels, args)
-    return dict(model=model, losses=losses, test_psnr=psnrs, test_psnr_mean=float(np.mean(psnrs)), frames=gots,
+    return dict(model=model, losses=losses, reg_terms=list(getattr(train, "last_reg_terms", [])), test_psnr=psnrs, test_psnr_mean=float(np.mean(psnrs)), frames=gots,
                 test_labels=test_labels, rank=rank, world=world)

@@ -72,3 +72,25 @@ def test_the_flag_is_per_launch():
     assert float((out_good - ref_good).abs().max()) <= 1e-4
     out3, _ = _frame(bad, "bf16x3")  # fp32-range operands: finite, and close to the oracle wherever the colour is not saturated
     assert torch.isfinite(out3).all()
+
+
+def test_a_stale_flag_never_matches_another_schedules_launch():
+    """The flag is ONE device word shared by every f16x schedule and launch ids come from ONE counter: after a saturated
+    PlainNeRF launch, the next launches of the OTHER f16x kernels (TinyNeRF here; whichever count they have reached) are not
+    poisoned.  Round 4 regression: per-schedule counters let the id left by this file's saturated launches equal the id of a later
+    VolSDF launch -- test_volsdf_tiled_frame_800[f16x] failed only when the whole suite ran in one process."""
+    from nerf_atlas_amd import ops
+    h = load_golden("g11_plain_view_b1")
+    bad = {k: v.clone() for k, v in golden_params(h).items()}
+    bad["first.layers.2.weight"] *= 1e7
+    t = load_golden("g13_tiny")
+    tp = golden_params(t)
+    names = ["estim.init"] + [f"estim.layers.{i}" for i in range(6)] + ["estim.out"]
+    tiny = ops.render_tiny_ls_pack("f16x", [tp[n + ".weight"].cuda() for n in names], [tp[n + ".bias"].cuda() for n in names])
+    ts, _ = ops.compute_ts(2.0, 6.0, 16, "cuda")
+    rays = h["rays"].cuda()
+    for round_ in range(3):
+        out_bad, _ = _frame(bad, "f16x")
+        assert torch.isnan(out_bad).all()
+        for _ in range(12):  # (per-schedule counters collide within the first few launches of the other schedule)
+            assert torch.isfinite(ops.render_tiny_ls(rays, ts, tiny, "f16x", "upshifted", "black")[0]).all()

@@ -125,6 +125,13 @@ def main():
         captured["psnr"].append(float(v))
         return v
     rutils.mse2psnr = mse2psnr
+    real_div = rutils.divergence
+
+    def divergence(x, field):  # (the --dyn-diverge-decay term per iteration: a diagnostic recorded next to the losses)
+        v = real_div(x, field)
+        captured.setdefault("reg_terms", []).append(float(v.mean().detach()))
+        return v
+    rutils.divergence = divergence
     runner.save_losses = lambda args, losses: captured.__setitem__("losses", list(losses))
     real_load_model = runner.load_model
 
@@ -158,7 +165,7 @@ def main():
         recipe=dict(size=cfg.size, crop_size=cfg.crop_size, batch_size=cfg.batch_size, steps=cfg.steps,
                     epochs=cfg.epochs, model_argv=model_argv, lr=5e-4, sched_min=5e-5, adam_eps=1e-7, near=2.0, far=6.0),
         losses=[float(x) for x in captured["losses"]],
-        test_psnr=psnrs, test_psnr_mean=mean,
+        test_psnr=psnrs, test_psnr_mean=mean, reg_terms=captured.get("reg_terms", []),
         torch=torch.__version__, threads=cfg.threads, wall_s=round(dt, 1),
     )
     path = cfg.out or os.path.join(REPO, "tests", "golden", f"train_parity_{cfg.name}.json")

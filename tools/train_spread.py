@@ -47,7 +47,9 @@ def main():
                         config.set_deterministic(False)
                     rows.append({"train_precision": prec, "deterministic": det, "test_psnr": [float(x) for x in r["test_psnr"]],
                                  "test_psnr_mean": float(r["test_psnr_mean"]), "loss_first10": [float(x) for x in r["losses"][:10]],
-                                 "loss_last20_mean": float(sum(r["losses"][-20:]) / 20)})
+                                 "loss_last20_mean": float(sum(r["losses"][-20:]) / 20),
+                                 "losses": [float(x) for x in r["losses"]] if det else None,
+                                 "reg_terms": [float(x) for x in r.get("reg_terms", [])] if det else None})
                     print(name, prec, "det" if det else f"run {k}", [round(x, 3) for x in r["test_psnr"]], round(r["test_psnr_mean"], 4),
                           flush=True)
             res[name] = {"reference": {"test_psnr": fx["test_psnr"], "test_psnr_mean": fx["test_psnr_mean"]}, "build": rows}
