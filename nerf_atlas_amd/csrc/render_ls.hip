@@ -127,8 +127,8 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // frequencies] -> 6 x 256, skip 3, out 65), rows to HBM.  The 256 Fourier features are K64 groups in the HIDDEN format, generated by
 // the row groups in a VALU phase wherever a Linear consumes them (init, L0, L3): init 4 | L0 4 + 4 | L1 | L2 | L3 4 + 4 | L4 | L5 |
 // out 4 = 40 records, and 3 pairs for the 3-wide position chunk
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 2 : model == 3 ? 13 : model == 4 ? 0 : model == 5 ? 3 : 2; }  // (6: 2)
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 22 : model == 3 ? 44 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : 44; }
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 2 : model == 3 ? 5 : model == 4 ? 0 : model == 5 ? 3 : 2; }  // (6: 2)
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 22 : model == 3 ? 46 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -1708,32 +1708,37 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
         x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 16, hb, lane);                     // L4
         SYNC();
-        f32x16 oq[1][NB], bo[1];
+        // sdf.out split by BLOCK like PlainNeRF's first.out (NB = 2): every row group runs two tiles for ONE block, rg & 1 -- row
+        // groups 0, 1 the two latent tiles (rows 0..63: the 32 values of an MFMA lane of the View MLP's latent group end up in one
+        // lane), row groups 2, 3 the signed-distance tile (row 64) and an all-zero tile.  Then the View half on records: 24 view.init
+        // (the latent group) | 25 skip group + 26..29 (view.L0) | 30.. L1..L3 | 42..45 view.out; pairs 3, 4 = the geometry chunk
+        static_assert(NB == 2, "sdf.out by block");
+        f32x16 ol[2][1];
         {
-          bo[0] = bias_tile(wrs, bias_rg + 6 * 1024, rg < 2 ? rg : 2, lane);
           x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
+          bvx[0] = bias_tile(wrs, bias_rg + 6 * 1024, rg < 2 ? 0 : 2, lane);
+          bvx[1] = bias_tile(wrs, bias_rg + 6 * 1024, rg < 2 ? 1 : 3, lane);  // (slot 3: zeros)
         }
         SYNC();
-        x::recs<1, NB, true, XNR>(oq, bo, XR, wrs, xrec, 20, hb, lane);                       // sdf.out (row-major)
+        x::recs<2, 1, true, XNR>(ol, bvx, XR, wrs, xrec, 20, hb + (rg & 1) * x::BLKH, lane);  // sdf.out
         SYNC();
         {
           xbias(7);
           geo_setup(pass);
           if (rg < 2) {
+            // the latent group of block rg: raw rows into the wave's own (idle) K64 region of block 1 for the skip connection, the
+            // group itself into the init region
+            char* st = hb + x::BLKH + rg * x::KQ + lane * 16;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              Frag<PREC> f0, f1;
-              acc_to_frags<PREC, NA_ACT_NONE>(oq[0][b], f0, f1);
-            x::latent_range(oq[0][b], a.sat_gen);
-              char* dst = ib + (b * 4 + 2 * rg) * FR + lane * 16;
-              fwrite<PREC>(dst, f0);
-              fwrite<PREC>(dst + FR, f1);
+            for (int c = 0; c < 4; ++c) {
+              *(f32x4*)(st + c * 1024) = f32x4{ol[0][0][4 * c], ol[0][0][4 * c + 1], ol[0][0][4 * c + 2], ol[0][0][4 * c + 3]};
+              *(f32x4*)(st + 4096 + c * 1024) = f32x4{ol[1][0][4 * c], ol[1][0][4 * c + 1], ol[1][0][4 * c + 2], ol[1][0][4 * c + 3]};
             }
-          } else if (rg == 2 && hi == 0) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) ((float*)hb)[b * 32 + ln] = oq[0][b][0];
+            x::store_block<NA_ACT_NONE, 4>(ib + rg * x::KQ, ol[0][0], ol[1][0], lane, a.sat_gen);
+          } else if (hi == 0) {
+            ((float*)hb)[(rg & 1) * 32 + ln] = ol[0][0][0];  // the signed distance of block rg & 1 (lane = step), for its owner
           }
-          x::pairs_prefetch(XR, wrs, xpair, lane, 3);
+          x::pairs_prefetch(XR, wrs, xpair, lane, 3, 1);
         }
         SYNC();
         if (owner) {  // signed distance -> Laplace density (src/utils.py:50-58, src/nerf.py:1000-1003), composited one pass later
@@ -1747,24 +1752,34 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           GeoRaw graw[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-          x::pairs<3, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                  // view.init: latent chunks + geometry
-          x::geo_pair<7, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
+          x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, 24, hb, lane, ib);     // view.init: latent group + geometry
+          x::geo_pair<1, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);                  // (pair 3 sits in ring slot 1)
         }
         SYNC();
         {
-          x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
+          x::store_acts<NA_ACT_SIN, NB, 0, 1>(acc, hb, rg, lane, a.sat_gen);
+          if (rg < 2) {  // sin(latent) for the skip connection, from the raw rows (before block 1's store overwrites their region)
+            const char* st = hb + x::BLKH + rg * x::KQ + lane * 16;
+            f32x16 l0, l1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 u = *(const f32x4*)(st + c * 1024), w = *(const f32x4*)(st + 4096 + c * 1024);
+              l0[4 * c] = u[0]; l0[4 * c + 1] = u[1]; l0[4 * c + 2] = u[2]; l0[4 * c + 3] = u[3];
+              l1[4 * c] = w[0]; l1[4 * c + 1] = w[1]; l1[4 * c + 2] = w[2]; l1[4 * c + 3] = w[3];
+            }
+            x::store_block<NA_ACT_SIN, 4>(ib + rg * x::KQ, l0, l1, lane, a.sat_gen);
+          }
+          x::store_acts<NA_ACT_SIN, NB, 1, 2>(acc, hb, rg, lane, a.sat_gen);
           xbias(8);
-          if (owner) activate_init<PREC, NA_ACT_SIN, 4>(ib, blk, lane);
-          x::pairs_prefetch(XR, wrs, xpair, lane, 8);
+          XR.pr[0] = x::wpair(wrs, lane, xpair, 4);
         }
         SYNC();
         {
           GeoRaw graw[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-          x::pairs<8, 4, NB, true>(acc, bvx, XR, wrs, xpair, ib, lane);                // view.L0: skip chunks, K = 256, geometry
-          x::recs<2, NB, false, XNR>(acc, bvx, XR, wrs, xrec, 24, hb, lane);
-          x::geo_pair<12, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
+          x::recs<2, NB, true, XNR, 5, 1, 1, 4>(acc, bvx, XR, wrs, xrec, 25, hb, lane, ib);     // view.L0: skip group, K = 256, geometry
+          x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
         }
         SYNC();
 #pragma unroll 1
@@ -1772,7 +1787,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
           xbias(9 + i);
           SYNC();
-          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 28 + 4 * i, hb, lane);        // view.L1..L3
+          x::recs<2, NB, true, XNR>(acc, bvx, XR, wrs, xrec, 30 + 4 * i, hb, lane);        // view.L1..L3
           SYNC();
         }
         f32x16 ocx[1][1], bo1[1];
@@ -1781,7 +1796,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
           x::store_acts<NA_ACT_SIN, NB>(acc, hb, rg, lane, a.sat_gen);
         }
         SYNC();
-        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 40, hb + blk * x::BLKH, lane);   // view.out (block per wave)
+        x::recs<1, 1, true, XNR>(ocx, bo1, XR, wrs, xrec, 42, hb + blk * x::BLKH, lane);   // view.out (block per wave)
         oc[0] = ocx[0][0];
         SYNC();
         prev = pass;
@@ -3163,8 +3178,8 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
     xs_add_mlp(sc, hashmlp, w0, b0, 7, 3, false, 2, true);
   } else {
     const NaMlpDesc siren = {3, NA_ENC_NONE, 0, 0, 5, 256, 65, 3, NA_ACT_SIN, NA_LAYOUT_PLAIN_FIRST};
-    xs_add_mlp(sc, siren, w0, b0, 7, 1, false, 1);
-    xs_add_mlp(sc, view, w1, b1, 6, 4, true, 2);
+    xs_add_mlp(sc, siren, w0, b0, 7, 1, false, 3);
+    xs_add_mlp(sc, view, w1, b1, 6, 4, true, 2, true);
   }
   if (sc.npair != x::npair(model) || sc.nrec != x::nrec(model)) {
     set_error("render_lsx_pack: schedule of model %d has %d pairs / %d records, the kernel expects %d / %d", model, sc.npair,
