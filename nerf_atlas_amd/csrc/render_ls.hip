@@ -621,7 +621,8 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
 // whose fourth chunk is padding that the fp6 operands hold as zeros and the f16 product skips); the others are the hidden
 // groups Q = 0, 1, ... of the blocks (hb0 + b * BLKH + Q * KQ).  PAR0 = parity of rec0 (which scale slot its dword sits in).
 // CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
-template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4, bool LAST0 = false, int BSTR = BLKH>
+template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4, bool LAST0 = false, int BSTR = BLKH,
+          int NCHL = 4>  // NCHL: live f16 chunks of the call's LAST record (MODEL 6: the second IPE group fills two)
 __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
                                      int rec0, const char* hb0, int lane, const char* ib0 = nullptr) {
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
@@ -629,7 +630,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
     if (G0 != 0 && gi == 0) return ib0 + b * KQ;
     return hb0 + b * BSTR + (gi - G0) * KQ;  // (BSTR: MODEL 6 parks the two IPE groups of block b at groups 2 b, 2 b + 1 of block 0)
   };
-  auto nch = [&](int gi) -> int { return (G0 != 0 && gi == 0) ? NCH0 : 4; };
+  auto nch = [&](int gi) -> int { return (G0 != 0 && gi == 0) ? NCH0 : (gi == NG - 1 ? NCHL : 4); };
   auto b16 = [&](int b, int gi, int c) -> f16x8 { return *(const f16x8*)(gbase(gi, b) + c * 1024 + lane * 16); };
   auto b6 = [&](int b, int gi, int k) -> i32x8 {  // k: 0 R, 1 T
     const char* p = gbase(gi, b) + 4096 + k * 2048 + lane * 16;
@@ -2280,7 +2281,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       constexpr int IPS = 2 * x::KQ;  // block stride of the parked IPE groups
       constexpr int RL1 = MIP ? 10 : 6, ROUT = MIP ? 22 : 18, RVI = MIP ? 26 : 22, RVL0 = MIP ? 29 : 23, RVL1 = MIP ? 36 : 28,
                     RVO = MIP ? 48 : 40;
-      if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 3, false, IPS>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);
+      if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 3, false, IPS, 2>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);
       else x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);  // first.init: the [hash | x] group
       SYNC();
       {
@@ -2295,7 +2296,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
         gen_ipe(std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
         SYNC();
-        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS>(acc, bvx, XR, wrs, xrec, 8, hb, lane);  // ... + the IPE groups
+        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS, 2>(acc, bvx, XR, wrs, xrec, 8, hb, lane);  // ... + the IPE groups
       } else {
         x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);     // first.L0: skip group, then K = 256
       }
@@ -2349,7 +2350,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 4, false, IPS>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);
+        if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 4, false, IPS, 2>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);
         else x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);  // view.init: latent group + geometry
         x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
       }
@@ -2381,7 +2382,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS>(acc, bvx, XR, wrs, xrec, RVL0 + 5, hb, lane);  // ... + IPE + geometry
+        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS, 2>(acc, bvx, XR, wrs, xrec, RVL0 + 5, hb, lane);  // ... + IPE + geometry
         x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       } else {
         GeoRaw graw[NB];
