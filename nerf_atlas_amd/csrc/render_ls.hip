@@ -622,7 +622,7 @@ __device__ __forceinline__ void geo_pair(f32x16 (&acc)[2][NB], Regs& R, __amdgpu
 // groups Q = 0, 1, ... of the blocks (hb0 + b * BLKH + Q * KQ).  PAR0 = parity of rec0 (which scale slot its dword sits in).
 // CB: the phase starts here -- the first MFMA of every accumulator reads the bias registers cb[t] as its C operand.
 template <int NT, int NBk, bool CB, int NREC, int NG = 4, int G0 = 0, int PAR0 = 0, int NCH0 = 4, bool LAST0 = false, int BSTR = BLKH,
-          int NCHL = 4>  // NCHL: live f16 chunks of the call's LAST record (MODEL 6: the second IPE group fills two)
+          int NCHL = 4, int NTAIL = 1>  // NCHL: live f16 chunks of the call's last NTAIL records (MODEL 6: an IPE group fills three)
 __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[NT], Regs& R, __amdgpu_buffer_rsrc_t rs, int xrec,
                                      int rec0, const char* hb0, int lane, const char* ib0 = nullptr) {
   if (NA_LSX_PRIO == 0) __builtin_amdgcn_s_setprio(1);
@@ -630,7 +630,7 @@ __device__ __forceinline__ void recs(f32x16 (&acc)[NT][NBk], const f32x16 (&cb)[
     if (G0 != 0 && gi == 0) return ib0 + b * KQ;
     return hb0 + b * BSTR + (gi - G0) * KQ;  // (BSTR: MODEL 6 parks the two IPE groups of block b at groups 2 b, 2 b + 1 of block 0)
   };
-  auto nch = [&](int gi) -> int { return (G0 != 0 && gi == 0) ? NCH0 : (gi == NG - 1 ? NCHL : 4); };
+  auto nch = [&](int gi) -> int { return (G0 != 0 && gi == 0) ? NCH0 : (gi >= NG - NTAIL ? NCHL : 4); };
   auto b16 = [&](int b, int gi, int c) -> f16x8 { return *(const f16x8*)(gbase(gi, b) + c * 1024 + lane * 16); };
   auto b6 = [&](int b, int gi, int k) -> i32x8 {  // k: 0 R, 1 T
     const char* p = gbase(gi, b) + 4096 + k * 2048 + lane * 16;
@@ -1266,10 +1266,10 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     }
   };
   // ---- MODEL 6 (mip, NA_PREC_F16X): the 96 IPE features of a sample (src/utils.py:23-27, 83-140; hook src/nerf.py:256-261) as two
-  // K64 groups in the hidden format.  Row group rg generates group rg & 1 of block rg >> 1: a lane (sample, k half h) computes
-  // its (degree, axis) pairs -- pidx = 16 h + j (group 0, j < 16) | 32 + 8 h + j (group 1, j < 8) -- sine and cosine feature
-  // of a pair from ONE reduced angle and one damping factor, into slots 2 j and 2 j + 1.  Block b's groups live at K64 groups
-  // 2 b, 2 b + 1 of block 0's hidden space (block 1's holds the raw [hash | x] / latent values that wait for the skip layer).
+  // K64 groups in the hidden format.  Row group rg generates group g = rg & 1 of block rg >> 1: a lane (sample, k half h) computes
+  // its 12 (degree, axis) pairs pidx = 24 g + 12 h + j -- sine and cosine feature of a pair from ONE reduced angle and one damping
+  // factor, into slots 2 j and 2 j + 1 (three live chunks per group: the four generating waves of a sample group do equal work).
+  // Block b's groups live at K64 groups 2 b, 2 b + 1 of block 0's hidden space (block 1's holds the raw [hash | x] / latent values that wait for the skip layer).
   float rad_u[NB];  // pixel radius of block b's ray (uniform)
   auto mip_setup = [&]() {
     if constexpr (MIP) {
@@ -1320,9 +1320,9 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       auto pairs = [&](auto g_tag) {
         constexpr int G = decltype(g_tag)::value;
 #pragma unroll
-        for (int j = 0; j < (G == 0 ? 16 : 8); ++j) {
+        for (int j = 0; j < 12; ++j) {
           // pair index of lane half 0 | 1 (compile-time: no per-lane division, one select per operand)
-          const int pl = G == 0 ? j : 32 + j, ph = G == 0 ? 16 + j : 40 + j;
+          const int pl = 24 * G + j, ph = 24 * G + 12 + j;
           const int kl = pl / 3, al = pl - 3 * kl, kh = ph / 3, ah = ph - 3 * kh;
           const float m = hi ? mm[ah] : mm[al], p0 = hi ? pr0[ah] : pr0[al], e0 = hi ? er0[ah] : er0[al];
           const float cK = hi ? ck[ah] : ck[al];
@@ -2281,7 +2281,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       constexpr int IPS = 2 * x::KQ;  // block stride of the parked IPE groups
       constexpr int RL1 = MIP ? 10 : 6, ROUT = MIP ? 22 : 18, RVI = MIP ? 26 : 22, RVL0 = MIP ? 29 : 23, RVL1 = MIP ? 36 : 28,
                     RVO = MIP ? 48 : 40;
-      if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 3, false, IPS, 2>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);
+      if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 3, false, IPS, 3, 2>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);
       else x::recs<2, NB, true, XNR, 1, 1, 0, 3>(acc, bvx, XR, wrs, xrec, 0, hb, lane, ib);  // first.init: the [hash | x] group
       SYNC();
       {
@@ -2296,7 +2296,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         SYNC();
         gen_ipe(std::integral_constant<int, NA_ACT_LEAKY_RELU>{});
         SYNC();
-        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS, 2>(acc, bvx, XR, wrs, xrec, 8, hb, lane);  // ... + the IPE groups
+        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS, 3, 2>(acc, bvx, XR, wrs, xrec, 8, hb, lane);  // ... + the IPE groups
       } else {
         x::recs<2, NB, true, XNR, 5, 1, 1, 3>(acc, bvx, XR, wrs, xrec, 1, hb, lane, ib);     // first.L0: skip group, then K = 256
       }
@@ -2350,7 +2350,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 4, false, IPS, 2>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);
+        if constexpr (MIP) x::recs<2, NB, true, XNR, 3, 1, 0, 4, false, IPS, 3, 2>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);
         else x::recs<2, NB, true, XNR, 1, 1, 0, 4>(acc, bvx, XR, wrs, xrec, RVI, hb, lane, ib);  // view.init: latent group + geometry
         x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, false);
       }
@@ -2382,7 +2382,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         GeoRaw graw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) graw[b] = geo_load(b);
-        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS, 2>(acc, bvx, XR, wrs, xrec, RVL0 + 5, hb, lane);  // ... + IPE + geometry
+        x::recs<2, NB, false, XNR, 2, 0, 0, 4, false, IPS, 3, 2>(acc, bvx, XR, wrs, xrec, RVL0 + 5, hb, lane);  // ... + IPE + geometry
         x::geo_pair<0, NB>(acc, XR, wrs, xpair, lane, graw, geo_make, true);
       } else {
         GeoRaw graw[NB];
@@ -2949,11 +2949,12 @@ __device__ __forceinline__ int xrec_col(const XSched& sc, const XRecD& rd, int c
     return (rd.kind == 4 ? kHidden : 0) + d.in_size + ((s & 1) ? F + f : f);
   }
   if (rd.kind == 5) {
-    // IPE group q (0, 1) as the MODEL 6 generator lays it out: slot s = 8 c + e of lane half h holds the (degree, axis) pair
-    // pidx = 16 h + s / 2 (group 0) | 32 + 8 h + s / 2 for s < 16 (group 1; the rest is padding), its sine feature (s even:
-    // latent column pidx) or cosine feature (s odd: column 48 + pidx); src/utils.py:23-27 layout [sin | cos], degree-major
+    // IPE group q (0, 1) as the MODEL 6 generator lays it out: slot s = 8 c + e < 24 of lane half h holds the (degree, axis)
+    // pair pidx = 24 q + 12 h + s / 2 (the fourth chunk of both groups is padding: the two generating waves do the same work),
+    // its sine feature (s even: latent column pidx) or cosine feature (s odd: column 48 + pidx); src/utils.py:23-27 layout
+    // [sin | cos], degree-major
     const int s = 8 * c + (kappa & 7), h = kappa >> 3;
-    const int pidx = rd.q == 0 ? 16 * h + (s >> 1) : (s < 16 ? 32 + 8 * h + (s >> 1) : -1);
+    const int pidx = s < 24 ? 24 * rd.q + 12 * h + (s >> 1) : -1;
     return pidx < 0 ? -1 : rd.off + ((s & 1) ? 48 : 0) + pidx;
   }
   int col = init_slot_feature(sc.desc[sc.lin[rd.lin].desc], c, kappa);
