@@ -119,10 +119,10 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
         #     (the range of n = 3 .. 7 runs is 1.7 .. 2.7 sigma: 3 x range is a generous 5 .. 8 sigma), capped by 1.3 / 0.9 dB.
         #   dnerf_div: the L2 part of that loss rides on the rounding noise of the unbounded term above (its gradient is 1e5 x the L2
         #     gradient in the sums Adam normalises), so the end point measures ACCUMULATION PRECISION, not parity: the reference's
-        #     own runs span 0.85 dB per view; the build's ensemble sits 0.3 - 0.5 dB ABOVE the reference's, its deterministic runs
+        #     own runs span 0.9 dB per view and 0.46 dB on the mean; the build's ensemble sits 0.2 - 0.4 dB ABOVE the reference's, its deterministic runs
         #     (64-bit fixed-point gradient sums, which keep the L2 part of a sum that fp32 rounds away) highest, and one of ten
         #     fp32-atomic runs fell out of the basin (15.99 dB).  Bars: the caps alone (1.3 dB per view = 1.5 x the reference's own
-        #     range; 0.9 dB on the mean), as a "same basin" statement; the derived bars are printed next to them.
+        #     range; 0.9 dB on the mean = 2 x), as a "same basin" statement; the derived bars are printed next to them.
         sp = json.load(open(os.path.join(GOLDEN, "train_spread.json")))[name]
         ref_runs = np.array([r["test_psnr"] + [r["test_psnr_mean"]] for r in sp["reference_runs"]])
         assert len(ref_runs) >= 3, len(ref_runs)

@@ -26,8 +26,8 @@ def main():
                  "loss_last20_mean": sum(fx["losses"][-20:]) / 20, "source": f"tests/golden/train_parity_{name}.json"}]
         for path in sorted(sys.argv[1:]):
             d = json.load(open(path))
-            if d.get("name") != name or d.get("seed") != fx.get("seed") or d.get("reg_terms"):
-                continue  # (the instrumented run repeats a thread count that is already in the list)
+            if d.get("name") != name or d.get("seed") != fx.get("seed") or any(r["threads"] == d["threads"] for r in runs):
+                continue  # (a thread count that is already in the list: the instrumented run repeats one)
             assert d["argv"] == fx["argv"] and len(d["losses"]) == len(fx["losses"]), path
             runs.append({"threads": d["threads"], "test_psnr": d["test_psnr"], "test_psnr_mean": d["test_psnr_mean"],
                          "loss_last20_mean": sum(d["losses"][-20:]) / 20, "source": "tools/ref_train_fixture.py --threads %d" % d["threads"]})
