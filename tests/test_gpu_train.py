@@ -102,16 +102,24 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
             # (runner.py:694-696, with the reference's own "TODO maybe this is wrong?"): it is unbounded below and training drives it
             # from 0 to -4.6e6 (x 0.05 against an L2 loss of 0.02).  The reference's trace of the term (instrumented run of
             # tools/ref_train_fixture.py, same recipe / seed / stream) and the build's must agree through those eight orders of
-            # magnitude: every one of the first 10 iterations and every 20-iteration window mean (measured: <= 1.8 % / 1.3 % with
-            # split bf16, 0.4 % / 0.6 % with fp32 GEMMs).  THIS is the parity statement of the recipe.
+            # magnitude: every one of the first 10 iterations and every 20-iteration window mean (measured against the nearer of the
+            # reference's two traces: <= 1.8 % / 1.2 % with split bf16, 0.2 % / 0.9 % with fp32 GEMMs).  THIS is the parity statement of the recipe.
             sp_reg = json.load(open(os.path.join(GOLDEN, "train_spread.json")))[name]["reference_reg"]
-            rr, br = np.array(sp_reg["reg_terms"]), np.array(res["reg_terms"])
-            assert len(rr) == len(br) == len(ref) and rr[-1] < -1e6, (len(rr), len(br), rr[-1])
-            e10 = np.abs(br[1:10] / rr[1:10] - 1).max()
-            ew = max(abs(br[a:a + 20].mean() / rr[a:a + 20].mean() - 1) for a in range(0, len(rr), 20))
-            print(f"[{name}/{train_prec}] divergence term: reference {rr[-1]:.4e} / build {br[-1]:.4e} at the end; deviation first 10 "
-                  f"iterations {e10:.4f}, worst 20-iteration window {ew:.4f}")
-            assert e10 <= (0.01 if train_prec == "fp32" else 0.04) and ew <= 0.03, (e10, ew)
+            refs = [np.array(r["reg_terms"]) for r in sp_reg]
+            br = np.array(res["reg_terms"])
+            assert len(refs) >= 2 and all(len(r) == len(br) == len(ref) and r[-1] < -1e6 for r in refs), [len(r) for r in refs]
+            win = lambda x, r: np.array([abs(x[a:a + 20].mean() / r[a:a + 20].mean() - 1) for a in range(0, len(r), 20)])
+            # the reference's OWN traces (two thread counts) drift apart by up to 3.3 % per window once the trajectories decorrelate
+            # (0.2 % over the first 10 iterations): the build must stay within 3 % of the NEARER one and within 3 % + that spread
+            # of every one
+            spread = max(win(refs[i], refs[j]).max() for i in range(len(refs)) for j in range(i))
+            e10 = min(np.abs(br[1:10] / r[1:10] - 1).max() for r in refs)
+            wins = np.array([win(br, r) for r in refs])
+            ew_near, ew_far = wins.min(axis=0).max(), wins.max()
+            print(f"[{name}/{train_prec}] divergence term: reference {refs[0][-1]:.4e} / build {br[-1]:.4e} at the end; deviation first 10 "
+                  f"iterations {e10:.4f}, worst 20-iteration window {ew_near:.4f} (nearer reference trace) / {ew_far:.4f} (any); the "
+                  f"reference's own traces differ by {spread:.4f}")
+            assert e10 <= (0.01 if train_prec == "fp32" else 0.04) and ew_near <= 0.03 and ew_far <= 0.03 + spread, (e10, ew_near, ew_far, spread)
         # The END POINT is a distribution, on both sides.  tests/golden/train_spread.json holds the reference's own end points
         # under a last-bit perturbation (same recipe, seed and random stream at several thread counts = another summation order
         # in its CPU kernels) next to this build's (fp32-atomic accumulation; tools/train_spread.py).

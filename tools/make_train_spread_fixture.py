@@ -31,11 +31,13 @@ def main():
             assert d["argv"] == fx["argv"] and len(d["losses"]) == len(fx["losses"]), path
             runs.append({"threads": d["threads"], "test_psnr": d["test_psnr"], "test_psnr_mean": d["test_psnr_mean"],
                          "loss_last20_mean": sum(d["losses"][-20:]) / 20, "source": "tools/ref_train_fixture.py --threads %d" % d["threads"]})
-        reg = None
-        for path in sorted(sys.argv[1:]):  # a reference run made after tools/ref_train_fixture.py learnt to record the term
+        reg = []  # reference runs made after tools/ref_train_fixture.py learnt to record the term (one trace per thread count)
+        for path in sorted(sys.argv[1:]):
             d = json.load(open(path))
-            if d.get("name") == name and d.get("seed") == fx.get("seed") and d.get("reg_terms"):
-                reg = {"threads": d["threads"], "reg_terms": d["reg_terms"], "losses": d["losses"]}
+            if (d.get("name") == name and d.get("seed") == fx.get("seed") and d.get("reg_terms")
+                    and not any(r["threads"] == d["threads"] for r in reg)):
+                reg.append({"threads": d["threads"], "reg_terms": d["reg_terms"]})
+        reg = reg or None
         out[name] = {"reference_reg": reg, "reference_runs": runs,
                      "build_runs": [{k: r[k] for k in ("train_precision", "deterministic", "test_psnr", "test_psnr_mean", "loss_last20_mean")}
                                     for r in build[name]["build"]]}
