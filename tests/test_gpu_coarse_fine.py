@@ -143,3 +143,34 @@ def test_plain_nerf_coarse_fine_64_128_end_to_end(prec):
         assert not torch.equal(out, m.coarse)
     finally:
         config.set_precision("bf16x3")
+
+
+def test_coarse_fine_full_frame_properties():
+    """BASELINE's full size (800 x 800 rays, 64 + 128): size-independent properties -- every ray's 192 steps are sorted, contain its
+    64 coarse steps, stay inside [near, far]; the fine weights partition unity against a white background; a row band rendered
+    alone reproduces the frame's rows bit for bit (resampling and the per-ray-step renderer are per-ray computations)."""
+    import math
+    import nerf_atlas_amd.nerf as nerf
+    from nerf_atlas_amd import config, ops
+    torch.manual_seed(2)
+    m = nerf.PlainNeRF(steps=64, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted", bg="white").cuda().eval()
+    size = 800
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[0.8, -0.36, 0.48, 1.9], [0.0, 0.8, 0.6, 2.4], [-0.6, -0.48, 0.64, 2.6]]]).cuda()
+    config.set_precision("f16x")
+    try:
+        rays = ops.raygen(c2w, focal, size, (0, 0, size, size))
+        out = m.forward_coarse_fine(rays, 128)
+        ts_f, w = m.ts, m.weights
+        assert out.shape == (1, size, size, 3) and torch.isfinite(out).all()
+        assert ts_f.shape == (1, size, size, 192)
+        assert bool((ts_f[..., 1:] >= ts_f[..., :-1]).all())
+        assert float(ts_f.min()) >= 2.0 - 1e-6 and float(ts_f.max()) <= 6.0 + 1e-5
+        coarse, _ = ops.compute_ts(2.0, 6.0, 64, "cuda")
+        pos = torch.searchsorted(ts_f.reshape(-1, 192), coarse.expand(size * size, 64).contiguous())
+        assert bool((torch.gather(ts_f.reshape(-1, 192), 1, pos.clamp(max=191)) == coarse).all())   # the coarse steps are among them
+        assert float((w.sum(0) - 1).abs().max()) <= 1e-5
+        band = ops.raygen(c2w, focal, size, (299, 0, 101, size))
+        assert torch.equal(m.forward_coarse_fine(band, 128), out[:, 299:400])
+    finally:
+        config.set_precision("bf16x3")
