@@ -11,6 +11,9 @@ Scheme grammar: a '+'-separated list of products "<xfmt>*<wfmt>", where a format
     f16lo | bf16lo                the residual (v - round(v)) rounded to the same type
     e4m3 | e2m1 | e2m3 | e3m2     MX block format (32-element blocks along K, power-of-two scale) of the operand
     e4m3lo(f16) ...               MX block format of the residual after f16 (or bf16) rounding
+    e2m3d0 | e2m3d1 | e2m3d2 ...  (round 5) the i-th MX "digit" of the operand: digit i = MX block format (own block scale)
+                                  of what digits 0..i-1 left over; "3x3" = all nine digit products, "3x3k6" = the six
+                                  most significant (d0d0 d0d1 d1d0 d1d1 d0d2 d2d0: 6 fp6 MFMAs = 1.5 bf16 products)
 """
 import argparse
 import math
@@ -79,6 +82,12 @@ def rnd(v, t):
 
 
 def fmt_apply(v, fmt):
+    m = re.fullmatch(r"(e\dm\d)d(\d)", fmt)
+    if m:
+        rest = v
+        for _ in range(int(m.group(2))):
+            rest = rest - mx_quant(rest, m.group(1))
+        return mx_quant(rest, m.group(1))
     m = re.fullmatch(r"(\w+?)lo\((\w+)\)", fmt)
     if m:
         base = {"f16": torch.float16, "bf16": torch.bfloat16}[m.group(2)]
@@ -163,7 +172,17 @@ def main():
         "f16*f16+e2m1lo(f16)*e2m1+e2m1*e2m1lo(f16)",
         "f16*f16+e3m2lo(f16)*e3m2+e3m2*e3m2lo(f16)",
     ]
-    schemes = [s for s in args.schemes.split(",") if s] or default
+    def digits(kind, pairs):
+        return "+".join(f"{kind}d{i}*{kind}d{j}" for i, j in pairs)
+    k6 = [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)]
+    k8 = k6 + [(1, 2), (2, 1)]
+    k9 = k8 + [(2, 2)]
+    alias = {"e2m3_3x3k6": digits("e2m3", k6), "e2m3_3x3k8": digits("e2m3", k8), "e2m3_3x3": digits("e2m3", k9),
+             "e3m2_3x3k6": digits("e3m2", k6), "e2m3_2x2": digits("e2m3", k6[:4]),
+             "e2m3_4x4k10": digits("e2m3", k6 + [(1, 2), (2, 1), (0, 3), (3, 0)]),
+             # asymmetric: three digits of the activations against f16-class weights is not an MFMA; kept symmetric
+             }
+    schemes = [alias.get(s, s) for s in args.schemes.split(",") if s] or default
     for spec in schemes:
         sch = Scheme(spec, names)
 
