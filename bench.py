@@ -457,6 +457,30 @@ def main():
     if fourth is not None:
         dt4, kern4_ms, _, _, _ = timed(fourth, args.steps, 1)
 
+    # N > 1: what one GPU needs for the WHOLE frame, measured in this very run on rank 0 after the timed regions (the other
+    # ranks wait at the final barrier), so that the line explains itself: scaling_efficiency = that / (N x slowest rank's kernel)
+    full_frame_ms = None
+    if world > 1:
+        if rank == 0:
+            ws_full = torch.empty(max(int(lib.na_render_workspace_bytes(STEPS_PER_RAY, SIZE * SIZE)),
+                                      int(lib.na_render_ls_workspace_bytes(STEPS_PER_RAY, SIZE * SIZE))), device=dev, dtype=torch.uint8)
+            rays_all = ops.raygen(c2w, focal, SIZE, (0, 0, SIZE, SIZE))
+            if engine == "ls":
+                pk = model.packed_ls(prec)
+                full = lambda: ops.render_plain_view_ls(rays_all, ts, tables, pk, prec, "upshifted", "black", False, ws_full)[0]
+            else:
+                _, pf = model.first.packed(prec, "plain_first")
+                _, pv = model.refl.mlp.packed(prec, "plain_view")
+                full = lambda: ops.render_plain_view(rays_all, ts, tables, pf, pv, prec, "upshifted", "black", False, ws_full)[0]
+            full()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3): full()
+            e1.record()
+            torch.cuda.synchronize()
+            full_frame_ms = e0.elapsed_time(e1) / 3
+        fence()
+
     if rank == 0:
         samples = SIZE * SIZE * STEPS_PER_RAY
         value = samples * args.steps / dt / 1e6
@@ -476,6 +500,9 @@ def main():
             # backend build lacks it)
             "backend": backend, "rccl_ranks": rccl_ranks, "gather_impl": gather.impl if world > 1 else "none",
         }
+        if full_frame_ms is not None:
+            res["single_gpu_full_frame_kernel_ms"] = round(full_frame_ms, 3)
+            res["scaling_efficiency"] = round(full_frame_ms / (world * kern_ms), 4)   # kernel time only; `value` also pays the gather
         if checksum is not None:
             res["config"]["frame_checksum"] = checksum
         if world == 1:

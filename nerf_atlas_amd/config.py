@@ -28,6 +28,36 @@ def kernel_precision(has_f16x: bool = False) -> str:
     return precision
 
 
+# f16x range guard at the model layer (the kernels' part: csrc/render_ls.hip g_lsx_saturated -- an activation at the half clamp
+# turns the launch's WHOLE output into NaN, stream-ordered, no host synchronisation).  What the host does about it:
+#   "nan"              (default) nothing: the caller sees the NaN frame; fully asynchronous
+#   "raise"            every f16x launch is followed by a one-element read-back (a host synchronisation) and a flagged launch
+#                      raises ops.F16xSaturated
+#   "rerender_bf16x3"  as "raise", but the model's forward catches it and renders the same call again in bf16x3 (fp32 range)
+f16x_on_saturation = "nan"
+
+
+def set_f16x_on_saturation(policy: str):
+    global f16x_on_saturation
+    if policy not in ("nan", "raise", "rerender_bf16x3"):
+        raise ValueError(policy)
+    f16x_on_saturation = policy
+
+
+class precision_as:
+    """`with config.precision_as("bf16x3"): ...`"""
+
+    def __init__(self, p: str):
+        self.p = p
+
+    def __enter__(self):
+        self.prev = precision
+        set_precision(self.p)
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+
+
 # Packed weight streams are cached per module and re-packed when a Parameter's version counter or address changes
 # (utils.invalidate_packed documents what that misses: writes through `.data`, out-of-band copies).  True = pack on every
 # forward instead (four small launches per model, ~30 us): for callers that update weights behind torch's back.

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void resample_ts_kernel(const float* __restric
     for (int j = lane; j < N; j += 64) {
       float uf;
       if (u != nullptr) uf = ut[j * 64 + rl];
-      else uf = j < N / 2 ? step * (float)j : 1.0f - step * (float)(N - 1 - j);  // torch.linspace(0, 1, N) in fp32
+      else uf = (N == 1 || j < N / 2) ? step * (float)j : 1.0f - step * (float)(N - 1 - j);  // torch.linspace(0, 1, N) in fp32 ([0] for N = 1)
       const double uj = (double)uf;
       int lo = 0, hi = T;  // first index with cdf > u
       while (lo < hi) {
@@ -640,12 +640,20 @@ __global__ __launch_bounds__(256) void resample_ts_kernel(const float* __restric
     wave_sync();
     // ---- stable rank sort of the T + N positions
     if (merged != nullptr) {
+      // (keys, not float compares: a strict total order -- NaN positions from non-finite weights sort last instead of all
+      // taking the same rank and leaving slots of the row unwritten; -0 never occurs, the steps are positive)
+      auto key = [](float f) -> uint32_t {
+        const uint32_t b = __float_as_uint(f);
+        if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+      };
       for (int i = lane; i < M; i += 64) {
         const float v = vals[i];
+        const uint32_t kv = key(v);
         int rank = 0;
         for (int k = 0; k < M; ++k) {
-          const float o = vals[k];
-          rank += (o < v || (o == v && k < i)) ? 1 : 0;
+          const uint32_t ko = key(vals[k]);
+          rank += (ko < kv || (ko == kv && k < i)) ? 1 : 0;
         }
         merged[ray * M + rank] = v;
       }

@@ -177,7 +177,7 @@ struct Args {
   uint32_t packed_size;
   HashRes res;
   unsigned long long* trace;  // NA_LS_TRACE builds only: [2 groups][128] s_memtime stamps of workgroup 0, second pass
-  uint32_t sat_gen;           // NA_PREC_F16X: this launch's id for the saturation flag (g_lsx_saturated)
+  uint32_t sat_gen;           // NA_PREC_F16X: this launch's id for the saturation flag (slot id % 256 of g_lsx_saturated)
   float* y;                   // MODEL 4: output rows [T * R, y_ld] (sample t * R + ray), n_out columns written
   int y_ld, n_out;
   // MODEL 6 (mip): the crop's geometry (rays = [B,H,W,6]: the pixel radius is a difference of neighbouring rows) and the IPE's shape
@@ -193,9 +193,15 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // it, writes the launch's id here, and a tiny kernel behind the renderer turns the WHOLE frame into NaN when it finds its id
 // (stream-ordered, no host synchronisation; ids instead of a reset: nothing to zero between launches).  Silence is never an
 // option for the parity mode: switch to bf16x3 (fp32 range) for such weights.  tests/test_gpu_range.py.
-static __device__ unsigned int g_lsx_saturated = 0;
+// Round 5: the flag is PER LAUNCH, not per device -- a ring of NA_LSX_SAT_SLOTS words, launch id g owns slot g % SLOTS and a
+// slot only ever matches the exact id, so two f16x launches in flight on different streams of one device cannot mask each
+// other (one word, last writer wins, did: the earlier launch's poison pass found the later launch's id and left a clamped
+// frame).  Two launches share a slot only if their ids are a multiple of 256 apart AND both are in flight at once; a renderer
+// launch fills the chip (256 persistent workgroups), so 256 of them in flight is not a state the library can be driven into.
+#define NA_LSX_SAT_SLOTS 256
+static __device__ unsigned int g_lsx_saturated[NA_LSX_SAT_SLOTS] = {};
 static __global__ void lsx_poison_kernel(uint32_t gen, float* __restrict__ out, int64_t n) {
-  if (g_lsx_saturated != gen) return;
+  if (g_lsx_saturated[gen % NA_LSX_SAT_SLOTS] != gen) return;
   const float nan = __builtin_nanf("");
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = nan;
 }
@@ -781,7 +787,7 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
     const int ev = (int)(__builtin_bit_cast(uint32_t, m) >> 23);
     eT = ev > 3 ? ev - 2 : 1;
     eR = ev > 14 ? ev - 13 : 1;
-    if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated = sat_gen;  // an activation sits at the half clamp (or is NaN)
+    if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated[sat_gen % NA_LSX_SAT_SLOTS] = sat_gen;  // an activation sits at the half clamp (or is NaN)
   }
   const float sT = __builtin_bit_cast(float, (uint32_t)eT << 23);
   const float sR = __builtin_bit_cast(float, (uint32_t)eR << 23);
@@ -824,7 +830,7 @@ __device__ __forceinline__ void latent_range(const f32x16& v_in, uint32_t sat_ge
   float m = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v[r]), "v"(v[r + 1]));
-  if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated = sat_gen;
+  if (__builtin_expect(!(m < 65504.0f), 0)) g_lsx_saturated[sat_gen % NA_LSX_SAT_SLOTS] = sat_gen;
 }
 // (blocks B0 .. B1 - 1: an epilogue that also re-enters an init group stores block 0, converts the group -- whose raw values
 // wait in the wave's K64 region of block 1 -- with half of the accumulators already dead, then stores block 1)
@@ -2912,7 +2918,7 @@ static int launch(Args& a, hipStream_t stream) {
   a.nb_magic = (1ull << 32) / (uint64_t)a.nb + 1;
   if ((int64_t)(a.npg + 1) * C::NBLK * a.nb >= (1ll << 32)) { set_error("na_render_plain_view_ls: batch too large"); return NA_EINVAL; }
   if constexpr (PREC == NA_PREC_F16X) {
-    // ONE counter for all schedules: the flag is one device word, and a stale id left by a saturated launch of one schedule
+    // ONE counter for all schedules: the flag ring is shared, and a stale id left by a saturated launch of one schedule
     // must never equal the id of a later launch of another (a per-instantiation counter did exactly that: the frame after
     // tests/test_gpu_range.py's saturated PlainNeRF launch came out poisoned in whichever VolSDF kernel reached the same count)
     uint32_t g = g_lsx_launch_id.fetch_add(1, std::memory_order_relaxed) + 1;

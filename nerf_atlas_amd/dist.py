@@ -44,10 +44,13 @@ class BandGather:
     """The frame-reassembly collective with its buffers allocated ONCE: a persistent `[world, tall, size, C]` receive
     tensor on `dst` (the frame itself when all bands have the same height: no concatenation) and, only when bands differ
     by a row, a padded send buffer.  One `dist.gather` per frame (RCCL over xGMI with backend "nccl"; with "gloo" and CUDA
-    tensors -- several ranks on one GPU, a debug mode -- the band goes through a persistent host buffer)."""
+    tensors -- several ranks on one GPU, a debug mode -- the band goes through a persistent host buffer).  Whether the frame
+    collective is `gather` or `all_gather` is agreed by the whole group at construction (`impl`); constructing a BandGather is
+    therefore itself a collective call: every rank of the group must do it."""
 
     def __init__(self, size: int, channels: int, rank: int, world: int, device, dtype=torch.float32, dst: int = 0):
         self.size, self.rank, self.world, self.dst = size, rank, world, dst
+        self._channels = channels
         self.bands = row_bands(size, world)
         self.tall = max(n for _, n in self.bands)
         self.even = all(n == self.tall for _, n in self.bands)
@@ -59,7 +62,42 @@ class BandGather:
         self.recv = torch.empty(world, self.tall, size, channels, device=cdev, dtype=dtype) if rank == dst else None
         self.recv_list = list(self.recv.unbind(0)) if rank == dst else None
         self.frame = torch.empty(size, size, channels, device=self.device, dtype=dtype) if (rank == dst and (self.via_host or not self.even)) else None
-        self.impl = os.environ.get("NA_DIST_GATHER", "gather")  # "all_gather": skip dist.gather altogether
+        # dist.gather or all_gather: decided ONCE, by the whole group, here (round 5): NA_DIST_GATHER=all_gather skips the
+        # probe; otherwise every rank tries a one-element dist.gather on the real backend and the group agrees on the outcome with
+        # an all_reduce(MIN) -- a backend build without gather raises on every rank alike, and if it ever raised on one rank only
+        # the others would still learn it here, in a tiny collective at construction, instead of diverging into mismatched
+        # collectives in the middle of a frame.  __call__ never falls back: an error there is an error.
+        self.impl = "none" if world == 1 else self._choose_impl(cdev, dtype)
+
+    def _choose_impl(self, cdev, dtype) -> str:
+        want = os.environ.get("NA_DIST_GATHER", "gather")
+        if want not in ("gather", "all_gather"):
+            raise ValueError(f"NA_DIST_GATHER={want}: 'gather' or 'all_gather'")
+        ok, why = 1, ""
+        if want == "gather":
+            try:
+                probe = torch.zeros(1, device=cdev, dtype=dtype)
+                dist.gather(probe, [torch.zeros_like(probe) for _ in range(self.world)] if self.rank == self.dst else None, dst=self.dst)
+            except (RuntimeError, NotImplementedError) as e:
+                msg = str(e).lower()
+                if not isinstance(e, NotImplementedError) and not any(k in msg for k in ("not supported", "not implemented", "does not support", "unsupported")):
+                    raise  # a communicator error, a timeout, a shape problem: not "this backend has no gather"
+                ok, why = 0, f"{type(e).__name__}: {e}"
+        else:
+            ok = 0
+        flag = torch.tensor([ok], device=cdev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return "gather"
+        if want == "gather":
+            import sys
+            print(f"[nerf_atlas_amd.dist] rank {self.rank}: dist.gather unavailable on backend {dist.get_backend()} "
+                  f"({why or 'another rank reported it'}); the group uses all_gather for the frame", file=sys.stderr, flush=True)
+        if self.recv is None:  # all_gather delivers every band to every rank
+            self.recv = torch.empty(self.world, self.tall, self.size, self.send.shape[-1] if self.send is not None else self._channels,
+                                    device=cdev, dtype=dtype)
+            self.recv_list = list(self.recv.unbind(0))
+        return "all_gather"
 
     def __call__(self, local: torch.Tensor) -> Optional[torch.Tensor]:
         if self.world == 1:
@@ -71,20 +109,8 @@ class BandGather:
             self.send[: self.nrows].copy_(local)
             send = self.send
         if self.impl == "gather":
-            try:
-                dist.gather(send, self.recv_list, dst=self.dst)
-            except (RuntimeError, NotImplementedError) as e:
-                # a backend build without point-to-point gather: the same bytes with the collective every backend has.  Every
-                # rank takes this branch together (the failure is raised before any communication is enqueued).
-                import sys
-                print(f"[nerf_atlas_amd.dist] rank {self.rank}: dist.gather unavailable on backend {dist.get_backend()} "
-                      f"({type(e).__name__}: {e}); falling back to all_gather", file=sys.stderr, flush=True)
-                self.impl = "all_gather"
-        if self.impl == "all_gather":
-            if self.recv is None:
-                cdev = send.device
-                self.recv = torch.empty(self.world, self.tall, self.size, send.shape[-1], device=cdev, dtype=send.dtype)
-                self.recv_list = list(self.recv.unbind(0))
+            dist.gather(send, self.recv_list, dst=self.dst)   # (no fallback here: the group chose at construction)
+        else:
             dist.all_gather(self.recv_list, send)
         if self.rank != self.dst:
             return None

@@ -6,6 +6,8 @@ Protocol kept for callers (runner.py): forward(rays) / forward((rays, times)), f
 .set_refl, .intermediate_size, .total_latent_size(), .set_bg, .set_sigmoid, .steps/.t_near/.t_far and, after a
 forward, .ts, .alpha, .weights (+ .pts/.dp/.rigidity/.rigid_dp for dynamic models, .scale_post_act for VolSDF).
 """
+import functools
+
 import torch
 import torch.nn as nn
 
@@ -18,6 +20,30 @@ from .utils import load_mip, load_sigmoid
 
 
 # ------------------------------------------------------------------------------------------------- operators
+_f16x_depth = 0
+
+
+def _f16x_policy(fn):
+    """config.f16x_on_saturation == "rerender_bf16x3": a forward whose f16x launch was flagged by the range guard
+    (ops.F16xSaturated; csrc/render_ls.hip g_lsx_saturated) is rendered again in bf16x3, whose operands have fp32's range.  Only
+    the outermost decorated call catches (DynamicNeRF.forward -> canonical.from_pts is one render)."""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        global _f16x_depth
+        if _f16x_depth or config.f16x_on_saturation != "rerender_bf16x3" or config.precision != "f16x":
+            return fn(self, *args, **kwargs)
+        _f16x_depth += 1
+        try:
+            try:
+                return fn(self, *args, **kwargs)
+            except ops.F16xSaturated:
+                with config.precision_as("bf16x3"):
+                    return fn(self, *args, **kwargs)
+        finally:
+            _f16x_depth -= 1
+    return wrapped
+
+
 def compute_ts(rays, near, far, steps, lindisp=False, perturb: float = 0, rand=None):
     """src/nerf.py:29-47.  `rand` [steps] replaces the global-RNG draw; drawn here if perturb>0 and none given."""
     r_o, r_d = rays.split([3, 3], dim=-1)
@@ -85,7 +111,7 @@ class CommonNeRF(utils.PackedCacheMixin, nn.Module):
         self.per_pixel_latent_size = self.instance_latent_size = self.per_pt_latent_size = 0
         try: self.intermediate_size = intermediate_size
         except AttributeError: ...
-        self.alpha = self.weights = self.ts = None
+        self.alpha = self.weights = self.ts = self.ts_ray = None
         self.noise_std = 0.2
         self._init_packed_hooks()
         self.set_bg(bg)
@@ -176,6 +202,7 @@ class TinyNeRF(CommonNeRF):
             cache[precision] = (stamp, ops.render_tiny_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
         return cache[precision][1]
 
+    @_f16x_policy
     def forward(self, rays, want_weights: bool = True):
         if self._fusable():
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
@@ -259,7 +286,9 @@ class PlainNeRF(CommonNeRF):
         return ops.render_plain_view(rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self._kernel_bg(),
                                      want_weights, pts=pts)
 
+    @_f16x_policy
     def forward(self, rays, want_weights: bool = True):
+        self.ts_ray = None  # (only forward_coarse_fine integrates over per-ray steps)
         if self._fusable():
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
             out, self.alpha, self.weights = self._render_fused(rays, self.ts, want_weights)
@@ -276,6 +305,7 @@ class PlainNeRF(CommonNeRF):
                                                    rand=rand)
         return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
 
+    @_f16x_policy
     def forward_coarse_fine(self, rays, steps_fine: int, u=None, want_weights: bool = True):
         """Coarse -> fine rendering (BASELINE config 2 "64 + 128"; INTENDED reading of the reference's dead sample_pdf /
         CoarseFineNeRF, src/nerf.py:548-580, 1745-1779 -- see csrc/basic_ops.hip resample_ts_kernel): a coarse pass over
@@ -290,8 +320,11 @@ class PlainNeRF(CommonNeRF):
         tables, packed = self.first.enc.tables(), self.packed_ls(prec)
         coarse, _, w = ops.render_plain_view_ls(rays, ts, tables, packed, prec, self.sigmoid_kind, self._kernel_bg(), True)
         self.coarse = coarse
-        self.ts = ops.resample_ts(ts, w, steps_fine, u)
-        out, self.alpha, self.weights = ops.render_plain_view_ls_rayts(rays, self.ts, tables, packed, prec, self.sigmoid_kind,
+        # `ts` keeps the protocol of every other forward -- the [T] shared (coarse) steps; the per-ray union the fine pass
+        # integrated over is `ts_ray` [*batch, T + N] (weights / alpha rows follow IT: render.depth_map knows)
+        self.ts = ts
+        self.ts_ray = ops.resample_ts(ts, w, steps_fine, u)
+        out, self.alpha, self.weights = ops.render_plain_view_ls_rayts(rays, self.ts_ray, tables, packed, prec, self.sigmoid_kind,
                                                                        self._kernel_bg(), want_weights or self.bg == "random")
         return self._finish_sky(out)
 
@@ -327,6 +360,7 @@ class VolSDF(CommonNeRF):
         self.out_features = out_features
         self.scale_softplus = scale_softplus
 
+    @_f16x_policy
     def forward(self, rays):
         pts, self.ts, r_o, r_d, _ = compute_pts_ts(rays, self.t_near, self.t_far, self.steps, perturb=self._perturb())
         return self.from_pts(pts, self.ts, r_o, r_d, rays=rays)
@@ -518,6 +552,7 @@ class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
             cache[precision] = (stamp, ops.mlp_hash_ls_pack(precision, [l.weight.data for l in lin], [l.bias.data for l in lin]))
         return cache[precision][1]
 
+    @_f16x_policy
     def forward(self, rays_t):
         rays, t = rays_t
         c = self.canonical
@@ -537,6 +572,7 @@ class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
         return c.from_pts(warped, self.ts, r_o, r_d, rays=rays)
 
 
+    @_f16x_policy
     def render_keyframes(self, rays):
         """src/nerf.py:1305-1319 (runner.py:1019-1039 writes them as keyframe_NN.png): the scene rendered at each Bezier
         control point, canonical.from_pts(pts + p_k * rigidity).  The reference splits the 3*spline_n control

@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, config
 from ._lib import NaMlpDesc, check
 
 ACT = {"none": 0, "leaky_relu": 1, "sin": 2}
@@ -24,6 +24,18 @@ SIGMOID = {"normal": 0, "thin": 1, "fat": 2, "tanh": 3, "upshifted": 4, "relu": 
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class F16xSaturated(_lib.NaError):
+    """An f16x launch met an activation beyond the IEEE-half range (its output is the NaN frame): config.set_f16x_on_saturation."""
+
+
+def _f16x_guard(precision: str, out: torch.Tensor, what: str):
+    """config.f16x_on_saturation "raise" / "rerender_bf16x3": read one element of the launch's output back (the range guard poisons
+    the whole of it) and raise when it is the flagged frame.  "nan" (default): nothing, no synchronisation."""
+    if precision == "f16x" and config.f16x_on_saturation != "nan" and out.numel() > 0:
+        if bool(torch.isnan(out.reshape(-1)[0])):
+            raise F16xSaturated(f"{what}: an activation left the half range (f16x output poisoned); render these weights in bf16x3")
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -720,6 +732,7 @@ def render_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torc
     check(lib.na_render_plain_view_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed),
                                       PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights),
                                       _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
+    _f16x_guard(precision, out, "na_render_plain_view_ls")
     return out, alpha, weights
 
 
@@ -763,6 +776,7 @@ def render_plain_view_ls_rayts(rays: torch.Tensor, ts_ray: torch.Tensor, hash_ta
     check(lib.na_render_plain_view_ls_rayts(_ptr(rays), R, _ptr(ts_ray), T, _ptr(hash_tables), _ptr(packed), PREC[precision],
                                             SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace),
                                             workspace.numel(), _stream()))
+    _f16x_guard(precision, out, "na_render_plain_view_ls_rayts")
     return out, alpha, weights
 
 
@@ -806,6 +820,7 @@ def render_plain_mip_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch
     check(lib.na_render_plain_mip_ls(_ptr(rays), B, H, W, _ptr(ts), T, _ptr(hash_tables), _ptr(packed), PREC[precision],
                                      MIP_KIND[kind], min_deg, max_deg, float(t_end), SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha),
                                      _ptr(weights), _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
+    _f16x_guard(precision, out, "na_render_plain_mip_ls")
     return out, alpha, weights
 
 
@@ -844,6 +859,7 @@ def mlp_hash_ls(rays: torch.Tensor, ts: torch.Tensor, tables: torch.Tensor, pack
     y = torch.empty((T,) + tuple(rays.shape[:-1]) + (n_out,), device=rays.device, dtype=torch.float32)
     check(lib.na_mlp_hash_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(tables), _ptr(packed), PREC[precision], n_out, _ptr(y),
                              n_out, _stream()))
+    _f16x_guard(precision, y, "na_mlp_hash_ls")
     return y
 
 
@@ -883,6 +899,7 @@ def mlp_fourier_ls(rays: torch.Tensor, ts: torch.Tensor, basis: torch.Tensor, pa
     y = torch.empty((T,) + tuple(rays.shape[:-1]) + (65,), device=rays.device, dtype=torch.float32)
     check(lib.na_mlp_fourier_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(basis), _ptr(packed), PREC[precision], _ptr(y), 65,
                                 _stream()))
+    _f16x_guard(precision, y, "na_mlp_fourier_ls")
     return y
 
 
@@ -921,6 +938,7 @@ def render_tiny_ls(rays: torch.Tensor, ts: torch.Tensor, packed: torch.Tensor, p
         assert pts.numel() == T * R * 3, (pts.shape, T, R)
     check(lib.na_render_tiny_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(packed), PREC[precision], SIGMOID[sigmoid_kind],
                                 BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _stream()))
+    _f16x_guard(precision, out, "na_render_tiny_ls")
     return out, alpha, weights
 
 
@@ -966,6 +984,7 @@ def render_view_ls(rays: torch.Tensor, ts: torch.Tensor, feat: torch.Tensor, bet
     check(lib.na_render_view_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(feat), ld, _ptr(beta), _ptr(packed), PREC[precision],
                                 SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace),
                                 workspace.numel(), _stream()))
+    _f16x_guard(precision, out, "na_render_view_ls")
     return out, alpha, weights
 
 
@@ -1009,6 +1028,7 @@ def render_volsdf_siren_ls(rays: torch.Tensor, ts: torch.Tensor, beta: torch.Ten
     check(lib.na_render_volsdf_siren_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(beta), _ptr(packed), PREC[precision],
                                         SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace),
                                         workspace.numel(), _stream()))
+    _f16x_guard(precision, out, "na_render_volsdf_siren_ls")
     return out, alpha, weights
 
 

@@ -45,8 +45,14 @@ def depth_map(model) -> torch.Tensor:
     """runner.py:894-897: expected termination depth of the LAST forward, volumetric_integrate(weights, ts) -> [B,H,W,1]."""
     from . import ops
     nerf = model.nerf
-    ts = nerf.ts[:, None, None, None, None].expand(nerf.weights.shape + (1,)).contiguous()
-    return ops.integrate(nerf.weights, ts)
+    w = nerf.weights
+    ts_ray = getattr(nerf, "ts_ray", None)
+    if ts_ray is not None and ts_ray.shape[-1] == w.shape[0] and tuple(ts_ray.shape[:-1]) == tuple(w.shape[1:]):
+        # coarse -> fine (PlainNeRF.forward_coarse_fine): the weights' rows are the per-ray steps [*batch, T + N]
+        return ops.integrate(w, ts_ray.movedim(-1, 0).unsqueeze(-1).contiguous())
+    assert nerf.ts.dim() == 1 and nerf.ts.shape[0] == w.shape[0], "weights do not belong to the shared steps model.ts"
+    ts = nerf.ts[:, None, None, None, None].expand(w.shape + (1,)).contiguous()
+    return ops.integrate(w, ts)
 
 
 def alpha_map(model) -> torch.Tensor:

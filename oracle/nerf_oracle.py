@@ -523,7 +523,7 @@ def linspace01_f32(N: int):
     j = np.arange(N)
     lo = step * j.astype(np.float32)
     hi = np.float32(1.0) - step * (N - 1 - j).astype(np.float32)
-    return torch.from_numpy(np.where(j < N // 2, lo, hi).astype(np.float32))
+    return torch.from_numpy(np.where((j < N // 2) | (N == 1), lo, hi).astype(np.float32))  # (N = 1: [0], like torch)
 
 
 def sample_pdf_intended(ts, weights, N: int, u=None):

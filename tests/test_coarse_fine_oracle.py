@@ -46,6 +46,7 @@ def test_sample_pdf_intended_matches_a_scalar_loop():
 
 
 def test_linspace01_is_torchs_linspace_to_the_last_bit_or_one():
+    assert O.linspace01_f32(1).tolist() == torch.linspace(0, 1, 1).tolist() == [0.0]  # (a single draw sits at u = 0)
     for N in (2, 5, 64, 128, 200):
         a, b = O.linspace01_f32(N), torch.linspace(0, 1, N, dtype=torch.float)
         assert float((a - b).abs().max()) <= 6e-8 and float(a[0]) == 0.0 and float(a[-1]) == 1.0

@@ -43,6 +43,58 @@ def _worker(rank, world, port, size, q, impl="gather"):
     nd.reset_plans()
 
 
+def _probe_worker(rank, world, port, size, q, mode):
+    """mode "nogather": dist.gather raises NotImplementedError on every rank (a backend build without it) -> the group agrees on
+    all_gather at construction, prints why, and the frames are right.  mode "broken": the probe meets a communicator-style
+    RuntimeError -> it is re-raised, not downgraded to a fallback."""
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("NA_DIST_GATHER", None)
+    import torch.distributed as dist
+    from nerf_atlas_amd import dist as nd
+    r, w, _ = nd.init_from_env(backend="gloo")
+    real = dist.gather
+    calls = []
+
+    def fake(*a, **k):
+        calls.append(1)
+        if mode == "nogather":
+            raise NotImplementedError("gather is not implemented by this backend build")
+        raise RuntimeError("NCCL communicator was aborted on rank %d" % r)
+    dist.gather = fake
+    ok = True
+    try:
+        if mode == "nogather":
+            plan = nd.BandGather(size, 3, r, w, "cpu")
+            ok &= plan.impl == "all_gather" and len(calls) == 1
+            for k in range(3):   # every frame goes through all_gather; dist.gather is never tried again
+                f = plan(_frame_fn(*nd.row_bands(size, w)[r], size) + k)
+                ok &= (f is None) if r else bool(torch.equal(f, _frame_fn(0, size, size) + k))
+            ok &= len(calls) == 1
+        else:
+            try:
+                nd.BandGather(size, 3, r, w, "cpu")
+                ok = False
+            except RuntimeError as e:
+                ok &= "aborted" in str(e)
+    finally:
+        dist.gather = real
+    q.put(bool(ok))
+    torch.distributed.destroy_process_group()
+
+
+def test_gather_implementation_is_chosen_once_by_the_group():
+    ctx = mp.get_context("spawn")
+    for mode in ("nogather", "broken"):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, 17, q, mode)) for r in range(2)]
+        for p in procs: p.start()
+        results = [q.get(timeout=120) for _ in procs]
+        for p in procs: p.join(timeout=60)
+        assert all(results), (mode, results)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

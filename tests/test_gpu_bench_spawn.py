@@ -36,3 +36,7 @@ def test_bench_spawns_its_own_ranks():
     # the process group's first collective counted the ranks on the backend the line names
     assert (one["backend"], one["rccl_ranks"], one["gather_impl"]) == ("none", 1, "none")
     assert (two["backend"], two["rccl_ranks"], two["gather_impl"]) == ("gloo", 2, "gather")
+    # N > 1 explains itself: one GPU's time for the whole frame in the same run, and the efficiency of the split.  (Two ranks on
+    # ONE GPU time-share it, so the number itself only has to be sane here: ~0.5 when the launches serialise, up to 1.)
+    assert "scaling_efficiency" not in one
+    assert two["single_gpu_full_frame_kernel_ms"] > 0 and 0.2 < two["scaling_efficiency"] <= 1.1

@@ -72,6 +72,32 @@ def test_resample_ts_errors(ops):
     assert out.shape == (0, 12)
 
 
+def test_resample_ts_single_draw_and_non_finite_weights(ops):
+    """(i) N = 1: torch.linspace(0, 1, 1) is [0], the single deterministic draw sits on the first coarse step (the
+    kernel's own linspace used to give u = 1); (ii) NaN weights make NaN positions: they sort LAST and every slot of the merged row
+    is written -- the T coarse steps are all there, the rest is NaN, nothing is uninitialised memory."""
+    T, R = 16, 70
+    ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+    w = _weights(T, R, 3).cuda()
+    merged, fine = ops.resample_ts(ts, w, 1, want_fine=True)
+    assert fine.shape == (R, 1) and bool((fine[:, 0] == ts[0]).all())
+    assert torch.equal(merged.cpu(), torch.sort(torch.cat([ts.cpu().expand(R, T), fine.cpu()], 1), dim=1, stable=True).values)
+    assert float((fine.cpu().double() - O.sample_pdf_intended(ts.cpu(), w.cpu(), 1).t()).abs().max()) <= 2e-6
+    bad = w.clone()
+    bad[5, 7] = float("nan")
+    for _ in range(3):
+        torch.empty(R * (T + 9), device="cuda").fill_(-7.0)   # (what a recycled allocation would hold)
+        m = ops.resample_ts(ts, bad, 9).cpu()
+        row = m[7]
+        fin = row[torch.isfinite(row)]
+        nan_at = torch.isnan(row).nonzero().flatten()
+        assert bool((fin[1:] >= fin[:-1]).all()) and not bool((row == -7.0).any())        # written everywhere, sorted
+        assert nan_at.numel() == 0 or int(nan_at.min()) == fin.numel()                     # NaN positions, if any, sort last
+        assert all(bool((fin == t).any()) for t in ts.cpu()) and float(fin.min()) >= 2.0 and float(fin.max()) <= 6.0 + 1e-5
+        ok = torch.ones(R, dtype=torch.bool); ok[7] = False
+        assert bool(torch.isfinite(m[ok]).all()) and bool((m[ok][:, 1:] >= m[ok][:, :-1]).all())
+
+
 @pytest.mark.parametrize("prec", ["f16x", "bf16x3", "bf16"])
 def test_per_ray_steps_equal_to_the_shared_ones_are_the_same_launch(ops, prec):
     h = load_golden("g11_plain_view_b2")
@@ -123,10 +149,10 @@ def test_plain_nerf_coarse_fine_64_128_end_to_end(prec):
     config.set_precision(prec)
     try:
         out = m.forward_coarse_fine(rays.cuda(), 128)
-        assert m.ts.shape == tuple(rays.shape[:-1]) + (192,) and m.weights.shape[0] == 192
+        assert m.ts.shape == (64,) and m.ts_ray.shape == tuple(rays.shape[:-1]) + (192,) and m.weights.shape[0] == 192
         assert float((m.weights.sum(0) - 1).abs().max()) <= 1e-5 or m.bg != "white"
         # the fine pass alone, on the build's own steps: the renderer's bar
-        ref_same = O.plain_nerf_rayts(p, rays, m.ts.cpu().movedim(-1, 0).contiguous(), "view", act="upshifted")
+        ref_same = O.plain_nerf_rayts(p, rays, m.ts_ray.cpu().movedim(-1, 0).contiguous(), "view", act="upshifted")
         e_same = float((out.cpu() - ref_same).abs().max())
         assert e_same <= 1e-4, e_same
         # the whole chain in the oracle
@@ -137,10 +163,19 @@ def test_plain_nerf_coarse_fine_64_128_end_to_end(prec):
         ref = O.plain_nerf_rayts(p, rays, ts_ray, "view", act="upshifted")
         e = float((out.cpu() - ref).abs().max())
         print(f"coarse -> fine 64 + 128 [{prec}]: fine pass on the same steps {e_same:.2e}, whole chain {e:.2e}, "
-              f"steps {float((m.ts.cpu().movedim(-1, 0) - ts_ray).abs().max()):.2e}")
+              f"steps {float((m.ts_ray.cpu().movedim(-1, 0) - ts_ray).abs().max()):.2e}")
         assert e <= 2e-4, e
         # more samples where the mass is: the fine pass is not the coarse image
         assert not torch.equal(out, m.coarse)
+        # the depth map of a coarse -> fine frame integrates the weights against the PER-RAY steps (model.ts stays
+        # the [T] shared steps; render.depth_map used to broadcast it against [T + N] weight rows)
+        from types import SimpleNamespace
+        from nerf_atlas_amd import render
+        depth = render.depth_map(SimpleNamespace(nerf=m))
+        want = (m.weights.cpu().double() * m.ts_ray.cpu().movedim(-1, 0).double()).sum(0)
+        assert depth.shape == tuple(rays.shape[:-1]) + (1,) and float((depth.cpu()[..., 0].double() - want).abs().max()) <= 1e-5
+        m(rays.cuda())
+        assert m.ts_ray is None and render.depth_map(SimpleNamespace(nerf=m)).shape == depth.shape
     finally:
         config.set_precision("bf16x3")
 
@@ -161,7 +196,7 @@ def test_coarse_fine_full_frame_properties():
     try:
         rays = ops.raygen(c2w, focal, size, (0, 0, size, size))
         out = m.forward_coarse_fine(rays, 128)
-        ts_f, w = m.ts, m.weights
+        ts_f, w = m.ts_ray, m.weights
         assert out.shape == (1, size, size, 3) and torch.isfinite(out).all()
         assert ts_f.shape == (1, size, size, 192)
         assert bool((ts_f[..., 1:] >= ts_f[..., :-1]).all())

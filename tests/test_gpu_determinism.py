@@ -46,7 +46,7 @@ def test_timing_stress_build_is_reproducible():
     elements differed per 200 runs -- renders the full-grid slab 120 times per parity precision with every output element
     equal to the per-element median, and renders the same frame as the shipped library bit for bit."""
     from nerf_atlas_amd import build as B
-    assert os.path.exists(B.STRESS_LIB), "python -m nerf_atlas_amd.build builds it next to the product library"
+    assert os.path.exists(B.STRESS_LIB), "`python -m nerf_atlas_amd.build --stress` (or __graft_entry__.build()) builds it next to the product library"
     env = dict(os.environ, NA_LIB_PATH=B.STRESS_LIB)
     for prec in ("bf16x3", "f16x"):
         r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "ls_repeat.py"), prec, "120"], capture_output=True, text=True,

@@ -94,3 +94,82 @@ def test_a_stale_flag_never_matches_another_schedules_launch():
         assert torch.isnan(out_bad).all()
         for _ in range(12):  # (per-schedule counters collide within the first few launches of the other schedule)
             assert torch.isfinite(ops.render_tiny_ls(rays, ts, tiny, "f16x", "upshifted", "black")[0]).all()
+
+
+def _launch(ops, rays, ts, tables, packed):
+    return ops.render_plain_view_ls(rays, ts, tables, packed, "f16x", "upshifted", "black", want_weights=False)[0]
+
+
+def test_the_flag_is_per_launch_across_streams():
+    """VERDICT r04 weak 2 / ADVICE: the flag used to be ONE device word, last writer wins -- two f16x launches in flight on different
+    streams of one device that both saturate: B overwrote A's id before A's poison pass ran and A's frame stayed clamped and
+    finite.  Round 5: a ring of per-launch slots (id % 256, exact id match).  (i) two saturating launches racing on two streams:
+    BOTH frames are NaN, every time; (ii) a clean launch racing a saturating one stays clean and exact."""
+    from nerf_atlas_amd import ops
+    from test_gpu_render_ls import pack_ls
+    h = load_golden("g11_plain_view_b1")
+    good = golden_params(h)
+    bad = {k: v.clone() for k, v in good.items()}
+    bad["first.layers.2.weight"] *= 1e7
+    size, T = 800, 128
+    focal = 0.5 * size / math.tan(0.5 * 0.6911)
+    c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]).cuda()
+    ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+    # big enough that the two launches overlap in time (each ~10 ms), small enough for a test
+    rays_a = ops.raygen(c2w, focal, size, (300, 0, 48, 800))
+    rays_b = ops.raygen(c2w, focal, size, (400, 0, 48, 800))
+    p_bad, tables_bad = pack_ls(ops, bad, "f16x")
+    p_good, tables_good = pack_ls(ops, good, "f16x")
+    ref_good = _launch(ops, rays_b, ts, tables_good, p_good).clone()
+    assert torch.isfinite(ref_good).all()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(6):
+        with torch.cuda.stream(s1):
+            a = _launch(ops, rays_a, ts, tables_bad, p_bad)
+        with torch.cuda.stream(s2):
+            b = _launch(ops, rays_b, ts, tables_bad, p_bad)
+        torch.cuda.synchronize()
+        assert torch.isnan(a).all() and torch.isnan(b).all(), (it, int(torch.isnan(a).sum()), int(torch.isnan(b).sum()))
+        # a clean launch beside a saturating one, in both issue orders
+        first, second = (s1, s2) if it % 2 == 0 else (s2, s1)
+        with torch.cuda.stream(first):
+            a = _launch(ops, rays_a, ts, tables_bad, p_bad)
+        with torch.cuda.stream(second):
+            b = _launch(ops, rays_b, ts, tables_good, p_good)
+        torch.cuda.synchronize()
+        assert torch.isnan(a).all() and torch.equal(b, ref_good), it
+
+
+def test_saturation_policy_at_the_model_layer():
+    """config.set_f16x_on_saturation: "nan" (default) returns the poisoned frame asynchronously; "raise" turns it into
+    ops.F16xSaturated; "rerender_bf16x3" renders the same forward again in the fp32-range parity mode."""
+    import nerf_atlas_amd.nerf as nerf
+    from nerf_atlas_amd import config, ops
+    from test_gpu_fullsize import load_params
+    h = load_golden("g11_plain_view_b1")
+    good = golden_params(h)
+    bad = {k: v.clone() for k, v in good.items()}
+    bad["first.layers.2.weight"] *= 1e7
+    m = nerf.PlainNeRF(steps=int(h["steps"]), t_near=float(h["near"]), t_far=float(h["far"]), intermediate_size=64,
+                       sigmoid_kind="upshifted").cuda().eval()
+    rays = h["rays"].cuda()
+    config.set_precision("f16x")
+    try:
+        load_params(m, bad)
+        assert config.f16x_on_saturation == "nan" and torch.isnan(m(rays)).all()
+        config.set_f16x_on_saturation("raise")
+        with pytest.raises(ops.F16xSaturated):
+            m(rays)
+        config.set_f16x_on_saturation("rerender_bf16x3")
+        out = m(rays)
+        assert torch.isfinite(out).all() and config.precision == "f16x"
+        with config.precision_as("bf16x3"):
+            assert torch.equal(out, m(rays))
+        load_params(m, good)          # in-range weights: the policy costs a read-back and changes nothing
+        out = m(rays)
+        config.set_f16x_on_saturation("nan")
+        assert torch.equal(out, m(rays)) and torch.isfinite(out).all()
+    finally:
+        config.set_f16x_on_saturation("nan")
+        config.set_precision("bf16x3")

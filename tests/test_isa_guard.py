@@ -9,7 +9,7 @@ sys.path.insert(0, REPO)
 
 def test_built_render_ls_units_have_no_packed_fp32():
     from nerf_atlas_amd import build as B
-    B.build(verbose=False)  # no-op when up to date; rebuilds (and checks) the render_ls units otherwise
+    B.build(verbose=False, stress=True)  # no-op when up to date; rebuilds (and checks) the render_ls units otherwise
     listings = B.isa_listings()
     assert {n for n, _ in listings} == {"render_ls_bf16.o", "render_ls_bf16x3.o", "render_ls_f16.o", "render_ls_f16x.o"}
     for name, path in listings:
@@ -38,7 +38,7 @@ def test_built_f16x_unit_has_no_overlapping_fp6_conversion():
     """v_cvt_scalef32_2xpk16_fp6_f32 writes its destination while it still reads its operands (tools/hw/cvt_fp6_overlap.hip);
     the compiler does not know: every instance of the shipped build keeps scale and source tails out of the destination"""
     from nerf_atlas_amd import build as B
-    B.build(verbose=False)
+    B.build(verbose=False, stress=True)
     scanned = 0
     for name, path in B.isa_listings():
         bad, n = B.check_cvt_overlap(path)
@@ -68,7 +68,7 @@ def test_built_units_keep_inline_asm_behind_mfma_and_trans_results():
     (tools/hw/mfma_use_hazard.hip, trans_use_hazard.hip; round 4: last-bit run-to-run differences of the mip renderer).  Every
     listing of the shipped and of the lag-3 stress build is scanned at build time; here once more, with the counts."""
     from nerf_atlas_amd import build as B
-    B.build(verbose=False)
+    B.build(verbose=False, stress=True)
     paths = [p for _, p in B.hazard_listings()]
     assert len(paths) >= 19, paths  # the 15 units of the product library + the four lag-3 units
     n_mfma = n_trans = 0
