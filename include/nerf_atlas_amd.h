@@ -258,6 +258,17 @@ int na_render_plain_view_pts(const float* rays, const float* pts, int64_t R, con
  * na_linear_dgrad_bf16x3  g_x0[N,in0] | g_x1[N,in1] = (dY[N,out] . W) * act'([x0|x1]); Wt = W^T as
  *                         [in0+in1, out] row-major; either output may be NULL; x0/x1 = the forward inputs.
  * na_linear_wgrad_bf16x3  same contract as na_linear_wgrad.
+ * na_linear_wgrad_bf16x3_ow  the same gradient WRITTEN to dW / db instead of accumulated (no zero fill by the caller).
+ * Round 5 -- one pack launch per training step instead of one per GEMM (the reference's loop, runner.py:647-825, re-reads
+ * nn.Linear.weight in every F.linear; here the bf16 hi / lo MFMA fragments of every Linear are built once per step):
+ * na_train_packed_bytes   bytes of the packed form of an [M, K] B operand (0: no packed form, M > 1024).
+ * na_train_pack_many      n operands in ONE launch: operand i is the M[i] x K[i] matrix B[m,k] = W[i][m * ld[i] + k], or with
+ *                         transposed[i] B[m,k] = W[i][k * ld[i] + m] (the input gradient's W^T read straight from
+ *                         nn.Linear.weight: no transposing copy); dst[i]: na_train_packed_bytes(M[i], K[i]) bytes, 16-byte aligned.
+ * na_train_gemm_packed_ok 1 if a batch of N rows with M output columns runs the kernels that take packed operands
+ *                         (N >= 2048, M <= 1024, NA_TRAIN_GEMM != tiled), else 0: call the unpacked entry points.
+ * na_linear_bf16x3_pk / na_linear_dgrad_bf16x3_pk   na_linear_bf16x3 / na_linear_dgrad_bf16x3 with the packed W [out, in0+in1] /
+ *                         packed W^T [in0+in1, out] in place of the matrix (NA_EUNSUPPORTED where ..._packed_ok says 0).
  * na_hash_encode_backward  tables_grad[8,65536,4] += trilinear weights x g_out[N, 32(+3)]
  *                      (src/neural_blocks.py:166-190).
  * na_hash_encode_backward_input  g_x[N,3] = d(features)/d(position) . g_out (+ g_out[:, :3] with
@@ -302,6 +313,16 @@ int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt,
                            const float* x1, int in1, int pre_act, float* g_x0, float* g_x1, void* stream);
 int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
                            int pre_act, float* dW, float* db, void* stream);
+int na_linear_wgrad_bf16x3_ow(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                              int pre_act, float* dW, float* db, void* stream);
+size_t na_train_packed_bytes(int M, int K);
+int na_train_gemm_packed_ok(int64_t N, int M);
+int na_train_pack_many(int n, const float* const* W, const int* M, const int* K, const int* ld, const int* transposed,
+                       void* const* dst, void* stream);
+int na_linear_bf16x3_pk(const float* x0, int in0, const float* x1, int in1, int64_t N, const void* w_packed, const float* b,
+                        int out, int pre_act, float* y, void* stream);
+int na_linear_dgrad_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0,
+                              const float* x1, int in1, int pre_act, float* g_x0, float* g_x1, void* stream);
 int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
                     int pre_act, float* dW, float* db, void* stream);
 int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input,

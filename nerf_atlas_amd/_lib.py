@@ -103,6 +103,16 @@ SIGNATURES = {
                                   C.c_void_p]),
     "na_linear_wgrad_bf16x3": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p,
                                          c_f32p, C.c_void_p]),
+    "na_linear_wgrad_bf16x3_ow": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p,
+                                            c_f32p, C.c_void_p]),
+    "na_train_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "na_train_gemm_packed_ok": (C.c_int, [c_i64, C.c_int]),
+    "na_train_pack_many": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p]),
+    "na_linear_bf16x3_pk": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p,
+                                      C.c_void_p]),
+    "na_linear_dgrad_bf16x3_pk": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_void_p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, c_f32p,
+                                            c_f32p, C.c_void_p]),
     "na_hash_encode_backward": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_hash_encode_backward_input": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_hash_encode_jvp": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
@@ -188,7 +198,9 @@ def load():
 
 
 class NaError(RuntimeError):
-    def __init__(self, code, msg):
+    def __init__(self, code, msg=None):
+        if msg is None:  # raised by the host layer itself (ops.py): NaError("...") -- no C status code
+            code, msg = -1, code
         super().__init__(f"nerf_atlas_amd error {code}: {msg}")
         self.code = code
 

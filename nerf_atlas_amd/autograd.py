@@ -20,13 +20,17 @@ class LinearFn(Function):
     "fp32": exact f32-MFMA Linear, act_backward and weight-gradient kernels."""
 
     @staticmethod
-    def forward(ctx, x0, x1, W, b, act):
+    def forward(ctx, x0, x1, W, b, act, packs=None):
+        """packs: None or (packed W, packed W^T | None) from ops.train_pack_many (SkipConnMLP._forward_train packs every Linear of
+        the network with one launch per step) -- only meaningful in the "bf16x3" training arithmetic."""
         ctx.act = act
         ctx.fast = config.train_precision == "bf16x3"
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0, device=x0.device), W)
         ctx.has_x1 = x1 is not None
         ctx.has_b = b is not None
-        return ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=ctx.fast)
+        ctx.packed_t = packs[1] if (packs is not None and ctx.fast) else None
+        return ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=ctx.fast,
+                              packed=packs[0] if (packs is not None and ctx.fast) else None)
 
     @staticmethod
     def backward(ctx, gy):
@@ -37,7 +41,7 @@ class LinearFn(Function):
         gx0 = gx1 = gW = gb = None
         want0, want1 = ctx.needs_input_grad[0], ctx.has_x1 and ctx.needs_input_grad[1]
         if (want0 or want1) and ctx.fast:
-            gx0, gx1 = ops.linear_dgrad(gy, W, x0, ctx.act, x1, want0, want1)
+            gx0, gx1 = ops.linear_dgrad(gy, W, x0, ctx.act, x1, want0, want1, packed_t=ctx.packed_t)
         elif want0 or want1:
             g_act = ops.linear_f32(gy, W.t().contiguous(), None)  # [N, in0+in1] = dL/d act(x)
             if want0:
@@ -48,7 +52,7 @@ class LinearFn(Function):
                 gx1 = ops.act_backward(x1, g1, ctx.act) if ctx.act != "none" else g1
         if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
             gW, gb = ops.linear_wgrad(x0, gy, ctx.act, x1, want_bias=ctx.has_b, split_bf16=ctx.fast)
-        return gx0, gx1, gW, gb, None
+        return gx0, gx1, gW, gb, None, None
 
 
 class HashEncodeFn(Function):

@@ -198,7 +198,9 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // other (one word, last writer wins, did: the earlier launch's poison pass found the later launch's id and left a clamped
 // frame).  Two launches share a slot only if their ids are a multiple of 256 apart AND both are in flight at once; a renderer
 // launch fills the chip (256 persistent workgroups), so 256 of them in flight is not a state the library can be driven into.
+#ifndef NA_LSX_SAT_SLOTS  // (-DNA_LSX_SAT_SLOTS=1 rebuilds round 4's single word: tests/test_gpu_range.py's two-stream test then fails)
 #define NA_LSX_SAT_SLOTS 256
+#endif
 static __device__ unsigned int g_lsx_saturated[NA_LSX_SAT_SLOTS] = {};
 static __global__ void lsx_poison_kernel(uint32_t gen, float* __restrict__ out, int64_t n) {
   if (g_lsx_saturated[gen % NA_LSX_SAT_SLOTS] != gen) return;

@@ -592,6 +592,46 @@ __global__ void pack_kernel(const float* __restrict__ W, int M, int K, int NCH, 
   }
 }
 
+// Round 5: every B operand of a training step packed by ONE launch (na_train_pack_many: the forward's W and the input gradient's
+// W^T of all Linears of an MLP -- 24 pack launches, 12 transposing copies and their launch gaps per PlainNeRF step before).
+// Entry e packs B_e[m, k] = trans ? W[k * ld + m] : W[m * ld + k] (M x K, zero padded) into dst_e; same layout, same rounding as
+// pack_kernel.
+constexpr int kPackMany = 32;
+struct PackMany {
+  const float* W[kPackMany];
+  char* dst[kPackMany];
+  int M[kPackMany], K[kPackMany], ld[kPackMany], trans[kPackMany], NCH[kPackMany];
+  long long first[kPackMany + 1];  // thread index where entry e starts
+  int n;
+};
+__global__ void pack_many_kernel(PackMany pm) {
+  const long long total = pm.first[pm.n];
+  for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int e = 0;
+    while (e + 1 < pm.n && g >= pm.first[e + 1]) ++e;  // (wave-uniform but for the few waves that straddle two entries)
+    const long long i = g - pm.first[e];
+    const int M = pm.M[e], K = pm.K[e], NCH = pm.NCH[e], ld = pm.ld[e];
+    const float* __restrict__ W = pm.W[e];
+    const int lane = (int)(i & 63), ks = (int)((i >> 6) & 7), t = (int)((i >> 9) & 1);
+    const int c = (int)((i >> 10) % NCH), rg = (int)((i >> 10) / NCH);
+    const int m = 64 * rg + 32 * t + (lane & 31), k0 = KC * c + 16 * ks + 8 * (lane >> 5);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = 0.f;
+      if (m < M && k0 + q < K) v = pm.trans[e] ? W[(int64_t)(k0 + q) * ld + m] : W[(int64_t)m * ld + k0 + q];
+      const __bf16 h = (__bf16)v;
+      hi[q] = h;
+      lo[q] = (__bf16)(v - (float)h);
+    }
+    char* o = pm.dst[e] + (int64_t)(i >> 6) * 2048 + lane * 16;
+    *(bf16x8*)o = hi;
+    *(bf16x8*)(o + 1024) = lo;
+  }
+}
+static inline int pack_nch(int K) { int n = (K + KC - 1) / KC; return n < 2 ? 2 : n; }
+static inline size_t packed_bytes(int M, int K) { return (size_t)((M + 63) / 64) * pack_nch(K) * 2 * SEG; }
+
 // Four consecutive columns `col` .. `col + 3` of row `row` (tile-relative) of the concatenation [p0 (k0 columns) | p1 (k1)],
 // zero outside, WITHOUT branches or waits between pieces: buffer loads whose offset lies outside the tile's buffer return
 // zero, so every piece issues the same few loads and only the offsets differ (a branchy loader made the compiler wait for
@@ -1085,8 +1125,9 @@ static int cu_count() {
 }
 
 // Bmat = the [M, K] row-major operand (weights, or their transpose for the input gradient)
+// prepacked: the operand as na_train_pack_many left it (round 5) -- no scratch allocation, no pack launch
 template <int MODE>
-static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* what) {
+static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* what, const char* prepacked = nullptr) {
   const bool dact = MODE == 1 && a.act != NA_ACT_NONE;
   a.NCH = (K + KC - 1) / KC;
   if (a.NCH < 2) a.NCH = 2;  // the output tile in LDS is stored (and x parked) in a unit in which the consumers do not touch it
@@ -1094,11 +1135,13 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
   if (nrg > 16) { set_error("%s: more than 1024 output columns", what); return NA_EUNSUPPORTED; }
   const size_t wbytes = (size_t)nrg * a.NCH * 2 * SEG;
   char* wp = nullptr;
-  hipError_t e = hipMallocAsync((void**)&wp, wbytes, st);
-  if (e != hipSuccess) { (void)hipGetLastError(); return kNoScratch; }  // no stream-ordered scratch here: the caller takes the K-staged kernel
-  const int64_t nthr = (int64_t)nrg * a.NCH * 2 * 8 * 64;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.NCH, nrg, wp);
-  a.wp = wp;
+  if (prepacked == nullptr) {
+    hipError_t e = hipMallocAsync((void**)&wp, wbytes, st);
+    if (e != hipSuccess) { (void)hipGetLastError(); return kNoScratch; }  // no stream-ordered scratch here: the caller takes the K-staged kernel
+    const int64_t nthr = (int64_t)nrg * a.NCH * 2 * 8 * 64;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.NCH, nrg, wp);
+  }
+  a.wp = prepacked != nullptr ? prepacked : wp;
   a.ntiles = (a.a.rows + TS - 1) / TS;
   const int grid = a.ntiles < cu_count() ? (int)a.ntiles : cu_count();
   const bool straddle = a.a.k1 > 0 && a.a.k0 % KC != 0;  // (forward only: the gradient's A operand is a single matrix)
@@ -1117,7 +1160,7 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
     else done[2 * dact + straddle].fetch_or(bit, std::memory_order_release);
   }
   if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, st, a);
-  (void)hipFreeAsync(wp, st);
+  if (wp != nullptr) (void)hipFreeAsync(wp, st);
   if (rc != NA_OK) return rc;
   return check_launch(what);
 }
@@ -1333,42 +1376,76 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   }
 }
 
-// dW[row, col] += sum over workgroups; db likewise over workgroups x 8 row groups.  A block = 64 elements x 4 quarters of the
+// dW[row, col] (+)= sum over workgroups; db likewise over workgroups x 8 row groups.  A block = 64 items x 4 quarters of the
 // workgroup range: every thread sums its quarter in index order, the quarters are combined in LDS in a fixed order, so the result
 // does not depend on timing (and 256 sequential 256-KiB-strided reads per element became 4 x 64 in parallel).
+// Round 5: an item = FOUR consecutive columns of one row, read as one 16-byte load per partial (the partial rows have pitch 256:
+// always aligned) with four partials in flight -- the per-element order of additions is unchanged, so are the bits; 23 -> ~13 us per
+// 256 x 256 gradient (67 MB of partials).  `overwrite`: dW / db are written, not accumulated into (no zero fill by the caller).
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw,
-                                                     float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float red[4][64];
+                                                     float* __restrict__ dW, float* __restrict__ db, int overwrite) {
+  __shared__ f32x4 red[4][64];
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int in4 = (in + 3) >> 2;
+  const int nI = out * in4;                 // 4-column items of dW
+  const int nB = db != nullptr ? (out + 3) >> 2 : 0;
   const int idx = blockIdx.x * 64 + e;
-  const int nW = out * in;
   const int w0 = (int)((int64_t)nwg * q / 4), w1 = (int)((int64_t)nwg * (q + 1) / 4);
-  float s = 0.f;
-  if (idx < nW) {
-    const int row = idx / in, col = idx % in;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int row = 0, col = 0;
+  if (idx < nI) {
+    row = idx / in4;
+    col = 4 * (idx % in4);
     const float* p = part + row * 256 + col;
-    for (int w = w0; w < w1; ++w) s += p[(int64_t)w * PART];
-  } else if (db != nullptr && idx < nW + out) {
-    const float* p = part + 256 * 256 + (idx - nW);
-    for (int w = w0; w < w1; ++w) {
-      float t = 0.f;
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+      const f32x4 a = *(const f32x4*)(p + (int64_t)w * PART), b = *(const f32x4*)(p + (int64_t)(w + 1) * PART);
+      const f32x4 c = *(const f32x4*)(p + (int64_t)(w + 2) * PART), d = *(const f32x4*)(p + (int64_t)(w + 3) * PART);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += p[(int64_t)w * PART + k * 256];
-      s += t;
+      for (int k = 0; k < 4; ++k) s[k] = (((s[k] + a[k]) + b[k]) + c[k]) + d[k];
+    }
+    for (; w < w1; ++w) {
+      const f32x4 a = *(const f32x4*)(p + (int64_t)w * PART);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += a[k];
+    }
+  } else if (idx < nI + nB) {
+    col = 4 * (idx - nI);
+    const float* p = part + 256 * 256 + col;
+    for (int w = w0; w < w1; ++w) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const f32x4 a = *(const f32x4*)(p + (int64_t)w * PART + k * 256);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] += a[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += t[c];
     }
   }
   red[q][e] = s;
   __syncthreads();
   if (q == 0) {
-    const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-    if (idx < nW) dW[(int64_t)(idx / in) * ldw + idx % in] += t;
-    else if (db != nullptr && idx < nW + out) db[idx - nW] += t;
+    f32x4 t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = ((red[0][e][k] + red[1][e][k]) + red[2][e][k]) + red[3][e][k];
+    if (idx < nI) {
+      float* o = dW + (int64_t)row * ldw + col;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (col + k < in) o[k] = overwrite ? t[k] : o[k] + t[k];
+    } else if (idx < nI + nB) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (col + k < out) db[col + k] = overwrite ? t[k] : db[col + k] + t[k];
+    }
   }
 }
 
 // one source of the concatenation: dW[:, 0 .. in) at leading dimension ldw
 static int launch(const float* dY, int out, const float* x, int in, int act, int64_t N, float* dW, int ldw, float* db,
-                  hipStream_t st, const char* what) {
+                  hipStream_t st, const char* what, int overwrite = 0) {
   Args a{};
   a.dY = dY; a.x = x; a.out = out; a.in = in; a.act = act; a.N = N; a.want_db = db != nullptr;
   const int64_t nst = (N + SS - 1) / SS;
@@ -1394,8 +1471,8 @@ static int launch(const float* dY, int out, const float* x, int in, int act, int
   }
   if (rc == NA_OK) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, st, a);
-    const int n = out * in + (db != nullptr ? out : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, grid, out, in, ldw, dW, db);
+    const int n = out * ((in + 3) / 4) + (db != nullptr ? (out + 3) / 4 : 0);
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, grid, out, in, ldw, dW, db, overwrite);
   }
   (void)hipFreeAsync(part, st);
   if (rc != NA_OK) return rc;
@@ -1466,9 +1543,15 @@ int na_linear_dgrad_bf16x3(const float* dY, int out, int64_t N, const float* Wt,
   return dispatch_nt<1>(a, in0 + in1, (hipStream_t)stream, "na_linear_dgrad_bf16x3");
 }
 
-int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
-                    int pre_act, float* dW, float* db, void* stream) {
-  if (N == 0) return NA_OK;  // empty batch: nothing to read or write (zero-size tensors carry null pointers)
+static int wgrad_bf16x3_impl(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                             int pre_act, float* dW, float* db, void* stream, int overwrite) {
+  if (N == 0) {  // empty batch: nothing to read (zero-size tensors carry null pointers); an overwriting call still defines its outputs
+    if (overwrite && dW != nullptr && out >= 1 && in0 + in1 >= 1) {
+      (void)hipMemsetAsync(dW, 0, (size_t)out * (in0 + in1) * sizeof(float), (hipStream_t)stream);
+      if (db != nullptr) (void)hipMemsetAsync(db, 0, (size_t)out * sizeof(float), (hipStream_t)stream);
+    }
+    return NA_OK;
+  }
   NA_REQUIRE(x0 && dY && dW, NA_ENULL, "na_linear_wgrad_bf16x3: null pointer");
   NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_wgrad_bf16x3: bad shape");
   NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_wgrad_bf16x3: in1>0 needs x1");
@@ -1477,13 +1560,20 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
   // a skip layer are [hidden 256 | encoding 38 or 69]); wider shapes and small batches stay on the K-staged kernel.
   const bool ls0 = lsnt_wanted(N, out) && out <= 256 && in0 <= 256 && in1 <= 256;
   if (ls0) {
-    int rc = lstn::launch(dY, out, x0, in0, pre_act, N, dW, in0 + in1, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+    int rc = lstn::launch(dY, out, x0, in0, pre_act, N, dW, in0 + in1, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3", overwrite);
     if (rc != lsnt::kNoScratch) {
       if (rc != NA_OK || in1 == 0) return rc;
-      rc = lstn::launch(dY, out, x1, in1, pre_act, N, dW + in0, in0 + in1, nullptr, (hipStream_t)stream, "na_linear_wgrad_bf16x3");
+      rc = lstn::launch(dY, out, x1, in1, pre_act, N, dW + in0, in0 + in1, nullptr, (hipStream_t)stream, "na_linear_wgrad_bf16x3", overwrite);
       if (rc != lsnt::kNoScratch) return rc;
       // (no scratch for the second source only: the K-staged kernel below would add the first source's columns twice)
       set_error("na_linear_wgrad_bf16x3: stream-ordered scratch allocation failed between the two sources");
+      return NA_EHIP;
+    }
+  }
+  if (overwrite) {  // the K-staged kernel accumulates with atomics: define the outputs first
+    if (hipMemsetAsync(dW, 0, (size_t)out * (in0 + in1) * sizeof(float), (hipStream_t)stream) != hipSuccess ||
+        (db != nullptr && hipMemsetAsync(db, 0, (size_t)out * sizeof(float), (hipStream_t)stream) != hipSuccess)) {
+      set_error("na_linear_wgrad_bf16x3_ow: hipMemsetAsync failed");
       return NA_EHIP;
     }
   }
@@ -1528,6 +1618,78 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
     return NA_OK;
   }
   return check_launch("na_linear_wgrad_bf16x3");
+}
+
+int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                           int pre_act, float* dW, float* db, void* stream) {
+  return wgrad_bf16x3_impl(x0, in0, x1, in1, N, dY, out, pre_act, dW, db, stream, 0);
+}
+
+int na_linear_wgrad_bf16x3_ow(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
+                              int pre_act, float* dW, float* db, void* stream) {
+  return wgrad_bf16x3_impl(x0, in0, x1, in1, N, dY, out, pre_act, dW, db, stream, 1);
+}
+
+// ---- round 5: the B operands of a whole training step packed by one launch, and the GEMMs that take them --------------------
+int na_train_gemm_packed_ok(int64_t N, int M) { return (M >= 1 && lsnt_wanted(N, M)) ? 1 : 0; }
+
+size_t na_train_packed_bytes(int M, int K) { return (M >= 1 && M <= 1024 && K >= 1) ? lsnt::packed_bytes(M, K) : 0; }
+
+int na_train_pack_many(int n, const float* const* W, const int* M, const int* K, const int* ld, const int* transposed,
+                       void* const* dst, void* stream) {
+  NA_REQUIRE(n >= 0, NA_EINVAL, "na_train_pack_many: n < 0");
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(W && M && K && ld && transposed && dst, NA_ENULL, "na_train_pack_many: null pointer");
+  for (int base = 0; base < n; base += lsnt::kPackMany) {
+    lsnt::PackMany pm{};
+    pm.n = n - base < lsnt::kPackMany ? n - base : lsnt::kPackMany;
+    long long total = 0;
+    for (int e = 0; e < pm.n; ++e) {
+      const int i = base + e;
+      NA_REQUIRE(W[i] && dst[i], NA_ENULL, "na_train_pack_many: null matrix %d", i);
+      NA_REQUIRE(M[i] >= 1 && M[i] <= 1024 && K[i] >= 1 && ld[i] >= (transposed[i] ? M[i] : K[i]), NA_EINVAL,
+                 "na_train_pack_many: bad shape of matrix %d (M=%d K=%d ld=%d)", i, M[i], K[i], ld[i]);
+      NA_REQUIRE(((uintptr_t)dst[i] & 15) == 0, NA_EINVAL, "na_train_pack_many: destination %d is not 16-byte aligned", i);
+      pm.W[e] = W[i]; pm.dst[e] = (char*)dst[i]; pm.M[e] = M[i]; pm.K[e] = K[i]; pm.ld[e] = ld[i]; pm.trans[e] = transposed[i] != 0;
+      pm.NCH[e] = lsnt::pack_nch(K[i]);
+      pm.first[e] = total;
+      total += (long long)((M[i] + 63) / 64) * pm.NCH[e] * 2 * 8 * 64;
+    }
+    pm.first[pm.n] = total;
+    hipLaunchKernelGGL(lsnt::pack_many_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pm);
+  }
+  return check_launch("na_train_pack_many");
+}
+
+int na_linear_bf16x3_pk(const float* x0, int in0, const float* x1, int in1, int64_t N, const void* w_packed, const float* b,
+                        int out, int pre_act, float* y, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(x0 && w_packed && y, NA_ENULL, "na_linear_bf16x3_pk: null pointer");
+  NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_bf16x3_pk: bad shape");
+  NA_REQUIRE(in1 == 0 || x1 != nullptr, NA_ENULL, "na_linear_bf16x3_pk: in1>0 needs x1");
+  NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bf16x3_pk: activation %d", pre_act);
+  NA_REQUIRE(lsnt_wanted(N, out), NA_EUNSUPPORTED, "na_linear_bf16x3_pk: this batch / width runs the K-staged kernel: call "
+             "na_linear_bf16x3 (na_train_gemm_packed_ok says which)");
+  lsnt::Args l{};
+  l.a = RowSrc{x0, x1, in0, in1, N};
+  l.M = out; l.act = pre_act; l.bias = b; l.y0 = y; l.c0 = out;
+  return lsnt::launch<0>(l, nullptr, in0 + in1, (hipStream_t)stream, "na_linear_bf16x3_pk", (const char*)w_packed);
+}
+
+int na_linear_dgrad_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0,
+                              const float* x1, int in1, int pre_act, float* g_x0, float* g_x1, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(dY && wt_packed && (g_x0 || g_x1), NA_ENULL, "na_linear_dgrad_bf16x3_pk: null pointer");
+  NA_REQUIRE(in0 >= 1 && in1 >= 0 && out >= 1 && N >= 0, NA_EINVAL, "na_linear_dgrad_bf16x3_pk: bad shape");
+  NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_dgrad_bf16x3_pk: activation %d", pre_act);
+  NA_REQUIRE(pre_act == NA_ACT_NONE || ((g_x0 == nullptr || x0) && (g_x1 == nullptr || in1 == 0 || x1)), NA_ENULL,
+             "na_linear_dgrad_bf16x3_pk: the activation derivative needs the forward inputs");
+  NA_REQUIRE(lsnt_wanted(N, in0 + in1), NA_EUNSUPPORTED, "na_linear_dgrad_bf16x3_pk: this batch / width runs the K-staged kernel: call "
+             "na_linear_dgrad_bf16x3 (na_train_gemm_packed_ok says which)");
+  lsnt::Args l{};
+  l.a = RowSrc{dY, nullptr, out, 0, N};
+  l.M = in0 + in1; l.act = pre_act; l.y0 = g_x0; l.y1 = in1 > 0 ? g_x1 : nullptr; l.x0 = x0; l.x1 = x1; l.c0 = in0; l.c1 = in1;
+  return lsnt::launch<1>(l, nullptr, out, (hipStream_t)stream, "na_linear_dgrad_bf16x3_pk", (const char*)wt_packed);
 }
 
 }  // extern "C"

@@ -306,14 +306,46 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         if lat is not None:
             init = torch.cat([init, lat], dim=-1)
         init = init.contiguous()
-        x = ag.LinearFn.apply(init, None, self.init.weight, self.init.bias, "none")
+        packs = self._train_packs(init)
+        x = ag.LinearFn.apply(init, None, self.init.weight, self.init.bias, "none", packs[0])
         n = len(self.layers)
         for i, layer in enumerate(self.layers):
             skip = i != n - 1 and (i % self.skip) == 0
-            x = ag.LinearFn.apply(x, init if skip else None, layer.weight, layer.bias, self.act_name)
+            x = ag.LinearFn.apply(x, init if skip else None, layer.weight, layer.bias, self.act_name, packs[1 + i])
         if self.last_layer_act:
             setattr(self, "last_layer_out", x)
-        return ag.LinearFn.apply(x, None, self.out.weight, self.out.bias, self.act_name)
+        return ag.LinearFn.apply(x, None, self.out.weight, self.out.bias, self.act_name, packs[-1])
+
+    def _train_packs(self, init):
+        """[(packed W, packed W^T | None) | None per Linear] for the split-bf16 training GEMMs: the bf16 hi / lo MFMA fragments of
+        EVERY Linear of this network -- the forward's W and the input gradient's W^T, read straight from the Parameters -- built
+        by ONE launch per training step (round 5; 24 pack launches + 12 transposing copies per PlainNeRF step before).  None where
+        the batch or a shape takes the K-staged kernels (ops.train_gemm_packed_ok), or in the exact-fp32 arithmetic."""
+        lins = self._linears()
+        if config.train_precision != "bf16x3" or not init.is_cuda:
+            return [None] * len(lins)
+        N = init.shape[0]
+        need_in = [init.requires_grad] + [True] * (len(lins) - 1)   # (a hidden layer's input always needs its gradient)
+        want, mats = [], []
+        for lin, nd in zip(lins, need_in):
+            W = lin.weight
+            ok = (W.is_contiguous() and W.dtype == torch.float32 and ops.train_gemm_packed_ok(N, W.shape[0])
+                  and ops.train_gemm_packed_ok(N, W.shape[1]))
+            want.append((ok, ok and nd))
+            if ok:
+                mats.append((W, False))
+                if nd:
+                    mats.append((W, True))
+        views = iter(ops.train_pack_many(mats))
+        out = []
+        for ok, bw in want:
+            if not ok:
+                out.append(None)
+                continue
+            f = next(views)
+            t = next(views) if bw else None
+            out.append((f, t) if f is not None and (t is not None or not bw) else None)
+        return out
 
     def forward_with_input_tangents(self, p):
         """(y [N,out], t [3,N,out]) with t[j] = d y / d p_j, propagated FORWARD through the network next to the values

@@ -401,9 +401,9 @@ def occlusion_apply(spectrum: torch.Tensor, visible: Optional[torch.Tensor] = No
 
 
 def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre_act: str = "none",
-               x1: Optional[torch.Tensor] = None, split_bf16: bool = False) -> torch.Tensor:
+               x1: Optional[torch.Tensor] = None, split_bf16: bool = False, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = W . act([x0 | x1]) + b: exact fp32 (f32 MFMA), or with split_bf16 the 3-product bf16 split used by the
-    training step (relative error ~2^-16, 5x the matrix-core rate)."""
+    training step (relative error ~2^-16, 5x the matrix-core rate).  packed: W as train_pack_many left it (split_bf16 only)."""
     lib = _lib.load()
     x0, W = _f32(x0, "x0"), _f32(W, "W")
     N = x0.shape[0]
@@ -416,14 +416,52 @@ def linear_f32(x0: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], pre
     if b is not None:
         b = _f32(b, "b")
     y = torch.empty(N, W.shape[0], device=x0.device, dtype=torch.float32)
+    if split_bf16 and packed is not None:
+        check(lib.na_linear_bf16x3_pk(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(packed), _ptr(b), W.shape[0], ACT[pre_act], _ptr(y),
+                                      _stream()))
+        return y
     fn = lib.na_linear_bf16x3 if split_bf16 else lib.na_linear_f32
     check(fn(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(W), _ptr(b), W.shape[0], ACT[pre_act], _ptr(y), _stream()))
     return y
 
 
+def train_gemm_packed_ok(N: int, M: int) -> bool:
+    """Does a batch of N rows with M output columns run the training GEMMs that take packed operands (na_train_gemm_packed_ok)?"""
+    return bool(_lib.load().na_train_gemm_packed_ok(int(N), int(M)))
+
+
+def train_pack_many(mats):
+    """ONE launch packs every B operand of a training step (na_train_pack_many).  mats: [(W [rows, cols] fp32 contiguous,
+    transposed)] -- the operand is W itself (a forward's [out, in]) or, with transposed, W^T (an input gradient's [in, out], read
+    straight from W).  Returns the packed operands as uint8 views of one buffer (None where the shape has no packed form)."""
+    lib = _lib.load()
+    n = len(mats)
+    if n == 0:
+        return []
+    Ws = [_f32(w.detach(), "W") for w, _ in mats]
+    Ms = [int(w.shape[1] if t else w.shape[0]) for (w, t) in mats]
+    Ks = [int(w.shape[0] if t else w.shape[1]) for (w, t) in mats]
+    sizes = [int(lib.na_train_packed_bytes(m, k)) for m, k in zip(Ms, Ks)]
+    offs, total = [], 0
+    for sz in sizes:
+        offs.append(total)
+        total += (sz + 255) & ~255
+    buf = torch.empty(max(total, 16), device=Ws[0].device, dtype=torch.uint8)
+    views = [buf[o:o + sz] if sz else None for o, sz in zip(offs, sizes)]
+    idx = [i for i, sz in enumerate(sizes) if sz]
+    if idx:
+        k = len(idx)
+        check(lib.na_train_pack_many(k, (C.c_void_p * k)(*[Ws[i].data_ptr() for i in idx]), (C.c_int * k)(*[Ms[i] for i in idx]),
+                                     (C.c_int * k)(*[Ks[i] for i in idx]), (C.c_int * k)(*[int(Ws[i].shape[1]) for i in idx]),
+                                     (C.c_int * k)(*[int(bool(mats[i][1])) for i in idx]),
+                                     (C.c_void_p * k)(*[views[i].data_ptr() for i in idx]), _stream()))
+    return views
+
+
 def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, x0: torch.Tensor, pre_act: str = "none",
-                 x1: Optional[torch.Tensor] = None, want0: bool = True, want1: bool = True):
-    """(g_x0 [N,in0] | None, g_x1 [N,in1] | None) = (dY . W) * act'([x0|x1]) for y = W . act([x0|x1]) + b."""
+                 x1: Optional[torch.Tensor] = None, want0: bool = True, want1: bool = True, packed_t: Optional[torch.Tensor] = None):
+    """(g_x0 [N,in0] | None, g_x1 [N,in1] | None) = (dY . W) * act'([x0|x1]) for y = W . act([x0|x1]) + b.
+    packed_t: W^T as train_pack_many left it (no transposing copy, no pack launch)."""
     lib = _lib.load()
     dY, W, x0 = _f32(dY, "dY"), _f32(W, "W"), _f32(x0, "x0")
     N, in0 = x0.shape
@@ -433,11 +471,15 @@ def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, x0: torch.Tensor, pre_act: s
         in1 = x1.shape[1]
     out = dY.shape[1]
     assert W.shape == (out, in0 + in1) and dY.shape[0] == N
-    Wt = W.t().contiguous()  # [in, out]: the K-contiguous operand of the input-gradient GEMM (<= 0.6 MB)
     g0 = torch.empty_like(x0) if want0 else None
     g1 = torch.empty_like(x1) if (want1 and x1 is not None) else None
     if g0 is None and g1 is None:
         return None, None
+    if packed_t is not None:
+        check(lib.na_linear_dgrad_bf16x3_pk(_ptr(dY), out, N, _ptr(packed_t), _ptr(x0), in0, _ptr(x1), in1, ACT[pre_act], _ptr(g0),
+                                            _ptr(g1), _stream()))
+        return g0, g1
+    Wt = W.t().contiguous()  # [in, out]: the K-contiguous operand of the input-gradient GEMM (<= 0.6 MB)
     check(lib.na_linear_dgrad_bf16x3(_ptr(dY), out, N, _ptr(Wt), _ptr(x0), in0, _ptr(x1), in1, ACT[pre_act], _ptr(g0), _ptr(g1),
                               _stream()))
     return g0, g1
@@ -472,13 +514,15 @@ def linear_wgrad(x0: torch.Tensor, dY: torch.Tensor, pre_act: str = "none", x1: 
         x1 = _f32(x1, "x1")
         in1 = x1.shape[1]
     out = dY.shape[1]
-    # (one zero fill for both accumulators: db sits behind dW, on a 16-byte boundary)
+    # (one buffer for both results: db sits behind dW, on a 16-byte boundary; the split-bf16 entry point WRITES them -- round 5:
+    # no zero fill --, the exact-fp32 one accumulates)
     nW = out * (in0 + in1)
     pad = (-nW) % 4
-    acc = torch.zeros(nW + pad + (out if want_bias else 0), device=x0.device, dtype=torch.float32)
+    alloc = torch.empty if split_bf16 else torch.zeros
+    acc = alloc(nW + pad + (out if want_bias else 0), device=x0.device, dtype=torch.float32)
     dW = acc[:nW].view(out, in0 + in1)
     db = acc[nW + pad:] if want_bias else None
-    fn = lib.na_linear_wgrad_bf16x3 if split_bf16 else lib.na_linear_wgrad
+    fn = lib.na_linear_wgrad_bf16x3_ow if split_bf16 else lib.na_linear_wgrad
     check(fn(_ptr(x0), in0, _ptr(x1), in1, N, _ptr(dY), out, ACT[pre_act], _ptr(dW), _ptr(db), _stream()))
     return dW, db
 

@@ -111,3 +111,99 @@ def test_layer_synchronous_and_k_staged_kernels_agree(tmp_path):
             worst = max(worst, float((ta - tb).abs().max() / tb.abs().max()))
     print(f"layer-synchronous vs K-staged: worst relative difference {worst:.2e}")
     assert worst <= 2e-6, worst
+
+
+PK_SHAPES = [(4096, 256, 0, 256), (2048 + 37, 38, 0, 256), (4096 + 63, 256, 69, 256), (4096, 256, 38, 256), (4096 + 1, 256, 0, 65),
+             (4096, 256, 0, 3), (5000, 100, 0, 1000), (4096 + 3, 64, 38, 64)]
+
+
+@pytest.mark.parametrize("shape", PK_SHAPES, ids=lambda s: "N%d_in%d+%d_out%d" % s)
+def test_packed_operands_are_the_same_gemms(ops, shape):
+    """Round 5: ops.train_pack_many builds the bf16 hi / lo fragments of W and of W^T (read straight from W: no transposing copy)
+    in ONE launch; the _pk entry points run the same kernels on them: forward and input gradient bit for bit equal to the entry
+    points that pack per call."""
+    N, in0, in1, out = shape
+    torch.manual_seed(out + in0)
+    x0 = torch.randn(N, in0, device="cuda")
+    x1 = torch.randn(N, in1, device="cuda") if in1 else None
+    W = torch.randn(out, in0 + in1, device="cuda") * (1.0 / (in0 + in1)) ** 0.5
+    W2 = torch.randn(77, 300, device="cuda")          # an unrelated matrix in the same launch: entries do not disturb each other
+    b = torch.randn(out, device="cuda")
+    gy = torch.randn(N, out, device="cuda")
+    assert ops.train_gemm_packed_ok(N, out) and ops.train_gemm_packed_ok(N, in0 + in1) and not ops.train_gemm_packed_ok(100, out)
+    pf, p2, pt = ops.train_pack_many([(W, False), (W2, True), (W, True)])
+    for act in ("leaky_relu", "sin", "none"):
+        y = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True)
+        y_pk = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True, packed=pf)
+        assert torch.equal(y, y_pk)
+        g0, g1 = ops.linear_dgrad(gy, W, x0, act, x1=x1)
+        h0, h1 = ops.linear_dgrad(gy, W, x0, act, x1=x1, packed_t=pt)
+        assert torch.equal(g0, h0) and (g1 is None or torch.equal(g1, h1))
+    # the transposed entry is what packing the materialised transpose gives
+    (pt_ref,) = ops.train_pack_many([(W.t().contiguous(), False)])
+    assert torch.equal(pt, pt_ref)
+    (p2_ref,) = ops.train_pack_many([(W2.t().contiguous(), False)])
+    assert torch.equal(p2, p2_ref)
+
+
+def test_pack_many_takes_more_than_one_launch_worth_of_matrices(ops):
+    torch.manual_seed(3)
+    mats = [(torch.randn(16 + 3 * i, 40 + i, device="cuda"), bool(i & 1)) for i in range(70)]  # > 32 entries: several launches
+    packed = ops.train_pack_many(mats)
+    for (w, t), p in zip(mats, packed):
+        (ref,) = ops.train_pack_many([(w.t().contiguous(), False)] if t else [(w, False)])
+        assert torch.equal(p, ref)
+
+
+@pytest.mark.parametrize("shape", [(4096, 256, 0, 256), (4096 + 5, 256, 38, 256), (3000, 1000, 24, 72), (100, 256, 0, 65)],
+                         ids=lambda s: "N%d_in%d+%d_out%d" % s)
+def test_weight_gradient_accumulating_and_overwriting_entry_points(ops, shape):
+    """na_linear_wgrad_bf16x3 ACCUMULATES into dW / db (its contract since round 1); na_linear_wgrad_bf16x3_ow (round 5, what
+    ops.linear_wgrad calls: no zero fill) WRITES them -- onto whatever the buffer held."""
+    import ctypes as C
+    from nerf_atlas_amd import _lib
+    lib = _lib.load()
+    N, in0, in1, out = shape
+    torch.manual_seed(5)
+    x0 = torch.randn(N, in0, device="cuda")
+    x1 = torch.randn(N, in1, device="cuda") if in1 else None
+    gy = torch.randn(N, out, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    dW, db = ops.linear_wgrad(x0, gy, "sin", x1=x1, split_bf16=True)
+    junk_W = torch.full((out, in0 + in1), float("nan"), device="cuda")
+    junk_b = torch.full((out,), -3.0, device="cuda")
+    _lib.check(lib.na_linear_wgrad_bf16x3_ow(ptr(x0), in0, ptr(x1), in1, N, ptr(gy), out, 2, ptr(junk_W), ptr(junk_b), st))
+    ls = out <= 256 and in0 <= 256 and in1 <= 256 and N >= 2048
+    close = (lambda a, b: torch.equal(a, b)) if ls else (lambda a, b: float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()))
+    assert close(junk_W, dW) and close(junk_b, db)
+    acc_W = torch.ones(out, in0 + in1, device="cuda")
+    acc_b = torch.full((out,), 2.0, device="cuda")
+    _lib.check(lib.na_linear_wgrad_bf16x3(ptr(x0), in0, ptr(x1), in1, N, ptr(gy), out, 2, ptr(acc_W), ptr(acc_b), st))
+    assert close(acc_W, 1.0 + dW) and close(acc_b, 2.0 + db)
+
+
+def test_training_forward_packs_every_linear_once_and_changes_nothing(ops, monkeypatch):
+    """SkipConnMLP._forward_train packs all Linears of the network (W for the forward, W^T for the input gradient) with one launch;
+    outputs and every gradient are bit for bit those of the per-call packing."""
+    from nerf_atlas_amd.neural_blocks import SkipConnMLP, HashEncoder
+    torch.manual_seed(11)
+    m = SkipConnMLP(in_size=3, out=65, enc=HashEncoder(), num_layers=4, hidden_size=256).cuda()
+    p = (torch.rand(4096 + 7, 3, device="cuda") * 2 - 1)
+    w = torch.randn(4096 + 7, 65, device="cuda")
+
+    def run():
+        for q in m.parameters():
+            q.grad = None
+        (m(p) * w).sum().backward()
+        # (the Linears' gradients are bit-reproducible; the hash tables' scatter adds with fp32 atomics in arrival order)
+        return [q.grad.clone() for l in m._linears() for q in l.parameters()], [e.weight.grad.clone() for e in m.enc.embs]
+    calls = []
+    real = ops.train_pack_many
+    monkeypatch.setattr(ops, "train_pack_many", lambda mats: (calls.append(len(mats)), real(mats))[1])
+    got, got_t = run()
+    assert calls == [12]   # 6 Linears x (W, W^T): ONE call = one launch
+    monkeypatch.setattr(SkipConnMLP, "_train_packs", lambda self, init: [None] * len(self._linears()))
+    ref, ref_t = run()
+    assert len(got) == 12 and all(torch.equal(a, b) for a, b in zip(got, ref))
+    assert all(float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) for a, b in zip(got_t, ref_t))
