@@ -1380,8 +1380,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 // workgroup range: every thread sums its quarter in index order, the quarters are combined in LDS in a fixed order, so the result
 // does not depend on timing (and 256 sequential 256-KiB-strided reads per element became 4 x 64 in parallel).
 // Round 5: an item = FOUR consecutive columns of one row, read as one 16-byte load per partial (the partial rows have pitch 256:
-// always aligned) with four partials in flight -- the per-element order of additions is unchanged, so are the bits; 23 -> ~13 us per
-// 256 x 256 gradient (67 MB of partials).  `overwrite`: dW / db are written, not accumulated into (no zero fill by the caller).
+// always aligned) with sixteen partials in flight -- the per-element order of additions is unchanged, so are the bits.  `overwrite`: dW / db are written, not accumulated into (no zero fill by the caller).
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw,
                                                      float* __restrict__ dW, float* __restrict__ db, int overwrite) {
   __shared__ f32x4 red[4][64];
@@ -1398,6 +1397,16 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
     col = 4 * (idx % in4);
     const float* p = part + row * 256 + col;
     int w = w0;
+    // (a launch has one block per CU: what bounds it is bytes in flight -- sixteen 16-byte loads per lane before the first add)
+    for (; w + 16 <= w1; w += 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(p + (int64_t)(w + u) * PART);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += v[u][k];
+    }
     for (; w + 4 <= w1; w += 4) {
       const f32x4 a = *(const f32x4*)(p + (int64_t)w * PART), b = *(const f32x4*)(p + (int64_t)(w + 1) * PART);
       const f32x4 c = *(const f32x4*)(p + (int64_t)(w + 2) * PART), d = *(const f32x4*)(p + (int64_t)(w + 3) * PART);
@@ -1479,6 +1488,230 @@ static int launch(const float* dY, int out, const float* x, int in, int act, int
   return check_launch(what);
 }
 }  // namespace lstn
+
+// ================================================================================================ narrow outputs (round 5)
+// C[N, M] = f(A)[N, 256] . B[M, 256]^T for M <= 128: the out Linears of the networks (256 -> 65, 256 -> 3), the input gradient
+// of the encoder inputs (256 -> 38 / 69: the init Linears and the init part of a skip layer).  Their FLOPs are nothing; they are
+// one pass over an [N, 256] fp32 tensor.  The three-role kernel above is built around a 256-wide output tile (its movers,
+// its weight stream per 64-sample tile) and runs these shapes at 105-130 us per 268 MB, and a skip layer's input gradient
+// [256 | 38] as a second pass that costs as much as the first (393 us against 178 for a plain layer).  Here the whole B
+// operand of a wave's column tile lives in REGISTERS for the whole launch (16 k steps x (hi | lo) fragments = 128 VGPRs, read
+// once from the packed stream of na_train_pack_many), so the kernel is nothing but the row stream: a workgroup of four waves
+// fetches a 32-sample tile as whole contiguous rows one tile ahead, activates / splits it into padded bf16 planes in LDS
+// (double-buffered, one barrier per tile), wave t multiplies it with column tile t, and the 32 x 32 result leaves in the
+// accumulator layout (lane = sample, registers = columns): + bias (forward) or x act'(x) of the matching input (gradient).
+// Same three bf16 products per k, fp32 accumulation.
+namespace nrw {
+constexpr int TS = 32, K = 256;
+constexpr int PITCH = K * 2 + 16;      // 132 dwords = 4 mod 64: conflict-free b128 fragment reads
+constexpr int PLANE = TS * PITCH;
+constexpr int BUF = 2 * PLANE;         // hi | lo
+constexpr int LDS = 2 * BUF;           // 66 KiB
+constexpr int NP = TS * (K / 4) / 256; // 16-byte pieces per loader thread and tile (8)
+#ifndef NRW_AHEAD
+#define NRW_AHEAD 4
+#endif
+#ifndef NRW_ABLATE
+#define NRW_ABLATE 0  // experiments only: 1 no MFMAs, 2 no conversion / LDS stash, 4 no result stores / derivative loads, 8 no row fetches
+#endif
+constexpr int AHEAD = NRW_AHEAD;       // tiles a loader keeps in flight (even; 32 KiB each: the launch is bound by bytes in flight)
+
+struct Args {
+  const float* a;      // [N, 256]
+  int64_t N;
+  const char* wp;      // packed B, at the column group that holds row 0 of this launch (layout of lsnt::pack_kernel, K = 256)
+  int M;               // rows of B = output columns (<= 128)
+  int act;             // MODE 0: activation applied to A; MODE 1: activation whose derivative (at xd) scales the result
+  const float* bias;   // MODE 0 (nullable)
+  const float* xd;     // MODE 1: [N, M] pre-activation inputs (unused with NA_ACT_NONE)
+  float* y;            // [N, M]
+  int64_t ntiles;
+};
+
+// Eight waves, two roles (the rule of the three-role kernel above: the loads and stores of one wave retire in order, so a wave
+// that stores results must not be the wave whose next row fetch the pipeline waits for).  Waves 0-3 = LOADERS: whole contiguous
+// rows of tile i + AHEAD requested (branch-free: out-of-range pieces are dropped by the buffer hardware), tile i activated, split
+// and written into plane buffer i & 1.  Waves 4-7 = CONSUMERS of tile i - 1 in the other buffer: wave 4 + t multiplies it with
+// column tile t.  One workgroup barrier per tile.
+// The result of a tile, 32 rows of M floats, is ONE contiguous run of the output (and so are the derivative's inputs): the
+// consumers leave it in an LDS tile in [row][column] order and carry it out together one step later as 16-byte pieces in
+// address order -- sixteen 4-byte stores per lane scattered a row pitch apart (the accumulator layout) cost 25-50 us of the
+// first version's 70-100 us per launch (ablation, profiles/r05/narrow_bench.log); the derivative's inputs come in the same way.
+constexpr int OT = TS * 128 * 4;       // one output (or derivative-input) tile in LDS: 16 KiB
+constexpr int LDS_ALL = LDS + 2 * OT + 2 * OT;  // planes | two output tiles | two derivative-input tiles = 130 KiB
+template <int MODE>
+__global__ __launch_bounds__(512) void kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = (g.ntiles + gridDim.x - 1) / gridDim.x;       // a contiguous run of tiles per workgroup
+  const int64_t t0 = blockIdx.x * per;
+  const int nt = (int)(t0 >= g.ntiles ? 0 : (t0 + per <= g.ntiles ? per : g.ntiles - t0));
+  char* const otile = smem + LDS;            // [2][32 * M] floats: results of tile t in otile + (t & 1) * OT
+  char* const xtile = smem + LDS + 2 * OT;   // [2][32 * M] floats: derivative inputs of tile t
+  const bool deriv = MODE == 1 && g.act != NA_ACT_NONE;
+  const int npc = (TS * g.M + 3) >> 2;       // 16-byte pieces of a tile's output run (32 M floats: a multiple of 4)
+  if (wave < 4) {
+    // ---------------------------------------------------------------- loaders
+    const int lt = tid;  // 0..255
+    f32x4 pre[AHEAD][NP];
+    f32x4 xpre[AHEAD][4];   // the derivative's inputs of the same tile: <= 1024 pieces, 4 per loader thread
+    auto fetch = [&](int slot, int i) __attribute__((always_inline)) {
+      const int64_t m0 = (t0 + i) * TS;
+      const __amdgpu_buffer_rsrc_t rs = lsnt::tile_rsrc(i < nt ? g.a : nullptr, K, m0 < g.N ? m0 : g.N, g.N, g.a);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int p = lt + 256 * j;
+        if (NRW_ABLATE & 8) pre[slot][j] = f32x4{1.f, 2.f, 3.f, (float)i};
+        else pre[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(p * 16), 0, 0));
+      }
+      if (deriv && !(NRW_ABLATE & 4)) {
+        const __amdgpu_buffer_rsrc_t rx = lsnt::tile_rsrc(i < nt ? g.xd : nullptr, g.M, m0 < g.N ? m0 : g.N, g.N, g.a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = lt + 256 * j;
+          xpre[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, p < npc ? (uint32_t)(p * 16) : lsnt::OOB, 0, 0));
+        }
+      }
+    };
+    auto stash = [&](int slot, int i) __attribute__((always_inline)) {
+      char* buf = smem + (i & 1) * BUF;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int p = lt + 256 * j;
+        f32x4 v = pre[slot][j];
+        if (NRW_ABLATE & 2) { if (v[0] == 1.2345f) *(float*)buf = v[1] + v[2] + v[3]; continue; }
+        if (MODE == 0 && g.act != NA_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = tact(v[e], g.act);
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        char* o = buf + (p >> 6) * PITCH + (p & 63) * 8;
+        *(bf16x4*)o = hi;
+        *(bf16x4*)(o + PLANE) = lo;
+      }
+      if (deriv && !(NRW_ABLATE & 4)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = lt + 256 * j;
+          if (p < npc) *(f32x4*)(xtile + (i & 1) * OT + p * 16) = xpre[slot][j];
+        }
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) fetch(q, q);
+    // step t: tile t stashed, tile t + AHEAD requested (the consumers multiply tile t - 1 and carry out the results of tile t - 2:
+    // two more steps at the end drain them)
+    for (int i = 0; i < nt + 2; i += AHEAD) {  // (AHEAD tiles per trip: the register slots are compile-time)
+#pragma unroll
+      for (int q = 0; q < AHEAD; ++q) {
+        if (i + q < nt) stash(q, i + q);
+        fetch(q, i + q + AHEAD);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ consumers
+  const int ct = wave - 4;
+  const bool active = 32 * ct < g.M;
+  // this wave's column tile: rows 32 ct .. of B = tile (ct & 1) of column group (ct >> 1); K = 256 = 2 chunks x 8 k steps
+  bf16x8 bh[16], bl[16];
+  if (active) {
+    const char* base = g.wp + (size_t)(ct >> 1) * (2 * 2 * lsnt::SEG) + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const char* f = base + (size_t)(((ks >> 3) * 2 + (ct & 1)) * 8 + (ks & 7)) * 2048;
+      bh[ks] = *(const bf16x8*)f;
+      bl[ks] = *(const bf16x8*)(f + 1024);
+    }
+  }
+  const int s = lane & 31, h = lane >> 5;
+  float bias[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = 32 * ct + 8 * (i >> 2) + 4 * h + (i & 3);
+    bias[i] = (MODE == 0 && g.bias != nullptr && c < g.M) ? g.bias[c] : 0.f;
+  }
+  auto consume = [&](int i) __attribute__((always_inline)) {
+    if (!active || i < 0 || i >= nt) return;  // (wave-uniform)
+    const char* buf = smem + (i & 1) * BUF;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = bias[q];
+    const char* fr = buf + s * PITCH + h * 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 xh = *(const bf16x8*)(fr + ks * 32);
+      const bf16x8 xl = *(const bf16x8*)(fr + PLANE + ks * 32);
+      if (NRW_ABLATE & 1) { acc[ks] += (float)xh[0] + (float)xl[1] + (float)bl[ks][0] + (float)bh[ks][1]; continue; }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks], xh, acc, 0, 0, 0);
+    }
+    if ((NRW_ABLATE & 4) && acc[0] != 1.2345f) return;
+    float* ot = (float*)(otile + (i & 1) * OT) + s * g.M;
+    const float* xt = (const float*)(xtile + (i & 1) * OT) + s * g.M;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = 32 * ct + 8 * (q >> 2) + 4 * h + (q & 3);
+      if (c < g.M) {
+        float v = acc[q];
+        if (deriv) v *= tact_grad(xt[c], g.act);
+        ot[c] = v;
+      }
+    }
+  };
+  // results of tile i (left in the output tile before the previous barrier) -> global, in address order, by all four consumer
+  // waves (also those without a column tile): their memory queue holds nothing but these stores
+  const int ctid = tid - 256;
+  auto carry = [&](int i) __attribute__((always_inline)) {
+    if (i < 0 || i >= nt || (NRW_ABLATE & 4)) return;
+    const int64_t m0 = (t0 + i) * TS;
+    const __amdgpu_buffer_rsrc_t ry = lsnt::tile_rsrc(g.y, g.M, m0, g.N, g.a);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = ctid + 256 * j;
+      if (p < npc) {
+        const u32x4 v = *(const u32x4*)(otile + (i & 1) * OT + p * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ry, (uint32_t)(p * 16), 0, 0);
+      }
+    }
+  };
+  for (int i = 0; i < nt + 2; i += AHEAD) {
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) {
+      carry(i + q - 2);
+      consume(i + q - 1);   // (tile t: planes and derivative inputs in buffer t & 1, results into output tile t & 1)
+      __syncthreads();
+    }
+  }
+}
+
+static bool wanted(int64_t N, int M, int Kdim) {
+  static const bool off = [] { const char* e = getenv("NA_TRAIN_NARROW"); return e != nullptr && strcmp(e, "0") == 0; }();
+  return !off && Kdim == K && M >= 1 && M <= 128 && N >= 2048;
+}
+
+template <int MODE>
+static int launch(Args a, hipStream_t st, const char* what) {
+  a.ntiles = (a.N + TS - 1) / TS;
+  const int cus = lsnt::cu_count();
+  const int grid = a.ntiles < cus ? (int)a.ntiles : cus;
+  auto k = kernel<MODE>;
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALL);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return NA_EHIP; }
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_ALL, st, a);
+  return check_launch(what);
+}
+}  // namespace nrw
 
 }  // namespace na
 
@@ -1670,6 +1903,11 @@ int na_linear_bf16x3_pk(const float* x0, int in0, const float* x1, int in1, int6
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bf16x3_pk: activation %d", pre_act);
   NA_REQUIRE(lsnt_wanted(N, out), NA_EUNSUPPORTED, "na_linear_bf16x3_pk: this batch / width runs the K-staged kernel: call "
              "na_linear_bf16x3 (na_train_gemm_packed_ok says which)");
+  if (in1 == 0 && nrw::wanted(N, out, in0)) {  // a narrow output (256 -> 65 / 3): the row-stream kernel
+    nrw::Args n{};
+    n.a = x0; n.N = N; n.wp = (const char*)w_packed; n.M = out; n.act = pre_act; n.bias = b; n.y = y;
+    return nrw::launch<0>(n, (hipStream_t)stream, "na_linear_bf16x3_pk");
+  }
   lsnt::Args l{};
   l.a = RowSrc{x0, x1, in0, in1, N};
   l.M = out; l.act = pre_act; l.bias = b; l.y0 = y; l.c0 = out;
@@ -1686,6 +1924,27 @@ int na_linear_dgrad_bf16x3_pk(const float* dY, int out, int64_t N, const void* w
              "na_linear_dgrad_bf16x3_pk: the activation derivative needs the forward inputs");
   NA_REQUIRE(lsnt_wanted(N, in0 + in1), NA_EUNSUPPORTED, "na_linear_dgrad_bf16x3_pk: this batch / width runs the K-staged kernel: call "
              "na_linear_dgrad_bf16x3 (na_train_gemm_packed_ok says which)");
+  // narrow gradients on the row-stream kernel (round 5): a narrow single source (the init Linears: 256 -> 38 / 69), and the
+  // narrow SECOND source of a skip layer [256 | 38], whose 256 wide columns then run as a plain single-pass layer (the
+  // packed W^T is column-group major: rows 0..255 are its first four groups, the narrow rows start at group in0 / 64)
+  if (in1 == 0 && nrw::wanted(N, in0, out)) {
+    nrw::Args n{};
+    n.a = dY; n.N = N; n.wp = (const char*)wt_packed; n.M = in0; n.act = pre_act; n.xd = x0; n.y = g_x0;
+    return nrw::launch<1>(n, (hipStream_t)stream, "na_linear_dgrad_bf16x3_pk");
+  }
+  if (in1 > 0 && (in0 & 63) == 0 && nrw::wanted(N, in1, out)) {
+    if (g_x1 != nullptr) {
+      nrw::Args n{};
+      n.a = dY; n.N = N; n.wp = (const char*)wt_packed + (size_t)(in0 / 64) * (2 * 2 * lsnt::SEG); n.M = in1; n.act = pre_act; n.xd = x1;
+      n.y = g_x1;
+      const int rc = nrw::launch<1>(n, (hipStream_t)stream, "na_linear_dgrad_bf16x3_pk");
+      if (rc != NA_OK || g_x0 == nullptr) return rc;
+    }
+    lsnt::Args l{};
+    l.a = RowSrc{dY, nullptr, out, 0, N};
+    l.M = in0; l.act = pre_act; l.y0 = g_x0; l.y1 = nullptr; l.x0 = x0; l.x1 = nullptr; l.c0 = in0; l.c1 = 0;
+    return lsnt::launch<1>(l, nullptr, out, (hipStream_t)stream, "na_linear_dgrad_bf16x3_pk", (const char*)wt_packed);
+  }
   lsnt::Args l{};
   l.a = RowSrc{dY, nullptr, out, 0, N};
   l.M = in0 + in1; l.act = pre_act; l.y0 = g_x0; l.y1 = in1 > 0 ? g_x1 : nullptr; l.x0 = x0; l.x1 = x1; l.c0 = in0; l.c1 = in1;

@@ -114,7 +114,8 @@ def test_layer_synchronous_and_k_staged_kernels_agree(tmp_path):
 
 
 PK_SHAPES = [(4096, 256, 0, 256), (2048 + 37, 38, 0, 256), (4096 + 63, 256, 69, 256), (4096, 256, 38, 256), (4096 + 1, 256, 0, 65),
-             (4096, 256, 0, 3), (5000, 100, 0, 1000), (4096 + 3, 64, 38, 64)]
+             (4096, 256, 0, 3), (5000, 100, 0, 1000), (4096 + 3, 64, 38, 64), (40000 + 31, 256, 0, 128), (2048 + 1, 69, 0, 256),
+             (4096 + 9, 128, 100, 256), (262144, 256, 38, 256)]
 
 
 @pytest.mark.parametrize("shape", PK_SHAPES, ids=lambda s: "N%d_in%d+%d_out%d" % s)
@@ -132,13 +133,31 @@ def test_packed_operands_are_the_same_gemms(ops, shape):
     gy = torch.randn(N, out, device="cuda")
     assert ops.train_gemm_packed_ok(N, out) and ops.train_gemm_packed_ok(N, in0 + in1) and not ops.train_gemm_packed_ok(100, out)
     pf, p2, pt = ops.train_pack_many([(W, False), (W2, True), (W, True)])
+    # narrow outputs with K = 256 take the row-stream kernel (csrc/train_gemm.hip nrw: the same three products per k added in
+    # another order) -- equal to a few units in the last place, like the two wide implementations among themselves; a skip layer's
+    # wide half then runs as a plain single-pass layer: bit for bit the wide kernel on [W_h] alone
+    nf = in1 == 0 and in0 == 256 and out <= 128
+    n0 = in1 == 0 and out == 256 and in0 <= 128
+    n1 = in1 > 0 and out == 256 and in0 % 64 == 0 and in1 <= 128
+    same = lambda a, b, narrow: torch.equal(a, b) if not narrow else float((a - b).abs().max()) <= 3e-6 * float(b.abs().max())
     for act in ("leaky_relu", "sin", "none"):
         y = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True)
         y_pk = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True, packed=pf)
-        assert torch.equal(y, y_pk)
+        assert same(y_pk, y, nf), (act, float((y - y_pk).abs().max()))
         g0, g1 = ops.linear_dgrad(gy, W, x0, act, x1=x1)
         h0, h1 = ops.linear_dgrad(gy, W, x0, act, x1=x1, packed_t=pt)
-        assert torch.equal(g0, h0) and (g1 is None or torch.equal(g1, h1))
+        assert same(h0, g0, n0), (act, float((g0 - h0).abs().max()))
+        assert g1 is None or same(h1, g1, n1), (act, float((g1 - h1).abs().max()))
+        if n1:  # only one half requested
+            o0, z1 = ops.linear_dgrad(gy, W, x0, act, x1=x1, want1=False, packed_t=pt)
+            z0, o1 = ops.linear_dgrad(gy, W, x0, act, x1=x1, want0=False, packed_t=pt)
+            assert z1 is None and z0 is None and torch.equal(o0, h0) and torch.equal(o1, h1)
+        # against fp64, at the bar of the unpacked entry points
+        f, df = ACTS[act]
+        xin = (torch.cat([x0, x1], 1) if in1 else x0).double()
+        rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
+        assert rel(y_pk, f(xin) @ W.double().t() + b.double()) < 3e-5
+        assert rel(torch.cat([h0, h1], 1) if in1 else h0, (gy.double() @ W.double()) * df(xin)) < 3e-5
     # the transposed entry is what packing the materialised transpose gives
     (pt_ref,) = ops.train_pack_many([(W.t().contiguous(), False)])
     assert torch.equal(pt, pt_ref)
@@ -205,5 +224,7 @@ def test_training_forward_packs_every_linear_once_and_changes_nothing(ops, monke
     assert calls == [12]   # 6 Linears x (W, W^T): ONE call = one launch
     monkeypatch.setattr(SkipConnMLP, "_train_packs", lambda self, init: [None] * len(self._linears()))
     ref, ref_t = run()
-    assert len(got) == 12 and all(torch.equal(a, b) for a, b in zip(got, ref))
+    # (the 256 -> 65 out Linear and the 38-column input gradients run the row-stream kernel with packed operands: last-place
+    # differences in those rows and in what is back-propagated through them)
+    assert len(got) == 12 and all(float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) for a, b in zip(got, ref))
     assert all(float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) for a, b in zip(got_t, ref_t))
