@@ -35,6 +35,7 @@ UNITS = [
     ("linear_f32.hip", [], ""),
     ("backward.hip", [], ""),
     ("train_gemm.hip", [], ""),
+    ("train_bwd.hip", [], ""),
     ("march.hip", [], ""),
     ("mlp_fused.hip", [], ""),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"], "_bf16"),
@@ -93,7 +94,7 @@ def _headers_digest() -> str:
 def _unit_digest(unit, headers: str) -> str:
     src, extra, suffix, isa = unit
     h = hashlib.sha256(headers.encode())
-    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v5", str(isa)] if isa else [])).encode())
+    h.update(" ".join(FLAGS + extra + (["-save-temps=obj", "isa-check-v6", str(isa)] if isa else [])).encode())
     with open(os.path.join(CSRC, src), "rb") as fh:
         h.update(fh.read())
     return h.hexdigest()
@@ -324,6 +325,58 @@ def check_mfma_use(listing: str):
     return bad, n_seen
 
 
+_WIDE_STORE = re.compile(r"^\s*(buffer_store_dwordx[34])\s+(v\[\d+:\d+\])\s*,\s*([^,]+),\s*(s\[\d+:\d+\])\s*,\s*(\S+)")
+
+
+def check_store_data_overwrite(listing: str):
+    """A buffer store of more than 8 bytes reads its data registers AFTER it has issued: a VALU instruction that overwrites one of
+    them within the next two wait states can reach the register first.  LLVM's hazard recogniser (GCNHazardRecognizer::
+    createsVALUHazard, gfx940+: 2 wait states) inserts the wait -- but only when the store's soffset field is NOT an SGPR; with
+    an SGPR soffset it assumes the hardware has had time.  On gfx950 it has not (round 5: the g_x stores of csrc/train_bwd.hip,
+    `buffer_store_dwordx4 v[182:185], v176, s[20:23], s33 offen` directly followed by `v_lshlrev_b32 v182, 16, v171`, wrote the
+    shifted bf16 instead of the gradient in lanes 12-15 / 28-31 of some waves, 272 of 2 M elements, timing dependent; hardware
+    probe tools/hw/store_soffset_hazard.hip).  Every 12- / 16-byte buffer store with an SGPR soffset in the listing (all
+    functions) must therefore not be followed within two wait states (s_nop N counts N + 1) by a VALU instruction whose
+    DESTINATION overlaps the store's data.  Returns [(line, store, writer, waits)] and the number of such stores scanned."""
+    bad, n_seen = [], 0
+    live = []  # [line, text, d0, d1, waits]
+    with open(listing) as fh:
+        for n, line in enumerate(fh, 1):
+            t = line.split(";")[0].rstrip()
+            if not t.strip() or t.lstrip().startswith((".", "//")):
+                continue
+            if re.match(r"^[\w.$]+:", t):
+                if not t.startswith(".L"):
+                    live = []
+                continue
+            tt = t.strip()
+            mn = tt.split()[0]
+            if mn in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                live = []
+                continue
+            if mn.startswith("v_") and live and not mn.startswith("v_cmp") and " " in tt:
+                dst = _vrange(tt.split(None, 1)[1].split(",")[0])
+                if dst is not None:
+                    for e in live:
+                        if not (dst[1] < e[2] or e[3] < dst[0]):
+                            bad.append((e[0], e[1], f"line {n}: {tt}", e[4]))
+            inc = 1
+            if mn == "s_nop":
+                try:
+                    inc = int(tt.split()[1]) + 1
+                except (IndexError, ValueError):
+                    inc = 1
+            for e in live:
+                e[4] += inc
+            live = [e for e in live if e[4] < 2]
+            m = _WIDE_STORE.match(t)
+            if m and re.match(r"^s\d+$", m.group(5)):
+                n_seen += 1
+                d = _vrange(m.group(2))
+                live.append([n, tt, d[0], d[1], 0])
+    return bad, n_seen
+
+
 def _scan_failed(msg: str):
     """A build-time ISA scan found something: hard error, or a warning under NA_HAZARD_SCAN=warn (module docstring)."""
     if os.environ.get("NA_HAZARD_SCAN", "error").lower() == "warn":
@@ -367,6 +420,12 @@ def _compile(unit):
             _scan_failed(f"{src}{suffix}: a transcendental result is read by the very next VALU instruction (line {tbad[0][0]} of {lst}: "
                                f"{tbad[0][1]} -> {tbad[0][2]}): an inline-asm consumer the hazard recogniser cannot see; the hardware "
                                "then reads the register's old contents (tools/hw/trans_use_hazard.hip).  Fence the asm's operands.")
+        sbad, _ = check_store_data_overwrite(lst)
+        if sbad:
+            _scan_failed(f"{src}{suffix}: the data of a 16-byte buffer store with an SGPR soffset is overwritten {sbad[0][3]} wait states "
+                               f"after issue (line {sbad[0][0]} of {lst}: {sbad[0][1][:70]} -> {sbad[0][2]}): the compiler inserts no wait "
+                               "for that form and gfx950 needs one (tools/hw/store_soffset_hazard.hip).  Put the row step into the "
+                               "vector offset (soffset 0) so that the hazard recogniser covers the store.")
         mbad, _ = check_mfma_use(lst)
         if mbad:
             _scan_failed(f"{src}{suffix}: an MFMA result is read {mbad[0][3]} wait states after issue (line {mbad[0][0]} of {lst}: "

@@ -22,48 +22,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
+#include "train_shared.h"
 
 namespace na {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #ifndef TG_ABLATE
 #define TG_ABLATE 0  // experiments only: 1 no MFMA, 2 no global loads, 4 no LDS stash, 8 no fragment reads
 #endif
 constexpr int TK = 32;   // K per stage
 constexpr int TLD = 80;  // LDS row pitch, bytes
-
-__device__ __forceinline__ float tact(float v, int act) {
-  if (act == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, 3.0e38f);
-  if (act == NA_ACT_SIN) return sin_cw(v);
-  return v;
-}
-__device__ __forceinline__ float tact_grad(float v, int act) {
-  if (act == NA_ACT_LEAKY_RELU) return v > 0.f ? 1.f : 0.01f;
-  if (act == NA_ACT_SIN) return cos_cw(v);
-  return 1.f;
-}
-
-// v = hi + lo + O(2^-17 |v|), both halves rounded to nearest even.  Pairwise, so that each pair costs v_cvt_pk_bf16_f32, a shift,
-// a mask, v_pk_add_f32 and v_cvt_pk_bf16_f32 (element by element the compiler converted every high half twice)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const f32x2 w = {v[2 * p], v[2 * p + 1]};
-    const bf16x2 h = __builtin_convertvector(w, bf16x2);
-    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
-    const f32x2 f = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-    const bf16x2 l = __builtin_convertvector(w - f, bf16x2);
-    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
-    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
-  }
-}
 
 // One operand source: rows x K fp32, K contiguous, optionally the concatenation [p0 (k0 cols) | p1 (k1 cols)].
 struct RowSrc {
@@ -545,7 +512,6 @@ __device__ unsigned long long tgl_trace[3][32][4];
 #define TGL_STAMP(role, u, slot) do {} while (0)
 #endif
 constexpr int TS = 64;              // samples per tile
-constexpr int KC = 128;             // k per LDS fill = 8 k steps = one segment of the weight stream per column tile
 constexpr int PITCH = KC * 2 + 16;  // row pitch of a plane: 68 dwords = 4 mod 64 -> conflict-free b128 fragment reads
 constexpr int PLANE = TS * PITCH;
 constexpr int BUF = 2 * PLANE;      // hi | lo
@@ -556,7 +522,6 @@ constexpr int NPF = TS * (KC / 4) / PT;  // 16-byte pieces per loader thread and
 constexpr int XP = 260;             // float pitch of the output tile (= the forward-input tile of an input gradient with an activation)
 constexpr int XB = TS * XP * 4;     // 65 KiB behind the buffers
 constexpr int NXF = TS * 64 / PT;   // its 16-byte pieces per mover thread (16)
-constexpr int SEG = 8 * 2048;       // stream bytes of one (column group, chunk, column tile): 8 k steps x (hi | lo) fragments
 
 struct Args {
   RowSrc a;          // [samples, K] (concat)
@@ -640,14 +605,6 @@ struct Src2 {
   __amdgpu_buffer_rsrc_t r0, r1;
   int k0, k1;
 };
-constexpr uint32_t OOB = 0x78000000u;  // a byte offset past every tile buffer: the hardware drops the access
-constexpr int kNoScratch = 1;            // launch(): hipMallocAsync refused (returned to the dispatcher, never to the C ABI)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, int ld, int64_t m0, int64_t rows, const void* dummy) {
-  int64_t bytes = base == nullptr ? 0 : (rows - m0) * ld * 4;
-  if (bytes > 0x70000000ll) bytes = 0x70000000ll;
-  if (bytes < 0) bytes = 0;
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(base == nullptr ? (const float*)dummy : base + m0 * ld), 0, (int)bytes, 0x00020000);
-}
 // WHICH: 1 the first source only, 2 the second only -- a caller that knows where its columns lie (a whole k chunk inside one
 // source): ONE 16-byte load per piece whatever the row length.  Raw-buffer loads of 16 bytes need only 4-byte alignment and
 // are range-checked per dword (profiles/r03/unaligned_probe.log), so a 38-column source takes them too; a piece that crosses
@@ -1112,16 +1069,6 @@ __global__ __launch_bounds__(NTHR) void kernel(Args g) {
   };
   if ((nrg & 3) == 0) units(std::true_type{});
   else units(std::false_type{});
-}
-
-static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n = v;
-  }
-  return n;
 }
 
 // Bmat = the [M, K] row-major operand (weights, or their transpose for the input gradient)
@@ -1713,6 +1660,12 @@ static int launch(Args a, hipStream_t st, const char* what) {
 }
 }  // namespace nrw
 
+int train_reduce_partials(const float* part, int nwg, int out, int in, int ldw, float* dW, float* db, int overwrite, hipStream_t st) {
+  const int n = out * ((in + 3) / 4) + (db != nullptr ? (out + 3) / 4 : 0);
+  hipLaunchKernelGGL(lstn::reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, nwg, out, in, ldw, dW, db, overwrite);
+  return NA_OK;
+}
+
 }  // namespace na
 
 using namespace na;
@@ -1861,6 +1814,25 @@ int na_linear_wgrad_bf16x3(const float* x0, int in0, const float* x1, int in1, i
 int na_linear_wgrad_bf16x3_ow(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
                               int pre_act, float* dW, float* db, void* stream) {
   return wgrad_bf16x3_impl(x0, in0, x1, in1, N, dY, out, pre_act, dW, db, stream, 1);
+}
+
+// One source of a concatenated input on its own: dW[:, 0:in) at leading dimension ldw WRITTEN (db too when given).  The wide source
+// of a skip layer goes through na_linear_bwd_bf16x3_pk (train_bwd.hip), its narrow source [N, 38 / 69] through here.
+int na_linear_wgrad_bf16x3_cols(const float* x, int in, int64_t N, const float* dY, int out, int pre_act, float* dW, int ldw,
+                                float* db, void* stream) {
+  NA_REQUIRE(in >= 1 && in <= 256 && out >= 1 && out <= 256 && N >= 0 && ldw >= in, NA_EINVAL, "na_linear_wgrad_bf16x3_cols: bad shape");
+  NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_wgrad_bf16x3_cols: activation %d", pre_act);
+  NA_REQUIRE(dW != nullptr, NA_ENULL, "na_linear_wgrad_bf16x3_cols: null pointer");
+  if (N == 0) {
+    for (int r = 0; r < out; ++r) (void)hipMemsetAsync(dW + (size_t)r * ldw, 0, (size_t)in * sizeof(float), (hipStream_t)stream);
+    if (db != nullptr) (void)hipMemsetAsync(db, 0, (size_t)out * sizeof(float), (hipStream_t)stream);
+    return NA_OK;
+  }
+  NA_REQUIRE(x && dY, NA_ENULL, "na_linear_wgrad_bf16x3_cols: null pointer");
+  NA_REQUIRE(lsnt_wanted(N, out), NA_EUNSUPPORTED, "na_linear_wgrad_bf16x3_cols: this batch runs the K-staged kernel (na_train_gemm_packed_ok)");
+  const int rc = lstn::launch(dY, out, x, in, pre_act, N, dW, ldw, db, (hipStream_t)stream, "na_linear_wgrad_bf16x3_cols", 1);
+  if (rc == lsnt::kNoScratch) { set_error("na_linear_wgrad_bf16x3_cols: stream-ordered scratch allocation failed"); return NA_EHIP; }
+  return rc;
 }
 
 // ---- round 5: the B operands of a whole training step packed by one launch, and the GEMMs that take them --------------------

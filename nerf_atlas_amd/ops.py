@@ -485,6 +485,43 @@ def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, x0: torch.Tensor, pre_act: s
     return g0, g1
 
 
+def linear_bwd_fused_ok(N: int, out: int, in0: int) -> bool:
+    """Does (N, out, in0) run the one-pass input-gradient + weight-gradient kernel (na_linear_bwd_fused_ok)?"""
+    return bool(_lib.load().na_linear_bwd_fused_ok(int(N), int(out), int(in0)))
+
+
+def linear_bwd_fused(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t: torch.Tensor, in1: int = 0, want_bias: bool = True):
+    """(g_x0 [N,256], dW [out, 256+in1] with columns 0..255 WRITTEN, db [out] | None) of y = W . act([x0|x1]) + b in one pass over dY
+    and x0 (na_linear_bwd_bf16x3_pk).  packed_t: W^T as train_pack_many left it.  The in1 columns of a second source are left to
+    the caller (linear_wgrad_into / linear_dgrad on that source)."""
+    lib = _lib.load()
+    dY, x0 = _f32(dY, "dY"), _f32(x0, "x0")
+    N, in0 = x0.shape
+    out = dY.shape[1]
+    ld = in0 + in1
+    nW = out * ld
+    pad = (-nW) % 4
+    acc = torch.empty(nW + pad + (out if want_bias else 0), device=x0.device, dtype=torch.float32)
+    dW = acc[:nW].view(out, ld)
+    db = acc[nW + pad:] if want_bias else None
+    g0 = torch.empty_like(x0)
+    check(lib.na_linear_bwd_bf16x3_pk(_ptr(dY), out, N, _ptr(packed_t), _ptr(x0), in0, ACT[pre_act], _ptr(g0), _ptr(dW), ld, _ptr(db),
+                                      _stream()))
+    return g0, dW, db
+
+
+def linear_wgrad_cols(x: torch.Tensor, dY: torch.Tensor, pre_act: str, dW: torch.Tensor, col0: int):
+    """dW[:, col0:col0 + x.shape[1]] = dY^T . act(x) WRITTEN (na_linear_wgrad_bf16x3_cols): one source of a concatenated input."""
+    lib = _lib.load()
+    x, dY = _f32(x, "x"), _f32(dY, "dY")
+    N, k = x.shape
+    out = dY.shape[1]
+    assert dW.is_contiguous() and dW.shape[0] == out and col0 + k <= dW.shape[1]
+    check(lib.na_linear_wgrad_bf16x3_cols(_ptr(x), k, N, _ptr(dY), out, ACT[pre_act], dW.data_ptr() + 4 * col0, dW.shape[1], None,
+                                          _stream()))
+    return dW
+
+
 # ------------------------------------------------------------------------------------------------- backward
 def act_backward(x: torch.Tensor, g: torch.Tensor, act: str) -> torch.Tensor:
     lib = _lib.load()

@@ -228,3 +228,79 @@ def test_training_forward_packs_every_linear_once_and_changes_nothing(ops, monke
     # differences in those rows and in what is back-propagated through them)
     assert len(got) == 12 and all(float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) for a, b in zip(got, ref))
     assert all(float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) for a, b in zip(got_t, ref_t))
+
+
+# (N, in1, out): in0 = 256 always; ragged batches (partial last stage, slices of unequal length), the out Linears' 65 / 3 columns
+# (dY fetched as dwords, 5 / 1 k steps, idle weight-gradient waves), a skip layer's second source left to the other kernels
+BWD_SHAPES = [(8192, 0, 256), (8192 + 37, 0, 256), (65536 + 1, 0, 256), (12000, 38, 256), (8192 + 5, 0, 65), (9000, 0, 3),
+              (8192, 0, 64), (262144, 0, 256), (16384 + 33, 0, 128)]
+
+
+@pytest.mark.parametrize("shape", BWD_SHAPES, ids=lambda s: "N%d_in256+%d_out%d" % s)
+@pytest.mark.parametrize("act", ["leaky_relu", "sin", "none"])
+def test_fused_backward_vs_fp64_and_vs_the_two_launch_path(ops, shape, act):
+    """csrc/train_bwd.hip (round 5): input gradient + weight gradient + bias gradient of a Linear in one pass over dY and x."""
+    N, in1, out = shape
+    in0 = 256
+    if N > 100000 and act != "leaky_relu":
+        pytest.skip("the full-size batch once")
+    assert ops.linear_bwd_fused_ok(N, out, in0)
+    torch.manual_seed(N + 7 * in1 + out)
+    dev = "cuda"
+    x0 = torch.randn(N, in0, device=dev)
+    W = torch.randn(out, in0 + in1, device=dev) * (1.0 / (in0 + in1)) ** 0.5
+    gy = torch.randn(N, out, device=dev)
+    f, df = ACTS[act]
+    (pt,) = ops.train_pack_many([(W, True)])
+    g0, dW, db = ops.linear_bwd_fused(gy, x0, act, pt, in1=in1)
+    torch.cuda.synchronize()
+    # the two-launch path on the same operands
+    x1 = torch.randn(N, in1, device=dev) if in1 else None
+    h0, _ = ops.linear_dgrad(gy, W, x0, act, x1=x1, want1=False, packed_t=pt)
+    dW2, db2 = ops.linear_wgrad(x0, gy, act, x1=x1, split_bf16=True)
+
+    def rel(a, r):
+        return float((a.double() - r.double()).abs().max() / r.double().abs().max())
+    if N <= 100000:
+        g_ref = (gy.double() @ W.double()[:, :in0]) * df(x0.double())
+        dW_ref = gy.double().t() @ f(x0.double())
+        assert rel(g0, g_ref) < 3e-5
+        assert rel(dW[:, :in0], dW_ref) < 3e-5
+        assert rel(db, gy.double().sum(0)) < 3e-5
+    # same three products per k: the input gradient differs from the standalone kernel's by the order of the additions at most
+    assert rel(g0, h0) < 2e-6
+    assert rel(dW[:, :in0], dW2[:, :in0]) < 2e-6
+    assert rel(db, db2) < 2e-6
+    # run-to-run reproducible (fixed-order partial sums, no atomics)
+    g0b, dWb, dbb = ops.linear_bwd_fused(gy, x0, act, pt, in1=in1)
+    assert torch.equal(g0, g0b) and torch.equal(dW[:, :in0], dWb[:, :in0]) and torch.equal(db, dbb)
+
+
+@pytest.mark.parametrize("in1", [0, 38, 69, 259])
+def test_linear_fn_backward_through_the_fused_kernel_vs_fp64(ops, in1):
+    """autograd.LinearFn with packed operands: a 256 wide first source takes the one-pass backward, its narrow second source
+    (a skip layer's [256 | 38], [256 | 69]) the narrow kernels; a second source wider than 256 (the Fourier SDF network's skip)
+    keeps the two-launch path.  All four gradients against fp64 autograd."""
+    from nerf_atlas_amd import autograd as ag
+    N, in0, out = 9000 + in1, 256, 256
+    torch.manual_seed(in1)
+    dev = "cuda"
+    x0 = torch.randn(N, in0, device=dev, requires_grad=True)
+    x1 = torch.randn(N, in1, device=dev, requires_grad=True) if in1 else None
+    W = (torch.randn(out, in0 + in1, device=dev) * (1.0 / (in0 + in1)) ** 0.5).requires_grad_()
+    b = torch.randn(out, device=dev, requires_grad=True)
+    gy = torch.randn(N, out, device=dev)
+    pk = ops.train_pack_many([(W, False), (W, True)])
+    y = ag.LinearFn.apply(x0, x1, W, b, "leaky_relu", (pk[0], pk[1]))
+    y.backward(gy)
+    xin = (torch.cat([x0, x1], 1) if in1 else x0).detach().double().requires_grad_()
+    Wd, bd = W.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    (torch.nn.functional.leaky_relu(xin, 0.01) @ Wd.t() + bd).backward(gy.double())
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(x0.grad, xin.grad[:, :in0]) < 3e-5
+    if in1:
+        assert rel(x1.grad, xin.grad[:, in0:]) < 3e-5
+    assert rel(W.grad, Wd.grad) < 3e-5
+    assert rel(b.grad, bd.grad) < 3e-5
