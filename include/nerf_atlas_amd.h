@@ -325,11 +325,13 @@ int na_linear_dgrad_bf16x3_pk(const float* dY, int out, int64_t N, const void* w
                               const float* x1, int in1, int pre_act, float* g_x0, float* g_x1, void* stream);
 /* Round 5: input gradient AND weight gradient of one Linear in ONE pass over dY and the forward input (they read the same two
  * [N, .] tensors; src/neural_blocks.py:288-296 differentiated, runner.py:647-825's loss.backward()):
- *   g_x0[N,256] = (dY . W[:, 0:256]) * act'(x0);  dW[out, 0:256] (leading dimension ldw >= 256) and db[out] WRITTEN.
- * in0 must be 256, out <= 256; wt_packed = W^T [in >= 256, out] as na_train_pack_many packs it.  The second source of a
- * concatenated input (a skip layer's [256 | 38]) keeps its own launches (na_linear_dgrad_bf16x3_pk with g_x0 = NULL,
- * na_linear_wgrad_bf16x3_ow on that source).  na_linear_bwd_fused_ok: 1 if (N, out, in0) runs this kernel (N >= 8192,
- * NA_TRAIN_FUSED_BWD != 0), else the entry point returns NA_EUNSUPPORTED. */
+ *   g_x0[N,in0] = (dY . W[:, c0:c0+in0]) * act'(x0);  dW[out, 0:in0] (leading dimension ldw >= in0) and db[out] (if given) WRITTEN.
+ * in0 = 256 (a wide source) or in0 <= 128 (a narrow one: an init Linear's 38 / 69 columns, the second source of a skip layer);
+ * out <= 256; wt_packed = W^T [in, out] as na_train_pack_many packs it, at the column group of the source's first row c0 (a
+ * multiple of 64): na_train_packed_row_offset(c0, out) bytes into the packed stream.  The sources of a concatenated input are
+ * separate calls (dW + c0 with the full leading dimension).  na_linear_bwd_fused_ok: 1 if (N, out, in0) runs this kernel
+ * (N >= 8192, NA_TRAIN_FUSED_BWD != 0), else the entry point returns NA_EUNSUPPORTED. */
+size_t na_train_packed_row_offset(int row0, int K);
 int na_linear_bwd_fused_ok(int64_t N, int out, int in0);
 /* na_linear_wgrad_bf16x3_cols: the weight gradient of ONE source of a concatenated input: dW[:, 0:in) at leading dimension ldw and
  * (if given) db WRITTEN -- the narrow source [N, 38 / 69] of a skip layer whose wide source went through na_linear_bwd_bf16x3_pk. */

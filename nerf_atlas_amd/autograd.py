@@ -41,16 +41,20 @@ class LinearFn(Function):
         gx0 = gx1 = gW = gb = None
         want0, want1 = ctx.needs_input_grad[0], ctx.has_x1 and ctx.needs_input_grad[1]
         want_w = ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3])
-        if (ctx.fast and want0 and want_w and ctx.packed_t is not None and in0 == 256 and (x1 is None or x1.shape[1] <= 256)
-                and ops.linear_bwd_fused_ok(x0.shape[0], gy.shape[1], in0)):
-            # round 5: input gradient + weight gradient of the 256 wide source in ONE pass over dY and x0 (csrc/train_bwd.hip); the
-            # narrow second source of a skip layer keeps its own two launches
+        N, out = x0.shape[0], gy.shape[1]
+        if (ctx.fast and want0 and want_w and ctx.packed_t is not None and (x1 is None or (in0 == 256 and x1.shape[1] <= 256))
+                and ops.linear_bwd_fused_ok(N, out, in0)):
+            # round 5: input gradient + weight gradient of a source in ONE pass over dY and that source (csrc/train_bwd.hip): the
+            # 256 wide hidden input, an init Linear's narrow input, and the narrow second source of a skip layer as a call of its own
             in1 = x1.shape[1] if x1 is not None else 0
             gx0, gW, gb = ops.linear_bwd_fused(gy, x0, ctx.act, ctx.packed_t, in1=in1, want_bias=ctx.has_b)
             if x1 is not None:
-                ops.linear_wgrad_cols(x1, gy, ctx.act, gW, in0)
-                if want1:
-                    _, gx1 = ops.linear_dgrad(gy, W, x0, ctx.act, x1, False, True, packed_t=ctx.packed_t)
+                if want1 and ops.linear_bwd_fused_ok(N, out, in1):
+                    gx1, _, _ = ops.linear_bwd_fused(gy, x1, ctx.act, ctx.packed_t, dW=gW, col0=in0)
+                else:
+                    ops.linear_wgrad_cols(x1, gy, ctx.act, gW, in0)
+                    if want1:
+                        _, gx1 = ops.linear_dgrad(gy, W, x0, ctx.act, x1, False, True, packed_t=ctx.packed_t)
             return gx0, gx1, gW, gb, None, None
         if (want0 or want1) and ctx.fast:
             gx0, gx1 = ops.linear_dgrad(gy, W, x0, ctx.act, x1, want0, want1, packed_t=ctx.packed_t)

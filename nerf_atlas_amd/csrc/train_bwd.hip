@@ -57,6 +57,7 @@ struct Args {
   float* gx;         // [N, ldx]
   float* part;       // [nsl][PART]
   int out, act, ldx, nsl, xcd_map, want_db;
+  int in, nhalf;     // columns of x a workgroup owns (128 = one half of a 256 wide source; a narrow source: all of its <= 128) | 2 or 1
   int64_t N;
 };
 
@@ -67,15 +68,17 @@ __device__ __forceinline__ int rho(int r) { return (r & 16) | ((r & 3) << 2) | (
 
 // GA: dY's column count is a multiple of 4 (whole aligned 16-byte pieces); otherwise it is fetched as dwords (65, 3 columns).
 // ACT: the Linear's input activation (compile-time: a runtime switch around the conversion is a branch around memory waits).
-// FULL: out == 256 (no guards around k steps / row tiles).
+// FULL: out == 256 and a 256 wide source (no guards around k steps / row and column tiles).
+// XA: x / g_x rows are whole aligned 16-byte pieces; otherwise (a narrow source of 38 / 69 columns) dword accesses.
 // No conditional around ANY global access, no spill in the loop: a scratch reload is a vmcnt(0), i.e. a wait for the rows that
 // were just requested (the first version: 40 spilled registers, fetch time + MFMA time added up exactly: 381 us = 205 + 176).
-template <bool GA, int ACT, bool FULL>
+template <bool GA, int ACT, bool FULL, bool XA>
 __global__ __launch_bounds__(512) void kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int slice, h;
-  if (g.xcd_map) { const int p = blockIdx.x >> 3; h = p & 1; slice = (p >> 1) * 8 + (blockIdx.x & 7); }
+  if (g.nhalf == 1) { h = 0; slice = blockIdx.x; }
+  else if (g.xcd_map) { const int p = blockIdx.x >> 3; h = p & 1; slice = (p >> 1) * 8 + (blockIdx.x & 7); }
   else { h = blockIdx.x & 1; slice = blockIdx.x >> 1; }
   const int64_t nst_all = (g.N + SS - 1) / SS;
   const int64_t per = (nst_all + g.nsl - 1) / g.nsl;
@@ -92,7 +95,13 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) og[e & (GA ? 0 : 3)] = 4 * c4 + e < g.out ? (uint32_t)((r0 * g.out + 4 * c4 + e) * 4) : lsnt::OOB;
   }
-  const uint32_t ox = (uint32_t)((xr0 * g.ldx + 128 * h + 4 * xc) * 4);
+  const uint32_t ox = (uint32_t)((xr0 * g.ldx + 128 * h + 4 * xc) * 4);   // (XA: 4 xc < in always -- 128 columns, or whole pieces dropped below)
+  uint32_t oxe[XA ? 1 : 4];
+  if (XA) oxe[0] = 4 * xc < g.in ? ox : lsnt::OOB;
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oxe[e & (XA ? 0 : 3)] = 4 * xc + e < g.in ? ox + 4 * e : lsnt::OOB;
+  }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 gs[4], xs[2], d0[2], d1[2];
   // rows of stage st (past the slice: an empty buffer -- every piece reads zeros, every store is dropped)
@@ -112,7 +121,13 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ox, 16 * j * g.ldx * 4, 0));
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (XA) xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, oxe[0], 16 * j * g.ldx * 4, 0));
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, oxe[e & (XA ? 0 : 3)], 16 * j * g.ldx * 4, 0));
+      }
+    }
   };
   // LDS rows of this thread's pieces (sample s sits in row rho(s))
   const int gro = rho(r0) * GP + c4 * 8;            // sample r0 + 8 j -> row rho(r0) + 2 (j & 1) + 16 (j >> 1)
@@ -157,7 +172,13 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       }
       // (the row step in the VECTOR offset, soffset 0: with an SGPR soffset the compiler inserts no wait between a 16-byte store
       // and a VALU write of its data registers, and gfx950 needs one -- build.check_store_data_overwrite, tools/hw/store_soffset_hazard.hip)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, ox + (uint32_t)(16 * j * g.ldx * 4), 0, 0);
+      if constexpr (XA) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, oxe[0] + (uint32_t)(16 * j * g.ldx * 4), 0, 0);
+      else {
+        const u32x4 u = __builtin_bit_cast(u32x4, v);  // (the whole vector: a bit cast of v[e] in an unrolled loop reads element 0 four times)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __builtin_amdgcn_raw_buffer_store_b32(u[e], ry, oxe[e & (XA ? 0 : 3)] + (uint32_t)(16 * j * g.ldx * 4), 0, 0);
+      }
     }
   };
 
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
         bl[ks] = *(const bf16x8*)(f + 1024);
       }
     }
-    const int nks = FULL ? 16 : (g.out + 15) >> 4;
+    const int nks = FULL ? 16 : (32 * wave < g.in ? (g.out + 15) >> 4 : 0);  // (a narrow source: tiles past its columns idle)
     const int n = lane & 31, hh = lane >> 5;
     const int fro = n * GP + hh * 16;                           // LDS row n = sample rho(n)
     const int oto = rho(n) * OP + (32 * wave + 4 * hh) * 4;     // its row of the g_x tile
@@ -225,6 +246,8 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const int wm = wave - 4;  // rows 64 wm .. of dW; all four column tiles of the half
     const int ni = (g.out - 64 * wm + 31) / 32;
     const int NI = FULL ? 2 : (ni < 0 ? 0 : ni > 2 ? 2 : ni);
+    const int nj = (g.in + 31) / 32;
+    const int NJ = FULL ? 4 : (nj > 4 ? 4 : nj);
     f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -264,16 +287,17 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
         for (int jh = 0; jh < 2; ++jh) {  // the four column tiles in two halves: 16 fragment registers less
           bf16x8 bh[2], bl[2];
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            bh[jj] = fragX(buf + 2 * GPLANE, ks, 2 * jh + jj);
-            bl[jj] = fragX(buf + 2 * GPLANE + XPLANE, ks, 2 * jh + jj);
-          }
+          for (int jj = 0; jj < 2; ++jj)
+            if (FULL || 2 * jh + jj < NJ) {
+              bh[jj] = fragX(buf + 2 * GPLANE, ks, 2 * jh + jj);
+              bl[jj] = fragX(buf + 2 * GPLANE + XPLANE, ks, 2 * jh + jj);
+            }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
               const int j = 2 * jh + jj;
-              if (!FULL && i >= NI) continue;
+              if (!FULL && (i >= NI || j >= NJ)) continue;
               if (TBW_ABLATE & 4) { acc[i][j][0] += (float)al[i][0] + (float)bh[jj][1] + (float)ah[i][2] + (float)bl[jj][3]; continue; }
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], acc[i][j], 0, 0, 0);
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (!FULL && i >= NI) continue;  // (the reduction reads rows < out only)
+          if (!FULL && (i >= NI || j >= NJ)) continue;  // (the reduction reads rows < out, columns < in only)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             part[(64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 256 + 128 * h + 32 * j + (lane & 31)] = acc[i][j][r];
@@ -323,22 +347,25 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   }
 }
 
-template <bool GA, bool FULL>
+template <bool GA, bool FULL, bool XA>
 static auto pick_act(int act) -> void (*)(Args) {
-  if (act == NA_ACT_LEAKY_RELU) return kernel<GA, NA_ACT_LEAKY_RELU, FULL>;
-  if (act == NA_ACT_SIN) return kernel<GA, NA_ACT_SIN, FULL>;
-  return kernel<GA, NA_ACT_NONE, FULL>;
+  if (act == NA_ACT_LEAKY_RELU) return kernel<GA, NA_ACT_LEAKY_RELU, FULL, XA>;
+  if (act == NA_ACT_SIN) return kernel<GA, NA_ACT_SIN, FULL, XA>;
+  return kernel<GA, NA_ACT_NONE, FULL, XA>;
 }
 
 static bool wanted(int64_t N, int out, int in0) {
   static const bool off = [] { const char* e = getenv("NA_TRAIN_FUSED_BWD"); return e != nullptr && strcmp(e, "0") == 0; }();
-  return !off && in0 == 256 && out >= 1 && out <= 256 && N >= 8192;
+  return !off && (in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 8192;
 }
 
 static int launch(Args a, float* dW, int ldw, float* db, int overwrite, hipStream_t st, const char* what) {
   const int64_t nst = (a.N + SS - 1) / SS;
   const int cus = lsnt::cu_count();
-  int nsl = cus / 2;
+  const bool wide = a.ldx == 256;  // (a narrow source: ONE workgroup per slice owns all its <= 128 columns)
+  a.nhalf = wide ? 2 : 1;
+  a.in = wide ? 128 : a.ldx;
+  int nsl = wide ? cus / 2 : cus;
   if (nst / 4 < nsl) nsl = (int)(nst / 4 > 0 ? nst / 4 : 1);  // at least 4 stages per slice
   a.nsl = nsl;
   a.xcd_map = (nsl % 8) == 0;
@@ -347,10 +374,12 @@ static int launch(Args a, float* dW, int ldw, float* db, int overwrite, hipStrea
   hipError_t e = hipMallocAsync((void**)&part, (size_t)nsl * PART * sizeof(float), st);
   if (e != hipSuccess) { (void)hipGetLastError(); return lsnt::kNoScratch; }
   a.part = part;
-  const bool ga = (a.out & 3) == 0, full = a.out == 256;
-  auto k = full ? pick_act<true, true>(a.act) : ga ? pick_act<true, false>(a.act) : pick_act<false, false>(a.act);
-  const int which = (full ? 0 : ga ? 1 : 2) * 3 + (a.act == NA_ACT_LEAKY_RELU ? 1 : a.act == NA_ACT_SIN ? 2 : 0);
-  static std::atomic<uint64_t> done[9];
+  const bool ga = (a.out & 3) == 0, full = a.out == 256 && wide, xa = (a.ldx & 3) == 0;
+  auto k = full ? pick_act<true, true, true>(a.act)
+                : xa ? (ga ? pick_act<true, false, true>(a.act) : pick_act<false, false, true>(a.act))
+                     : (ga ? pick_act<true, false, false>(a.act) : pick_act<false, false, false>(a.act));
+  const int which = (full ? 0 : 1 + 2 * xa + ga) * 3 + (a.act == NA_ACT_LEAKY_RELU ? 1 : a.act == NA_ACT_SIN ? 2 : 0);
+  static std::atomic<uint64_t> done[15];
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
@@ -361,8 +390,8 @@ static int launch(Args a, float* dW, int ldw, float* db, int overwrite, hipStrea
     else done[which].fetch_or(bit, std::memory_order_release);
   }
   if (rc == NA_OK) {
-    hipLaunchKernelGGL(k, dim3(2 * nsl), dim3(512), LDS, st, a);
-    rc = train_reduce_partials(part, nsl, a.out, 256, ldw, dW, db, overwrite, st);
+    hipLaunchKernelGGL(k, dim3(a.nhalf * nsl), dim3(512), LDS, st, a);
+    rc = train_reduce_partials(part, nsl, a.out, a.ldx, ldw, dW, db, overwrite, st);
   }
   (void)hipFreeAsync(part, st);
   if (rc != NA_OK) return rc;
@@ -377,12 +406,17 @@ extern "C" {
 
 int na_linear_bwd_fused_ok(int64_t N, int out, int in0) { return lsbw::wanted(N, out, in0) ? 1 : 0; }
 
-// g_x0[N, 256] = (dY . W[:, 0:256]) * act'(x0);  dW[out, 0:256] (leading dimension ldw) and db WRITTEN (not accumulated).
-// wt_packed: W^T ([in, out], in >= 256) as na_train_pack_many packs it.  A second source of a concatenation (a skip layer's
-// [256 | 38]) is the caller's business: its columns of dW and its input gradient come from the kernels that own narrow shapes.
+// g_x0[N, in0] = (dY . W[:, c0:c0+in0]) * act'(x0);  dW[out, 0:in0] (leading dimension ldw) and db WRITTEN (not accumulated).
+// in0 = 256 (a wide source: two workgroups per sample slice, one per column half) or in0 <= 128 (a narrow source -- an init
+// Linear's 38 / 69 columns, the second source of a skip layer: one workgroup per slice).  wt_packed: W^T ([in, out]) as
+// na_train_pack_many packs it, AT the column group that holds the source's first row (row c0, a multiple of 64:
+// na_train_packed_row_offset(c0, out) bytes into the stream).  The sources of a concatenation are separate calls.
+size_t na_train_packed_row_offset(int row0, int K) { return (size_t)(row0 / 64) * (size_t)((K + lsnt::KC - 1) / lsnt::KC < 2 ? 2 : (K + lsnt::KC - 1) / lsnt::KC) * 2 * lsnt::SEG; }
+
 int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
                             float* g_x0, float* dW, int ldw, float* db, void* stream) {
-  NA_REQUIRE(in0 == 256 && out >= 1 && out <= 256 && N >= 0 && ldw >= in0, NA_EINVAL, "na_linear_bwd_bf16x3_pk: bad shape (in0 = %d, out = %d)", in0, out);
+  NA_REQUIRE((in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 0 && ldw >= in0, NA_EINVAL,
+             "na_linear_bwd_bf16x3_pk: bad shape (in0 = %d, out = %d)", in0, out);
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bwd_bf16x3_pk: activation %d", pre_act);
   NA_REQUIRE(dW != nullptr, NA_ENULL, "na_linear_bwd_bf16x3_pk: null pointer");
   if (N == 0) {  // empty batch: the outputs are still defined

@@ -490,23 +490,31 @@ def linear_bwd_fused_ok(N: int, out: int, in0: int) -> bool:
     return bool(_lib.load().na_linear_bwd_fused_ok(int(N), int(out), int(in0)))
 
 
-def linear_bwd_fused(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t: torch.Tensor, in1: int = 0, want_bias: bool = True):
-    """(g_x0 [N,256], dW [out, 256+in1] with columns 0..255 WRITTEN, db [out] | None) of y = W . act([x0|x1]) + b in one pass over dY
-    and x0 (na_linear_bwd_bf16x3_pk).  packed_t: W^T as train_pack_many left it.  The in1 columns of a second source are left to
-    the caller (linear_wgrad_into / linear_dgrad on that source)."""
+def linear_bwd_fused(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t: torch.Tensor, in1: int = 0, want_bias: bool = True,
+                     dW: Optional[torch.Tensor] = None, col0: int = 0):
+    """(g_x [N,in0], dW, db | None) of one source x0 of y = W . act([.. x0 ..]) + b in one pass over dY and x0
+    (na_linear_bwd_bf16x3_pk): in0 = 256, or a narrow source of <= 128 columns.  packed_t: W^T as train_pack_many left it.
+    dW None: a fresh [out, in0 + in1] buffer whose columns 0..in0-1 are WRITTEN (in1 columns of a second source left to the caller);
+    dW given: its columns col0..col0+in0-1 are written (the second source of a skip layer: col0 = the first source's width)."""
     lib = _lib.load()
     dY, x0 = _f32(dY, "dY"), _f32(x0, "x0")
     N, in0 = x0.shape
     out = dY.shape[1]
-    ld = in0 + in1
-    nW = out * ld
-    pad = (-nW) % 4
-    acc = torch.empty(nW + pad + (out if want_bias else 0), device=x0.device, dtype=torch.float32)
-    dW = acc[:nW].view(out, ld)
-    db = acc[nW + pad:] if want_bias else None
+    db = None
+    if dW is None:
+        assert col0 == 0
+        ld = in0 + in1
+        nW = out * ld
+        pad = (-nW) % 4
+        acc = torch.empty(nW + pad + (out if want_bias else 0), device=x0.device, dtype=torch.float32)
+        dW = acc[:nW].view(out, ld)
+        db = acc[nW + pad:] if want_bias else None
+    else:
+        assert dW.is_contiguous() and dW.shape[0] == out and col0 % 64 == 0 and col0 + in0 <= dW.shape[1]
     g0 = torch.empty_like(x0)
-    check(lib.na_linear_bwd_bf16x3_pk(_ptr(dY), out, N, _ptr(packed_t), _ptr(x0), in0, ACT[pre_act], _ptr(g0), _ptr(dW), ld, _ptr(db),
-                                      _stream()))
+    wp = packed_t.data_ptr() + int(lib.na_train_packed_row_offset(col0, out))
+    check(lib.na_linear_bwd_bf16x3_pk(_ptr(dY), out, N, wp, _ptr(x0), in0, ACT[pre_act], _ptr(g0), dW.data_ptr() + 4 * col0, dW.shape[1],
+                                      _ptr(db), _stream()))
     return g0, dW, db
 
 

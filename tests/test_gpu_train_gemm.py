@@ -304,3 +304,40 @@ def test_linear_fn_backward_through_the_fused_kernel_vs_fp64(ops, in1):
         assert rel(x1.grad, xin.grad[:, in0:]) < 3e-5
     assert rel(W.grad, Wd.grad) < 3e-5
     assert rel(b.grad, bd.grad) < 3e-5
+
+
+# (N, in0 of the narrow source, c0 = first row of the source in W^T = width of the source in front of it, out)
+NARROW_BWD = [(8192 + 3, 38, 0, 256), (9000, 69, 0, 256), (8192, 38, 256, 256), (12000 + 1, 69, 256, 256), (8192, 64, 0, 256),
+              (8200, 128, 0, 256), (9001, 100, 64, 128), (8192, 3, 256, 65)]
+
+
+@pytest.mark.parametrize("shape", NARROW_BWD, ids=lambda s: "N%d_in%d_at%d_out%d" % s)
+@pytest.mark.parametrize("act", ["leaky_relu", "sin", "none"])
+def test_fused_backward_of_a_narrow_source_vs_fp64(ops, shape, act):
+    """The one-pass backward on a narrow source (an init Linear's 38 / 69 columns; the second source of a skip layer, whose rows
+    of W^T start at column group c0 / 64 of the packed stream and whose columns of dW start at c0): unaligned rows are fetched
+    and stored as dwords, column tiles past the source idle."""
+    N, in0, c0, out = shape
+    assert ops.linear_bwd_fused_ok(N, out, in0)
+    torch.manual_seed(N + in0 + c0 + out)
+    dev = "cuda"
+    x = torch.randn(N, in0, device=dev)
+    W = torch.randn(out, c0 + in0, device=dev) * (1.0 / (c0 + in0)) ** 0.5
+    gy = torch.randn(N, out, device=dev)
+    f, df = ACTS[act]
+    (pt,) = ops.train_pack_many([(W, True)])
+    dW = torch.full((out, c0 + in0), 7.0, device=dev)
+    g, dW_, _ = ops.linear_bwd_fused(gy, x, act, pt, dW=dW, col0=c0)
+    assert dW_ is dW
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    g_ref = (gy.double() @ W.double()[:, c0:]) * df(x.double())
+    dW_ref = gy.double().t() @ f(x.double())
+    assert rel(g, g_ref) < 3e-5
+    assert rel(dW[:, c0:], dW_ref) < 3e-5
+    assert bool((dW[:, :c0] == 7.0).all()), "columns of the other source are not touched"
+    if c0 == 0:  # a single narrow source: fresh buffers, the bias gradient too
+        g2, dW2, db2 = ops.linear_bwd_fused(gy, x, act, pt)
+        assert torch.equal(g2, g) and torch.equal(dW2, dW)
+        assert rel(db2, gy.double().sum(0)) < 3e-5
