@@ -80,11 +80,11 @@ def hipcc():
 
 
 def _headers_digest() -> str:
-    """sha256 over every header a unit can include (csrc/*.h, include/*.h): content, not mtime."""
+    """sha256 over every header a unit can include (csrc/*.h, csrc/*.inc, include/*.h): content, not mtime."""
     h = hashlib.sha256()
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in sorted(os.listdir(root)):
-            if f.endswith(".h"):
+            if f.endswith((".h", ".inc")):
                 h.update(f.encode())
                 with open(os.path.join(root, f), "rb") as fh:
                     h.update(fh.read())
@@ -127,6 +127,31 @@ def hazard_listings():
             out += [(os.path.basename(_obj_path(u)), os.path.join(_isa_dir(u), f)) for f in sorted(os.listdir(_isa_dir(u)))
                     if f.endswith(".s") and "amdgcn" in f]
     return out
+
+
+HEADLINE_SYMBOL = "_ZN2na2ls16render_ls_kernelILi3ELi0EEEvNS0_4ArgsE"  # render_ls_kernel<NA_PREC_F16X, MODEL 0>: bench.py's kernel
+HEADLINE_PIN = os.path.join(CSRC, "ls_headline_isa.sha256")
+
+
+def function_isa_digest(listing: str, symbol: str):
+    """sha256 of the instructions of ONE function of a device listing (comments, directives and blank lines dropped, local labels
+    kept): what tests/test_isa_guard.py pins for the headline kernel -- a change to a schedule file of another MODEL, to the
+    packing code or to the C ABI must leave it untouched; a change that moves it is re-blessed on purpose
+    (`python tools/check_isa.py --bless-headline`, then the determinism / stress tests on the GPU).  None if the symbol is absent."""
+    h, inside, n = hashlib.sha256(), False, 0
+    with open(listing) as fh:
+        for line in fh:
+            if not inside:
+                inside = line.startswith(symbol + ":")
+                continue
+            if line.startswith(".Lfunc_end"):
+                break
+            t = line.split(";")[0].strip()
+            if not t or (t.startswith(".") and not t.endswith(":")):
+                continue
+            h.update(t.encode() + b"\n")
+            n += 1
+    return (h.hexdigest(), n) if n else None
 
 
 def check_isa(listing: str, kernel: str = ISA_KERNEL, forbidden=ISA_FORBIDDEN):

@@ -116,3 +116,52 @@ def test_check_mfma_use_and_trans_use_flag_what_the_hardware_gets_wrong(tmp_path
         "\tv_mul_f32_e32 v13, v11, v3\n")                                        # second instruction behind: fine
     bad, n = B.check_trans_use(str(lst))
     assert n == 5 and [b[0] for b in bad] == [1], bad
+
+
+def test_headline_kernel_isa_is_the_pinned_one():
+    """the seven schedules of render_ls_kernel live in files of their own (csrc/ls_sched_*.inc) and the engine in
+    ls_engine.h / ls_kernel.h; editing another MODEL's schedule, the packing code or the C ABI must not move ONE instruction of
+    the headline kernel render_ls_kernel<f16x, MODEL 0>.  Its instruction stream is pinned by digest (csrc/ls_headline_isa.sha256);
+    a deliberate change re-blesses it with `python tools/check_isa.py --bless-headline` and re-runs the GPU determinism tests."""
+    from nerf_atlas_amd import build as B
+    B.build(verbose=False, stress=True)
+    path = [p for n, p in B.isa_listings() if n == "render_ls_f16x.o"][0]
+    got = B.function_isa_digest(path, B.HEADLINE_SYMBOL)
+    assert got is not None, "the headline instantiation is missing from the f16x listing"
+    want = open(B.HEADLINE_PIN).read().split()[0]
+    assert got[0] == want, (got, "re-bless on purpose: python tools/check_isa.py --bless-headline")
+    assert B.function_isa_digest(path, "_ZN2na2ls16render_ls_kernelILi3ELi9EEEvNS0_4ArgsE") is None
+
+
+def test_no_source_file_of_the_engine_is_a_monolith():
+    """the layer-synchronous engine was one 3 600-line file with seven `if constexpr` schedules in one kernel body"""
+    from nerf_atlas_amd import build as B
+    for f in os.listdir(B.CSRC):
+        if f.startswith(("ls_", "render_ls")):
+            n = sum(1 for _ in open(os.path.join(B.CSRC, f)))
+            assert n <= 1500, (f, n)
+
+
+def test_store_data_overwrite_scan_flags_the_unprotected_pair(tmp_path):
+    """tools/hw/store_soffset_hazard.hip: a VALU write of a 16-byte buffer store's data right behind the store is only protected by
+    the compiler when the soffset is an immediate"""
+    from nerf_atlas_amd import build as B
+    lst = tmp_path / "fake.s"
+    lst.write_text(
+        "_ZN2na1kEv:\n"
+        "\tbuffer_store_dwordx4 v[182:185], v176, s[20:23], s33 offen\n"
+        "\tv_lshlrev_b32_e32 v182, 16, v171\n"                       # 0 wait states: the pair gfx950 gets wrong
+        "\tbuffer_store_dwordx4 v[10:13], v176, s[20:23], s33 offen\n"
+        "\ts_nop 1\n"
+        "\tv_mov_b32_e32 v10, 0\n"                                    # 2 wait states: fine
+        "\tbuffer_store_dwordx4 v[20:23], v176, s[20:23], 0 offen\n"
+        "\tv_mov_b32_e32 v20, 0\n"                                    # immediate soffset: the compiler's own business
+        "\tbuffer_store_dwordx4 v[30:33], v176, s[20:23], s33 offen\n"
+        "\tv_mov_b32_e32 v40, v30\n"                                  # reads the data: fine
+        ".Lfunc_end0:\n")
+    bad, n = B.check_store_data_overwrite(str(lst))
+    assert n == 3 and [b[0] for b in bad] == [2]
+    B.build(verbose=False, stress=True)
+    for name, path in B.hazard_listings():
+        bad, _ = B.check_store_data_overwrite(path)
+        assert not bad, (name, bad[:2])
