@@ -36,6 +36,7 @@ UNITS = [
     ("backward.hip", [], ""),
     ("train_gemm.hip", [], ""),
     ("train_bwd.hip", [], ""),
+    ("train_fwd.hip", [], ""),
     ("march.hip", [], ""),
     ("mlp_fused.hip", [], ""),
     ("mlp_fwd_inst.hip", ["-DNA_PREC_INST=0"], "_bf16"),

@@ -136,7 +136,7 @@ def test_packed_operands_are_the_same_gemms(ops, shape):
     # narrow outputs with K = 256 take the row-stream kernel (csrc/train_gemm.hip nrw: the same three products per k added in
     # another order) -- equal to a few units in the last place, like the two wide implementations among themselves; a skip layer's
     # wide half then runs as a plain single-pass layer: bit for bit the wide kernel on [W_h] alone
-    nf = in1 == 0 and in0 == 256 and out <= 128
+    nf = (in1 == 0 and in0 == 256 and out <= 128) or (in0 == 256 and out == 256 and in1 <= 80 and N >= 8192)  # (+ train_fwd.hip: W resident in registers)
     n0 = in1 == 0 and out == 256 and in0 <= 128
     n1 = in1 > 0 and out == 256 and in0 % 64 == 0 and in1 <= 128
     same = lambda a, b, narrow: torch.equal(a, b) if not narrow else float((a - b).abs().max()) <= 3e-6 * float(b.abs().max())
@@ -341,3 +341,64 @@ def test_fused_backward_of_a_narrow_source_vs_fp64(ops, shape, act):
         g2, dW2, db2 = ops.linear_bwd_fused(gy, x, act, pt)
         assert torch.equal(g2, g) and torch.equal(dW2, dW)
         assert rel(db2, gy.double().sum(0)) < 3e-5
+
+
+# (N, in1): 256 -> 256 with an optional narrow second source
+FWD_SHAPES = [(8192, 0), (8192 + 37, 0), (65536 + 1, 0), (12000, 38), (9000 + 5, 69), (8192, 80), (8192 + 31, 3), (262144, 38)]
+
+
+@pytest.mark.parametrize("shape", FWD_SHAPES, ids=lambda s: "N%d_in256+%d" % s)
+@pytest.mark.parametrize("act", ["leaky_relu", "sin", "none"])
+def test_register_resident_forward_vs_fp64_and_vs_the_streaming_kernel(ops, shape, act):
+    """csrc/train_fwd.hip (round 5): the forward of a 256 wide Linear (hidden layers, skip layers [256 | 38], [256 | 69] in ONE
+    pass) with W resident in registers, through na_linear_bf16x3_pk."""
+    N, in1 = shape
+    if N > 100000 and act != "leaky_relu":
+        pytest.skip("the full-size batch once")
+    torch.manual_seed(N + in1)
+    dev = "cuda"
+    x0 = torch.randn(N, 256, device=dev)
+    x1 = torch.randn(N, in1, device=dev) if in1 else None
+    W = torch.randn(256, 256 + in1, device=dev) * (1.0 / (256 + in1)) ** 0.5
+    b = torch.randn(256, device=dev)
+    f, _ = ACTS[act]
+    (pf,) = ops.train_pack_many([(W, False)])
+    y = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True, packed=pf)
+    y_stream = ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True)   # (unpacked entry point: lsnt::kernel<0>)
+    y_nobias = ops.linear_f32(x0, W, None, pre_act=act, x1=x1, split_bf16=True, packed=pf)
+
+    def rel(a, r):
+        return float((a.double() - r.double()).abs().max() / r.double().abs().max())
+    if N <= 100000:
+        xin = (torch.cat([x0, x1], 1) if in1 else x0).double()
+        assert rel(y, f(xin) @ W.double().t() + b.double()) < 3e-5
+    assert rel(y, y_stream) < 2e-6
+    assert float((y_nobias + b - y).abs().max()) <= 1e-5
+    assert torch.equal(y, ops.linear_f32(x0, W, b, pre_act=act, x1=x1, split_bf16=True, packed=pf))
+
+
+def test_register_resident_forward_with_sin_in_its_own_process():
+    """The sin instantiations of lsfw::kernel are not the default (each column half converts all of x0: the Cody-Waite sin twice
+    per element makes them slower than the streaming kernel); NA_TRAIN_FUSED_FWD=all selects them -- once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch, sys
+sys.path.insert(0, %r)
+from nerf_atlas_amd import ops
+torch.manual_seed(5)
+for N, in1 in ((8192 + 7, 0), (9000, 38), (8192, 69)):
+    x0 = torch.randn(N, 256, device="cuda"); x1 = torch.randn(N, in1, device="cuda") if in1 else None
+    W = torch.randn(256, 256 + in1, device="cuda") / 17; b = torch.randn(256, device="cuda")
+    (pf,) = ops.train_pack_many([(W, False)])
+    y = ops.linear_f32(x0, W, b, pre_act="sin", x1=x1, split_bf16=True, packed=pf)
+    xin = (torch.cat([x0, x1], 1) if in1 else x0).double()
+    ref = torch.sin(xin) @ W.double().t() + b.double()
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-5, (N, in1, err)
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NA_TRAIN_FUSED_FWD="all")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
