@@ -320,6 +320,47 @@ def self_spawn(n):
     return rc
 
 
+def measure_traffic(prec, engine, kernel_name):
+    """roofline.traffic measured by THIS run (the key used to be a constant from an earlier profile): two child runs
+    of this script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, counters only (no trace domain), as
+    MI355X_MICROARCH.md "HBM" prescribes -- each rendering the same full frame three times in the primary mode; bytes per launch
+    = (2 x FETCH_SIZE + WRITE_SIZE) KiB (the guide's gfx950 correction: FETCH_SIZE counts half of a wide coalesced read).
+    Returns (bytes per launch, source text) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself under a profiler"
+    work = tempfile.mkdtemp(prefix="bench_traffic_")
+    cmd = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--precision", prec, "--engine", engine, "--steps", "2", "--warmup", "1"]
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, ctr)
+            try:
+                r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "--"] + cmd, cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr}: timed out"
+            total, launches = 0.0, set()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_name in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        total += float(row["Counter_Value"])
+                        launches.add(row.get("Dispatch_Id"))
+            if not launches:
+                return None, f"rocprofv3 --pmc {ctr}: no rows for {kernel_name} (rc={r.returncode})"
+            vals[ctr] = total / len(launches)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), \
+        "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of `bench.py --traffic-child` (same frame, same mode), (2 x FETCH + WRITE) KiB per launch"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,6 +374,8 @@ def main():
     ap.add_argument("--engine", default=None, choices=["ls", "reg"], help="fused renderer engine (default: config.engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the slab timings of BASELINE configs 1, 3, 4, 5")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic live (two rocprofv3 --pmc child runs, ~1 min)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # the child of measure_traffic: primary mode only, no JSON
     args = ap.parse_args()
     if args.engine == "reg" and args.precision in ("f16", "f16x"):
         ap.error(f"--precision {args.precision} exists on the layer-synchronous engine only (--engine ls)")
@@ -439,10 +482,13 @@ def main():
                 # doubled per MI355X_MICROARCH.md "HBM"); None when the shard differs from the profiled full frame
                 "traffic": HBM_TRAFFIC_FULL_FRAME.get((engine, prec)) if world == 1 else None,
                 "traffic_unit": "bytes/launch",
-                # NOT measured by this run: the PMC passes need rocprofv3 around the process
+                # (an earlier profile's figure; the primary mode's is replaced by a live measurement: measure_traffic)
                 "traffic_source": TRAFFIC_SOURCE.get((engine, prec)) if world == 1 else None}
 
     prec = args.precision
+    if args.traffic_child:  # (under rocprofv3 --pmc: the primary mode's launches only)
+        timed(prec, args.steps, args.warmup)
+        return
     dt, kern_ms, gath_ms, per_rank, frame = timed(prec, args.steps, args.warmup)
     # (now: with N > 1 `frame` is the gather's persistent receive buffer, which the next timed() call overwrites)
     checksum = round(float(frame.double().sum()), 3) if frame is not None else None
@@ -484,6 +530,14 @@ def main():
     if rank == 0:
         samples = SIZE * SIZE * STEPS_PER_RAY
         value = samples * args.steps / dt / 1e6
+        primary_roofline = roofline(prec, kern_ms)
+        if world == 1 and not args.no_traffic:
+            t_live, t_src = measure_traffic(prec, engine, primary_roofline["kernel"])
+            if t_live is not None:
+                primary_roofline["traffic_profiled_earlier"] = primary_roofline["traffic"]
+                primary_roofline["traffic"], primary_roofline["traffic_source"] = t_live, t_src
+            else:  # keep the earlier profile's figure, say why
+                primary_roofline["traffic_source"] = f"{primary_roofline['traffic_source']}; live measurement failed: {t_src}"
         res = {
             "metric": "Msamples/sec (rays x samples) at 800^2 x 128", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -493,7 +547,7 @@ def main():
                        "rays": SIZE * SIZE, "samples_per_ray": STEPS_PER_RAY, "flop_per_sample": FLOP_PER_SAMPLE,
                        "precision": prec, "engine": engine,
                        "parallelism": f"rays sharded in {world} row band(s) + 1 RCCL gather"},
-            "roofline": roofline(prec, kern_ms),
+            "roofline": primary_roofline,
             "per_rank_kernel_ms": [round(x, 3) for x in per_rank], "gather_ms": round(gath_ms, 3),
             # torch.distributed backend of the run ("nccl" IS RCCL on ROCm; "none" for one process) and the ranks an
             # all-reduce of ones on the device counted; the frame gather's implementation (dist.gather, or all_gather if the

@@ -500,39 +500,68 @@ __global__ void composite_backward_kernel(const float* __restrict__ density, con
     for (int c = 0; c < C; ++c) { g[c] = g_out[r * C + c]; gsum += g[c]; }
     // d sky / d w_t (t < T-1): -1 per channel for white, -rand[r] for the random background (src/nerf.py:98,101-103)
     const float gsky = bg_kind == NA_BG_WHITE ? gsum : bg_kind == NA_BG_RANDOM ? gsum * sky_rand[r] : 0.f;
+    // Both sweeps are dependent chains over T; a step that waits for its own loads costs one memory latency (round 5: 94 us for
+    // 4 096 rays x 64 steps, one thread per ray = 64 waves on the chip).  Rows are fetched U = 8 steps at a time, like the forward
+    // kernel does -- 8 (first sweep) / 8 x (2 + C) (second) independent loads in flight per thread; the arithmetic and its order
+    // are unchanged (bit-identical gradients).
+    constexpr int U = 8;
     float trans = 1.0f;
-    for (int t = 0; t < T; ++t) {
-      const float d = density[(int64_t)t * R + r];
-      const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
-      float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
-      dist *= nrm;
-      const float a = 1.0f - expf(-sigma * dist);
-      g_density[(int64_t)t * R + r] = trans;  // scratch: T_t
-      trans = trans * ((1.0f - a) + 1e-10f);
+    for (int t0 = 0; t0 < T; t0 += U) {
+      float dv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) dv[u] = density[(int64_t)(t0 + u < T ? t0 + u : T - 1) * R + r];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u;
+        if (t < T) {
+          const float d = dv[u];
+          const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
+          float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
+          dist *= nrm;
+          const float a = 1.0f - expf(-sigma * dist);
+          g_density[(int64_t)t * R + r] = trans;  // scratch: T_t
+          trans = trans * ((1.0f - a) + 1e-10f);
+        }
+      }
     }
     float suffix = 0.f;  // sum_{s>t} G_s * w_s
-    for (int t = T - 1; t >= 0; --t) {
-      const float d = density[(int64_t)t * R + r];
-      const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
-      float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
-      dist *= nrm;
-      const float e = expf(-sigma * dist);
-      const float a = 1.0f - e;
-      const float f = (1.0f - a) + 1e-10f;
-      const float Tt = g_density[(int64_t)t * R + r];
-      const float w = a * Tt;
-      const float* ct = feat + ((int64_t)t * R + r) * C;
-      float G = 0.f;
+    for (int t1 = T - 1; t1 >= 0; t1 -= U) {
+      float dv[U], tv[U], cv[U][C];
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        G += g[c] * ct[c];
-        g_feat[((int64_t)t * R + r) * C + c] = w * g[c];
+      for (int u = 0; u < U; ++u) {
+        const int t = t1 - u >= 0 ? t1 - u : 0;  // (clamped: the head re-reads row 0 and ignores it)
+        dv[u] = density[(int64_t)t * R + r];
+        tv[u] = g_density[(int64_t)t * R + r];
+        const float* ct = feat + ((int64_t)t * R + r) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) cv[u][c] = ct[c];
       }
-      if (t < T - 1) G -= gsky;
-      const float dLda = G * Tt - suffix / f;
-      suffix += G * w;
-      const float dsig = density_kind == NA_DENSITY_SOFTPLUS_M1 ? sigmoidf_(d - 1.0f) : (d > 0.f ? 1.f : 0.f);
-      g_density[(int64_t)t * R + r] = dLda * dist * e * dsig;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t1 - u;
+        if (t >= 0) {
+          const float d = dv[u];
+          const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
+          float dist = t < T - 1 ? fmaxf(ts[t + 1] - ts[t], 1e-5f) : 1e10f;
+          dist *= nrm;
+          const float e = expf(-sigma * dist);
+          const float a = 1.0f - e;
+          const float f = (1.0f - a) + 1e-10f;
+          const float Tt = tv[u];
+          const float w = a * Tt;
+          float G = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            G += g[c] * cv[u][c];
+            g_feat[((int64_t)t * R + r) * C + c] = w * g[c];
+          }
+          if (t < T - 1) G -= gsky;
+          const float dLda = G * Tt - suffix / f;
+          suffix += G * w;
+          const float dsig = density_kind == NA_DENSITY_SOFTPLUS_M1 ? sigmoidf_(d - 1.0f) : (d > 0.f ? 1.f : 0.f);
+          g_density[(int64_t)t * R + r] = dLda * dist * e * dsig;
+        }
+      }
     }
   }
 }
@@ -766,7 +795,7 @@ int na_composite_backward(const float* density, const float* feat, const float* 
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_composite_backward: bad shape");
   NA_REQUIRE(C == 3 || C == 1, NA_EUNSUPPORTED, "na_composite_backward: C=%d (1 or 3)", C);
   if (R == 0) return NA_OK;
-  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
+  dim3 g(grid_for(R, 64, 1 << 16)), b(64);  // (one wave per workgroup: 4 096 rays reach 64 CUs instead of 32)
   if (C == 3)
     hipLaunchKernelGGL(composite_backward_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
                        density_kind, bg_kind, g_out, g_density, g_feat);
@@ -784,7 +813,7 @@ int na_composite_random_bg_backward(const float* density, const float* feat, con
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_composite_random_bg_backward: bad shape");
   NA_REQUIRE(C == 3 || C == 1, NA_EUNSUPPORTED, "na_composite_random_bg_backward: C=%d (1 or 3)", C);
   if (R == 0) return NA_OK;
-  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
+  dim3 g(grid_for(R, 64, 1 << 16)), b(64);  // (one wave per workgroup: 4 096 rays reach 64 CUs instead of 32)
   if (C == 3)
     hipLaunchKernelGGL(composite_backward_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
                        density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand);
