@@ -15,7 +15,7 @@ def _bench(gpus, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-other-configs", "--no-traffic"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
