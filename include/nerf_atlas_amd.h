@@ -337,8 +337,12 @@ int na_linear_bwd_fused_ok(int64_t N, int out, int in0);
  * (if given) db WRITTEN -- the narrow source [N, 38 / 69] of a skip layer whose wide source went through na_linear_bwd_bf16x3_pk. */
 int na_linear_wgrad_bf16x3_cols(const float* x, int in, int64_t N, const float* dY, int out, int pre_act, float* dW, int ldw,
                                 float* db, void* stream);
+/* workspace: na_linear_bwd_workspace_bytes(N, in0) bytes of device memory for the partial gradients (16-byte aligned; the caller's
+ * allocator -- torch's is stream-ordered and costs microseconds), or NULL: the call then takes them from hipMallocAsync, which
+ * costs ~230 us of host time per call on ROCm 7.2. */
+size_t na_linear_bwd_workspace_bytes(int64_t N, int in0);
 int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
-                            float* g_x0, float* dW, int ldw, float* db, void* stream);
+                            float* g_x0, float* dW, int ldw, float* db, void* workspace, void* stream);
 int na_linear_wgrad(const float* x0, int in0, const float* x1, int in1, int64_t N, const float* dY, int out,
                     int pre_act, float* dW, float* db, void* stream);
 int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int include_input,

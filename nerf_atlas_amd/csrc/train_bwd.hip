@@ -359,20 +359,29 @@ static bool wanted(int64_t N, int out, int in0) {
   return !off && (in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 8192;
 }
 
-static int launch(Args a, float* dW, int ldw, float* db, int overwrite, hipStream_t st, const char* what) {
-  const int64_t nst = (a.N + SS - 1) / SS;
-  const int cus = lsnt::cu_count();
+// sample slices of a launch (= partial gradients the reduction sums)
+static int slices(int64_t N, bool wide) {
+  const int64_t nst = (N + SS - 1) / SS;
+  int nsl = wide ? lsnt::cu_count() / 2 : lsnt::cu_count();
+  if (nst / 4 < nsl) nsl = (int)(nst / 4 > 0 ? nst / 4 : 1);  // at least 4 stages per slice
+  return nsl;
+}
+
+// workspace: nsl x PART floats from the caller (torch's allocator: stream-ordered, microseconds), or null = the per-stream scratch
+// of train_shared.h (hipMallocAsync here cost 230 us of HOST time per call: tools/train_host_time.py)
+static int launch(Args a, float* dW, int ldw, float* db, int overwrite, float* workspace, hipStream_t st, const char* what) {
   const bool wide = a.ldx == 256;  // (a narrow source: ONE workgroup per slice owns all its <= 128 columns)
   a.nhalf = wide ? 2 : 1;
   a.in = wide ? 128 : a.ldx;
-  int nsl = wide ? cus / 2 : cus;
-  if (nst / 4 < nsl) nsl = (int)(nst / 4 > 0 ? nst / 4 : 1);  // at least 4 stages per slice
+  const int nsl = slices(a.N, wide);
   a.nsl = nsl;
   a.xcd_map = (nsl % 8) == 0;
   a.want_db = db != nullptr;
-  float* part = nullptr;
-  hipError_t e = hipMallocAsync((void**)&part, (size_t)nsl * PART * sizeof(float), st);
-  if (e != hipSuccess) { (void)hipGetLastError(); return lsnt::kNoScratch; }
+  float* part = workspace;
+  if (part == nullptr) {
+    part = (float*)train_scratch(st, (size_t)nsl * PART * sizeof(float));
+    if (part == nullptr) return lsnt::kNoScratch;
+  }
   a.part = part;
   const bool ga = (a.out & 3) == 0, full = a.out == 256 && wide, xa = (a.ldx & 3) == 0;
   auto k = full ? pick_act<true, true, true>(a.act)
@@ -393,7 +402,6 @@ static int launch(Args a, float* dW, int ldw, float* db, int overwrite, hipStrea
     hipLaunchKernelGGL(k, dim3(a.nhalf * nsl), dim3(512), LDS, st, a);
     rc = train_reduce_partials(part, nsl, a.out, a.ldx, ldw, dW, db, overwrite, st);
   }
-  (void)hipFreeAsync(part, st);
   if (rc != NA_OK) return rc;
   return check_launch(what);
 }
@@ -413,8 +421,12 @@ int na_linear_bwd_fused_ok(int64_t N, int out, int in0) { return lsbw::wanted(N,
 // na_train_packed_row_offset(c0, out) bytes into the stream).  The sources of a concatenation are separate calls.
 size_t na_train_packed_row_offset(int row0, int K) { return (size_t)(row0 / 64) * (size_t)((K + lsnt::KC - 1) / lsnt::KC < 2 ? 2 : (K + lsnt::KC - 1) / lsnt::KC) * 2 * lsnt::SEG; }
 
+size_t na_linear_bwd_workspace_bytes(int64_t N, int in0) {
+  return N > 0 ? (size_t)lsbw::slices(N, in0 == 256) * lsbw::PART * sizeof(float) : 0;
+}
+
 int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
-                            float* g_x0, float* dW, int ldw, float* db, void* stream) {
+                            float* g_x0, float* dW, int ldw, float* db, void* workspace, void* stream) {
   NA_REQUIRE((in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 0 && ldw >= in0, NA_EINVAL,
              "na_linear_bwd_bf16x3_pk: bad shape (in0 = %d, out = %d)", in0, out);
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bwd_bf16x3_pk: activation %d", pre_act);
@@ -429,7 +441,7 @@ int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_
              "(na_linear_bwd_fused_ok says which)");
   lsbw::Args a{};
   a.dY = dY; a.x = x0; a.wp = (const char*)wt_packed; a.gx = g_x0; a.out = out; a.act = pre_act; a.ldx = in0; a.N = N;
-  const int rc = lsbw::launch(a, dW, ldw, db, 1, (hipStream_t)stream, "na_linear_bwd_bf16x3_pk");
+  const int rc = lsbw::launch(a, dW, ldw, db, 1, (float*)workspace, (hipStream_t)stream, "na_linear_bwd_bf16x3_pk");
   if (rc == lsnt::kNoScratch) { set_error("na_linear_bwd_bf16x3_pk: stream-ordered scratch allocation failed"); return NA_EHIP; }
   return rc;
 }

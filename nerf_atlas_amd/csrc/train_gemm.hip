@@ -18,6 +18,8 @@
 // arithmetic (the same three products per k, fp32 accumulation; the order of the additions differs: last-bit differences) and
 // reorganise the data flow.
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
@@ -1083,8 +1085,8 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
   const size_t wbytes = (size_t)nrg * a.NCH * 2 * SEG;
   char* wp = nullptr;
   if (prepacked == nullptr) {
-    hipError_t e = hipMallocAsync((void**)&wp, wbytes, st);
-    if (e != hipSuccess) { (void)hipGetLastError(); return kNoScratch; }  // no stream-ordered scratch here: the caller takes the K-staged kernel
+    wp = (char*)train_scratch(st, wbytes);
+    if (wp == nullptr) return kNoScratch;  // no scratch here: the caller takes the K-staged kernel
     const int64_t nthr = (int64_t)nrg * a.NCH * 2 * 8 * 64;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, Bmat, a.M, K, a.NCH, nrg, wp);
   }
@@ -1107,7 +1109,6 @@ static int launch(Args a, const float* Bmat, int K, hipStream_t st, const char* 
     else done[2 * dact + straddle].fetch_or(bit, std::memory_order_release);
   }
   if (rc == NA_OK) hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, st, a);
-  if (wp != nullptr) (void)hipFreeAsync(wp, st);
   if (rc != NA_OK) return rc;
   return check_launch(what);
 }
@@ -1408,9 +1409,8 @@ static int launch(const float* dY, int out, const float* x, int in, int act, int
   int grid = lsnt::cu_count();
   if (nst / 4 < grid) grid = (int)(nst / 4 > 0 ? nst / 4 : 1);  // at least 4 stages per workgroup
   const size_t bytes = (size_t)grid * PART * sizeof(float);
-  float* part = nullptr;
-  hipError_t e = hipMallocAsync((void**)&part, bytes, st);
-  if (e != hipSuccess) { (void)hipGetLastError(); return lsnt::kNoScratch; }
+  float* part = (float*)train_scratch(st, bytes);
+  if (part == nullptr) return lsnt::kNoScratch;
   a.part = part;
   const bool ga = (out & 3) == 0, xa = (in & 3) == 0;
   auto k = ga ? (xa ? kernel<true, true> : kernel<true, false>) : (xa ? kernel<false, true> : kernel<false, false>);
@@ -1430,7 +1430,6 @@ static int launch(const float* dY, int out, const float* x, int in, int act, int
     const int n = out * ((in + 3) / 4) + (db != nullptr ? (out + 3) / 4 : 0);
     hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, grid, out, in, ldw, dW, db, overwrite);
   }
-  (void)hipFreeAsync(part, st);
   if (rc != NA_OK) return rc;
   return check_launch(what);
 }
@@ -1659,6 +1658,28 @@ static int launch(Args a, hipStream_t st, const char* what) {
   return check_launch(what);
 }
 }  // namespace nrw
+
+void* train_scratch(hipStream_t st, size_t bytes) {
+  struct Slot { int dev; hipStream_t st; void* p; size_t n; };
+  static std::mutex mu;
+  static std::vector<Slot> slots;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Slot& s : slots)
+    if (s.dev == dev && s.st == st) {
+      if (s.n >= bytes) return s.p;
+      void* p = nullptr;  // grow: the old buffer stays alive (in-flight kernels), this slot moves on
+      if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      s.p = p; s.n = bytes;
+      return p;
+    }
+  void* p = nullptr;
+  const size_t n = bytes < (64u << 20) ? (64u << 20) : bytes;  // (one 256 x 256 layer's partials are 35-69 MB)
+  if (hipMalloc(&p, n) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  slots.push_back(Slot{dev, st, p, n});
+  return p;
+}
 
 int train_reduce_partials(const float* part, int nwg, int out, int in, int ldw, float* dW, float* db, int overwrite, hipStream_t st) {
   const int n = out * ((in + 3) / 4) + (db != nullptr ? (out + 3) / 4 : 0);

@@ -1,6 +1,7 @@
 // Pieces shared by the training-step GEMM units (train_gemm.hip, train_bwd.hip): the 2-way bf16 split, the activations, the
 // branch-free tile buffers, the packed-operand geometry of lsnt::pack_kernel / pack_many_kernel.
 #pragma once
+#include <atomic>
 #include "common.h"
 
 namespace na {
@@ -62,6 +63,14 @@ static int cu_count() {
 }
 
 }  // namespace lsnt
+
+// Scratch of the training GEMMs (partial gradients, a per-call packed operand): ONE grow-only device buffer per (device, stream),
+// handed out without any driver call once it exists.  Uses on one stream are stream-ordered, so the next call may overwrite it;
+// another stream gets another buffer.  (hipMallocAsync / hipFreeAsync around every launch, rounds 3-5, cost ~230 us of HOST time
+// per call on ROCm 7.2 whatever the pool's release threshold: 14 calls made the training step host-bound at 5.5 ms with 5.15 ms
+// of kernels -- tools/train_host_time.py.)  A buffer that has to grow is replaced, the old one is kept until process exit (kernels
+// may still be reading it).  nullptr = the allocation failed (the caller falls back or reports).  Defined in train_gemm.hip.
+void* train_scratch(hipStream_t st, size_t bytes);
 
 // dW[row, col] (+)= the sum over `nwg` partials of lstn::PART floats each (dW 256 x 256 | 8 row groups of db), in a fixed order
 // (lstn::reduce_kernel, defined in train_gemm.hip)

@@ -513,8 +513,11 @@ def linear_bwd_fused(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t:
         assert dW.is_contiguous() and dW.shape[0] == out and col0 % 64 == 0 and col0 + in0 <= dW.shape[1]
     g0 = torch.empty_like(x0)
     wp = packed_t.data_ptr() + int(lib.na_train_packed_row_offset(col0, out))
+    # (the partial gradients' workspace from torch's allocator: stream-ordered reuse for microseconds; hipMallocAsync inside the
+    # call cost 230 us of host time)
+    ws = torch.empty(int(lib.na_linear_bwd_workspace_bytes(N, in0)), device=x0.device, dtype=torch.uint8)
     check(lib.na_linear_bwd_bf16x3_pk(_ptr(dY), out, N, wp, _ptr(x0), in0, ACT[pre_act], _ptr(g0), dW.data_ptr() + 4 * col0, dW.shape[1],
-                                      _ptr(db), _stream()))
+                                      _ptr(db), _ptr(ws), _stream()))
     return g0, dW, db
 
 
