@@ -31,6 +31,10 @@ def build():
         for prec in PRECS:
             subprocess.run([sys.executable, LSV, "build", f"{prec}_{tag(st)}", "--prec", prec] + flags, check=True)
         subprocess.run([sys.executable, LSV, "build-unit", "train_gemm.hip", f"tg_{tag(st)}"] + flags, check=True)
+        for unit, t in (("train_bwd.hip", "tb"), ("train_fwd.hip", "tf")):  # round 5 (iterative-ilp crashes the compiler on both: skipped)
+            r = subprocess.run([sys.executable, LSV, "build-unit", unit, f"{t}_{tag(st)}"] + flags)
+            if r.returncode != 0:
+                print(f"{unit} does not compile under {st}: no variant")
 
 
 def run():
@@ -64,6 +68,23 @@ def run():
                 same = same and bool(torch.equal(a, b))
                 worst = max(worst, float((a - b).abs().max()))
         print(f"{n:>14s} [training GEMMs, forward + input gradient of 5 shapes]: bit-identical to shipped {same} (max abs diff {worst:.2e})")
+        rc = rc or (0 if same else 1)
+    # round 5: the one-pass backward and the register-resident forward (each unit under each strategy, against the shipped library)
+    fouts = {}
+    fnames = ["shipped"] + [f"{u}_{tag(st)}" for u in ("tb", "tf") for st in STRATEGIES
+                            if os.path.exists(os.path.join(REPO, "gpurun_ablate", f"lib_var_{u}_{tag(st)}.so"))]
+    for n in fnames:
+        lib = os.path.join(REPO, "nerf_atlas_amd", "libnerf_atlas_amd.so") if n == "shipped" else os.path.join(REPO, "gpurun_ablate", f"lib_var_{n}.so")
+        out = f"/tmp/sched_fuzz_fused_{n}.pt"
+        r = subprocess.run([sys.executable, "-c", code.format(repo=REPO, lib=lib, out=out, script=os.path.join(REPO, "tools", "train_fused_dump.py"))],
+                           capture_output=True, text=True, env=dict(os.environ, NA_TRAIN_FUSED_FWD="all"))
+        if r.returncode != 0:
+            print(n, "failed:", r.stderr[-800:])
+            return 1
+        fouts[n] = torch.load(out)
+    for n in fnames[1:]:
+        same = all(torch.equal(a, b) for k in fouts["shipped"] for a, b in zip(fouts["shipped"][k], fouts[n][k]))
+        print(f"{n:>14s} [one-pass backward + register-resident forward, 4 cases]: bit-identical to shipped {same}")
         rc = rc or (0 if same else 1)
     print("scheduler fuzz:", "all variants bit-identical" if rc == 0 else "DIFFERENCES")
     return rc
