@@ -13,7 +13,8 @@
 //             32 x 32 result goes into an LDS tile;
 //   waves 4-7 ("wgrad"): wave u owns rows 64 u .. 64 u + 63 of dW's half (2 x 4 tiles = 128 accumulator registers), the samples
 //             are the MFMA's k: 48 MFMAs per stage, operands through the transposing LDS read like lstn::kernel.
-// ALL eight waves fetch the stage two stages ahead (whole contiguous rows: dY 1 KiB, the x half 512 B), activate / split it into
+// ALL eight waves fetch the stage ONE stage ahead (whole contiguous rows: dY 1 KiB, the x half 512 B; a stage lasts ~2.8 us, and a
+// second prefetch set spilled: a scratch reload is a vmcnt(0)), activate / split it into
 // bf16 hi | lo planes in LDS, and carry out the previous stage's g_x tile: the thread that fetched x[s, c..c+3] keeps act'(x) in
 // registers and finishes exactly those four elements, so the forward input is read ONCE for both gradients and its derivative
 // never touches LDS.  Neither role refills anything from L2 inside the loop (the weight stream of lsnt::kernel -- 256 KiB per
@@ -23,7 +24,10 @@
 // banks apart (conflict-free, and the next four samples are ONE row further: constant offsets), and the 16 lanes of a
 // ds_read_b128 group read 16 rows that are distinct mod 16 (conflict-free).  The input gradient's MFMA sees the samples in the
 // permuted order and un-permutes when it writes its tile.
-// The two halves of a slice are workgroups b and b + 8: same XCD (round-robin dispatch), same time -> dY's second read is an L2 hit.
+// The two halves of a slice are workgroups b and b + 8: same XCD (round-robin dispatch), same time -> dY's second read is an L2 hit
+// (842 MB of HBM traffic per launch measured against 805 + 34 of partials).  The two roles of a SIMD run in ANTIPHASE (the wgrad
+// wave multiplies first, then converts).  A narrow source (<= 128 columns: an init Linear's 38 / 69, the second source of a skip
+// layer) runs the same kernel with ONE workgroup per slice, dword accesses for unaligned rows and idle tiles past its columns.
 // Same arithmetic as the two kernels it replaces (three bf16 products per k, fp32 accumulation); the input gradient's k order is
 // unchanged, the weight gradient's partials are per slice (128 instead of 256 per layer) and summed by lstn::reduce_kernel in
 // a fixed order: bit-reproducible, last-bit differences against the two-launch path.
