@@ -239,3 +239,29 @@ class CompositeFn(Function):
         density, feat, ts, rays = ctx.saved_tensors
         gd, gf = ops.composite_backward(density, feat, ts, rays, g_out.contiguous(), ctx.softplus, ctx.bg, rand=ctx.rand)
         return gd, gf, None, None, None, None, None
+
+
+class SplitHeadFn(Function):
+    """(y[..., 0] contiguous, y[..., 1:] as a view) of a network output [.., 1 + C] -- PlainNeRF's density | intermediate
+    (src/nerf.py:338-342).  The same values as the two slices; the point is the BACKWARD: autograd's own slice gradients are a
+    zero-filled [.., 1 + C] tensor per slice plus their sum (fill + copy + fill + copy + add over a [N, 65] tensor: ~110 us per
+    training step at N = 262 144); here the two gradients are written side by side into one uninitialised buffer: two copies."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.shape = y.shape
+        tail = y[..., 1:]
+        return y[..., 0].contiguous(), tail
+
+    @staticmethod
+    def backward(ctx, g_head, g_tail):
+        g = torch.empty(ctx.shape, device=(g_head if g_head is not None else g_tail).device, dtype=torch.float32)
+        if g_head is not None:
+            g[..., 0].copy_(g_head)
+        else:
+            g[..., 0].zero_()
+        if g_tail is not None:
+            g[..., 1:].copy_(g_tail)
+        else:
+            g[..., 1:].zero_()
+        return g

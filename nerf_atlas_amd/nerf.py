@@ -336,10 +336,12 @@ class PlainNeRF(CommonNeRF):
             return self._finish_sky(out)
         latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
         first_out = self.first(pts, latent)
-        density = first_out[..., 0].contiguous()
+        if ag.needs_grad(first_out):
+            density, intermediate = ag.SplitHeadFn.apply(first_out)  # (the slices' gradients written side by side: autograd.py)
+        else:
+            density, intermediate = first_out[..., 0].contiguous(), first_out[..., 1:]
         if self.training and self.noise_std > 0:
             density = density + utils.randn(density.shape, density.device) * self.noise_std
-        intermediate = first_out[..., 1:]
         view = r_d.unsqueeze(0).expand_as(pts)
         rl = cat_not_none(latent, cat_not_none(intermediate, refl_latent))
         rgb = self.refl(x=pts, view=view, latent=rl)  # `intermediate` is a column slice of first_out: passed by pitch
