@@ -265,3 +265,64 @@ class SplitHeadFn(Function):
         else:
             g[..., 1:].zero_()
         return g
+
+
+class MlpTrainFn(Function):
+    """A whole SkipConnMLP (src/neural_blocks.py:279-296) as ONE autograd node (round 5): the forward is the same chain of training
+    Linears as LinearFn; the backward walks the layers itself -- the one-pass input + weight gradient kernel per source
+    (csrc/train_bwd.hip) WITHOUT its reduction -- and sums the partial gradients of ALL Linears with one launch at the end
+    (14 reduce launches and their gaps per PlainNeRF step before), with one host round trip through autograd instead of one per
+    Linear.  Used when every Linear of the network takes the fused kernels (SkipConnMLP._mlp_fn_ok); otherwise the per-layer nodes."""
+
+    @staticmethod
+    def forward(ctx, init, spec, *params):
+        """spec: {"act": str, "skips": [bool per hidden layer], "packs": [(packed W, packed W^T)] per Linear};
+        params: W, b of init, the hidden layers, out (b may be None)."""
+        act, skips, packs = spec["act"], spec["skips"], spec["packs"]
+        Ws, bs = params[0::2], params[1::2]
+        L = len(Ws)
+        acts = ["none"] + [act] * (L - 1)
+        x1s = [None] + [init if s else None for s in skips] + [None]
+        xs, x = [], init
+        for li in range(L):
+            xs.append(x)
+            x = ops.linear_f32(x, Ws[li], bs[li], pre_act=acts[li], x1=x1s[li], split_bf16=True, packed=packs[li][0])
+        ctx.save_for_backward(*xs, *Ws)
+        ctx.L, ctx.acts, ctx.has_x1 = L, acts, [t is not None for t in x1s]
+        ctx.has_b = [b is not None for b in bs]
+        ctx.packed_t = [p[1] for p in packs]
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        xs, Ws = saved[:L], saved[L:]
+        init = xs[0]
+        g = gy.contiguous()
+        pending, gWs, gbs, g_init = [], [None] * L, [None] * L, None
+        for li in range(L - 1, -1, -1):
+            x0, W = xs[li], Ws[li]
+            out, in0 = W.shape[0], x0.shape[1]
+            in1 = init.shape[1] if ctx.has_x1[li] else 0
+            nW = out * (in0 + in1)
+            pad = (-nW) % 4
+            buf = torch.empty(nW + pad + (out if ctx.has_b[li] else 0), device=g.device, dtype=torch.float32)
+            dW = buf[:nW].view(out, in0 + in1)
+            db = buf[nW + pad:] if ctx.has_b[li] else None
+            gx0, ws, npart = ops.linear_bwd_partials(g, x0, ctx.acts[li], ctx.packed_t[li], 0, ctx.has_b[li])
+            pending.append((ws, npart, out, in0, dW, 0, db))
+            if in1:
+                gx1, ws1, np1 = ops.linear_bwd_partials(g, init, ctx.acts[li], ctx.packed_t[li], in0, False)
+                pending.append((ws1, np1, out, in1, dW, in0, None))
+                g_init = gx1 if g_init is None else g_init + gx1
+            gWs[li], gbs[li] = dW, db
+            if li == 0:
+                g_init = gx0 if g_init is None else g_init + gx0
+            else:
+                g = gx0
+        ops.train_reduce_many(pending)
+        grads = []
+        for li in range(L):
+            grads += [gWs[li], gbs[li]]
+        return (g_init if ctx.needs_input_grad[0] else None, None, *grads)

@@ -373,7 +373,8 @@ static int slices(int64_t N, bool wide) {
 
 // workspace: nsl x PART floats from the caller (torch's allocator: stream-ordered, microseconds), or null = the per-stream scratch
 // of train_shared.h (hipMallocAsync here cost 230 us of HOST time per call: tools/train_host_time.py)
-static int launch(Args a, float* dW, int ldw, float* db, int overwrite, float* workspace, hipStream_t st, const char* what) {
+// reduce = false: the partial gradients stay in `workspace` (required then) for na_train_reduce_many
+static int launch(Args a, float* dW, int ldw, float* db, int overwrite, float* workspace, hipStream_t st, const char* what, bool reduce = true) {
   const bool wide = a.ldx == 256;  // (a narrow source: ONE workgroup per slice owns all its <= 128 columns)
   a.nhalf = wide ? 2 : 1;
   a.in = wide ? 128 : a.ldx;
@@ -404,7 +405,7 @@ static int launch(Args a, float* dW, int ldw, float* db, int overwrite, float* w
   }
   if (rc == NA_OK) {
     hipLaunchKernelGGL(k, dim3(a.nhalf * nsl), dim3(512), LDS, st, a);
-    rc = train_reduce_partials(part, nsl, a.out, a.ldx, ldw, dW, db, overwrite, st);
+    if (reduce) rc = train_reduce_partials(part, nsl, a.out, a.ldx, ldw, dW, db, overwrite, st);
   }
   if (rc != NA_OK) return rc;
   return check_launch(what);
@@ -448,6 +449,41 @@ int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_
   const int rc = lsbw::launch(a, dW, ldw, db, 1, (float*)workspace, (hipStream_t)stream, "na_linear_bwd_bf16x3_pk");
   if (rc == lsnt::kNoScratch) { set_error("na_linear_bwd_bf16x3_pk: stream-ordered scratch allocation failed"); return NA_EHIP; }
   return rc;
+}
+
+// The same pass WITHOUT the reduction: the partial gradients (na_linear_bwd_workspace_bytes(N, in0) bytes = slices x 67 584 floats) stay
+// in `workspace` (required); na_train_reduce_many sums the partials of many Linears in one launch.  want_db: the bias gradient's
+// partial sums are produced too (reduce it by passing db there).
+int na_linear_bwd_partials_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
+                                     float* g_x0, int want_db, void* workspace, void* stream) {
+  NA_REQUIRE((in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 1, NA_EINVAL,
+             "na_linear_bwd_partials_bf16x3_pk: bad shape (in0 = %d, out = %d)", in0, out);
+  NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bwd_partials_bf16x3_pk: activation %d", pre_act);
+  NA_REQUIRE(dY && wt_packed && x0 && g_x0 && workspace, NA_ENULL, "na_linear_bwd_partials_bf16x3_pk: null pointer");
+  NA_REQUIRE(lsbw::wanted(N, out, in0), NA_EUNSUPPORTED, "na_linear_bwd_partials_bf16x3_pk: this batch runs the two-launch path");
+  lsbw::Args a{};
+  a.dY = dY; a.x = x0; a.wp = (const char*)wt_packed; a.gx = g_x0; a.out = out; a.act = pre_act; a.ldx = in0; a.N = N;
+  float dummy_db = 0.f;  // (launch() reads db only as "wanted or not" when it does not reduce)
+  return lsbw::launch(a, nullptr, in0, want_db ? &dummy_db : nullptr, 1, (float*)workspace, (hipStream_t)stream,
+                      "na_linear_bwd_partials_bf16x3_pk", false);
+}
+
+// dW_i[out_i, 0:in_i) (leading dimension ldw_i) and db_i[out_i] (nullable) WRITTEN = the sum of nwg_i partials of 67 584 floats each
+// (the layout of na_linear_bwd_partials_bf16x3_pk's workspace), i = 0 .. n-1, in one launch per 32 entries; fixed order of the
+// additions (the bits of na_linear_bwd_bf16x3_pk's own reduction).
+int na_train_reduce_many(int n, const float* const* part, const int* nwg, const int* out, const int* in, const int* ldw, float* const* dW,
+                         float* const* db, void* stream) {
+  NA_REQUIRE(n >= 0, NA_EINVAL, "na_train_reduce_many: n < 0");
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(part && nwg && out && in && ldw && dW && db, NA_ENULL, "na_train_reduce_many: null pointer");
+  for (int i = 0; i < n; ++i) {
+    NA_REQUIRE(part[i] && dW[i], NA_ENULL, "na_train_reduce_many: null entry %d", i);
+    NA_REQUIRE(nwg[i] >= 1 && out[i] >= 1 && out[i] <= 256 && in[i] >= 1 && in[i] <= 256 && ldw[i] >= in[i], NA_EINVAL,
+               "na_train_reduce_many: bad shape of entry %d", i);
+  }
+  const int rc = train_reduce_many(n, part, nwg, out, in, ldw, dW, db, (hipStream_t)stream);
+  if (rc != NA_OK) return rc;
+  return check_launch("na_train_reduce_many");
 }
 
 }  // extern "C"

@@ -904,14 +904,14 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 // does not depend on timing (and 256 sequential 256-KiB-strided reads per element became 4 x 64 in parallel).
 // Round 5: an item = FOUR consecutive columns of one row, read as one 16-byte load per partial (the partial rows have pitch 256:
 // always aligned) with sixteen partials in flight -- the per-element order of additions is unchanged, so are the bits.  `overwrite`: dW / db are written, not accumulated into (no zero fill by the caller).
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw,
-                                                     float* __restrict__ dW, float* __restrict__ db, int overwrite) {
+__device__ __forceinline__ void reduce_body(const float* __restrict__ part, int nwg, int out, int in, int ldw,
+                                            float* __restrict__ dW, float* __restrict__ db, int overwrite, int block) {
   __shared__ f32x4 red[4][64];
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int in4 = (in + 3) >> 2;
   const int nI = out * in4;                 // 4-column items of dW
   const int nB = db != nullptr ? (out + 3) >> 2 : 0;
-  const int idx = blockIdx.x * 64 + e;
+  const int idx = block * 64 + e;
   const int w0 = (int)((int64_t)nwg * q / 4), w1 = (int)((int64_t)nwg * (q + 1) / 4);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int row = 0, col = 0;
@@ -973,6 +973,30 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ p
         if (col + k < out) db[col + k] = overwrite ? t[k] : db[col + k] + t[k];
     }
   }
+}
+
+
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int nwg, int out, int in, int ldw,
+                                                     float* __restrict__ dW, float* __restrict__ db, int overwrite) {
+  reduce_body(part, nwg, out, in, ldw, dW, db, overwrite, blockIdx.x);
+}
+
+// Round 5: the partial gradients of EVERY Linear of a network summed by ONE launch (na_train_reduce_many: the whole-network backward
+// of autograd.MlpTrainFn keeps all partial buffers alive and reduces at the end -- 14 launches of 16 us + their gaps per PlainNeRF
+// step before).  Entry e owns blocks first[e] .. first[e + 1); same per-element order of additions as reduce_kernel: same bits.
+constexpr int kReduceMany = 32;
+struct ReduceMany {
+  const float* part[kReduceMany];
+  float* dW[kReduceMany];
+  float* db[kReduceMany];
+  int nwg[kReduceMany], out[kReduceMany], in[kReduceMany], ldw[kReduceMany];
+  int first[kReduceMany + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_many_kernel(ReduceMany rm) {
+  int e = 0;
+  while (e + 1 < rm.n && (int)blockIdx.x >= rm.first[e + 1]) ++e;  // (block-uniform)
+  reduce_body(rm.part[e], rm.nwg[e], rm.out[e], rm.in[e], rm.ldw[e], rm.dW[e], rm.db[e], 1, (int)blockIdx.x - rm.first[e]);
 }
 
 // one source of the concatenation: dW[:, 0 .. in) at leading dimension ldw
@@ -1254,6 +1278,25 @@ void* train_scratch(hipStream_t st, size_t bytes) {
   if (hipMalloc(&p, n) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   slots.push_back(Slot{dev, st, p, n});
   return p;
+}
+
+int train_reduce_many(int n, const float* const* part, const int* nwg, const int* out, const int* in, const int* ldw, float* const* dW,
+                      float* const* db, hipStream_t st) {
+  for (int base = 0; base < n; base += lstn::kReduceMany) {
+    lstn::ReduceMany rm{};
+    rm.n = n - base < lstn::kReduceMany ? n - base : lstn::kReduceMany;
+    int blocks = 0;
+    for (int e = 0; e < rm.n; ++e) {
+      const int i = base + e;
+      rm.part[e] = part[i]; rm.dW[e] = dW[i]; rm.db[e] = db[i]; rm.nwg[e] = nwg[i]; rm.out[e] = out[i]; rm.in[e] = in[i]; rm.ldw[e] = ldw[i];
+      rm.first[e] = blocks;
+      const int items = out[i] * ((in[i] + 3) / 4) + (db[i] != nullptr ? (out[i] + 3) / 4 : 0);
+      blocks += (items + 63) / 64;
+    }
+    rm.first[rm.n] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(lstn::reduce_many_kernel, dim3(blocks), dim3(256), 0, st, rm);
+  }
+  return NA_OK;
 }
 
 int train_reduce_partials(const float* part, int nwg, int out, int in, int ldw, float* dW, float* db, int overwrite, hipStream_t st) {

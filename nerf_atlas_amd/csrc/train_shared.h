@@ -74,6 +74,8 @@ void* train_scratch(hipStream_t st, size_t bytes);
 
 // dW[row, col] (+)= the sum over `nwg` partials of lstn::PART floats each (dW 256 x 256 | 8 row groups of db), in a fixed order
 // (lstn::reduce_kernel, defined in train_gemm.hip)
+int train_reduce_many(int n, const float* const* part, const int* nwg, const int* out, const int* in, const int* ldw, float* const* dW,
+                      float* const* db, hipStream_t st);
 int train_reduce_partials(const float* part, int nwg, int out, int in, int ldw, float* dW, float* db, int overwrite, hipStream_t st);
 
 // y[N, 256] = act([x0 (256) | x1 (in1)]) . W^T + b with W resident in registers (train_fwd.hip); w_packed: W [256, 256 + in1] as

@@ -8,6 +8,8 @@ same operators run through nerf_atlas_amd/autograd.py (HIP forward + backward ke
 import math
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -307,6 +309,14 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
             init = torch.cat([init, lat], dim=-1)
         init = init.contiguous()
         packs = self._train_packs(init)
+        if self._mlp_fn_ok(init, packs):
+            # every Linear takes the fused training kernels: the network is ONE autograd node (autograd.MlpTrainFn)
+            n = len(self.layers)
+            spec = {"act": self.act_name, "skips": [i != n - 1 and (i % self.skip) == 0 for i in range(n)], "packs": packs}
+            params = []
+            for lin in self._linears():
+                params += [lin.weight, lin.bias]
+            return ag.MlpTrainFn.apply(init, spec, *params)
         x = ag.LinearFn.apply(init, None, self.init.weight, self.init.bias, "none", packs[0])
         n = len(self.layers)
         for i, layer in enumerate(self.layers):
@@ -315,6 +325,23 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         if self.last_layer_act:
             setattr(self, "last_layer_out", x)
         return ag.LinearFn.apply(x, None, self.out.weight, self.out.bias, self.act_name, packs[-1])
+
+    def _mlp_fn_ok(self, init, packs) -> bool:
+        """Can the whole network run as autograd.MlpTrainFn?  The split-bf16 arithmetic with packed operands for every Linear, the
+        input needs its gradient, every source of every Linear runs the one-pass backward kernel (256 wide or <= 128 columns, at
+        most 256 outputs, N >= 8 192), nobody asks for the last hidden layer's output."""
+        if (config.train_precision != "bf16x3" or self.last_layer_act or not init.requires_grad or os.environ.get("NA_TRAIN_MLP_FN") == "0"
+                or any(p is None or p[1] is None for p in packs)):
+            return False
+        N, w0 = init.shape
+        n = len(self.layers)
+        for i, lin in enumerate(self._linears()):
+            out, k = lin.weight.shape
+            skip = 1 <= i <= n and (i - 1) != n - 1 and ((i - 1) % self.skip) == 0
+            in0 = k - (w0 if skip else 0)
+            if not lin.weight.requires_grad or not ops.linear_bwd_fused_ok(N, out, in0) or (skip and not ops.linear_bwd_fused_ok(N, out, w0)):
+                return False
+        return True
 
     def _train_packs(self, init):
         """[(packed W, packed W^T | None) | None per Linear] for the split-bf16 training GEMMs: the bf16 hi / lo MFMA fragments of

@@ -521,6 +521,37 @@ def linear_bwd_fused(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t:
     return g0, dW, db
 
 
+def linear_bwd_partials(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t: torch.Tensor, col0: int = 0, want_bias: bool = True):
+    """The one-pass backward of a source WITHOUT its reduction (na_linear_bwd_partials_bf16x3_pk): (g_x [N, in0], workspace holding
+    the partial gradients, number of partials).  train_reduce_many sums the partials of many Linears in one launch."""
+    lib = _lib.load()
+    dY, x0 = _f32(dY, "dY"), _f32(x0, "x0")
+    N, in0 = x0.shape
+    out = dY.shape[1]
+    nbytes = int(lib.na_linear_bwd_workspace_bytes(N, in0))
+    ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
+    g0 = torch.empty_like(x0)
+    wp = packed_t.data_ptr() + int(lib.na_train_packed_row_offset(col0, out))
+    check(lib.na_linear_bwd_partials_bf16x3_pk(_ptr(dY), out, N, wp, _ptr(x0), in0, ACT[pre_act], _ptr(g0), int(want_bias), _ptr(ws),
+                                               _stream()))
+    return g0, ws, nbytes // (67584 * 4)
+
+
+def train_reduce_many(entries):
+    """entries: [(workspace, partials, out, in, dW [out, ld] contiguous, col0, db | None)]: dW[:, col0:col0+in] and db WRITTEN, all
+    entries by one launch (na_train_reduce_many)."""
+    lib = _lib.load()
+    n = len(entries)
+    if n == 0:
+        return
+    vp, ip = C.c_void_p * n, C.c_int * n
+    check(lib.na_train_reduce_many(
+        n, vp(*[e[0].data_ptr() for e in entries]), ip(*[int(e[1]) for e in entries]), ip(*[int(e[2]) for e in entries]),
+        ip(*[int(e[3]) for e in entries]), ip(*[int(e[4].shape[1]) for e in entries]),
+        vp(*[e[4].data_ptr() + 4 * int(e[5]) for e in entries]), vp(*[(e[6].data_ptr() if e[6] is not None else None) for e in entries]),
+        _stream()))
+
+
 def linear_wgrad_cols(x: torch.Tensor, dY: torch.Tensor, pre_act: str, dW: torch.Tensor, col0: int):
     """dW[:, col0:col0 + x.shape[1]] = dY^T . act(x) WRITTEN (na_linear_wgrad_bf16x3_cols): one source of a concatenated input."""
     lib = _lib.load()

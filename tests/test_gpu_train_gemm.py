@@ -402,3 +402,25 @@ print("OK")
     env = dict(os.environ, NA_TRAIN_FUSED_FWD="all")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_whole_network_node_matches_the_per_layer_nodes(ops, monkeypatch):
+    """autograd.MlpTrainFn (one node per SkipConnMLP, partial gradients of all Linears reduced by ONE launch) against the chain of
+    LinearFn nodes: same forward bits, gradients equal to the last place (same kernels, same order of the partial sums)."""
+    from nerf_atlas_amd.neural_blocks import SkipConnMLP, HashEncoder
+    torch.manual_seed(11)
+    m = SkipConnMLP(in_size=3, out=65, latent_size=0, enc=HashEncoder(input_dims=3), num_layers=5, hidden_size=256).cuda()
+    p = (torch.rand(9000, 3, device="cuda") * 2 - 1)
+    gy = torch.randn(9000, 65, device="cuda")
+    res = {}
+    for mode in ("node", "layers"):
+        if mode == "layers":
+            monkeypatch.setattr(SkipConnMLP, "_mlp_fn_ok", lambda self, init, packs: False)
+        m.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            y = m(p)
+            y.backward(gy)
+        res[mode] = (y.detach().clone(), [q.grad.clone() for q in m.parameters()])
+    assert torch.equal(res["node"][0], res["layers"][0])
+    for a, b in zip(res["node"][1], res["layers"][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
