@@ -378,8 +378,9 @@ def test_register_resident_forward_vs_fp64_and_vs_the_streaming_kernel(ops, shap
 
 
 def test_register_resident_forward_with_sin_in_its_own_process():
-    """The sin instantiations of lsfw::kernel are not the default (each column half converts all of x0: the Cody-Waite sin twice
-    per element makes them slower than the streaming kernel); NA_TRAIN_FUSED_FWD=all selects them -- once per process."""
+    """lsfw::kernel with the sin activation against fp64 in a fresh process (the first version of the kernel split the output columns
+    over two workgroups and was not the default for sin; since the full-width version it is: this keeps a process-level check that
+    the environment switch parses -- NA_TRAIN_FUSED_FWD=all is simply "on")."""
     import os
     import subprocess
     import sys

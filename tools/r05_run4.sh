@@ -1,6 +1,7 @@
 O=gpurun_out/r05g; mkdir -p $O; rm -f $O/fwd_bench.log
-timeout 900 python -m pytest tests/test_gpu_train_gemm.py -x -q -k "register_resident or packed_operands" 2>&1 | tail -2 | tee $O/pytest.log
-for i1 in 0 38; do python tools/fwd_bench.py $i1 2>/dev/null | tee -a $O/fwd_bench.log; done
-python tools/fwd_bench.py 0 sin 2>/dev/null | tee -a $O/fwd_bench.log
-for v in 1 2 4 8; do NA_LIB_PATH=$PWD/gpurun_ablate/lib_var_tfw$v.so python tools/fwd_bench.py 0 2>/dev/null | sed "s/^/ablate$v /" | tee -a $O/fwd_bench.log; done
+timeout 900 python -m pytest tests/test_gpu_train_gemm.py -x -q -k "register_resident or packed_operands or whole_network" 2>&1 | tail -2 | tee $O/pytest.log
 for i in 1 2; do python tools/train_bench.py --iters 30 2>/dev/null | tail -1 | cut -c90-160; NA_TRAIN_FUSED_FWD=0 python tools/train_bench.py --iters 30 2>/dev/null | tail -1 | cut -c90-160 | sed 's/^/fwd-off /'; done | tee $O/train_step.log
+export TMPDIR=/tmp
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -- python $GRAFT_REPO_ROOT/tools/train_bench.py > /dev/null 2>&1)
+find /tmp/prof_train -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_train.csv
+grep "lsfw\|lsnt" $O/kernel_stats_train.csv | cut -d, -f1-4 | cut -c1-120
