@@ -31,12 +31,16 @@ constexpr int SS = 32;                  // samples per stage
 constexpr int KMAX = 336;               // 256 + 80
 constexpr int OP = 1040;                // row pitch of the output tile (256 floats + 4: 260 dwords = 4 mod 64)
 constexpr int OT = SS * OP;
-template <bool X1> struct Geo {
-  static constexpr int P = X1 ? KMAX * 2 + 16 : 528;   // row pitch of a plane: 172 / 132 dwords = 4 x odd mod 64: conflict-free b128 reads
+// MODE 0: a 256 wide source; 1: + a narrow second source (a skip layer); 2: a narrow source alone (an init Linear: 38 / 69 columns)
+template <int MODE> struct Geo {
+  static constexpr bool X0 = MODE != 2, X1 = MODE != 0;
+  static constexpr int KOFF = X0 ? 256 : 0;            // column of the image where the narrow source starts
+  static constexpr int KTOT = KOFF + (X1 ? KMAX - 256 : 0);
+  static constexpr int P = KTOT * 2 + 16;              // row pitch of a plane: 132 / 172 / 44 dwords = 4 x odd mod 64: conflict-free b128 reads
   static constexpr int PLANE = SS * P;
   static constexpr int STAGE = 2 * PLANE;              // hi | lo
   static constexpr int LDS = 2 * STAGE + 2 * OT;       // two stage buffers + two output tiles: 131 / 151 KiB
-  static constexpr int NK = X1 ? KMAX / 16 : 16;       // k steps (a wave holds them all)
+  static constexpr int NK = KTOT / 16;                 // k steps (a wave holds them all): 16 / 21 / 5
 };
 
 struct Args {
@@ -46,12 +50,15 @@ struct Args {
   const float* bias; // [256] or null
   float* y;          // [N, 256]
   int in1, NCH, nks, nsl, xcd_map;
+  int out;           // output columns: 256, or (NOUT instantiations: the out Linears, 256 -> 65 / 3) <= 128
   int64_t N;
 };
 
-template <int ACT, bool X1>
+// NOUT: a narrow output (<= 128 columns, unaligned rows): column tiles past it idle, the tile leaves as dwords
+template <int ACT, int MODE, bool NOUT = false>
 __global__ __launch_bounds__(512) void kernel(Args g) {
-  using G = Geo<X1>;
+  using G = Geo<MODE>;
+  constexpr bool X0 = G::X0, X1 = G::X1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slice = blockIdx.x;
@@ -74,9 +81,11 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   };
   auto load = [&](f32x4 (&a)[4], f32x4 (&b)[2], int st) __attribute__((always_inline)) {  // (both sets have this shape when they exist)
     if (TFW_ABLATE & 1) return;
-    const __amdgpu_buffer_rsrc_t r0s = stage_rsrc(g.x0, 256, st);
+    if constexpr (X0) {
+      const __amdgpu_buffer_rsrc_t r0s = stage_rsrc(g.x0, 256, st);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0s, o0, 8 * j * 256 * 4, 0));
+      for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0s, o0, 8 * j * 256 * 4, 0));
+    }
     if constexpr (X1) {
       const __amdgpu_buffer_rsrc_t r1s = stage_rsrc(g.x1, g.in1, st);
 #pragma unroll
@@ -85,19 +94,21 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
         for (int e = 0; e < 4; ++e) b[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1s, o1[e], 16 * j * g.in1 * 4, 0));
     }
   };
-  const int ro0 = r0 * G::P + c4 * 8, ro1 = xr0 * G::P + (256 + 4 * xc) * 2;
+  const int ro0 = r0 * G::P + c4 * 8, ro1 = xr0 * G::P + (G::KOFF + 4 * xc) * 2;
   auto convert = [&](const f32x4 (&a)[4], const f32x4 (&b)[2], char* buf) __attribute__((always_inline)) {
     if (TFW_ABLATE & 2) return;
+    if constexpr (X0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v = a[j];
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = a[j];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = tact(v[e], ACT);
-      bf16x4 hi, lo;
-      split4(v, hi, lo);
-      char* p = buf + ro0 + 8 * j * G::P;
-      *(bf16x4*)p = hi;
-      *(bf16x4*)(p + G::PLANE) = lo;
+        for (int e = 0; e < 4; ++e) v[e] = tact(v[e], ACT);
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        char* p = buf + ro0 + 8 * j * G::P;
+        *(bf16x4*)p = hi;
+        *(bf16x4*)(p + G::PLANE) = lo;
+      }
     }
     if constexpr (X1) {
       if (4 * xc < KMAX - 256) {  // (columns 256 .. 335 of the image: 20 pieces per row)
@@ -116,14 +127,28 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     }
   };
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  const int ncol = tid & 127, nrow0 = tid >> 7;   // NOUT: element (row nrow0 + 4 j, column ncol)
   if (g.bias != nullptr) {
+    if constexpr (NOUT) {}  // (added in the accumulators: below)
+    else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias4[e] = g.bias[4 * c4 + e];
+      for (int e = 0; e < 4; ++e) bias4[e] = g.bias[4 * c4 + e];
+    }
   }
   // y of stage st: the tile + bias, as whole row pieces (the thread's pieces = the ones it fetches of x0: same offsets)
   auto finish = [&](int st) __attribute__((always_inline)) {
     if (TFW_ABLATE & 8) return;
-    const __amdgpu_buffer_rsrc_t ry = stage_rsrc(g.y, 256, st);
+    const __amdgpu_buffer_rsrc_t ry = stage_rsrc(g.y, g.out, st);
+    if constexpr (NOUT) {
+      const char* ot = otile + (st & 1) * OT + nrow0 * OP + ncol * 4;
+      const uint32_t oy = ncol < g.out ? (uint32_t)((nrow0 * g.out + ncol) * 4) : lsnt::OOB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = *(const float*)(ot + 4 * j * OP);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ry, oy, 4 * j * g.out * 4, 0);
+      }
+      return;
+    }
     const char* ot = otile + (st & 1) * OT + r0 * OP + c4 * 16;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -143,7 +168,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const int ks = i < g.nks ? i : g.nks - 1;  // (slots past nks: a valid address, never used)
-      const char* f = base + (size_t)(((ks >> 3) * 2 + (wave & 1)) * 8 + (ks & 7)) * 2048;
+      const char* f = (NOUT && 64 * (wave >> 1) >= g.out ? g.wp + lane * 16 : base) + (size_t)(((ks >> 3) * 2 + (wave & 1)) * 8 + (ks & 7)) * 2048;  // (NOUT: column groups past the output do not exist in the stream)
       wh[i] = *(const bf16x8*)f;
       wl[i] = *(const bf16x8*)(f + 1024);
     }
@@ -151,14 +176,24 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   const int n = lane & 31, hh = lane >> 5;
   const int fro = n * G::P + hh * 16;
   const int oto = n * OP + (32 * wave + 4 * hh) * 4;
+  const bool tile_on = !NOUT || 32 * wave < g.out;  // (wave-uniform)
+  // NOUT: the accumulators START at the bias, like nrw::kernel<0> which ran these layers before -- the same bits as that kernel
+  // (the chaotic D-NeRF recipes of tests/test_gpu_train.py amplify a last-place difference in a forward into another end point)
+  float bias_acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = 32 * wave + 8 * (q >> 2) + 4 * hh + (q & 3);
+    bias_acc[q] = (NOUT && g.bias != nullptr && c < g.out) ? g.bias[c] : 0.f;
+  }
   auto mma = [&](const char* buf, char* ot) __attribute__((always_inline)) {
+    if (!tile_on) return;
     f32x16 acc;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[q] = NOUT ? bias_acc[q] : 0.f;
     const char* fr = buf + fro;
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-      if (i < 16 || i < g.nks) {  // (wave-uniform; K = 256: exactly 16)
+      if ((X0 && i < 16) || i < g.nks) {  // (wave-uniform; K = 256: exactly 16)
         const bf16x8 xh = *(const bf16x8*)(fr + i * 32);
         const bf16x8 xl = *(const bf16x8*)(fr + G::PLANE + i * 32);
         if (TFW_ABLATE & 4) { acc[i & 15] += (float)xh[0] + (float)xl[1] + (float)wl[i][0] + (float)wh[i][1]; continue; }
@@ -175,7 +210,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   // step s: [finish(s - 1) | convert(s + 1) | fetch] and mma(s), one barrier; waves 0-3 multiply first, waves 4-7 convert first
   // (the two waves of a SIMD in antiphase).  Without a second source the rows are fetched TWO stages ahead (two register sets).
   const bool mfirst = wave < 4;
-  if constexpr (!X1) {
+  if constexpr (MODE == 0) {
     load(a0, b0, 0);
     load(a1, b1, 1);
     convert(a0, b0, smem);
@@ -230,18 +265,21 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 static bool wanted(int64_t N, int out, int in0, int in1, int act) {
   static const bool off = [] { const char* e = getenv("NA_TRAIN_FUSED_FWD"); return e != nullptr && strcmp(e, "0") == 0; }();
   (void)act;
-  return !off && in0 == 256 && out == 256 && in1 >= 0 && in1 <= KMAX - 256 && N >= 8192;
+  const bool wide = in0 == 256 && in1 >= 0 && in1 <= KMAX - 256, narrow = in1 == 0 && in0 >= 1 && in0 <= KMAX - 256;
+  const bool nout = out >= 1 && out <= 128 && in0 == 256 && in1 == 0;   // (the out Linears: 256 -> 65 / 3)
+  return !off && ((out == 256 && (wide || narrow)) || nout) && N >= 8192;
 }
 
-template <bool X1>
+template <int MODE, bool NOUT = false>
 static auto pick_act(int act) -> void (*)(Args) {
-  if (act == NA_ACT_LEAKY_RELU) return kernel<NA_ACT_LEAKY_RELU, X1>;
-  if (act == NA_ACT_SIN) return kernel<NA_ACT_SIN, X1>;
-  return kernel<NA_ACT_NONE, X1>;
+  if (act == NA_ACT_LEAKY_RELU) return kernel<NA_ACT_LEAKY_RELU, MODE, NOUT>;
+  if (act == NA_ACT_SIN) return kernel<NA_ACT_SIN, MODE, NOUT>;
+  return kernel<NA_ACT_NONE, MODE, NOUT>;
 }
 
 static int launch(Args a, int act, hipStream_t st, const char* what) {
-  const int K = 256 + a.in1;
+  const int mode = a.x0 == nullptr ? 2 : a.in1 > 0 ? 1 : 0;
+  const int K = (mode == 2 ? 0 : 256) + a.in1;
   a.NCH = (K + lsnt::KC - 1) / lsnt::KC;
   if (a.NCH < 2) a.NCH = 2;
   a.nks = (K + 15) / 16;
@@ -251,11 +289,10 @@ static int launch(Args a, int act, hipStream_t st, const char* what) {
   if (nst / 4 < nsl) nsl = (int)(nst / 4 > 0 ? nst / 4 : 1);
   a.nsl = nsl;
   a.xcd_map = 0;
-  const bool x1 = a.in1 > 0;
-  auto k = x1 ? pick_act<true>(act) : pick_act<false>(act);
-  const int lds = x1 ? Geo<true>::LDS : Geo<false>::LDS;
-  const int which = (x1 ? 3 : 0) + (act == NA_ACT_LEAKY_RELU ? 1 : act == NA_ACT_SIN ? 2 : 0);
-  static std::atomic<uint64_t> done[6];
+  auto k = a.out != 256 ? pick_act<0, true>(act) : mode == 2 ? pick_act<2>(act) : mode == 1 ? pick_act<1>(act) : pick_act<0>(act);
+  const int lds = mode == 2 ? Geo<2>::LDS : mode == 1 ? Geo<1>::LDS : Geo<0>::LDS;
+  const int which = 3 * (a.out != 256 ? 3 : mode) + (act == NA_ACT_LEAKY_RELU ? 1 : act == NA_ACT_SIN ? 2 : 0);
+  static std::atomic<uint64_t> done[12];
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
@@ -271,10 +308,13 @@ static int launch(Args a, int act, hipStream_t st, const char* what) {
 
 bool train_fwd_wanted(int64_t N, int out, int in0, int in1, int act) { return lsfw::wanted(N, out, in0, in1, act); }
 
-int train_fwd_launch(const float* x0, const float* x1, int in1, int64_t N, const void* w_packed, const float* b, int pre_act, float* y,
-                     hipStream_t st, const char* what) {
+int train_fwd_launch(const float* x0, int in0, const float* x1, int in1, int64_t N, const void* w_packed, const float* b, int out,
+                     int pre_act, float* y, hipStream_t st, const char* what) {
   lsfw::Args a{};
-  a.x0 = x0; a.x1 = in1 > 0 ? x1 : nullptr; a.in1 = in1; a.wp = (const char*)w_packed; a.bias = b; a.y = y; a.N = N;
+  a.out = out;
+  if (in0 == 256) { a.x0 = x0; a.x1 = in1 > 0 ? x1 : nullptr; a.in1 = in1; }
+  else { a.x0 = nullptr; a.x1 = x0; a.in1 = in0; }  // a narrow source alone rides in the second source's slot
+  a.wp = (const char*)w_packed; a.bias = b; a.y = y; a.N = N;
   return lsfw::launch(a, pre_act, st, what);
 }
 }  // namespace na

@@ -1515,7 +1515,7 @@ int na_linear_bf16x3_pk(const float* x0, int in0, const float* x1, int in1, int6
   NA_REQUIRE(lsnt_wanted(N, out), NA_EUNSUPPORTED, "na_linear_bf16x3_pk: this batch / width runs the K-staged kernel: call "
              "na_linear_bf16x3 (na_train_gemm_packed_ok says which)");
   if (train_fwd_wanted(N, out, in0, in1, pre_act))  // a 256 wide layer (hidden, skip [256 | 38 / 69]): W resident in registers, one pass (train_fwd.hip)
-    return train_fwd_launch(x0, x1, in1, N, w_packed, b, pre_act, y, (hipStream_t)stream, "na_linear_bf16x3_pk");
+    return train_fwd_launch(x0, in0, x1, in1, N, w_packed, b, out, pre_act, y, (hipStream_t)stream, "na_linear_bf16x3_pk");
   if (in1 == 0 && nrw::wanted(N, out, in0)) {  // a narrow output (256 -> 65 / 3): the row-stream kernel
     nrw::Args n{};
     n.a = x0; n.N = N; n.wp = (const char*)w_packed; n.M = out; n.act = pre_act; n.bias = b; n.y = y;

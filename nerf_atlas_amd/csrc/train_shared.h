@@ -81,7 +81,7 @@ int train_reduce_partials(const float* part, int nwg, int out, int in, int ldw, 
 // y[N, 256] = act([x0 (256) | x1 (in1)]) . W^T + b with W resident in registers (train_fwd.hip); w_packed: W [256, 256 + in1] as
 // na_train_pack_many packs it
 bool train_fwd_wanted(int64_t N, int out, int in0, int in1, int act);
-int train_fwd_launch(const float* x0, const float* x1, int in1, int64_t N, const void* w_packed, const float* b, int pre_act, float* y,
-                     hipStream_t st, const char* what);
+int train_fwd_launch(const float* x0, int in0, const float* x1, int in1, int64_t N, const void* w_packed, const float* b, int out,
+                     int pre_act, float* y, hipStream_t st, const char* what);
 
 }  // namespace na

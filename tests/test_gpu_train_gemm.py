@@ -136,7 +136,8 @@ def test_packed_operands_are_the_same_gemms(ops, shape):
     # narrow outputs with K = 256 take the row-stream kernel (csrc/train_gemm.hip nrw: the same three products per k added in
     # another order) -- equal to a few units in the last place, like the two wide implementations among themselves; a skip layer's
     # wide half then runs as a plain single-pass layer: bit for bit the wide kernel on [W_h] alone
-    nf = (in1 == 0 and in0 == 256 and out <= 128) or (in0 == 256 and out == 256 and in1 <= 80 and N >= 8192)  # (+ train_fwd.hip: W resident in registers)
+    nf = ((in1 == 0 and in0 == 256 and out <= 128) or (in0 == 256 and out == 256 and in1 <= 80 and N >= 8192)  # (+ train_fwd.hip: W resident in registers)
+          or (in1 == 0 and in0 <= 80 and out == 256 and N >= 8192))
     n0 = in1 == 0 and out == 256 and in0 <= 128
     n1 = in1 > 0 and out == 256 and in0 % 64 == 0 and in1 <= 128
     same = lambda a, b, narrow: torch.equal(a, b) if not narrow else float((a - b).abs().max()) <= 3e-6 * float(b.abs().max())
@@ -425,3 +426,39 @@ def test_whole_network_node_matches_the_per_layer_nodes(ops, monkeypatch):
     assert torch.equal(res["node"][0], res["layers"][0])
     for a, b in zip(res["node"][1], res["layers"][1]):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("shape", [(8192 + 3, 38), (9000, 69), (8192, 64), (12000 + 1, 80), (8192, 3)], ids=lambda s: "N%d_in%d" % s)
+@pytest.mark.parametrize("act", ["none", "leaky_relu", "sin"])
+def test_register_resident_forward_of_a_narrow_source_alone(ops, shape, act):
+    """lsfw::kernel MODE 2: an init Linear (38 / 69 -> 256): the narrow source alone, unaligned rows as dwords, 3-5 k steps."""
+    N, in0 = shape
+    torch.manual_seed(N + in0)
+    x = torch.randn(N, in0, device="cuda")
+    W = torch.randn(256, in0, device="cuda") * (1.0 / in0) ** 0.5
+    b = torch.randn(256, device="cuda")
+    f, _ = ACTS[act]
+    (pf,) = ops.train_pack_many([(W, False)])
+    y = ops.linear_f32(x, W, b, pre_act=act, split_bf16=True, packed=pf)
+    ref = f(x.double()) @ W.double().t() + b.double()
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 3e-5
+    y_stream = ops.linear_f32(x, W, b, pre_act=act, split_bf16=True)
+    assert float((y - y_stream).abs().max()) <= 2e-6 * float(y_stream.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(9000, 65), (8192 + 1, 3), (12000, 128), (8200, 100), (8192, 32)], ids=lambda s: "N%d_out%d" % s)
+@pytest.mark.parametrize("act", ["leaky_relu", "sin"])
+def test_register_resident_forward_with_a_narrow_output(ops, shape, act):
+    """lsfw::kernel NOUT: the out Linears (256 -> 65 / 3): column tiles past the output idle, the tile leaves as dwords."""
+    N, out = shape
+    torch.manual_seed(N + out)
+    x = torch.randn(N, 256, device="cuda")
+    W = torch.randn(out, 256, device="cuda") / 16
+    b = torch.randn(out, device="cuda")
+    f, _ = ACTS[act]
+    (pf,) = ops.train_pack_many([(W, False)])
+    y = ops.linear_f32(x, W, b, pre_act=act, split_bf16=True, packed=pf)
+    ref = f(x.double()) @ W.double().t() + b.double()
+    assert y.shape == (N, out) and float((y.double() - ref).abs().max() / ref.abs().max()) < 3e-5
+    y0 = ops.linear_f32(x, W, None, pre_act=act, split_bf16=True, packed=pf)
+    assert float((y0 + b - y).abs().max()) <= 1e-5
