@@ -12,6 +12,6 @@ find /tmp/prof_train -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/k
 find /tmp/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bench.csv
 timeout 600 python tools/train_hbm.py --out $O/train_hbm.json > /dev/null 2>&1
 python tools/pmc_collect.py --kernel "lsbw::kernel<true, 1, true, true>" --out $O/pmc_train_bwd.json -- python $PWD/tools/train_bench.py --iters 10 > /dev/null 2>&1
-python tools/pmc_collect.py --kernel "lsfw::kernel<1, false>" --out $O/pmc_train_fwd.json -- python $PWD/tools/train_bench.py --iters 10 > /dev/null 2>&1
+python tools/pmc_collect.py --kernel "lsfw::kernel<1, 0, false>" --out $O/pmc_train_fwd.json -- python $PWD/tools/train_bench.py --iters 10 > /dev/null 2>&1
 python tools/pmc_collect.py --kernel "render_ls_kernel" --out $O/pmc_render_ls_f16x.json -- python $PWD/bench.py --steps 3 --warmup 1 --no-other-configs --no-cpu-baseline --no-traffic > /dev/null 2>&1
 cat $O/train_step.json | cut -c90-170
