@@ -94,10 +94,10 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
   const int c4 = tid & 63, r0 = tid >> 6;    // dY: piece c4 (4 columns) of rows r0 + 8 j, j = 0..3
   const int xc = tid & 31, xr0 = tid >> 5;   // x half: piece xc of rows xr0 + 16 j, j = 0..1
   uint32_t og[GA ? 1 : 4];
-  if (GA) og[0] = 4 * c4 < g.out ? (uint32_t)((r0 * g.out + 4 * c4) * 4) : lsnt::OOB;
-  else {
+  og[0] = 4 * c4 < g.out ? (uint32_t)((r0 * g.out + 4 * c4) * 4) : lsnt::OOB;
+  if (!GA) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) og[e & (GA ? 0 : 3)] = 4 * c4 + e < g.out ? (uint32_t)((r0 * g.out + 4 * c4 + e) * 4) : lsnt::OOB;
+    for (int e = 1; e < 4; ++e) og[e & (GA ? 0 : 3)] = 4 * c4 + e < g.out ? 1u : 0u;   // element e of the piece belongs to this row
   }
   const uint32_t ox = (uint32_t)((xr0 * g.ldx + 128 * h + 4 * xc) * 4);   // (XA: 4 xc < in always -- 128 columns, or whole pieces dropped below)
   uint32_t oxe[XA ? 1 : 4];
@@ -118,19 +118,16 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const __amdgpu_buffer_rsrc_t rg = stage_rsrc(g.dY, g.out, st), rx = stage_rsrc(g.x, g.ldx, st);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if constexpr (GA) gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, 0));
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, og[e & (GA ? 0 : 3)], 8 * j * g.out * 4, 0));
-      }
+      // ONE 16-byte load per piece whatever the row length: raw-buffer loads of 16 bytes need only 4-byte alignment and are
+      // range-checked per dword (profiles/r03/unaligned_probe.log); a piece that crosses the end of its row (65, 3 columns) brings
+      // elements of the NEXT row along, which the conversion zeroes (og[1..3] keep the per-element validity)
+      gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, 0));
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if constexpr (XA) xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, oxe[0], 16 * j * g.ldx * 4, 0));
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xs[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, oxe[e & (XA ? 0 : 3)], 16 * j * g.ldx * 4, 0));
-      }
+      // (one 16-byte load per piece here too; the elements of the next row a piece of a 38 / 69 wide source brings along are
+      // zeroed at conversion.  The STORES of such a source stay dwords: a 16-byte store across the row end would clobber.)
+      xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, oxe[0], 16 * j * g.ldx * 4, 0));
     }
   };
   // LDS rows of this thread's pieces (sample s sits in row rho(s))
@@ -142,7 +139,11 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     for (int j = 0; j < 4; ++j) {
       char* p = buf + gro + (2 * (j & 1) + 16 * (j >> 1)) * GP;
       bf16x4 hi, lo;
-      const f32x4 gv = gs[j];
+      f32x4 gv = gs[j];
+      if constexpr (!GA) {
+#pragma unroll
+        for (int e = 1; e < 4; ++e) gv[e] = og[e & (GA ? 0 : 3)] ? gv[e] : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) bsum[e] += gv[e];
       split4(gv, hi, lo);
@@ -153,6 +154,10 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     for (int j = 0; j < 2; ++j) {
       char* p = buf + 2 * GPLANE + xro + 16 * j * XP;
       f32x4 xv = xs[j], dv;
+      if constexpr (!XA) {
+#pragma unroll
+        for (int e = 1; e < 4; ++e) xv[e] = oxe[e & (XA ? 0 : 3)] != lsnt::OOB ? xv[e] : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dv[e] = tact_grad(xv[e], ACT); xv[e] = tact(xv[e], ACT); }
       d[j] = dv;

@@ -88,10 +88,10 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     }
     if constexpr (X1) {
       const __amdgpu_buffer_rsrc_t r1s = stage_rsrc(g.x1, g.in1, st);
+      // (one 16-byte load per piece whatever the row length -- 4-byte aligned raw-buffer loads are legal and range-checked per dword;
+      // the elements of the next row a piece brings along are zeroed at conversion)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1s, o1[e], 16 * j * g.in1 * 4, 0));
+      for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1s, o1[0], 16 * j * g.in1 * 4, 0));
     }
   };
   const int ro0 = r0 * G::P + c4 * 8, ro1 = xr0 * G::P + (G::KOFF + 4 * xc) * 2;
@@ -115,6 +115,8 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x4 v = b[j];
+#pragma unroll
+          for (int e = 1; e < 4; ++e) v[e] = o1[e] != lsnt::OOB ? v[e] : 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = tact(v[e], ACT);
           bf16x4 hi, lo;
