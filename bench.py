@@ -178,9 +178,20 @@ def train_step(dev, crop=64, steps_per_ray=64, iters=10):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     n = crop * crop * steps_per_ray
-    return {"workload": f"PlainNeRF(view) training step, {crop} x {crop} rays x {steps_per_ray} samples, fwd + bwd + Adam",
-            "dtype": "bf16x3", "samples_per_step": n, "ms_per_step": round(dt * 1e3, 2), "Msamples_s": round(n / dt / 1e6, 2),
-            "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
+    res = {"workload": f"PlainNeRF(view) training step, {crop} x {crop} rays x {steps_per_ray} samples, fwd + bwd + Adam",
+           "dtype": "bf16x3", "samples_per_step": n, "ms_per_step": round(dt * 1e3, 2), "Msamples_s": round(n / dt / 1e6, 2),
+           "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
+    # HBM-bound path: the bytes of one step from the committed PMC profile of this workload (NOT measured by this run), and the
+    # rate they imply at this run's step time
+    try:
+        with open(os.path.join(REPO, "profiles", "r05", "train_hbm.json")) as f:
+            gb = float(json.load(f)["GB_per_step"])
+        res["roofline"] = {"bound": "hbm", "traffic_gb_per_step": gb, "achieved": round(gb / dt / 1e3, 2), "peak": 8.0, "unit": "TB/s",
+                           "frac": round(gb / dt / 1e3 / 8.0, 3),
+                           "traffic_source": "profiles/r05/train_hbm.json (tools/train_hbm.py: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the step, separate passes)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return res
 
 
 def coarse_fine(dev, rays, coarse=64, fine=128, iters=3):
