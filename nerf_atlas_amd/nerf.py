@@ -334,6 +334,11 @@ class PlainNeRF(CommonNeRF):
             # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
             out, self.alpha, self.weights = self._render_fused(rays, ts, True, pts=pts.contiguous())
             return self._finish_sky(out)
+        if not self.training and not ag.needs_grad(pts, *self.parameters()) and refl_latent is None and self.mip is None:
+            utils.note_fallback(f"plain-unfused-{type(self.refl).__name__}-{self.intermediate_size}",
+                                f"PlainNeRF with {type(self.refl).__name__} reflectance / intermediate size {self.intermediate_size} is not one of the "
+                                "fused renderer's schedules (View head, intermediate 64, 3 channels): inference runs the generic MLP kernels "
+                                "+ separate compositing")
         latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
         first_out = self.first(pts, latent)
         if ag.needs_grad(first_out):

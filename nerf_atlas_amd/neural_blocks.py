@@ -285,6 +285,11 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         if ag.needs_grad(flat, lat, *self.parameters()):
             return self._forward_train(flat, lat).reshape(batches + (out_size,))
         # any-shape path: exact-fp32 Linears (src/neural_blocks.py:288-296)
+        if not self.last_layer_act and flat.is_cuda:
+            utils.note_fallback(f"mlp-fp32-{self.in_size}-{self.init.out_features}-{len(self.layers)}-{self.out.out_features}",
+                                f"SkipConnMLP(in {self.in_size}, hidden {self.init.out_features} x {len(self.layers)}, out {self.out.out_features}, "
+                                f"enc {type(self.enc).__name__}) has no packed form for the fused MLP kernels: inference runs one exact-fp32 "
+                                "Linear launch per layer")
         init = flat
         if self.enc is not None:
             init = torch.cat([init, self.enc(flat)], dim=-1)

@@ -196,3 +196,20 @@ def pack_stamp(linears):
     if config.repack_always:
         return None
     return tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in linears)
+
+
+# ------------------------------------------------------------------------------------------------- fallback notices
+_noted = set()
+
+
+def note_fallback(tag: str, msg: str):
+    """ONE line on stderr per process and tag when an inference call leaves the fused kernels for a slower path because of its
+    shape (the schedules of the layer-synchronous engine serve exactly the reference's default shapes; any
+    other --hidden / layer count used to drop to the generic kernels, or to the exact-fp32 any-shape Linears, silently).
+    NA_QUIET_FALLBACK=1 silences it."""
+    import os
+    import sys
+    if tag in _noted or os.environ.get("NA_QUIET_FALLBACK") == "1":
+        return
+    _noted.add(tag)
+    print(f"[nerf_atlas_amd] note: {msg}", file=sys.stderr, flush=True)
