@@ -310,7 +310,11 @@ class MlpTrainFn(Function):
             buf = torch.empty(nW + pad + (out if ctx.has_b[li] else 0), device=g.device, dtype=torch.float32)
             dW = buf[:nW].view(out, in0 + in1)
             db = buf[nW + pad:] if ctx.has_b[li] else None
-            gx0, ws, npart = ops.linear_bwd_partials(g, x0, ctx.acts[li], ctx.packed_t[li], 0, ctx.has_b[li])
+            # (the init Linear's input gradient takes the skip layers' gradient of the same tensor as an addend: no add launch)
+            fuse_add = li == 0 and g_init is not None and not (in0 == 256 and out == 256)
+            gx0, ws, npart = ops.linear_bwd_partials(g, x0, ctx.acts[li], ctx.packed_t[li], 0, ctx.has_b[li], add=g_init if fuse_add else None)
+            if fuse_add:
+                g_init = None
             pending.append((ws, npart, out, in0, dW, 0, db))
             if in1:
                 gx1, ws1, np1 = ops.linear_bwd_partials(g, init, ctx.acts[li], ctx.packed_t[li], in0, False)

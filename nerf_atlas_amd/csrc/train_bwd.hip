@@ -59,6 +59,8 @@ struct Args {
   const float* x;    // [N, ldx]: the forward input (columns 0..255 used)
   const char* wp;    // packed W^T (rows = input columns, k = out), layout of lsnt::pack_many_kernel
   float* gx;         // [N, ldx]
+  const float* add;  // [N, ldx] or null: g_x = (dY . W) * act'(x) + add (another consumer's gradient of the same tensor: a skip
+                     // layer's second source and the init Linear both produce d/d init; not in the FULL instantiations)
   float* part;       // [nsl][PART]
   int out, act, ldx, nsl, xcd_map, want_db;
   int in, nhalf;     // columns of x a workgroup owns (128 = one half of a 256 wide source; a narrow source: all of its <= 128) | 2 or 1
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     for (int e = 0; e < 4; ++e) oxe[e & (XA ? 0 : 3)] = 4 * xc + e < g.in ? ox + 4 * e : lsnt::OOB;
   }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  f32x4 gs[4], xs[2], d0[2], d1[2];
+  f32x4 gs[4], xs[2], d0[2], d1[2], as[2];
   // rows of stage st (past the slice: an empty buffer -- every piece reads zeros, every store is dropped)
   auto stage_rsrc = [&](const float* base, int ld, int st) __attribute__((always_inline)) {
     const int64_t m0 = (st >= 0 && st < nst) ? (st0 + st) * SS : g.N;
@@ -128,6 +130,12 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       // (one 16-byte load per piece here too; the elements of the next row a piece of a 38 / 69 wide source brings along are
       // zeroed at conversion.  The STORES of such a source stay dwords: a 16-byte store across the row end would clobber.)
       xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, oxe[0], 16 * j * g.ldx * 4, 0));
+    }
+    if constexpr (!FULL) {  // the addend of the stage that is FINISHED in the next step (this fetch is for stage st = step + 2, the
+      // next step finishes stage step = st - 2); no pointer: an empty buffer, zeros
+      const __amdgpu_buffer_rsrc_t ra = stage_rsrc(g.add, g.ldx, g.add != nullptr ? st - 2 : -1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) as[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, oxe[0], 16 * j * g.ldx * 4, 0));
     }
   };
   // LDS rows of this thread's pieces (sample s sits in row rho(s))
@@ -178,6 +186,10 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       if (ACT != NA_ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= d[j][e];
+      }
+      if constexpr (!FULL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += as[j][e];
       }
       // (the row step in the VECTOR offset, soffset 0: with an SGPR soffset the compiler inserts no wait between a 16-byte store
       // and a VALU write of its data registers, and gfx950 needs one -- build.check_store_data_overwrite, tools/hw/store_soffset_hazard.hip)
@@ -458,16 +470,20 @@ int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_
 
 // The same pass WITHOUT the reduction: the partial gradients (na_linear_bwd_workspace_bytes(N, in0) bytes = slices x 67 584 floats) stay
 // in `workspace` (required); na_train_reduce_many sums the partials of many Linears in one launch.  want_db: the bias gradient's
-// partial sums are produced too (reduce it by passing db there).
+// partial sums are produced too (reduce it by passing db there).  g_add (nullable, [N, in0]): added to the input gradient before
+// it is stored -- another consumer's gradient of the same tensor (a skip layer's second source and the init Linear both produce
+// d/d init: the sum costs no launch); narrow sources / narrow outputs only.
 int na_linear_bwd_partials_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
-                                     float* g_x0, int want_db, void* workspace, void* stream) {
+                                     float* g_x0, const float* g_add, int want_db, void* workspace, void* stream) {
   NA_REQUIRE((in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 1, NA_EINVAL,
              "na_linear_bwd_partials_bf16x3_pk: bad shape (in0 = %d, out = %d)", in0, out);
   NA_REQUIRE(pre_act >= NA_ACT_NONE && pre_act <= NA_ACT_SIN, NA_EUNSUPPORTED, "na_linear_bwd_partials_bf16x3_pk: activation %d", pre_act);
   NA_REQUIRE(dY && wt_packed && x0 && g_x0 && workspace, NA_ENULL, "na_linear_bwd_partials_bf16x3_pk: null pointer");
   NA_REQUIRE(lsbw::wanted(N, out, in0), NA_EUNSUPPORTED, "na_linear_bwd_partials_bf16x3_pk: this batch runs the two-launch path");
   lsbw::Args a{};
-  a.dY = dY; a.x = x0; a.wp = (const char*)wt_packed; a.gx = g_x0; a.out = out; a.act = pre_act; a.ldx = in0; a.N = N;
+  NA_REQUIRE(g_add == nullptr || !(in0 == 256 && out == 256), NA_EUNSUPPORTED,
+             "na_linear_bwd_partials_bf16x3_pk: g_add is for narrow sources / narrow outputs (not the 256 x 256 instantiation)");
+  a.dY = dY; a.x = x0; a.wp = (const char*)wt_packed; a.gx = g_x0; a.add = g_add; a.out = out; a.act = pre_act; a.ldx = in0; a.N = N;
   float dummy_db = 0.f;  // (launch() reads db only as "wanted or not" when it does not reduce)
   return lsbw::launch(a, nullptr, in0, want_db ? &dummy_db : nullptr, 1, (float*)workspace, (hipStream_t)stream,
                       "na_linear_bwd_partials_bf16x3_pk", false);

@@ -521,7 +521,8 @@ def linear_bwd_fused(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t:
     return g0, dW, db
 
 
-def linear_bwd_partials(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t: torch.Tensor, col0: int = 0, want_bias: bool = True):
+def linear_bwd_partials(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed_t: torch.Tensor, col0: int = 0, want_bias: bool = True,
+                        add: Optional[torch.Tensor] = None):
     """The one-pass backward of a source WITHOUT its reduction (na_linear_bwd_partials_bf16x3_pk): (g_x [N, in0], workspace holding
     the partial gradients, number of partials).  train_reduce_many sums the partials of many Linears in one launch."""
     lib = _lib.load()
@@ -532,8 +533,11 @@ def linear_bwd_partials(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed
     ws = torch.empty(nbytes, device=x0.device, dtype=torch.uint8)
     g0 = torch.empty_like(x0)
     wp = packed_t.data_ptr() + int(lib.na_train_packed_row_offset(col0, out))
-    check(lib.na_linear_bwd_partials_bf16x3_pk(_ptr(dY), out, N, wp, _ptr(x0), in0, ACT[pre_act], _ptr(g0), int(want_bias), _ptr(ws),
-                                               _stream()))
+    if add is not None:  # (another consumer's gradient of x0: summed into g_x inside the kernel; narrow sources / outputs only)
+        add = _f32(add, "add")
+        assert add.shape == x0.shape
+    check(lib.na_linear_bwd_partials_bf16x3_pk(_ptr(dY), out, N, wp, _ptr(x0), in0, ACT[pre_act], _ptr(g0), _ptr(add), int(want_bias),
+                                               _ptr(ws), _stream()))
     return g0, ws, nbytes // (67584 * 4)
 
 

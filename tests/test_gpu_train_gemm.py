@@ -462,3 +462,22 @@ def test_register_resident_forward_with_a_narrow_output(ops, shape, act):
     assert y.shape == (N, out) and float((y.double() - ref).abs().max() / ref.abs().max()) < 3e-5
     y0 = ops.linear_f32(x, W, None, pre_act=act, split_bf16=True, packed=pf)
     assert float((y0 + b - y).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(9000, 38, 256, "none"), (8192 + 7, 69, 256, "sin"), (8200, 256, 65, "leaky_relu"), (8192, 64, 256, "leaky_relu")],
+                         ids=lambda s: "N%d_in%d_out%d_%s" % s)
+def test_one_pass_backward_adds_another_gradient_of_the_same_tensor(ops, shape):
+    """g_add of na_linear_bwd_partials_bf16x3_pk: g_x = (dY . W) * act'(x) + add, the bits of the separate torch add."""
+    N, in0, out, act = shape
+    torch.manual_seed(N + in0)
+    x = torch.randn(N, in0, device="cuda"); W = torch.randn(out, in0, device="cuda") / in0 ** 0.5
+    gy = torch.randn(N, out, device="cuda"); add = torch.randn(N, in0, device="cuda")
+    (pt,) = ops.train_pack_many([(W, True)])
+    g_plain, ws0, n0 = ops.linear_bwd_partials(gy, x, act, pt)
+    g_sum, ws1, n1 = ops.linear_bwd_partials(gy, x, act, pt, add=add)
+    assert n0 == n1   # (the partial gradients do not see the addend: checked through their reduction below -- rows past `out` of a workspace are never written)
+    assert torch.equal(g_sum, g_plain + add)
+    dW = torch.empty(out, in0, device="cuda"); db = torch.empty(out, device="cuda")
+    ops.train_reduce_many([(ws1, n1, out, in0, dW, 0, db)])
+    _, dW_ref, db_ref = ops.linear_bwd_fused(gy, x, act, pt)
+    assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
