@@ -111,6 +111,9 @@ int na_positional_encode(const float* x, int64_t N, int D, const float* bands, i
 
 /* A7 dir_to_elev_azim (src/utils.py:247-254): dirs [N,3] -> out [N,2].                         */
 int na_view_elaz(const float* dirs, int64_t N, float* out, void* stream);
+/* rows [x, y, z, elev, azim] [N, 5] of the View reflectance's input: pts [N = T x R, 3] with the per-RAY directions dirs [R, 3]
+ * broadcast along the samples (n = t R + r) -- src/refl.py:190-207's cat([x, dir_to_elev_azim(view)]) in one launch. */
+int na_view_rows(const float* pts, const float* dirs, int64_t N, int64_t R, float* out, void* stream);
 
 /* sigmoid_kinds (src/utils.py:484-518) elementwise, in place allowed.                          */
 int na_sigmoid(const float* x, int64_t N, int kind, float* out, void* stream);

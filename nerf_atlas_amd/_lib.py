@@ -42,6 +42,7 @@ SIGNATURES = {
     "na_fourier_encode": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
     "na_positional_encode": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_view_elaz": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
+    "na_view_rows": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, c_f32p, C.c_void_p]),
     "na_sigmoid": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_mip_encode": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_float, C.c_int,
                                 C.c_int, c_f32p, C.c_void_p]),

@@ -330,3 +330,16 @@ class MlpTrainFn(Function):
         for li in range(L):
             grads += [gWs[li], gbs[li]]
         return (g_init if ctx.needs_input_grad[0] else None, None, *grads)
+
+
+class ViewInputFn(Function):
+    """cat([x, dir_to_elev_azim(view)]) with the view direction of a ray broadcast along its samples (src/refl.py:190-207) as one
+    kernel; the directions carry no gradient (they come from the camera), the points get their three columns back."""
+
+    @staticmethod
+    def forward(ctx, x, dirs):
+        return ops.view_rows(x, dirs)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g[..., :3] if ctx.needs_input_grad[0] else None), None

@@ -149,6 +149,17 @@ def view_elaz(dirs: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def view_rows(pts: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """[..., R, 5] rows [x, y, z, elev, azim]: pts [..., R, 3] with one direction per ray dirs [R, 3] (na_view_rows)."""
+    lib = _lib.load()
+    pts, dirs = _f32(pts, "pts"), _f32(dirs, "dirs")
+    R = dirs.shape[0]
+    assert pts.shape[-2] == R and pts.shape[-1] == 3 and dirs.shape == (R, 3)
+    out = torch.empty(tuple(pts.shape[:-1]) + (5,), device=pts.device, dtype=torch.float32)
+    check(lib.na_view_rows(_ptr(pts), _ptr(dirs), pts.numel() // 3, R, _ptr(out), _stream()))
+    return out
+
+
 def sigmoid(x: torch.Tensor, kind: str) -> torch.Tensor:
     lib = _lib.load()
     if kind not in SIGMOID:

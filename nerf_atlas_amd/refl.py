@@ -58,6 +58,11 @@ class View(Reflectance):
                                hidden_size=256, init="siren", activation=torch.sin)
 
     def forward(self, x, view, normal=None, light=None, latent=None):
+        if (view.dim() == 3 and view.stride(0) == 0 and x.shape == view.shape and x.is_cuda and x.dtype == torch.float32
+                and x.is_contiguous() and not view.requires_grad):
+            # [T, R, 3] points, directions broadcast along the sample axis: the rows [x | elev, azim] by ONE kernel (round 5)
+            from . import autograd as ag
+            return self.act(self.mlp(ag.ViewInputFn.apply(x, view[0].contiguous()), latent))
         if view.dim() > 1 and view.stride(0) == 0:
             # directions broadcast along the sample axis (r_d.unsqueeze(0).expand_as(pts)): one elev/azim per RAY
             v = ops.view_elaz(view[0].contiguous()).unsqueeze(0).expand(view.shape[:-1] + (2,))

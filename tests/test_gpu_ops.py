@@ -304,3 +304,16 @@ def test_unsupported_mlp_shape_fails_loudly(ops):
     assert ops.mlp_packed_bytes(desc, "bf16") == 0
     with pytest.raises(NaError):
         ops.mlp_pack(desc, "bf16", [], [])
+
+
+def test_view_rows_is_the_cat_of_points_and_broadcast_elaz():
+    """na_view_rows (round 5): [x | elev, azim] rows of the View reflectance's input in one launch = the elaz + expand + cat it replaces"""
+    import torch
+    from nerf_atlas_amd import ops
+    torch.manual_seed(3)
+    T, R = 7, 333
+    pts = torch.randn(T, R, 3, device="cuda")
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1)
+    rows = ops.view_rows(pts, dirs)
+    ref = torch.cat([pts, ops.view_elaz(dirs).unsqueeze(0).expand(T, R, 2)], dim=-1)
+    assert rows.shape == (T, R, 5) and torch.equal(rows, ref)
