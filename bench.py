@@ -354,7 +354,7 @@ def measure_traffic(prec, engine, kernel_name):
             out = os.path.join(work, ctr)
             try:
                 r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "--"] + cmd, cwd="/tmp",
-                                   env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+                                   env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             except subprocess.TimeoutExpired:
                 return None, f"rocprofv3 --pmc {ctr}: timed out"
             total, launches = 0.0, set()
