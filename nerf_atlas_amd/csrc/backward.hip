@@ -198,6 +198,9 @@ __device__ __forceinline__ float wave_total_lane63(float x) {
 // to the global atomic), flushed once at the end: the 4096 waves of a coarse level used to queue on the same few dozen
 // addresses in L2 (613 us for 262 144 samples; per-lane atomics 8.9 ms).  In deterministic mode the LDS rows hold the
 // same 2^-40 fixed-point integers as the global accumulator, so the result stays independent of the order.
+#ifndef HB_MAXWG
+#define HB_MAXWG 512  // workgroups per level (tools/hash_bwd_run.py, N = 262 144: 128 -> 173.9 us, 256 -> 157.0, 512 -> 144.6, 1024 -> 146.6; 64 -> 280)
+#endif
 constexpr int HB_ROWS = 1024;
 __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restrict__ x, int64_t N,
                                                             const float* __restrict__ g_out, int include_input,
@@ -708,7 +711,7 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
   const size_t ntab = (size_t)8 * 65536 * 4;
   long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_backward", &rc);
   if (rc != NA_OK) return rc;
-  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 128), 8), dim3(256), 0, (hipStream_t)stream, x, N,
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, HB_MAXWG), 8), dim3(256), 0, (hipStream_t)stream, x, N,
                      g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, (const float*)nullptr);
   if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_backward");
   return check_launch("na_hash_encode_backward");
@@ -743,7 +746,7 @@ int na_hash_encode_jvp_backward(const float* x, const float* tangent, int64_t N,
   int rc;
   long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_jvp_backward", &rc);
   if (rc != NA_OK) return rc;
-  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, 128), 8), dim3(256), 0, (hipStream_t)stream, x, N,
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, HB_MAXWG), 8), dim3(256), 0, (hipStream_t)stream, x, N,
                      g_t, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, tangent);
   if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_jvp_backward");
   return check_launch("na_hash_encode_jvp_backward");

@@ -17,7 +17,7 @@ dev = torch.device("cuda", 0)
 focal = 0.5 * bench.SIZE / math.tan(0.5 * bench.FOV)
 c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]], device=dev)
 rays = ops.raygen(c2w, focal, bench.SIZE, (368, 368, 64, 64))
-ts, _ = ops.compute_ts(bench.NEAR, bench.FAR, 64, dev)
+ts, _ = ops.compute_ts(bench.NEAR, bench.FAR, int(os.environ.get("HB_STEPS", "64")), dev)
 pts = ops.compute_pts(rays, ts).reshape(-1, 3).contiguous()
 N = pts.shape[0]
 torch.manual_seed(0)
