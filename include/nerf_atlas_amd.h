@@ -347,7 +347,7 @@ size_t na_linear_bwd_workspace_bytes(int64_t N, int in0);
 /* The pass without its reduction (the whole-network backward of a SkipConnMLP: every Linear's partial gradients stay in a
  * workspace of its own -- na_linear_bwd_workspace_bytes(N, in0) bytes = slices x 67 584 floats -- and ONE na_train_reduce_many
  * sums them all: dW_i[out_i, 0:in_i) at leading dimension ldw_i and db_i (nullable) WRITTEN from nwg_i = slices partials).
- * g_add (nullable, [N, in0]; narrow sources / narrow outputs only): added to the input gradient before it is stored. */
+ * g_add (nullable, [N, in0]; narrow sources, in0 <= 128, only): added to the input gradient before it is stored. */
 int na_linear_bwd_partials_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
                                      float* g_x0, const float* g_add, int want_db, void* workspace, void* stream);
 int na_train_reduce_many(int n, const float* const* part, const int* nwg, const int* out, const int* in, const int* ldw, float* const* dW,

@@ -311,7 +311,7 @@ class MlpTrainFn(Function):
             dW = buf[:nW].view(out, in0 + in1)
             db = buf[nW + pad:] if ctx.has_b[li] else None
             # (the init Linear's input gradient takes the skip layers' gradient of the same tensor as an addend: no add launch)
-            fuse_add = li == 0 and g_init is not None and not (in0 == 256 and out == 256)
+            fuse_add = li == 0 and g_init is not None and in0 <= 128
             gx0, ws, npart = ops.linear_bwd_partials(g, x0, ctx.acts[li], ctx.packed_t[li], 0, ctx.has_b[li], add=g_init if fuse_add else None)
             if fuse_add:
                 g_init = None

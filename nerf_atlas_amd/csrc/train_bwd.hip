@@ -472,7 +472,7 @@ int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_
 // in `workspace` (required); na_train_reduce_many sums the partials of many Linears in one launch.  want_db: the bias gradient's
 // partial sums are produced too (reduce it by passing db there).  g_add (nullable, [N, in0]): added to the input gradient before
 // it is stored -- another consumer's gradient of the same tensor (a skip layer's second source and the init Linear both produce
-// d/d init: the sum costs no launch); narrow sources / narrow outputs only.
+// d/d init: the sum costs no launch); narrow sources (in0 <= 128) only.
 int na_linear_bwd_partials_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
                                      float* g_x0, const float* g_add, int want_db, void* workspace, void* stream) {
   NA_REQUIRE((in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 1, NA_EINVAL,
@@ -481,8 +481,7 @@ int na_linear_bwd_partials_bf16x3_pk(const float* dY, int out, int64_t N, const 
   NA_REQUIRE(dY && wt_packed && x0 && g_x0 && workspace, NA_ENULL, "na_linear_bwd_partials_bf16x3_pk: null pointer");
   NA_REQUIRE(lsbw::wanted(N, out, in0), NA_EUNSUPPORTED, "na_linear_bwd_partials_bf16x3_pk: this batch runs the two-launch path");
   lsbw::Args a{};
-  NA_REQUIRE(g_add == nullptr || !(in0 == 256 && out == 256), NA_EUNSUPPORTED,
-             "na_linear_bwd_partials_bf16x3_pk: g_add is for narrow sources / narrow outputs (not the 256 x 256 instantiation)");
+  NA_REQUIRE(g_add == nullptr || in0 <= 128, NA_EUNSUPPORTED, "na_linear_bwd_partials_bf16x3_pk: g_add is for narrow sources (in0 <= 128)");
   a.dY = dY; a.x = x0; a.wp = (const char*)wt_packed; a.gx = g_x0; a.add = g_add; a.out = out; a.act = pre_act; a.ldx = in0; a.N = N;
   float dummy_db = 0.f;  // (launch() reads db only as "wanted or not" when it does not reduce)
   return lsbw::launch(a, nullptr, in0, want_db ? &dummy_db : nullptr, 1, (float*)workspace, (hipStream_t)stream,
