@@ -541,6 +541,38 @@ int na_render_plain_mip_ls(const float* rays, int B, int H, int W, const float* 
                            int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* PlainNeRF with the reference's OTHER two colour heads, each as ONE launch of the layer-synchronous engine (NA_PREC_F16X only):
+ *   na_render_plain_pos_ls   `--refl-kind pos` (`make original`, makefile:8-13): PlainNeRF.from_pts (src/nerf.py:340-361) with
+ *                            refl.Positional (src/refl.py:230-245) -- a second hash-encoded SkipConnMLP (5 x 256, skip 3, its OWN
+ *                            HashEncoder tables, latent = the 64 intermediate rows of `first`) -> 3, act, compositing.
+ *                            w_pos / b_pos: {init [256,102], layers.0 [256,358], layers.1, layers.2 [256,256], layers.3 [256,358],
+ *                            layers.4 [256,256], out [3,256]}, reference column order [p 3 | x 3 + hash 32 | latent 64].
+ *   na_render_plain_plv_ls   `--refl-kind pos-linear-view` (`make dnerf`, makefile:106-114): refl.PosLinearView (src/refl.py:248-290):
+ *                            pos = SkipConnMLP(hash, 2 x 256) -> act -> [colour 3 | intermediate 64]; view = SkipConnMLP(in
+ *                            [x | normalize(r_d)], latent [latent | intermediate], 2 x 128, sin) -> 1; colour * (sigmoid(view) / 2 + 0.5).
+ *                            w_head / b_head: {pos.init [256,102+n], pos.layers.0 [256,358+n], pos.layers.1 [256,256], pos.out [67,256],
+ *                            view.init [128,134+n], view.layers.0 [128,262+n], view.layers.1 [128,128], view.out [1,128]}.
+ *                            n = n_rl in 0..3: DynamicNeRF's refl_latent columns (src/nerf.py:1245-1248, 1272-1278, 1303:
+ *                            `--dyn-refl-latent`), rows refl_latent[T * R, rl_ld] (sample t * R + ray), appended to the latent of
+ *                            both MLPs as the reference does (src/nerf.py:352-358).
+ * rays / pts / ts / hash_tables (of `first`) / outputs / range guard as na_render_plain_view_ls; hash_tables_refl [8,65536,4] = the
+ * head's own encoder.  workspace: na_render_head_ls_workspace_bytes(T, R) bytes (per-ray scratch + an 8-MiB L2-resident park
+ * where a workgroup keeps the raw latent rows of its blocks between the Linears that consume them).                            */
+size_t na_render_plain_pos_ls_packed_bytes(int precision);
+size_t na_render_plain_plv_ls_packed_bytes(int precision);
+size_t na_render_head_ls_workspace_bytes(int T, int64_t R);
+int na_render_plain_pos_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                const float* const* w_pos, const float* const* b_pos, void* packed, void* stream);
+int na_render_plain_plv_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                const float* const* w_head, const float* const* b_head, int n_rl, void* packed, void* stream);
+int na_render_plain_pos_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                           const float* hash_tables_refl, const void* packed, int precision, int sigmoid_kind, int bg_kind,
+                           float* alpha, float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int na_render_plain_plv_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                           const float* hash_tables_refl, const float* refl_latent, int64_t rl_ld, int n_rl, const void* packed,
+                           int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

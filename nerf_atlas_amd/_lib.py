@@ -154,6 +154,17 @@ SIGNATURES = {
     "na_render_plain_mip_ls": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                          C.c_size_t, C.c_void_p]),
+    "na_render_plain_pos_ls_packed_bytes": (C.c_size_t, [C.c_int]),
+    "na_render_plain_plv_ls_packed_bytes": (C.c_size_t, [C.c_int]),
+    "na_render_head_ls_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),
+    "na_render_plain_pos_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "na_render_plain_plv_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]),
+    "na_render_plain_pos_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "na_render_plain_plv_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_i64, C.c_int, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "na_mlp_hash_ls_packed_bytes": (C.c_size_t, [C.c_int]),
     "na_mlp_hash_ls_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "na_mlp_hash_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int, C.c_int, c_f32p, c_i64,

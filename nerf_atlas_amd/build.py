@@ -136,7 +136,8 @@ HEADLINE_PIN = os.path.join(CSRC, "ls_headline_isa.sha256")
 
 def function_isa_digest(listing: str, symbol: str):
     """sha256 of the instructions of ONE function of a device listing (comments, directives and blank lines dropped, local labels
-    kept): what tests/test_isa_guard.py pins for the headline kernel -- a change to a schedule file of another MODEL, to the
+    kept, their per-function NUMBER dropped -- `.LBB11_3` and `.LBB13_3` are the same label of the same function once another
+    instantiation is added to the unit): what tests/test_isa_guard.py pins for the headline kernel -- a change to a schedule file of another MODEL, to the
     packing code or to the C ABI must leave it untouched; a change that moves it is re-blessed on purpose
     (`python tools/check_isa.py --bless-headline`, then the determinism / stress tests on the GPU).  None if the symbol is absent."""
     h, inside, n = hashlib.sha256(), False, 0
@@ -150,7 +151,7 @@ def function_isa_digest(listing: str, symbol: str):
             t = line.split(";")[0].strip()
             if not t or (t.startswith(".") and not t.endswith(":")):
                 continue
-            h.update(t.encode() + b"\n")
+            h.update(re.sub(r"\.LBB\d+_", ".LBB_", t).encode() + b"\n")
             n += 1
     return (h.hexdigest(), n) if n else None
 

@@ -103,8 +103,17 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // frequencies] -> 6 x 256, skip 3, out 65), rows to HBM.  The 256 Fourier features are K64 groups in the HIDDEN format, generated by
 // the row groups in a VALU phase wherever a Linear consumes them (init, L0, L3): init 4 | L0 4 + 4 | L1 | L2 | L3 4 + 4 | L4 | L5 |
 // out 4 = 40 records, and 3 pairs for the 3-wide position chunk
-__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 2 : model == 3 ? 5 : model == 4 ? 0 : model == 5 ? 3 : 2; }  // (6: 2)
-__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 22 : model == 3 ? 46 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : 44; }
+// MODEL 7 (round 6): PlainNeRF + the Positional head (`make original`, src/refl.py:230-245: a second hash-encoded SkipConnMLP 3 -> 5 x 256,
+// skip 3, latent 64 -> 3): MODEL 0's 22 records of `first`, then pos.init 2 ([hash' | x] group, latent group) | L0 5 + 1 | L1 4 | L2 4 |
+// L3 5 + 1 | L4 4 | out 4 = 52 records, no pairs.  The latent group of a skip layer is consumed in a second MFMA phase of that layer: the
+// init region holds ONE K64 group per block (the [hash' | x] group), so act(latent) is rebuilt in a dead hidden slot from the raw rows,
+// which wait in a per-workgroup scratch in global memory (Args::park)
+// MODEL 8 (round 6): PlainNeRF + PosLinearView (`make dnerf`, src/refl.py:248-290): `first` 22 | pos (2 x 256 -> 3 + 64): init 2 | L0 5 + 1 |
+// L1 4 | out 4 (three tiles, split by block like first.out) | view (2 x 128, sin; [x | dir | latent | refl_latent | intermediate] -> 1):
+// init 2 | L0 4 | L1 2 | out 2 = 48 records + 2 geometry pairs ([x, y, z, dir, refl_latent]); up to 3 refl_latent columns
+// (--dyn-refl-latent) ride in the spare slots of the [hash' | x] group and of the geometry chunk
+__host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 2 : model == 3 ? 5 : model == 4 ? 0 : model == 5 ? 3 : model == 7 ? 0 : 2; }  // (6, 8: 2)
+__host__ __device__ constexpr int nrec(int model) { return model == 1 ? 28 : model == 2 ? 22 : model == 3 ? 46 : model == 4 ? 27 : model == 5 ? 40 : model == 6 ? 52 : model == 7 ? 52 : model == 8 ? 48 : 44; }
 __host__ __device__ constexpr int stream_rg(int model) { return npair(model) * PAIRB + nrec(model) * REC; }
 __host__ __device__ constexpr int hdr_units(int model) { return npair(model) + nrec(model); }  // header word 2 of an F16X stream
 }  // namespace x
@@ -159,7 +168,14 @@ struct Args {
   // MODEL 6 (mip): the crop's geometry (rays = [B,H,W,6]: the pixel radius is a difference of neighbouring rows) and the IPE's shape
   int mip_H, mip_W, mip_kind, mip_min_deg, mip_nd;
   float mip_t_end;
+  // MODEL 7 / 8 (appended: the kernel-argument offsets of the older schedules do not move)
+  const float4* tables2 = nullptr;  // hash tables of the reflectance head's own encoder [8,65536]
+  float* park = nullptr;            // per-workgroup scratch: [workgroup][group][block][slot] x 8 KiB of raw latent rows
+  const float* rl = nullptr;        // MODEL 8: refl_latent rows [T * R, rl_ld] (--dyn-refl-latent), nullable
+  int rl_ld = 0, n_rl = 0;
 };
+constexpr int kParkSlots = 2;       // raw K64 groups a block parks in global memory (MODEL 7: latent; MODEL 8: latent, intermediate)
+constexpr size_t kParkBytes = (size_t)256 * 2 * 2 * kParkSlots * 8192;  // 256 workgroups x 2 groups x 2 blocks
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -186,16 +202,21 @@ static __global__ void lsx_poison_kernel(uint32_t gen, float* __restrict__ out, 
 
 // NA_PREC_F16X stream schedules (pack side): the Linears of the model and which of them every pair / record / bias block packs
 struct XLin { const float* W; const float* B; int in_dim, out_dim, desc; };  // nn.Linear layout [out,in]
-struct XPairD { int8_t lin, q, skip; };      // init chunk q of Linear lin (skip: its columns sit behind the kHidden hidden ones)
+// init chunk q of Linear lin (skip: its columns sit behind the kHidden hidden ones).  q = 32: MODEL 8's geometry chunk [x y z | dir | refl_latent]
+// (columns 0..5, then 6 + 64 + j; skip: behind the 128 hidden columns of PosLinearView's view MLP)
+struct XPairD { int8_t lin, q, skip; };
 // K64 group of Linear lin.  kind 0: hidden features 64 q .. 64 q + 63; kind 1 / 2: the init chunks 0..3 of the MLP (columns by
 // init_slot_feature; 2: behind the kHidden hidden columns of a skip layer); kind 3 / 4: Fourier features 64 q .. 64 q + 63 in the
 // generator's slot order (fourier_slot_col; 4: behind the hidden columns of a skip layer).  out_mode 0 hidden rows, 1 out row-major (tile
 // min(rg, 2)), 2 out, one tile, 3 out split by block: row groups 0,1 hold tiles 0 and 1, row groups 2,3 tile 2
+// kind 6: 64 columns off .. off + 63 in the hidden slot order (a group that was produced by an out Linear's accumulators: the latent /
+// intermediate rows); kind 7: the [hash' | x | refl_latent] group of MODEL 8 -- kind 1's slots + refl_latent column j in slot 6 + j of chunk 2
+// (weight column off2 + j, off2 = q * 1 ... see xrec_col), everything shifted by `off`
 struct XRecD { int8_t lin, q, out_mode, kind; int16_t off; };  // off: added to the column (kinds 1, 2, 5: where the group's columns start)
 struct XSched {
-  int npair, nrec, nphase, nlin, ndesc;
-  XLin lin[13];  // (<= 13 Linears: SIREN VolSDF 7 + 6)
-  NaMlpDesc desc[2];
+  int npair, nrec, nphase, nlin, ndesc, n_rl;
+  XLin lin[16];  // (<= 14 Linears: PlainNeRF + PosLinearView 6 + 4 + 4)
+  NaMlpDesc desc[3];
   XPairD pair[16];
   XRecD rec[56];
   int8_t bias_lin[16], bias_mode[16];

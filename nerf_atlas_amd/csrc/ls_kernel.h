@@ -13,7 +13,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
-  constexpr bool M0 = MODEL == 0 || MODEL == 6;  // the PlainNeRF(view) schedule (6: + mip)
+  constexpr bool M0 = MODEL == 0 || MODEL == 6 || MODEL == 7 || MODEL == 8;  // the PlainNeRF schedules (0: View head, 6: + mip, 7: Positional, 8: PosLinearView)
+  constexpr bool HEAD2 = MODEL == 7 || MODEL == 8;  // the reflectance head has a hash encoder of its own (src/refl.py:230-290)
   constexpr bool MIP = MODEL == 6;
   constexpr int PPP = PREC == NA_PREC_F16X ? x::hdr_units(MODEL)
                       : MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
@@ -233,9 +234,11 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   };
   // compositing of block rg of pass `pass` (src/nerf.py:22-27,60-80); the hi=0 half holds the samples
   auto composite = [&](const Prev& q, const f32x16& oc, float density) {
-    const float cr = fast_sigmoid_kind(oc[0], a.sigmoid_kind);
-    const float cg = fast_sigmoid_kind(oc[1], a.sigmoid_kind);
-    const float cb = fast_sigmoid_kind(oc[2], a.sigmoid_kind);
+    // (MODEL 8: the colour arrives finished -- (sigmoid(linear) / 2 + 0.5) * act(pos), src/refl.py:284-290)
+    const int sgk = MODEL == 8 ? (int)NA_SIG_IDENTITY : a.sigmoid_kind;
+    const float cr = fast_sigmoid_kind(oc[0], sgk);
+    const float cg = fast_sigmoid_kind(oc[1], sgk);
+    const float cb = fast_sigmoid_kind(oc[2], sgk);
     // (MODEL 2: `density` is VolSDF's Laplace density, used as it is: src/nerf.py:1004-1006, softplus = False)
     const float sigma = (MODEL == 2 || MODEL == 3) ? fmaxf(density, 0.f) : fast_softplus(density - 1.0f);
     const float alpha = q.t_ok ? 1.0f - fast_exp(-sigma * q.dist) : 0.f;
@@ -547,6 +550,98 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         }
     }
   };
+  // ---- MODEL 7 / 8 (round 6): the reflectance head's OWN hash encoder (src/refl.py:233-237, 253-257: `enc=HashEncoder()`, a second set
+  // of tables) at the same positions.  Gathered in the epilogue of first.out by the four waves exactly like hash_group_ep -- the init
+  // region is free again (first.L0 consumed [hash | x]) and the raw values wait in the wave's K64 region of block 1 for the
+  // re-entry through the activation -- with two differences: the T plane's spare dword is left alone (KEEP7: the block's density
+  // waits there, as in MODEL 0's latent group) and MODEL 8 puts up to three refl_latent columns (--dyn-refl-latent, rows from
+  // HBM) into the spare slots 6.. of chunk 2.
+  auto hash_group2 = [&](int pass) {
+    if constexpr (PREC == NA_PREC_F16X && HEAD2) {
+      const int part = owner ? 0 : 1;
+      const TsPair tp = ts_load(pass);
+      const Geom q = geom(pass, blk, tp);
+      float rlv[3] = {0.f, 0.f, 0.f};
+      if constexpr (MODEL == 8) {
+        if (a.rl != nullptr) {
+          const float* rr = a.rl + ((int64_t)(q.t_ok ? q.t : a.T - 1) * a.R + q.ray) * a.rl_ld;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j < a.n_rl) rlv[j] = rr[j];
+        }
+      }
+      float f8[8];
+      HashGather hg;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int lvl0 = 4 * part + k;                      // (j = 0) | + 2 (j = 1)
+        hash_level_issue(q.px, q.py, q.pz, a.tables2, hi ? a.res.n[lvl0 + 2] : a.res.n[lvl0], lvl0 + 2 * hi, hg);
+        float f[4];
+        hash_level_finish(hg, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f8[4 * k + e] = f[e];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x16 n0, n1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        n0[e] = f8[e];
+        n0[8 + e] = __shfl_down(f8[e], 32, 64);
+        n1[e] = 0.f; n1[8 + e] = 0.f;
+      }
+      if (part == 0) { n1[0] = q.px; n1[1] = q.py; n1[2] = q.pz; n1[3] = q.px; n1[4] = q.py; n1[5] = q.pz; n1[6] = rlv[0]; n1[7] = rlv[1]; }
+      else n1[0] = rlv[2];
+      if (hi == 0) {
+        const int ml = ln + 32 * part;
+        char* st = hb + x::BLKH + rg * x::KQ + ml * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f32x4*)(st + c * 1024) = f32x4{n0[4 * c], n0[4 * c + 1], n0[4 * c + 2], n0[4 * c + 3]};
+        *(f32x4*)(st + 4096) = f32x4{n1[0], n1[1], n1[2], n1[3]};
+        *(f32x4*)(st + 5120) = f32x4{n1[4], n1[5], n1[6], n1[7]};
+        x::store_block<NA_ACT_NONE, 3, true>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
+      }
+    }
+  };
+  auto reenter_hash2 = [&]() {  // reenter_hash with the spare dword kept
+    if constexpr (PREC == NA_PREC_F16X && HEAD2) {
+      if (hi == 0) {
+        const int part = owner ? 0 : 1, ml = ln + 32 * part;
+        const char* st = hb + x::BLKH + rg * x::KQ + ml * 16;
+        f32x16 n0, n1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = *(const f32x4*)(st + c * 1024);
+          n0[4 * c] = v[0]; n0[4 * c + 1] = v[1]; n0[4 * c + 2] = v[2]; n0[4 * c + 3] = v[3];
+        }
+        const f32x4 u = *(const f32x4*)(st + 4096), w = *(const f32x4*)(st + 5120);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) n1[e] = 0.f;
+        n1[0] = u[0]; n1[1] = u[1]; n1[2] = u[2]; n1[3] = u[3]; n1[4] = w[0]; n1[5] = w[1]; n1[6] = w[2]; n1[7] = w[3];
+        x::store_block<NA_ACT_LEAKY_RELU, 3, true>(ib + blk * x::KQ, n0, n1, ml, a.sat_gen);
+      }
+    }
+  };
+  // raw rows of a K64 group (the lane's 32 accumulator values) parked in global memory: slot `slot` of block b of this sample group.
+  // Written and read by waves of ONE workgroup with a workgroup barrier in between (L2-resident: 32 KiB per workgroup).
+  auto park_ptr = [&](int b, int slot) -> float* {
+    return a.park + ((((int64_t)blockIdx.x * 2 + g) * 2 + b) * kParkSlots + slot) * 2048 + lane * 4;
+  };
+  auto park_store = [&](int b, int slot, const f32x16& v0, const f32x16& v1) {
+    float* p = park_ptr(b, slot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(f32x4*)(p + j * 256) = f32x4{v0[4 * j], v0[4 * j + 1], v0[4 * j + 2], v0[4 * j + 3]};
+      *(f32x4*)(p + (4 + j) * 256) = f32x4{v1[4 * j], v1[4 * j + 1], v1[4 * j + 2], v1[4 * j + 3]};
+    }
+  };
+  auto park_load = [&](int b, int slot, f32x16& v0, f32x16& v1) {
+    const float* p = park_ptr(b, slot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 u = *(const f32x4*)(p + j * 256), w = *(const f32x4*)(p + (4 + j) * 256);
+      v0[4 * j] = u[0]; v0[4 * j + 1] = u[1]; v0[4 * j + 2] = u[2]; v0[4 * j + 3] = u[3];
+      v1[4 * j] = w[0]; v1[4 * j + 1] = w[1]; v1[4 * j + 2] = w[2]; v1[4 * j + 3] = w[3];
+    }
+  };
   if constexpr (M0 || MODEL == 4) {
     tnext = ts_load(0);
     own_setup(0);
@@ -561,6 +656,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #include "ls_sched_volsdf_siren.inc"
 #include "ls_sched_view.inc"
 #include "ls_sched_tiny.inc"
+#include "ls_sched_plain_pos.inc"
+#include "ls_sched_plain_plv.inc"
 #include "ls_sched_plain.inc"
     prev = pass;
   }

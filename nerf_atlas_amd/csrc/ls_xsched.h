@@ -10,6 +10,14 @@ namespace ls {
 // column of Linear rd.lin's weight matrix that sits in k-slot kappa of chunk c of the record's K64 group; -1 = zero
 __device__ __forceinline__ int xrec_col(const XSched& sc, const XRecD& rd, int c, int kappa) {
   if (rd.kind == 0) return 64 * rd.q + 16 * c + pi_perm(kappa);  // hidden feature (the skip layers store [hidden | init])
+  if (rd.kind == 6) return rd.off + 16 * c + pi_perm(kappa);     // 64 columns from `off` on, in the slot order of accumulator rows
+  if (rd.kind == 7) {
+    // MODEL 8: [hash' | x | refl_latent] of PosLinearView.pos, weight columns [p 3 | x 3 + hash 32 | intermediate 64 | refl_latent]
+    // (src/nerf.py:352-358, src/refl.py:277): the hash desc's slots, + refl_latent column j in slot 6 + j of chunk 2
+    if (c == 2 && kappa >= 6 && kappa < 6 + sc.n_rl) return rd.off + 38 + 64 + (kappa - 6);
+    const int col = init_slot_feature(sc.desc[sc.lin[rd.lin].desc], c, kappa);
+    return col < 0 ? col : col + rd.off;
+  }
   if (rd.kind == 3 || rd.kind == 4) {
     // Fourier group q as the MODEL 5 generator lays it out: slot s = 8 c + e of lane half h holds frequency f = 32 q + 16 h + s / 2,
     // its sine (s even) or cosine (s odd).  Reference columns: [p | sin(128) | cos(128)] (src/neural_blocks.py:36-55, 283-287)
@@ -35,6 +43,9 @@ __device__ __forceinline__ int xrec_row(const XSched& sc, const XRecD& rd, int r
   const NaMlpDesc& d = sc.desc[sc.lin[rd.lin].desc];
   if (rd.out_mode == 0) return 32 * (2 * rg + t) + (l & 31);
   if (rd.out_mode == 3) return rg < 2 ? out_row_map(d, 32 * t + (l & 31)) : (t == 0 ? out_row_map(d, 64 + (l & 31)) : -1);
+  // 4: PosLinearView.pos.out (src/refl.py:275-276: rows 0..2 colour, 3..66 intermediate), split by block like mode 3: row groups
+  // 0, 1 hold the two intermediate tiles, row groups 2, 3 the colour rows
+  if (rd.out_mode == 4) return rg < 2 ? 3 + 32 * t + (l & 31) : (t == 0 && (l & 31) < 3 ? (l & 31) : -1);
   return t == 0 ? out_row_map(d, (rd.out_mode == 1 ? 32 * (rg < 2 ? rg : 2) : 0) + (l & 31)) : -1;
 }
 __global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
@@ -48,11 +59,12 @@ __global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
       const int pi = (int)((i >> 10) % sc.npair), rg = (int)((i >> 10) / sc.npair);
       const XPairD pd = sc.pair[pi];
       const XLin L = sc.lin[pd.lin];
-      int col = init_slot_feature(sc.desc[L.desc], pd.q, 8 * (l >> 5) + e);
-      if (col >= 0 && pd.skip) col += kHidden;
+      const int kap = 8 * (l >> 5) + e;
+      int col = pd.q == 32 ? (kap < 6 ? kap : kap < 6 + sc.n_rl ? 6 + 64 + (kap - 6) : -1) : init_slot_feature(sc.desc[L.desc], pd.q, kap);
+      if (col >= 0 && pd.skip) col += sc.desc[L.desc].hidden;
       const int row = 32 * (2 * rg + t) + (l & 31);
       float v = 0.f;
-      if (col >= 0 && col < L.in_dim) v = L.W[(int64_t)row * L.in_dim + col];
+      if (col >= 0 && col < L.in_dim && row < L.out_dim) v = L.W[(int64_t)row * L.in_dim + col];
       const __bf16 h = to_elem<NA_PREC_F16X>(v);
       const __bf16 lo = to_elem<NA_PREC_F16X, false>(v - from_elem<NA_PREC_F16X>(h));
       char* o = dst + kHeaderBytes + kBiasBytes + (int64_t)rg * srg + pi * x::PAIRB + t * 2048 + l * 16 + e * 2;
@@ -134,8 +146,11 @@ __global__ void pack_lsx_bias_kernel(XSched sc, char* __restrict__ dst) {
       const XLin L = sc.lin[sc.bias_lin[p]];
       const int mode = sc.bias_mode[p];  // 0 hidden rows, 1 / 3 out Linear with 3 tiles, 2 out Linear, one tile
       if (L.B != nullptr) {
-        if (mode == 0) { if (slot < 2) v = L.B[32 * (2 * rg + slot) + rin]; }
-        else {
+        if (mode == 0) { if (slot < 2 && 32 * (2 * rg + slot) + rin < L.out_dim) v = L.B[32 * (2 * rg + slot) + rin]; }
+        else if (mode == 4) {
+          const int row = slot < 2 ? 3 + 32 * slot + rin : (slot == 2 && rin < 3 ? rin : -1);
+          if (row >= 0 && row < L.out_dim) v = L.B[row];
+        } else {
           const int row = slot < ((mode == 1 || mode == 3) ? 3 : 1) ? out_row_map(sc.desc[L.desc], 32 * slot + rin) : -1;
           if (row >= 0 && row < L.out_dim) v = L.B[row];
         }
@@ -242,6 +257,61 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
       if (first || skip) {
         for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)i, (int8_t)q, 0, (int8_t)(skip ? 4 : 3), 0};
         sc.pair[sc.npair++] = XPairD{(int8_t)i, 16, (int8_t)(skip ? 1 : 0)};  // the position chunk: init chunk F / 8 of the Fourier layout
+      }
+    }
+  } else if (model == 7 || model == 8) {
+    // PlainNeRF + Positional (7) / PosLinearView (8): `first` exactly as in MODEL 0, then the head's Linears (w1 / b1: 7: init,
+    // layers.0..4, out;  8: pos.init, pos.layers.0..1, pos.out, view.init, view.layers.0..1, view.out).  n_out carries n_rl (8).
+    const NaMlpDesc first = {3, NA_ENC_HASH, 35, 0, 4, 256, 65, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_PLAIN_FIRST};
+    xs_add_mlp(sc, first, w0, b0, 6, 3, false, 3, true);
+    const int n_rl = model == 8 ? n_out : 0;
+    sc.n_rl = n_rl;
+    const int npos = model == 7 ? 7 : 4;
+    const NaMlpDesc pos = {3, NA_ENC_HASH, 35, 0, npos - 2, 256, model == 7 ? 3 : 67, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
+    const int dpos = sc.ndesc++;
+    sc.desc[dpos] = pos;
+    const int dim_pos = 38 + 64 + n_rl;
+    for (int i = 0; i < npos; ++i) {
+      const bool fst = i == 0, last = i == npos - 1, skip = i == 1 || (model == 7 && i == 4);
+      XLin L;
+      L.W = w1[i]; L.B = b1[i]; L.desc = dpos;
+      L.in_dim = fst ? dim_pos : skip ? kHidden + dim_pos : kHidden;
+      L.out_dim = last ? pos.out_size : kHidden;
+      const int li = sc.nlin;
+      sc.lin[sc.nlin++] = L;
+      const int om = last ? (model == 7 ? 2 : 4) : 0;
+      sc.bias_lin[sc.nphase] = (int8_t)li;
+      sc.bias_mode[sc.nphase++] = (int8_t)om;
+      const int so = skip ? kHidden : 0;
+      // consumption order: the [hash' | x] group (init region), the four hidden groups (skip layers), the latent group
+      if (fst || skip) sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)7, (int16_t)so};
+      if (!fst) for (int q = 0; q < 4; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, (int8_t)om, 0, 0};
+      if (fst || skip) sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)6, (int16_t)(so + 38)};
+    }
+    if (model == 8) {
+      // view: SkipConnMLP(in 6, latent 64 + n_rl + 64, 2 x 128, sin) -> 1; weight columns [x 3 | dir 3 | latent 64 | refl_latent | intermediate 64]
+      const NaMlpDesc vw = {6, NA_ENC_NONE, 0, 128 + n_rl, 2, 128, 1, 3, NA_ACT_SIN, NA_LAYOUT_GENERIC};
+      const int dv = sc.ndesc++;
+      sc.desc[dv] = vw;
+      const int dim_v = 6 + 128 + n_rl, H = 128;
+      for (int i = 0; i < 4; ++i) {
+        const bool fst = i == 0, last = i == 3, skip = i == 1;
+        XLin L;
+        L.W = w1[4 + i]; L.B = b1[4 + i]; L.desc = dv;
+        L.in_dim = fst ? dim_v : skip ? H + dim_v : H;
+        L.out_dim = last ? 1 : H;
+        const int li = sc.nlin;
+        sc.lin[sc.nlin++] = L;
+        sc.bias_lin[sc.nphase] = (int8_t)li;
+        sc.bias_mode[sc.nphase++] = (int8_t)(last ? 2 : 0);
+        const int so = skip ? H : 0;
+        // consumption order: the two hidden groups, the latent group, the intermediate group, the geometry pair
+        if (!fst) for (int q = 0; q < 2; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, (int8_t)(last ? 2 : 0), 0, 0};
+        if (fst || skip) {
+          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)6, (int16_t)(so + 6)};
+          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)6, (int16_t)(so + 6 + 64 + n_rl)};
+          sc.pair[sc.npair++] = XPairD{(int8_t)li, 32, (int8_t)(skip ? 1 : 0)};
+        }
       }
     }
   } else if (model == 4) {

@@ -39,7 +39,12 @@ int render_ls_dispatch_f16x(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_F16X, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_F16X, 2>(a, s)
          : model == 3 ? ls::launch<NA_PREC_F16X, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_F16X, 4>(a, s)
          : model == 5 ? ls::launch<NA_PREC_F16X, 5>(a, s) : model == 6 ? ls::launch<NA_PREC_F16X, 6>(a, s)
+         : model == 7 ? ls::launch<NA_PREC_F16X, 7>(a, s) : model == 8 ? ls::launch<NA_PREC_F16X, 8>(a, s)
          : ls::launch<NA_PREC_F16X>(a, s);
+}
+int render_lsx_pack_head(int model, const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1,
+                         int n_rl, char* packed, hipStream_t stream) {
+  return ls::render_lsx_pack(model, w0, b0, w1, b1, packed, stream, n_rl);
 }
 int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_out, char* packed, hipStream_t stream) {
   return ls::render_lsx_pack(4, w, b, nullptr, nullptr, packed, stream, n_out);
@@ -75,6 +80,8 @@ int render_lsx_pack_hashmlp(const float* const* w, const float* const* b, int n_
 int render_lsx_pack_fouriermlp(const float* const* w, const float* const* b, char* packed, hipStream_t stream);
 int render_lsx_pack_mip(const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1, char* packed,
                         hipStream_t stream);
+int render_lsx_pack_head(int model, const float* const* w0, const float* const* b0, const float* const* w1, const float* const* b1,
+                         int n_rl, char* packed, hipStream_t stream);
 
 }  // namespace na
 
@@ -213,6 +220,80 @@ extern "C" int na_render_plain_mip_ls(const float* rays, int B, int H, int W, co
   a.res = hash_resolutions();
   a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
   return render_ls_dispatch_f16x(a, (hipStream_t)stream, 6);
+}
+
+// ---- PlainNeRF with the Positional head (`make original`: src/nerf.py:340-361 + src/refl.py:230-245) and with PosLinearView
+// (`make dnerf`: src/refl.py:248-290, optional refl_latent rows of src/nerf.py:1272-1278) as ONE launch each (MODEL 7 / 8), NA_PREC_F16X only
+extern "C" size_t na_render_plain_pos_ls_packed_bytes(int precision) { return precision == NA_PREC_F16X ? ls::packed_bytes_x(7) : 0; }
+extern "C" size_t na_render_plain_plv_ls_packed_bytes(int precision) { return precision == NA_PREC_F16X ? ls::packed_bytes_x(8) : 0; }
+
+extern "C" size_t na_render_head_ls_workspace_bytes(int T, int64_t R) {
+  if (T < 1 || R < 0) return 0;
+  return na_render_ls_workspace_bytes(T, R) + 256 + ls::kParkBytes;
+}
+
+extern "C" int na_render_plain_pos_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                           const float* const* w_pos, const float* const* b_pos, void* packed, void* stream) {
+  NA_REQUIRE(w_first && b_first && w_pos && b_pos && packed, NA_ENULL, "na_render_plain_pos_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_render_plain_pos_ls_pack: precision %d (f16x only)", precision);
+  for (int i = 0; i < 6; ++i) NA_REQUIRE(w_first[i] && b_first[i], NA_ENULL, "na_render_plain_pos_ls_pack: first Linear %d is null", i);
+  for (int i = 0; i < 7; ++i) NA_REQUIRE(w_pos[i] && b_pos[i], NA_ENULL, "na_render_plain_pos_ls_pack: pos Linear %d is null", i);
+  return render_lsx_pack_head(7, w_first, b_first, w_pos, b_pos, 0, (char*)packed, (hipStream_t)stream);
+}
+
+extern "C" int na_render_plain_plv_ls_pack(int precision, const float* const* w_first, const float* const* b_first,
+                                           const float* const* w_head, const float* const* b_head, int n_rl, void* packed, void* stream) {
+  NA_REQUIRE(w_first && b_first && w_head && b_head && packed, NA_ENULL, "na_render_plain_plv_ls_pack: null pointer");
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_render_plain_plv_ls_pack: precision %d (f16x only)", precision);
+  NA_REQUIRE(n_rl >= 0 && n_rl <= 3, NA_EUNSUPPORTED, "na_render_plain_plv_ls_pack: %d refl_latent columns (0..3)", n_rl);
+  for (int i = 0; i < 6; ++i) NA_REQUIRE(w_first[i] && b_first[i], NA_ENULL, "na_render_plain_plv_ls_pack: first Linear %d is null", i);
+  for (int i = 0; i < 8; ++i) NA_REQUIRE(w_head[i] && b_head[i], NA_ENULL, "na_render_plain_plv_ls_pack: head Linear %d is null", i);
+  return render_lsx_pack_head(8, w_first, b_first, w_head, b_head, n_rl, (char*)packed, (hipStream_t)stream);
+}
+
+static int render_plain_head_ls_impl(const char* what, int model, const float* rays, const float* pts, int64_t R, const float* ts, int T,
+                                     const float* hash_tables, const float* hash_tables_refl, const float* refl_latent, int64_t rl_ld,
+                                     int n_rl, const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
+                                     float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "%s: bad shape T=%d R=%lld", what, T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(rays && ts && hash_tables && hash_tables_refl && packed && out && workspace, NA_ENULL, "%s: null pointer", what);
+  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "%s: precision %d (f16x only)", what, precision);
+  NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "%s: sigmoid %d", what, sigmoid_kind);
+  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "%s: bg %d", what, bg_kind);
+  NA_REQUIRE(n_rl >= 0 && n_rl <= 3 && (n_rl == 0 || (refl_latent && rl_ld >= n_rl && rl_ld < (1 << 20))), NA_EINVAL,
+             "%s: refl_latent n=%d ld=%lld", what, n_rl, (long long)rl_ld);
+  NA_REQUIRE(workspace_bytes >= na_render_head_ls_workspace_bytes(T, R), NA_EWORKSPACE, "%s: workspace %zu < %zu bytes", what,
+             workspace_bytes, na_render_head_ls_workspace_bytes(T, R));
+  ls::Args a;
+  a.rays = rays; a.ts = ts; a.ts_stride = 0; a.pts = pts; a.tables = (const float4*)hash_tables;
+  a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
+  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes_x(model);
+  a.alpha = alpha; a.weights = weights; a.out = out; a.bg_kind = bg_kind;
+  a.R = R; a.T = T; a.nb = (T + 31) / 32;
+  a.elaz = rays;  // (MODEL 8's group-wide ray table also fetches two floats per ray from here: any readable 8 R bytes)
+  a.sigmoid_kind = sigmoid_kind;
+  a.res = hash_resolutions();
+  a.trace = nullptr;
+  a.tables2 = (const float4*)hash_tables_refl;
+  a.park = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.rl = n_rl > 0 ? refl_latent : nullptr; a.rl_ld = (int)rl_ld; a.n_rl = n_rl;
+  return render_ls_dispatch_f16x(a, (hipStream_t)stream, model);
+}
+
+extern "C" int na_render_plain_pos_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                                      const float* hash_tables_refl, const void* packed, int precision, int sigmoid_kind, int bg_kind,
+                                      float* alpha, float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  return render_plain_head_ls_impl("na_render_plain_pos_ls", 7, rays, pts, R, ts, T, hash_tables, hash_tables_refl, nullptr, 0, 0, packed,
+                                   precision, sigmoid_kind, bg_kind, alpha, weights, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int na_render_plain_plv_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                                      const float* hash_tables_refl, const float* refl_latent, int64_t rl_ld, int n_rl, const void* packed,
+                                      int precision, int sigmoid_kind, int bg_kind, float* alpha, float* weights, float* out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return render_plain_head_ls_impl("na_render_plain_plv_ls", 8, rays, pts, R, ts, T, hash_tables, hash_tables_refl, refl_latent, rl_ld,
+                                   n_rl, packed, precision, sigmoid_kind, bg_kind, alpha, weights, out, workspace, workspace_bytes, stream);
 }
 
 // ---- TinyNeRF on the same engine (src/nerf.py:278-305)

@@ -243,6 +243,48 @@ class PlainNeRF(CommonNeRF):
                 and self.intermediate_size == 64 and self.refl.out_features == 3 and not self.training
                 and not wants_grad)
 
+    def _fusable_head(self, refl_latent=None):
+        """PlainNeRF + refl.Positional / refl.PosLinearView as ONE launch of the layer-synchronous engine (csrc/ls_sched_plain_pos.inc,
+        ls_sched_plain_plv.inc: MODEL 7 / 8; f16x only): "pos" | "plv" | None.  PosLinearView takes up to three refl_latent columns
+        (DynamicNeRF, --dyn-refl-latent)."""
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if (config.engine != "ls" or config.precision != "f16x" or self.mip is not None or self.intermediate_size != 64
+                or self.training or wants_grad or self.refl.out_features != 3 or getattr(self.refl, "act_kind", None) not in ops.SIGMOID):
+            return None
+        n_rl = 0 if refl_latent is None else refl_latent.shape[-1]
+        if type(self.refl) is refl.Positional and n_rl == 0 and self.refl.latent_size == 64:
+            return "pos"
+        if type(self.refl) is refl.PosLinearView and n_rl <= 3 and self.refl.latent_size == 64 + n_rl and self.refl.im == 64:
+            return "plv"
+        return None
+
+    def packed_head_ls(self, kind: str, precision: str, n_rl: int = 0):
+        r = self.refl
+        heads = r.mlp._linears() if kind == "pos" else r.pos._linears() + r.view._linears()
+        lin = self.first._linears() + heads
+        stamp = utils.pack_stamp(lin)
+        cache = self.__dict__.setdefault("_packed_head_ls", {})
+        key = (kind, precision, n_rl)
+        hit = cache.get(key)
+        if hit is None or stamp is None or hit[0] != stamp:
+            wb = lambda ls: ([l.weight.data for l in ls], [l.bias.data for l in ls])
+            if kind == "pos":
+                packed = ops.render_plain_pos_ls_pack(precision, wb(self.first._linears()), wb(heads))
+            else:
+                packed = ops.render_plain_plv_ls_pack(precision, wb(self.first._linears()), wb(heads), n_rl)
+            cache[key] = (stamp, packed)
+        return cache[key][1]
+
+    def _render_head(self, kind, rays, ts, want_weights, pts=None, refl_latent=None):
+        want_weights = want_weights or self.bg == "random"
+        r = self.refl
+        if kind == "pos":
+            return ops.render_plain_pos_ls(rays, ts, self.first.enc.tables(), r.mlp.enc.tables(), self.packed_head_ls("pos", "f16x"),
+                                           "f16x", self.sigmoid_kind, self._kernel_bg(), want_weights, pts=pts)
+        n_rl = 0 if refl_latent is None else refl_latent.shape[-1]
+        return ops.render_plain_plv_ls(rays, ts, self.first.enc.tables(), r.pos.enc.tables(), self.packed_head_ls("plv", "f16x", n_rl),
+                                       "f16x", self.sigmoid_kind, self._kernel_bg(), want_weights, pts=pts, refl_latent=refl_latent)
+
     def _fusable_mip(self, rays):
         """mip + f16x on the layer-synchronous engine (csrc/render_ls.hip MODEL 6): whole crops [B,H,W,6], 16 IPE degrees."""
         wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
@@ -293,6 +335,11 @@ class PlainNeRF(CommonNeRF):
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
             out, self.alpha, self.weights = self._render_fused(rays, self.ts, want_weights)
             return self._finish_sky(out)
+        head = self._fusable_head()
+        if head is not None:
+            _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
+            out, self.alpha, self.weights = self._render_head(head, rays.contiguous(), self.ts, want_weights)
+            return self._finish_sky(out)
         if self._fusable_mip(rays):
             # config 3 under f16x: sample -> hash -> IPE -> first -> View -> composite as ONE launch
             _, _, self.ts, _ = compute_ts(rays, self.t_near, self.t_far, self.steps)
@@ -333,6 +380,11 @@ class PlainNeRF(CommonNeRF):
         if self._fusable(refl_latent) and not ag.needs_grad(pts):
             # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
             out, self.alpha, self.weights = self._render_fused(rays, ts, True, pts=pts.contiguous())
+            return self._finish_sky(out)
+        head = self._fusable_head(refl_latent)
+        if head is not None and not ag.needs_grad(pts) and (refl_latent is None or not ag.needs_grad(refl_latent)):
+            # explicit sample positions (D-NeRF: warped points, + its per-sample reflectance latent) through the one-launch renderer
+            out, self.alpha, self.weights = self._render_head(head, rays.contiguous(), ts, True, pts=pts.contiguous(), refl_latent=refl_latent)
             return self._finish_sky(out)
         if not self.training and not ag.needs_grad(pts, *self.parameters()) and refl_latent is None and self.mip is None:
             utils.note_fallback(f"plain-unfused-{type(self.refl).__name__}-{self.intermediate_size}",

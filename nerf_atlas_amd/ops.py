@@ -962,6 +962,108 @@ def render_plain_mip_ls(rays: torch.Tensor, ts: torch.Tensor, hash_tables: torch
     return out, alpha, weights
 
 
+def _wb_arrays(lists):
+    return [(C.c_void_p * len(lst))(*[0 if t is None else t.data_ptr() for t in lst]) for lst in lists]
+
+
+_FIRST_SHAPES = [(256, 38), (256, 294), (256, 256), (256, 256), (256, 256), (65, 256)]
+
+
+def render_plain_pos_ls_pack(precision: str, first_wb, pos_wb) -> torch.Tensor:
+    """PlainNeRF.first and refl.Positional.mlp ({init, layers.0..4, out}) as one weight stream of the layer-synchronous renderer
+    (na_render_plain_pos_ls_pack; f16x only)."""
+    lib = _lib.load()
+    (w1, b1), (w2, b2) = first_wb, pos_wb
+    assert len(w1) == 6 and len(w2) == 7
+    keep = [[_f32(w.detach(), "weight") for w in w1], [_f32(b.detach(), "bias") for b in b1],
+            [_f32(w.detach(), "weight") for w in w2], [_f32(b.detach(), "bias") for b in b2]]
+    shapes2 = [(256, 102), (256, 358), (256, 256), (256, 256), (256, 358), (256, 256), (3, 256)]
+    for w, shp in zip(keep[0] + keep[2], _FIRST_SHAPES + shapes2):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS pos renderer: weight shape {tuple(w.shape)} != {shp}")
+    nbytes = int(lib.na_render_plain_pos_ls_packed_bytes(PREC[precision]))
+    if nbytes == 0:
+        raise _lib.NaError(f"LS pos renderer: precision {precision} not supported (f16x)")
+    arrs = _wb_arrays(keep)
+    packed = torch.empty(nbytes, device=keep[0][0].device, dtype=torch.uint8)
+    check(lib.na_render_plain_pos_ls_pack(PREC[precision], arrs[0], arrs[1], arrs[2], arrs[3], _ptr(packed), _stream()))
+    return packed
+
+
+def render_plain_plv_ls_pack(precision: str, first_wb, head_wb, n_rl: int = 0) -> torch.Tensor:
+    """PlainNeRF.first and refl.PosLinearView ({pos.init, pos.layers.0..1, pos.out, view.init, view.layers.0..1, view.out}) as one
+    weight stream (na_render_plain_plv_ls_pack; f16x only); n_rl = DynamicNeRF's refl_latent columns (0..3)."""
+    lib = _lib.load()
+    (w1, b1), (w2, b2) = first_wb, head_wb
+    assert len(w1) == 6 and len(w2) == 8
+    keep = [[_f32(w.detach(), "weight") for w in w1], [_f32(b.detach(), "bias") for b in b1],
+            [_f32(w.detach(), "weight") for w in w2], [_f32(b.detach(), "bias") for b in b2]]
+    n = int(n_rl)
+    shapes2 = [(256, 102 + n), (256, 358 + n), (256, 256), (67, 256), (128, 134 + n), (128, 262 + n), (128, 128), (1, 128)]
+    for w, shp in zip(keep[0] + keep[2], _FIRST_SHAPES + shapes2):
+        if tuple(w.shape) != shp:
+            raise ValueError(f"LS pos-linear-view renderer: weight shape {tuple(w.shape)} != {shp}")
+    nbytes = int(lib.na_render_plain_plv_ls_packed_bytes(PREC[precision]))
+    if nbytes == 0 or not 0 <= n <= 3:
+        raise _lib.NaError(f"LS pos-linear-view renderer: precision {precision} / {n} refl_latent columns not supported (f16x, 0..3)")
+    arrs = _wb_arrays(keep)
+    packed = torch.empty(nbytes, device=keep[0][0].device, dtype=torch.uint8)
+    check(lib.na_render_plain_plv_ls_pack(PREC[precision], arrs[0], arrs[1], arrs[2], arrs[3], n, _ptr(packed), _stream()))
+    return packed
+
+
+def _render_head_ls(which: str, rays, ts, hash_tables, hash_tables_refl, packed, precision, sigmoid_kind, bg, want_weights, workspace,
+                    pts, refl_latent=None):
+    lib = _lib.load()
+    rays, ts = _f32(rays, "rays"), _f32(ts, "ts")
+    hash_tables, hash_tables_refl = _f32(hash_tables, "hash_tables"), _f32(hash_tables_refl, "hash_tables_refl")
+    R = rays.numel() // 6
+    T = ts.shape[0]
+    if bg not in BG:
+        raise NotImplementedError(bg)
+    nbytes = int(lib.na_render_head_ls_workspace_bytes(T, R))
+    if workspace is None:
+        workspace = torch.empty(nbytes, device=rays.device, dtype=torch.uint8)
+    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
+    shape_t = (T,) + tuple(rays.shape[:-1])
+    alpha = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    weights = torch.empty(shape_t, device=rays.device, dtype=torch.float32) if want_weights else None
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        assert pts.numel() == T * R * 3, (pts.shape, T, R)
+    if which == "pos":
+        assert refl_latent is None
+        check(lib.na_render_plain_pos_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(hash_tables), _ptr(hash_tables_refl), _ptr(packed),
+                                         PREC[precision], SIGMOID[sigmoid_kind], BG[bg], _ptr(alpha), _ptr(weights), _ptr(out),
+                                         _ptr(workspace), workspace.numel(), _stream()))
+    else:
+        n_rl, ld = 0, 0
+        if refl_latent is not None:
+            n_rl = refl_latent.shape[-1]
+            refl_latent, ld = _rows(refl_latent, n_rl, "refl_latent")
+            assert refl_latent.shape[0] == T * R, (refl_latent.shape, T, R)
+        check(lib.na_render_plain_plv_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(hash_tables), _ptr(hash_tables_refl),
+                                         _ptr(refl_latent), ld, n_rl, _ptr(packed), PREC[precision], SIGMOID[sigmoid_kind], BG[bg],
+                                         _ptr(alpha), _ptr(weights), _ptr(out), _ptr(workspace), workspace.numel(), _stream()))
+    _f16x_guard(precision, out, f"na_render_plain_{which}_ls")
+    return out, alpha, weights
+
+
+def render_plain_pos_ls(rays, ts, hash_tables, hash_tables_refl, packed, precision: str, sigmoid_kind: str = "thin", bg: str = "black",
+                        want_weights: bool = False, workspace: Optional[torch.Tensor] = None, pts: Optional[torch.Tensor] = None):
+    """PlainNeRF + refl.Positional (`--refl-kind pos`) forward as one launch; same contract as render_plain_view_ls."""
+    return _render_head_ls("pos", rays, ts, hash_tables, hash_tables_refl, packed, precision, sigmoid_kind, bg, want_weights, workspace, pts)
+
+
+def render_plain_plv_ls(rays, ts, hash_tables, hash_tables_refl, packed, precision: str, sigmoid_kind: str = "thin", bg: str = "black",
+                        want_weights: bool = False, workspace: Optional[torch.Tensor] = None, pts: Optional[torch.Tensor] = None,
+                        refl_latent: Optional[torch.Tensor] = None):
+    """PlainNeRF + refl.PosLinearView (`--refl-kind pos-linear-view`) forward as one launch; refl_latent [T, ..., n <= 3] =
+    DynamicNeRF's per-sample reflectance latent (rows may be a column slice: passed by pitch)."""
+    return _render_head_ls("plv", rays, ts, hash_tables, hash_tables_refl, packed, precision, sigmoid_kind, bg, want_weights, workspace, pts,
+                           refl_latent)
+
+
 def mlp_hash_ls_pack(precision: str, weights, biases) -> torch.Tensor:
     """Pack a hash-encoded SkipConnMLP (in 3, HashEncoder, 5 x 256, skip 3, out <= 32: {init, layers.0..4, out}) into the weight
     stream of the layer-synchronous engine (f16x only; D-NeRF's deformation network)."""
