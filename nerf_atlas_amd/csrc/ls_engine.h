@@ -109,7 +109,8 @@ constexpr int PAIRB = 4096;                  // stream bytes per init / geometry
 // init region holds ONE K64 group per block (the [hash' | x] group), so act(latent) is rebuilt in a dead hidden slot from the raw rows,
 // which wait in a per-workgroup scratch in global memory (Args::park)
 // MODEL 8 (round 6): PlainNeRF + PosLinearView (`make dnerf`, src/refl.py:248-290): `first` 22 | pos (2 x 256 -> 3 + 64): init 2 | L0 5 + 1 |
-// L1 4 | out 4 (three tiles, split by block like first.out) | view (2 x 128, sin; [x | dir | latent | refl_latent | intermediate] -> 1):
+// L1 4 | out 4 (three tiles, split by block like first.out) | view (2 x 128, sin; [x | dir | latent | refl_latent | intermediate] -> 1;
+// split by BLOCK: a row group computes rows 64 (rg & 1) .. + 63 for block rg >> 1, so all four waves work and convert):
 // init 2 | L0 4 | L1 2 | out 2 = 48 records + 2 geometry pairs ([x, y, z, dir, refl_latent]); up to 3 refl_latent columns
 // (--dyn-refl-latent) ride in the spare slots of the [hash' | x] group and of the geometry chunk
 __host__ __device__ constexpr int npair(int model) { return model == 1 ? 3 : model == 2 ? 2 : model == 3 ? 5 : model == 4 ? 0 : model == 5 ? 3 : model == 7 ? 0 : 2; }  // (6, 8: 2)
@@ -170,11 +171,11 @@ struct Args {
   float mip_t_end;
   // MODEL 7 / 8 (appended: the kernel-argument offsets of the older schedules do not move)
   const float4* tables2 = nullptr;  // hash tables of the reflectance head's own encoder [8,65536]
-  float* park = nullptr;            // per-workgroup scratch: [workgroup][group][block][slot] x 8 KiB of raw latent rows
+  float* park = nullptr;            // per-workgroup scratch: [workgroup][group][block] x 8 KiB of raw latent rows
   const float* rl = nullptr;        // MODEL 8: refl_latent rows [T * R, rl_ld] (--dyn-refl-latent), nullable
   int rl_ld = 0, n_rl = 0;
 };
-constexpr int kParkSlots = 2;       // raw K64 groups a block parks in global memory (MODEL 7: latent; MODEL 8: latent, intermediate)
+constexpr int kParkSlots = 1;       // raw K64 groups a block parks in global memory: the latent rows (8 KiB)
 constexpr size_t kParkBytes = (size_t)256 * 2 * 2 * kParkSlots * 8192;  // 256 workgroups x 2 groups x 2 blocks
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -208,7 +209,8 @@ struct XPairD { int8_t lin, q, skip; };
 // K64 group of Linear lin.  kind 0: hidden features 64 q .. 64 q + 63; kind 1 / 2: the init chunks 0..3 of the MLP (columns by
 // init_slot_feature; 2: behind the kHidden hidden columns of a skip layer); kind 3 / 4: Fourier features 64 q .. 64 q + 63 in the
 // generator's slot order (fourier_slot_col; 4: behind the hidden columns of a skip layer).  out_mode 0 hidden rows, 1 out row-major (tile
-// min(rg, 2)), 2 out, one tile, 3 out split by block: row groups 0,1 hold tiles 0 and 1, row groups 2,3 tile 2
+// min(rg, 2)), 2 out, one tile, 3 out split by block: row groups 0,1 hold tiles 0 and 1, row groups 2,3 tile 2; 4: ls_xsched.h; 5 hidden rows
+// split by block (a 128-wide Linear: row group rg holds rows 64 (rg & 1) .. + 63)
 // kind 6: 64 columns off .. off + 63 in the hidden slot order (a group that was produced by an out Linear's accumulators: the latent /
 // intermediate rows); kind 7: the [hash' | x | refl_latent] group of MODEL 8 -- kind 1's slots + refl_latent column j in slot 6 + j of chunk 2
 // (weight column off2 + j, off2 = q * 1 ... see xrec_col), everything shifted by `off`

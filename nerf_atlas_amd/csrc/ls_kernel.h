@@ -556,30 +556,41 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   // re-entry through the activation -- with two differences: the T plane's spare dword is left alone (KEEP7: the block's density
   // waits there, as in MODEL 0's latent group) and MODEL 8 puts up to three refl_latent columns (--dyn-refl-latent, rows from
   // HBM) into the spare slots 6.. of chunk 2.
-  auto hash_group2 = [&](int pass) {
+  // (both gather rounds are ISSUED first -- hash2_issue -- and combined after the epilogue's other work -- hash2_finish: the gathers of
+  // this phase queue behind the partner group's weight stream, which keeps the vector memory path ~94 % busy during its MFMA phases)
+  struct Hash2 { HashGather g[2]; float px, py, pz, r0, r1, r2; };
+  auto hash2_issue = [&](int pass, Hash2& H) {
     if constexpr (PREC == NA_PREC_F16X && HEAD2) {
       const int part = owner ? 0 : 1;
       const TsPair tp = ts_load(pass);
       const Geom q = geom(pass, blk, tp);
-      float rlv[3] = {0.f, 0.f, 0.f};
+      H.px = q.px; H.py = q.py; H.pz = q.pz;
+      H.r0 = H.r1 = H.r2 = 0.f;
       if constexpr (MODEL == 8) {
         if (a.rl != nullptr) {
           const float* rr = a.rl + ((int64_t)(q.t_ok ? q.t : a.T - 1) * a.R + q.ray) * a.rl_ld;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) if (j < a.n_rl) rlv[j] = rr[j];
+          if (a.n_rl > 0) H.r0 = rr[0];
+          if (a.n_rl > 1) H.r1 = rr[1];
+          if (a.n_rl > 2) H.r2 = rr[2];
         }
       }
-      float f8[8];
-      HashGather hg;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int lvl0 = 4 * part + k;                      // (j = 0) | + 2 (j = 1)
-        hash_level_issue(q.px, q.py, q.pz, a.tables2, hi ? a.res.n[lvl0 + 2] : a.res.n[lvl0], lvl0 + 2 * hi, hg);
+        hash_level_issue(q.px, q.py, q.pz, a.tables2, hi ? a.res.n[lvl0 + 2] : a.res.n[lvl0], lvl0 + 2 * hi, H.g[k]);
+      }
+    }
+  };
+  auto hash2_finish = [&](const Hash2& H) {
+    if constexpr (PREC == NA_PREC_F16X && HEAD2) {
+      const int part = owner ? 0 : 1;
+      float f8[8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
         float f[4];
-        hash_level_finish(hg, f);
+        hash_level_finish(H.g[k], f);
 #pragma unroll
         for (int e = 0; e < 4; ++e) f8[4 * k + e] = f[e];
-        __builtin_amdgcn_sched_barrier(0);
       }
       f32x16 n0, n1;
 #pragma unroll
@@ -588,8 +599,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
         n0[8 + e] = __shfl_down(f8[e], 32, 64);
         n1[e] = 0.f; n1[8 + e] = 0.f;
       }
-      if (part == 0) { n1[0] = q.px; n1[1] = q.py; n1[2] = q.pz; n1[3] = q.px; n1[4] = q.py; n1[5] = q.pz; n1[6] = rlv[0]; n1[7] = rlv[1]; }
-      else n1[0] = rlv[2];
+      if (part == 0) { n1[0] = H.px; n1[1] = H.py; n1[2] = H.pz; n1[3] = H.px; n1[4] = H.py; n1[5] = H.pz; n1[6] = H.r0; n1[7] = H.r1; }
+      else n1[0] = H.r2;
       if (hi == 0) {
         const int ml = ln + 32 * part;
         char* st = hb + x::BLKH + rg * x::KQ + ml * 16;

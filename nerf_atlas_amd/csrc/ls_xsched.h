@@ -42,6 +42,7 @@ __device__ __forceinline__ int xrec_col(const XSched& sc, const XRecD& rd, int c
 __device__ __forceinline__ int xrec_row(const XSched& sc, const XRecD& rd, int rg, int t, int l) {
   const NaMlpDesc& d = sc.desc[sc.lin[rd.lin].desc];
   if (rd.out_mode == 0) return 32 * (2 * rg + t) + (l & 31);
+  if (rd.out_mode == 5) return 32 * (2 * (rg & 1) + t) + (l & 31);  // a 128-wide Linear split by block (MODEL 8's view MLP)
   if (rd.out_mode == 3) return rg < 2 ? out_row_map(d, 32 * t + (l & 31)) : (t == 0 ? out_row_map(d, 64 + (l & 31)) : -1);
   // 4: PosLinearView.pos.out (src/refl.py:275-276: rows 0..2 colour, 3..66 intermediate), split by block like mode 3: row groups
   // 0, 1 hold the two intermediate tiles, row groups 2, 3 the colour rows
@@ -62,7 +63,7 @@ __global__ void pack_lsx_f16_kernel(XSched sc, char* __restrict__ dst) {
       const int kap = 8 * (l >> 5) + e;
       int col = pd.q == 32 ? (kap < 6 ? kap : kap < 6 + sc.n_rl ? 6 + 64 + (kap - 6) : -1) : init_slot_feature(sc.desc[L.desc], pd.q, kap);
       if (col >= 0 && pd.skip) col += sc.desc[L.desc].hidden;
-      const int row = 32 * (2 * rg + t) + (l & 31);
+      const int row = 32 * (2 * (pd.q == 32 ? (rg & 1) : rg) + t) + (l & 31);  // (q = 32: a Linear split by block)
       float v = 0.f;
       if (col >= 0 && col < L.in_dim && row < L.out_dim) v = L.W[(int64_t)row * L.in_dim + col];
       const __bf16 h = to_elem<NA_PREC_F16X>(v);
@@ -147,6 +148,7 @@ __global__ void pack_lsx_bias_kernel(XSched sc, char* __restrict__ dst) {
       const int mode = sc.bias_mode[p];  // 0 hidden rows, 1 / 3 out Linear with 3 tiles, 2 out Linear, one tile
       if (L.B != nullptr) {
         if (mode == 0) { if (slot < 2 && 32 * (2 * rg + slot) + rin < L.out_dim) v = L.B[32 * (2 * rg + slot) + rin]; }
+        else if (mode == 5) { if (slot < 2) v = L.B[32 * (2 * (rg & 1) + slot) + rin]; }
         else if (mode == 4) {
           const int row = slot < 2 ? 3 + 32 * slot + rin : (slot == 2 && rin < 3 ? rin : -1);
           if (row >= 0 && row < L.out_dim) v = L.B[row];
@@ -303,15 +305,16 @@ int render_lsx_pack(int model, const float* const* w0, const float* const* b0, c
         const int li = sc.nlin;
         sc.lin[sc.nlin++] = L;
         sc.bias_lin[sc.nphase] = (int8_t)li;
-        sc.bias_mode[sc.nphase++] = (int8_t)(last ? 2 : 0);
+        sc.bias_mode[sc.nphase++] = (int8_t)(last ? 2 : 5);
         const int so = skip ? H : 0;
-        // consumption order: the two hidden groups, the latent group, the intermediate group, the geometry pair
-        if (!fst) for (int q = 0; q < 2; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, (int8_t)(last ? 2 : 0), 0, 0};
+        // consumption order = the K64 groups 0..3 of a block as the kernel lays them out: view.init [latent, intermediate] (groups 2, 3);
+        // view.L0 [sin(latent), sin(intermediate), hidden 0, hidden 1]; view.L1 / out [hidden 0, hidden 1]; then the geometry pair
         if (fst || skip) {
-          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)6, (int16_t)(so + 6)};
-          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 0, (int8_t)6, (int16_t)(so + 6 + 64 + n_rl)};
+          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 5, (int8_t)6, (int16_t)(so + 6)};
+          sc.rec[sc.nrec++] = XRecD{(int8_t)li, 0, 5, (int8_t)6, (int16_t)(so + 6 + 64 + n_rl)};
           sc.pair[sc.npair++] = XPairD{(int8_t)li, 32, (int8_t)(skip ? 1 : 0)};
         }
+        if (!fst) for (int q = 0; q < 2; ++q) sc.rec[sc.nrec++] = XRecD{(int8_t)li, (int8_t)q, (int8_t)(last ? 2 : 5), 0, 0};
       }
     }
   } else if (model == 4) {

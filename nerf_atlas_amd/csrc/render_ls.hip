@@ -277,6 +277,7 @@ static int render_plain_head_ls_impl(const char* what, int model, const float* r
   a.trace = nullptr;
   a.tables2 = (const float4*)hash_tables_refl;
   a.park = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  if (NA_LS_TRACE) a.trace = (unsigned long long*)((char*)a.park + ls::kParkBytes);  // (tools/head_trace.py; the base size's per-ray scratch is unused here)
   a.rl = n_rl > 0 ? refl_latent : nullptr; a.rl_ld = (int)rl_ld; a.n_rl = n_rl;
   return render_ls_dispatch_f16x(a, (hipStream_t)stream, model);
 }
