@@ -162,6 +162,13 @@ int na_laplace_density(const float* sdf, int64_t N, const float* beta, float* de
  * out_pts = pts + bezier(t) * sigmoid(rigidity/2); optional dp, rigidity_out [N,3],[N].       */
 int na_bezier_warp(const float* est, int est_stride, const float* pts, const float* t, int64_t N,
                    int n_ctrl, float* out_pts, float* dp, float* rigidity_out, void* stream);
+/* the same with DynamicNeRF's reflectance latent (--dyn-refl-latent n_rl > 0; src/nerf.py:1246-1248, 1272-1278):
+ * est [N, >= 2 + (3 + n_rl) n] = rigidity | n control points | enc_rigidity | n latent control rows of n_rl;
+ * refl_latent [N, n_rl] = bezier(latent control rows, t) * sigmoid(enc_rigidity) -- what from_pts receives as
+ * `refl_latent` (src/nerf.py:1303).  n_rl 1..16.                                                               */
+int na_bezier_warp_latent(const float* est, int est_stride, const float* pts, const float* t, int64_t N,
+                          int n_ctrl, int n_rl, float* out_pts, float* dp, float* rigidity_out,
+                          float* refl_latent, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A4 SkipConnMLP (src/neural_blocks.py:204-296).
@@ -379,6 +386,10 @@ int na_laplace_density_backward(const float* sdf, int64_t N, const float* beta, 
 int na_bezier_warp_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl,
                             const float* g_out_pts, const float* g_dp, const float* g_rigidity, float* g_est,
                             void* stream);
+/* gradient of na_bezier_warp_latent: + g_refl_latent [N, n_rl] (nullable) into the enc_rigidity / latent control columns */
+int na_bezier_warp_latent_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl, int n_rl,
+                                   const float* g_out_pts, const float* g_dp, const float* g_rigidity,
+                                   const float* g_refl_latent, float* g_est, void* stream);
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays,
                           int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
                           float* g_density, float* g_feat, void* stream);

@@ -59,6 +59,8 @@ SIGNATURES = {
     "na_laplace_density": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),
     "na_bezier_warp": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_f32p,
                                  C.c_void_p]),
+    "na_bezier_warp_latent": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_i64, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
+                                        c_f32p, C.c_void_p]),
     "na_linear_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p,
                                 C.c_void_p]),
     "na_mlp_packed_bytes": (C.c_size_t, [C.POINTER(NaMlpDesc), C.c_int]),
@@ -132,6 +134,8 @@ SIGNATURES = {
     "na_laplace_density_backward": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_bezier_warp_backward": (C.c_int, [c_f32p, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.c_void_p]),
+    "na_bezier_warp_latent_backward": (C.c_int, [c_f32p, C.c_int, c_f32p, c_i64, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
+                                                 c_f32p, c_f32p, C.c_void_p]),
     "na_composite_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,
                                         c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_render_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),

@@ -127,20 +127,20 @@ class LaplaceDensityFn(Function):
 
 
 class BezierWarpFn(Function):
-    """DynamicNeRF spline warp (src/nerf.py:1267-1278) -> (warped pts, dp, rigidity); gradient w.r.t. the
-    estimator output and the (pass-through) points."""
+    """DynamicNeRF spline warp (src/nerf.py:1267-1278) -> (warped pts, dp, rigidity [, refl_latent when n_rl > 0]); gradient
+    w.r.t. the estimator output and the (pass-through) points."""
 
     @staticmethod
-    def forward(ctx, est, pts, t, n_ctrl):
+    def forward(ctx, est, pts, t, n_ctrl, n_rl=0):
         ctx.save_for_backward(est, t)
-        ctx.n_ctrl = n_ctrl
-        return ops.bezier_warp(est, pts, t, n_ctrl)
+        ctx.n_ctrl, ctx.n_rl = n_ctrl, n_rl
+        return ops.bezier_warp(est, pts, t, n_ctrl, n_rl)
 
     @staticmethod
-    def backward(ctx, g_pts, g_dp, g_rig):
+    def backward(ctx, g_pts, g_dp, g_rig, g_enc=None):
         est, t = ctx.saved_tensors
-        g_est = ops.bezier_warp_backward(est, t, ctx.n_ctrl, g_pts, g_dp, g_rig)
-        return g_est, (g_pts if ctx.needs_input_grad[1] else None), None, None
+        g_est = ops.bezier_warp_backward(est, t, ctx.n_ctrl, g_pts, g_dp, g_rig, ctx.n_rl, g_enc)
+        return g_est, (g_pts if ctx.needs_input_grad[1] else None), None, None, None
 
 
 class SigmoidFn(Function):

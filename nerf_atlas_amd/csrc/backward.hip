@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void laplace_density_backward_kernel(const flo
 __global__ void bezier_warp_backward_kernel(const float* __restrict__ est, int est_stride,
                                             const float* __restrict__ tt, int64_t N, int n,
                                             const float* __restrict__ g_pts, const float* __restrict__ g_dp,
-                                            const float* __restrict__ g_rig, float* __restrict__ g_est) {
+                                            const float* __restrict__ g_rig, float* __restrict__ g_est, int n_rl = 0,
+                                            const float* __restrict__ g_enc = nullptr) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const float* e = est + i * est_stride;
     float* ge = g_est + i * est_stride;
@@ -479,7 +480,25 @@ __global__ void bezier_warp_backward_kernel(const float* __restrict__ est, int e
     ge[0] = d_rig * rig * (1.f - rig) * 0.5f;
     for (int k = 0; k < n; ++k)
       for (int a = 0; a < 3; ++a) ge[1 + 3 * k + a] = B[k] * d_dp[a];
-    for (int c = 1 + 3 * n; c < est_stride; ++c) ge[c] = 0.f;
+    int c0 = 1 + 3 * n;
+    if (n_rl > 0 && g_enc != nullptr) {
+      // enc_j = (sum_k B_k(t) C_kj) * s, s = sigmoid(est[3n + 1])  (src/nerf.py:1272-1278)
+      const float* cp = e + 3 * n + 2;
+      const float s = sigmoidf_(e[3 * n + 1]);
+      float d_s = 0.f;
+      for (int j = 0; j < n_rl; ++j) {
+        const float g = g_enc[i * n_rl + j];
+        float v = 0.f;
+        for (int k = 0; k < n; ++k) {
+          v += B[k] * cp[k * n_rl + j];
+          ge[3 * n + 2 + k * n_rl + j] = B[k] * (g * s);
+        }
+        d_s += g * v;
+      }
+      ge[3 * n + 1] = d_s * s * (1.f - s);
+      c0 = 2 + (3 + n_rl) * n;
+    }
+    for (int c = c0; c < est_stride; ++c) ge[c] = 0.f;
   }
 }
 
@@ -787,8 +806,21 @@ int na_bezier_warp_backward(const float* est, int est_stride, const float* t, in
              "na_bezier_warp_backward: n_ctrl=%d (2..8) stride=%d", n_ctrl, est_stride);
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
   hipLaunchKernelGGL(bezier_warp_backward_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
-                     est_stride, t, N, n_ctrl, g_out_pts, g_dp, g_rigidity, g_est);
+                     est_stride, t, N, n_ctrl, g_out_pts, g_dp, g_rigidity, g_est, 0, (const float*)nullptr);
   return check_launch("na_bezier_warp_backward");
+}
+
+int na_bezier_warp_latent_backward(const float* est, int est_stride, const float* t, int64_t N, int n_ctrl, int n_rl,
+                                   const float* g_out_pts, const float* g_dp, const float* g_rigidity,
+                                   const float* g_refl_latent, float* g_est, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(est && t && g_est, NA_ENULL, "na_bezier_warp_latent_backward: null pointer");
+  NA_REQUIRE(n_ctrl >= 2 && n_ctrl <= 8 && n_rl >= 1 && n_rl <= 16 && est_stride >= 2 + (3 + n_rl) * n_ctrl, NA_EINVAL,
+             "na_bezier_warp_latent_backward: n_ctrl=%d (2..8) n_rl=%d (1..16) stride=%d", n_ctrl, n_rl, est_stride);
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(bezier_warp_backward_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
+                     est_stride, t, N, n_ctrl, g_out_pts, g_dp, g_rigidity, g_est, n_rl, g_refl_latent);
+  return check_launch("na_bezier_warp_latent_backward");
 }
 
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays, int T,

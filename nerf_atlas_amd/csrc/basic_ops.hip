@@ -517,9 +517,12 @@ __global__ void laplace_density_kernel(const float* __restrict__ sdf, int64_t N,
 }
 
 // src/nerf.py:1173-1178 (de Casteljau), 1201-1206 (cubic), 1267-1278 (warp)
+// + the reflectance latent of --dyn-refl-latent (src/nerf.py:1246-1248, 1272-1278): n_rl more columns ride through the same
+// spline (control point k of column j at est[3n + 2 + k * n_rl + j]) and leave scaled by sigmoid(est[3n + 1]).
 __global__ void bezier_warp_kernel(const float* __restrict__ est, int est_stride, const float* __restrict__ pts,
                                    const float* __restrict__ tt, int64_t N, int n, float* __restrict__ out_pts,
-                                   float* __restrict__ dp_out, float* __restrict__ rig_out) {
+                                   float* __restrict__ dp_out, float* __restrict__ rig_out, int n_rl = 0,
+                                   float* __restrict__ enc_out = nullptr) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const float* e = est + i * est_stride;
     float rig = sigmoidf_(e[0] / 2.f);
@@ -544,6 +547,25 @@ __global__ void bezier_warp_kernel(const float* __restrict__ est, int est_stride
       if (dp_out != nullptr) dp_out[i * 3 + a] = dp[a];
     }
     if (rig_out != nullptr) rig_out[i] = rig;
+    if (n_rl > 0) {
+      const float* c = e + 3 * n + 2;
+      const float enc_rig = sigmoidf_(e[3 * n + 1]);
+      for (int j = 0; j < n_rl; ++j) {
+        float v;
+        if (n == 4) {
+          float m2 = m1t * m1t, t2 = t * t;
+          float k0 = m2 * m1t, k1 = 3.f * m2 * t, k2 = 3.f * t2 * m1t, k3 = t2 * t;
+          v = ((k0 * c[j] + k1 * c[n_rl + j]) + k2 * c[2 * n_rl + j]) + k3 * c[3 * n_rl + j];
+        } else {
+          float b[8];
+          for (int k = 0; k < n; ++k) b[k] = c[k * n_rl + j];
+          for (int it = 1; it < n; ++it)
+            for (int k = 0; k < n - it; ++k) b[k] = b[k] * m1t + b[k + 1] * t;
+          v = b[0];
+        }
+        enc_out[i * n_rl + j] = v * enc_rig;
+      }
+    }
   }
 }
 
@@ -896,8 +918,20 @@ int na_bezier_warp(const float* est, int est_stride, const float* pts, const flo
              "na_bezier_warp: n_ctrl=%d (2..8) stride=%d", n_ctrl, est_stride);
   if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
   hipLaunchKernelGGL(bezier_warp_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
-                     est_stride, pts, t, N, n_ctrl, out_pts, dp, rigidity_out);
+                     est_stride, pts, t, N, n_ctrl, out_pts, dp, rigidity_out, 0, (float*)nullptr);
   return check_launch("na_bezier_warp");
+}
+
+int na_bezier_warp_latent(const float* est, int est_stride, const float* pts, const float* t, int64_t N, int n_ctrl,
+                          int n_rl, float* out_pts, float* dp, float* rigidity_out, float* refl_latent, void* stream) {
+  NA_REQUIRE(est && pts && t && out_pts && refl_latent, NA_ENULL, "na_bezier_warp_latent: null pointer");
+  NA_REQUIRE(n_ctrl >= 2 && n_ctrl <= 8 && n_rl >= 1 && n_rl <= 16 && est_stride >= 2 + (3 + n_rl) * n_ctrl, NA_EINVAL,
+             "na_bezier_warp_latent: n_ctrl=%d (2..8) n_rl=%d (1..16) stride=%d (>= 2 + (3 + n_rl) * n_ctrl)", n_ctrl, n_rl,
+             est_stride);
+  if (N <= 0) return N == 0 ? NA_OK : NA_EINVAL;
+  hipLaunchKernelGGL(bezier_warp_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, est,
+                     est_stride, pts, t, N, n_ctrl, out_pts, dp, rigidity_out, n_rl, refl_latent);
+  return check_launch("na_bezier_warp_latent");
 }
 
 int na_normalize3(const float* v, int64_t N, float* out, void* stream) {

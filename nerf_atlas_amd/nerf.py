@@ -529,8 +529,9 @@ class VolSDF(CommonNeRF):
 
 # ------------------------------------------------------------------------------------------------- DynamicNeRF
 class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
-    """src/nerf.py:1209-1303, Bezier-spline deformation (spline > 1, refl_latent = 0).  The delta path
-    (spline = 0) raises at HEAD in the reference (SURVEY header table) and raises here too."""
+    """src/nerf.py:1209-1303, Bezier-spline deformation (spline > 1), with `refl_latent` columns riding through the spline into the
+    canonical model's reflectance (`make dnerf`: --dyn-refl-latent 3).  The delta path (spline = 0) raises at HEAD in the reference
+    (SURVEY header table) and raises here too."""
 
     def __init__(self, canonical: CommonNeRF, spline: int = 0, refl_latent: int = 0):
         super().__init__()
@@ -539,11 +540,16 @@ class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
         self.refl_latent = max(refl_latent, 0)
         if spline <= 1:
             raise NotImplementedError("DynamicNeRF without a spline is broken in the reference (self.dp unset); use --spline N>1")
-        if self.refl_latent != 0:
-            raise NotImplementedError("--dyn-refl-latent > 0 is outside the configs of the hot path")
+        if self.refl_latent > 16:
+            raise NotImplementedError("--dyn-refl-latent > 16 (na_bezier_warp_latent carries 1..16 columns)")
         self.spline_n = spline
-        self.mlp_out_layout = [1, 3 * spline, 0, 0]
-        self.delta_estim = SkipConnMLP(in_size=3, out=spline * 3 + 1, num_layers=5, hidden_size=256, init="xavier",
+        # src/nerf.py:1243-1249: with a reflectance latent the network also emits enc_rigidity | spline * refl_latent control rows
+        out_dims, enc_layout = spline * 3 + 1, [0, 0]
+        if self.refl_latent > 0:
+            out_dims += spline * self.refl_latent + 1
+            enc_layout = [1, self.refl_latent * spline]
+        self.mlp_out_layout = [1, 3 * spline] + enc_layout
+        self.delta_estim = SkipConnMLP(in_size=3, out=out_dims, num_layers=5, hidden_size=256, init="xavier",
                                        enc=HashEncoder())
         self.delta_estim.zero_last_layer()
         self._init_packed_hooks()
@@ -624,11 +630,17 @@ class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
                                   self.delta_estim.out.out_features)
         else:
             est = self.delta_estim(self.pts)
+        # (the reference hands from_pts a zero-width `enc` when refl_latent == 0, src/nerf.py:1272-1278, 1303: None here)
+        enc = None
         if ag.needs_grad(est):
-            warped, self.dp, self.rigidity = ag.BezierWarpFn.apply(est.contiguous(), self.pts, tt, self.spline_n)
+            res = ag.BezierWarpFn.apply(est.contiguous(), self.pts, tt, self.spline_n, self.refl_latent)
         else:
-            warped, self.dp, self.rigidity = ops.bezier_warp(est, self.pts, tt, self.spline_n)
-        return c.from_pts(warped, self.ts, r_o, r_d, rays=rays)
+            res = ops.bezier_warp(est, self.pts, tt, self.spline_n, self.refl_latent)
+        if self.refl_latent > 0:
+            warped, self.dp, self.rigidity, enc = res
+        else:
+            warped, self.dp, self.rigidity = res
+        return c.from_pts(warped, self.ts, r_o, r_d, refl_latent=enc, rays=rays)
 
 
     @_f16x_policy

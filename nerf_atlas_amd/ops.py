@@ -281,8 +281,9 @@ def laplace_density(sdf: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def bezier_warp(est: torch.Tensor, pts: torch.Tensor, t: torch.Tensor, n_ctrl: int):
-    """est [...,>=1+3n] (rigidity | control points), pts [...,3], t [...] -> (pts', dp, rigidity)."""
+def bezier_warp(est: torch.Tensor, pts: torch.Tensor, t: torch.Tensor, n_ctrl: int, n_rl: int = 0):
+    """est [...,>=1+3n] (rigidity | control points), pts [...,3], t [...] -> (pts', dp, rigidity); with n_rl > 0 (DynamicNeRF's
+    refl_latent: est [..., >= 2 + (3 + n_rl) n] = ... | enc_rigidity | latent control rows) -> (pts', dp, rigidity, refl_latent [..., n_rl])."""
     lib = _lib.load()
     est, pts, t = _f32(est, "est"), _f32(pts, "pts"), _f32(t, "t")
     N = pts.numel() // 3
@@ -290,6 +291,11 @@ def bezier_warp(est: torch.Tensor, pts: torch.Tensor, t: torch.Tensor, n_ctrl: i
     out = torch.empty_like(pts)
     dp = torch.empty_like(pts)
     rig = torch.empty(tuple(pts.shape[:-1]) + (1,), device=pts.device, dtype=torch.float32)
+    if n_rl > 0:
+        enc = torch.empty(tuple(pts.shape[:-1]) + (n_rl,), device=pts.device, dtype=torch.float32)
+        check(lib.na_bezier_warp_latent(_ptr(est), est.shape[-1], _ptr(pts), _ptr(t), N, n_ctrl, n_rl, _ptr(out), _ptr(dp), _ptr(rig),
+                                        _ptr(enc), _stream()))
+        return out, dp, rig, enc
     check(lib.na_bezier_warp(_ptr(est), est.shape[-1], _ptr(pts), _ptr(t), N, n_ctrl, _ptr(out), _ptr(dp), _ptr(rig),
                              _stream()))
     return out, dp, rig
@@ -687,7 +693,7 @@ def laplace_density_backward(sdf: torch.Tensor, beta: torch.Tensor, g: torch.Ten
     return g_sdf, g_beta
 
 
-def bezier_warp_backward(est: torch.Tensor, t: torch.Tensor, n_ctrl: int, g_pts=None, g_dp=None, g_rig=None):
+def bezier_warp_backward(est: torch.Tensor, t: torch.Tensor, n_ctrl: int, g_pts=None, g_dp=None, g_rig=None, n_rl: int = 0, g_enc=None):
     lib = _lib.load()
     est, t = _f32(est, "est"), _f32(t, "t")
     N = t.numel()
@@ -695,9 +701,15 @@ def bezier_warp_backward(est: torch.Tensor, t: torch.Tensor, n_ctrl: int, g_pts=
     g_dp = None if g_dp is None else _f32(g_dp, "g_dp")
     g_rig = None if g_rig is None else _f32(g_rig, "g_rig")
     g_est = torch.empty_like(est)
-    check(lib.na_bezier_warp_backward(_ptr(est), est.shape[-1], _ptr(t), N, n_ctrl,
-                                      None if g_pts is None else _ptr(g_pts), None if g_dp is None else _ptr(g_dp),
-                                      None if g_rig is None else _ptr(g_rig), _ptr(g_est), _stream()))
+    opt = lambda g: None if g is None else _ptr(g)
+    if n_rl > 0:
+        g_enc = None if g_enc is None else _f32(g_enc, "g_enc")
+        assert g_enc is None or g_enc.numel() == N * n_rl
+        check(lib.na_bezier_warp_latent_backward(_ptr(est), est.shape[-1], _ptr(t), N, n_ctrl, n_rl, opt(g_pts), opt(g_dp), opt(g_rig),
+                                                 opt(g_enc), _ptr(g_est), _stream()))
+        return g_est
+    check(lib.na_bezier_warp_backward(_ptr(est), est.shape[-1], _ptr(t), N, n_ctrl, opt(g_pts), opt(g_dp), opt(g_rig), _ptr(g_est),
+                                      _stream()))
     return g_est
 
 

@@ -609,22 +609,30 @@ def volsdf(params, rays, near, far, steps, sdf_kind="mlp", refl_kind="view", act
 
 
 def dynamic_nerf_spline(params, rays, times, near, far, steps, spline: int, refl_kind="view", act="thin",
-                        bg="black", aux=None):
-    """src/nerf.py:1241-1303 DynamicNeRF (spline>1, refl_latent=0) over a canonical PlainNeRF."""
+                        bg="black", aux=None, refl_latent: int = 0):
+    """src/nerf.py:1241-1303 DynamicNeRF (spline>1) over a canonical PlainNeRF; refl_latent > 0 (:1246-1248, 1272-1278): the
+    network's extra enc_rigidity | spline * refl_latent columns go through the same spline, scaled by sigmoid(enc_rigidity),
+    and reach the canonical model's reflectance as `refl_latent` (:1303)."""
     r_o, r_d = rays.split([3, 3], dim=-1)
     ts, _ = compute_ts(near, far, steps)
     pts = compute_pts(r_o, r_d, ts)
     t = times[None, :, None, None, None].expand(*pts.shape[:-1], 1)
     est = skip_mlp(params, "delta_estim.", pts, enc=_hash_enc_from(params, "delta_estim.enc."))
-    rigidity, ps = est[..., :1], est[..., 1:1 + 3 * spline]
+    layout = [1, 3 * spline] + ([1, refl_latent * spline] if refl_latent > 0 else [0, 0])
+    rigidity, ps, enc_rigidity, enc = est.split(layout, dim=-1)
     rigidity = (rigidity / 2).sigmoid()
     ps = torch.stack(ps.split([3] * spline, dim=-1), dim=0)
     fn = cubic_bezier if spline == 4 else de_casteljau
-    dp = fn(ps, t, spline)
+    if refl_latent > 0:
+        enc = torch.stack(enc.split([refl_latent] * spline, dim=-1), dim=0)
+        dp, enc = fn(torch.cat([ps, enc], dim=-1), t, spline).split([3, refl_latent], dim=-1)
+        enc = enc * enc_rigidity.sigmoid()
+    else:
+        dp, enc = fn(ps, t, spline), None
     rigid_dp = dp * rigidity
     if aux is not None:
-        aux.update(dp=dp, rigidity=rigidity, rigid_dp=rigid_dp, pts=pts)
-    return plain_nerf_from_pts(params, pts + rigid_dp, ts, r_o, r_d, refl_kind, act, bg, aux=aux,
+        aux.update(dp=dp, rigidity=rigidity, rigid_dp=rigid_dp, pts=pts, refl_latent=enc)
+    return plain_nerf_from_pts(params, pts + rigid_dp, ts, r_o, r_d, refl_kind, act, bg, refl_latent=enc, aux=aux,
                                prefix="canonical.")
 
 

@@ -63,6 +63,10 @@ def rel(a, b):
     return float((a.detach().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
+def maxdiff(a, b):
+    return float((a.detach().cpu() - b).abs().max())
+
+
 def test_composite_backward(ops):
     g = load_golden("g3_composite")
     T, B, H, W = g["density"].shape
@@ -251,6 +255,43 @@ def test_bezier_warp_backward(ops, n):
     assert rel(ops.bezier_warp_backward(est.cuda(), t.cuda(), n, gs[0].cuda()), e.grad) <= 2e-5
 
 
+@pytest.mark.parametrize("n,n_rl", [(6, 3), (4, 2), (2, 1), (8, 16), (5, 7)])
+def test_bezier_warp_latent_forward_and_backward(ops, n, n_rl):
+    """na_bezier_warp_latent / _backward (DynamicNeRF --dyn-refl-latent, src/nerf.py:1246-1248, 1272-1278) against the oracle's
+    spline on the concatenated control rows and torch autograd; est carries 2 unused trailing columns whose gradient must be 0."""
+    N = 2049
+    W = 2 + (3 + n_rl) * n + 2
+    est = torch.from_numpy(proc_uniform((N, W), 43, 1.5))
+    pts = torch.from_numpy(proc_uniform((N, 3), 44, 2.0))
+    t = torch.from_numpy(proc_uniform((N,), 45, 0.5)) + 0.5
+    gs = [torch.from_numpy(proc_uniform(s, 46 + i, 1.0)) for i, s in enumerate([(N, 3), (N, 3), (N, 1), (N, n_rl)])]
+    e = est.clone().requires_grad_()
+    rig, ps, er, enc, _ = e.split([1, 3 * n, 1, n_rl * n, 2], dim=-1)
+    rig = (rig / 2).sigmoid()
+    ps = torch.stack(ps.split([3] * n, dim=-1), dim=0)
+    enc = torch.stack(enc.split([n_rl] * n, dim=-1), dim=0)
+    dp, enc = (O.cubic_bezier if n == 4 else O.de_casteljau)(torch.cat([ps, enc], dim=-1), t[:, None], n).split([3, n_rl], dim=-1)
+    enc = enc * er.sigmoid()
+    warped = pts + dp * rig
+    ((warped * gs[0]).sum() + (dp * gs[1]).sum() + (rig * gs[2]).sum() + (enc * gs[3]).sum()).backward()
+    w, d, r, l = ops.bezier_warp(est.cuda(), pts.cuda(), t.cuda(), n, n_rl)
+    assert maxdiff(w, warped.detach()) <= 2e-6 and maxdiff(d, dp.detach()) <= 2e-6 and maxdiff(r, rig.detach()) <= 1e-6
+    assert l.shape == (N, n_rl) and maxdiff(l, enc.detach()) <= 2e-6
+    w0, d0, r0 = ops.bezier_warp(est.cuda(), pts.cuda(), t.cuda(), n)   # the latent columns change nothing in the warp itself
+    assert torch.equal(w, w0) and torch.equal(d, d0) and torch.equal(r, r0)
+    ge = ops.bezier_warp_backward(est.cuda(), t.cuda(), n, *[g.cuda() for g in gs[:3]], n_rl=n_rl, g_enc=gs[3].cuda())
+    assert rel(ge, e.grad) <= 2e-5 and float(ge[:, -2:].abs().max()) == 0
+    # no latent gradient: the latent columns' gradient is zero, the rest as the plain warp's
+    ge0 = ops.bezier_warp_backward(est.cuda(), t.cuda(), n, *[g.cuda() for g in gs[:3]], n_rl=n_rl)
+    assert float(ge0[:, 1 + 3 * n:].abs().max()) == 0 and torch.equal(ge0[:, :1 + 3 * n], ge[:, :1 + 3 * n])
+    # through autograd.BezierWarpFn
+    from nerf_atlas_amd import autograd as ag
+    eg = est.cuda().requires_grad_()
+    res = ag.BezierWarpFn.apply(eg, pts.cuda(), t.cuda(), n, n_rl)
+    sum((o * g.cuda()).sum() for o, g in zip(res, gs)).backward()
+    assert rel(eg.grad, e.grad) <= 2e-5
+
+
 def _grad_parity(m, ref_p, out, ref_out, target, min_checked, tol=5e-4, loss_tol=1e-6, train_prec="fp32", what="",
                  l2_tol=0.3):
     loss = torch.nn.functional.mse_loss(out, target.cuda())
@@ -310,6 +351,34 @@ def test_dnerf_training_gradients_match_oracle_autograd(ops, spline, train_prec)
                  train_prec=train_prec, what=f"dnerf-{spline}", l2_tol=0.3)  # measured 4.4e-5 / 7.5e-2 (cell flips)
     g = dict(m.named_parameters())["delta_estim.init.weight"].grad
     assert float(g.abs().max()) > 0  # the deformation network really received a gradient through the warp
+
+
+@pytest.mark.parametrize("name", ["spline6_rl3_plv", "spline6_rl3_view"])
+def test_dnerf_refl_latent_training_gradients_match_oracle_autograd(ops, name, train_prec):
+    """`make dnerf` as shipped (--dyn-refl-latent 3, pos-linear-view): the reflectance latent's gradient flows from the head's
+    MLPs through na_bezier_warp_latent_backward into the deformation network's extra output columns."""
+    import nerf_atlas_amd as na
+    import nerf_atlas_amd.nerf, nerf_atlas_amd.refl, nerf_atlas_amd.sdf  # noqa: F401,E401
+    h = load_golden(f"g9_dnerf_{name}")
+    params = golden_params(h)
+    spline, n_rl, kind = int(name[6]), int(h["n_rl"]), str(h["refl_kind"])
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=spline, refl_latent=n_rl)
+    m.set_refl(na.refl.refl_kinds[kind](latent_size=m.intermediate_size, act="upshifted", out_features=3))
+    m = m.cuda().eval()
+    sd = m.state_dict()
+    for k, v in params.items():
+        sd[k].copy_(v)
+    target = torch.from_numpy(proc_uniform(tuple(h["out"].shape), 79, 0.5)) + 0.5
+    out = m((h["rays"].cuda(), h["times"].cuda()))
+    assert out.requires_grad
+    ref_p = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in params.items()}
+    ref_out = O.dynamic_nerf_spline(ref_p, h["rays"], h["times"], 2.0, 6.0, int(h["steps"]), spline, kind, act="upshifted",
+                                    refl_latent=n_rl)
+    _grad_parity(m, ref_p, out, ref_out, target, 50, tol=2e-3, loss_tol=1e-6 * E2E_TOL[train_prec],
+                 train_prec=train_prec, what=f"dnerf-{name}", l2_tol=0.3)
+    g = dict(m.named_parameters())["delta_estim.out.weight"].grad
+    assert float(g[1 + 3 * spline:].abs().max()) > 0  # the latent control rows received a gradient
 
 
 @pytest.mark.parametrize("shape", [(5000, 256, 0, 256), (4097, 256, 38, 256), (1000, 38, 0, 256), (3001, 256, 0, 65),

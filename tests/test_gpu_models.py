@@ -260,6 +260,38 @@ def test_dynamic_nerf_spline(na, spline):
     assert m.nerf is canon and maxdiff(canon.weights, h["weights"]) <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["spline6_rl3_plv", "spline6_rl3_view", "spline4_rl2_plv"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x"])
+def test_dynamic_nerf_refl_latent(na, name, prec):
+    """`make dnerf` as shipped (makefile:106-114: --spline 6 --dyn-refl-latent 3 --refl-kind pos-linear-view): the deformation
+    network's extra columns ride through the Bezier (na_bezier_warp_latent) and arrive in the canonical model's reflectance as
+    `refl_latent` (src/nerf.py:1245-1248, 1272-1278, 1303) -- against the reference's own outputs.  In f16x the canonical
+    PlainNeRF + PosLinearView is ONE launch of the layer-synchronous engine (MODEL 8) taking the latent rows by pitch."""
+    from nerf_atlas_amd import config, utils
+    h = load_golden(f"g9_dnerf_{name}")
+    spline, n_rl, kind = int(name[6]), int(h["n_rl"]), str(h["refl_kind"])
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=spline, refl_latent=n_rl)
+    assert m.intermediate_size == 64 + n_rl and m.mlp_out_layout == [1, 3 * spline, 1, n_rl * spline]
+    m.set_refl(na.refl.refl_kinds[kind](latent_size=m.intermediate_size, act="upshifted", out_features=3))
+    m = m.cuda().eval()
+    load_params(m, golden_params(h))
+    config.set_precision(prec)
+    try:
+        seen = {}
+        orig = canon.from_pts
+        canon.from_pts = lambda *a, **k: (seen.update(rl=k.get("refl_latent")), orig(*a, **k))[1]
+        out = m((h["rays"].cuda(), h["times"].cuda()))
+        assert maxdiff(seen["rl"], h["refl_latent"]) <= 1e-4
+        assert maxdiff(out, h["out"]) <= 1e-4
+        assert maxdiff(m.rigidity, h["rigidity"]) <= 1e-4 and maxdiff(m.dp, h["dp"]) <= 1e-4
+        assert maxdiff(canon.weights, h["weights"]) <= 1e-4
+        if prec == "f16x" and kind == "pos-linear-view":
+            assert canon._fusable_head(seen["rl"]) == "plv"   # the one-launch renderer took it, not the generic chain
+    finally:
+        config.set_precision("bf16x3")
+
+
 def test_tiled_frame_and_psnr(na):
     h = load_golden("g12_tiled_frame")
     size, cs = int(h["size"]), int(h["crop_size"])

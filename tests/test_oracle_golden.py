@@ -170,6 +170,15 @@ def test_g9_bezier_and_dnerf():
         close(out, h["out"], 2e-6, 1e-5)
         close(aux["rigidity"], h["rigidity"], 1e-6, 1e-5)
         close(aux["dp"], h["dp"], 2e-6, 1e-5)
+    # --dyn-refl-latent (make dnerf: spline 6, 3 columns, pos-linear-view): the latent rides through the spline
+    for name in ("spline6_rl3_plv", "spline6_rl3_view", "spline4_rl2_plv"):
+        h = load_golden(f"g9_dnerf_{name}")
+        aux = {}
+        out = O.dynamic_nerf_spline(golden_params(h), h["rays"], h["times"], float(h["near"]), float(h["far"]), int(h["steps"]),
+                                    int(name[6]), str(h["refl_kind"]), act="upshifted", aux=aux, refl_latent=int(h["n_rl"]))
+        close(out, h["out"], 2e-6, 1e-5)
+        close(aux["refl_latent"], h["refl_latent"], 2e-6, 1e-5)
+        close(aux["dp"], h["dp"], 2e-6, 1e-5)
 
 
 def test_g10_laplace_volsdf():

@@ -371,6 +371,26 @@ def g9():
         out = m((rays, times))
         save(f"g9_dnerf_spline{spline}", rays=rays, times=times, out=out, steps=T, near=2.0, far=6.0,
              rigidity=m.rigidity, dp=m.dp, weights=canon.weights, **spec(names, shapes))
+    # `make dnerf` as shipped (makefile:106-114): --spline 6 --dyn-refl-latent 3 --refl-kind pos-linear-view; + the View head and
+    # the cubic spline with the same latent (runner.py:1169-1211 builds the head with latent_size = model.intermediate_size)
+    for spline, kind, rl in ((6, "pos-linear-view", 3), (6, "view", 3), (4, "pos-linear-view", 2)):
+        size, T = 6, 8
+        canon = rnerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+        m = rnerf.DynamicNeRF(canonical=canon, spline=spline, refl_latent=rl)
+        m.set_refl(rrefl.refl_kinds[kind](latent_size=m.intermediate_size, act="upshifted", out_features=3))
+        m.eval()
+        names, shapes = fill_procedural(m)
+        c, focal = cam(POSES[:2], size)
+        rays = c.sample_positions(ref_pixel_grid(size, (0, 0, size, size)), size=size)
+        times = torch.tensor([0.25, 0.8])
+        captured = {}
+        orig = canon.from_pts
+        canon.from_pts = lambda pts, ts, r_o, r_d, enc=None: (captured.update(enc=enc), orig(pts, ts, r_o, r_d, enc))[1]
+        out = m((rays, times))
+        tag = {"pos-linear-view": "plv", "view": "view"}[kind]
+        save(f"g9_dnerf_spline{spline}_rl{rl}_{tag}", rays=rays, times=times, out=out, steps=T, near=2.0, far=6.0,
+             rigidity=m.rigidity, dp=m.dp, weights=canon.weights, refl_latent=captured["enc"], refl_kind=kind, n_rl=rl,
+             **spec(names, shapes))
 
 
 # ------------------------------------------------------------------ G10 laplace + VolSDF
