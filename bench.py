@@ -144,26 +144,42 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
 
 
 KERNELS_F16X = {"3": "ONE f16x launch of the layer-synchronous engine (MODEL 6: IPE groups generated in the kernel for the four Linears that take them)",
-                "4": "deformation MLP bf16x3 + canonical model f16x",
+                "2-pos": "ONE f16x launch of the layer-synchronous engine (MODEL 7: both hash grids gathered in the kernel)",
+                "4": "deformation MLP bf16x3 + canonical model f16x (one launch)",
+                "4-plv": "deformation MLP bf16x3 + na_bezier_warp_latent + canonical model f16x (MODEL 8, one launch: warped points and the 3 latent columns by pitch)",
                 "5m": "SDF MLP: ONE f16x launch of the layer-synchronous engine (Fourier features generated in the kernel) + View half f16x"}
-OTHER_SLAB = (300, 0, 200, SIZE)   # rows 300..499 of the 800-wide frame: 160 000 rays x 128 = 20.48 M samples
+FULL_FRAME = (0, 0, SIZE, SIZE)    # BASELINE's 1 x MI355X configs (1, 2, 3): the whole 800 x 800 frame, 81.92 M samples
+OTHER_SLAB = (300, 0, 100, SIZE)   # BASELINE's 8 x MI355X configs (4, 5): ONE GPU's shard of the frame = a 100-row band (rows 300..399), 10.24 M samples
+
+
+def train_algorithmic_bytes_per_sample():
+    """HBM bytes per sample a LAYER-BY-LAYER training step of PlainNeRF(view) has to move: every Linear's forward reads its
+    input row(s) once and writes its output row once (4 (in + out) B), its backward reads dY and the forward input once and writes the
+    input gradient once (4 (out + 2 in) B); fp32 rows; the two networks' Linears (src/nerf.py:320-324, src/refl.py:201-204).  Encoder,
+    compositing and weight traffic are < 2 % and not counted."""
+    first = [(38, 256), (256 + 38, 256), (256, 256), (256, 256), (256, 256), (256, 65)]
+    view = [(69, 256), (256 + 69, 256), (256, 256), (256, 256), (256, 256), (256, 3)]
+    return sum(4 * (i + o) + 4 * (o + 2 * i) for i, o in first + view)
 
 
 def train_step(dev, crop=64, steps_per_ray=64, iters=10):
     """SURVEY 8(f) N1 in the driver-run line: one PlainNeRF(view) training step (forward + backward HIP kernels in the split-bf16
-    parity-class arithmetic + torch.optim.Adam) on 64 x 64 rays x 64 samples = 262 144 samples, tools/train_bench.py's workload"""
+    parity-class arithmetic + the product's Adam, train.load_optim) on crop x crop rays x 64 samples (64: 262 144 samples,
+    tools/train_bench.py's workload; 128: 1 048 576)"""
+    import types
     import nerf_atlas_amd.nerf as nerf
-    from nerf_atlas_amd import ops
+    from nerf_atlas_amd import ops, train
     torch.manual_seed(0)
     focal = 0.5 * SIZE / math.tan(0.5 * FOV)
     c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]], device=dev)
     m = nerf.PlainNeRF(steps=steps_per_ray, t_near=NEAR, t_far=FAR, intermediate_size=64, sigmoid_kind="upshifted").to(dev)
     m.eval()  # deterministic sampling; gradients still flow
-    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    opt = train.load_optim(types.SimpleNamespace(opt_kind="adam", learning_rate=2e-4, decay=0), m.parameters())
     target = torch.rand(1, crop, crop, 3, device=dev)
+    c0 = (SIZE - crop) // 2
 
     def step():
-        rays = ops.raygen(c2w, focal, SIZE, (368, 368, crop, crop))
+        rays = ops.raygen(c2w, focal, SIZE, (c0, c0, crop, crop))
         opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.mse_loss(m(rays), target)
         loss.backward()
@@ -181,16 +197,22 @@ def train_step(dev, crop=64, steps_per_ray=64, iters=10):
     res = {"workload": f"PlainNeRF(view) training step, {crop} x {crop} rays x {steps_per_ray} samples, fwd + bwd + Adam",
            "dtype": "bf16x3", "samples_per_step": n, "ms_per_step": round(dt * 1e3, 2), "Msamples_s": round(n / dt / 1e6, 2),
            "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
-    # HBM-bound path: the bytes of one step from the committed PMC profile of this workload (NOT measured by this run), and the
-    # rate they imply at this run's step time
-    try:
-        with open(os.path.join(REPO, "profiles", "r05", "train_hbm.json")) as f:
-            gb = float(json.load(f)["GB_per_step"])
-        res["roofline"] = {"bound": "hbm", "traffic_gb_per_step": gb, "achieved": round(gb / dt / 1e3, 2), "peak": 8.0, "unit": "TB/s",
-                           "frac": round(gb / dt / 1e3 / 8.0, 3),
-                           "traffic_source": "profiles/r05/train_hbm.json (tools/train_hbm.py: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the step, separate passes)"}
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM-bound path.  `achieved` / `frac` = ALGORITHMIC bytes of the layer-by-layer design (train_algorithmic_bytes_per_sample) over
+    # this run's step time; `traffic_gb_per_step` = the PMC counters of the committed profile of the 262 144-sample workload (NOT
+    # measured by this run; keyed to that size only)
+    alg = train_algorithmic_bytes_per_sample() * n / 1e9
+    res["roofline"] = {"bound": "hbm", "algorithmic_gb": round(alg, 2), "achieved": round(alg / dt / 1e3, 2), "peak": 8.0, "unit": "TB/s",
+                       "frac": round(alg / dt / 1e3 / 8.0, 3)}
+    if n == 262144:
+        for rel in ("profiles/r06/train_hbm.json", "profiles/r05/train_hbm.json"):
+            try:
+                with open(os.path.join(REPO, rel)) as f:
+                    gb = float(json.load(f)["GB_per_step"])
+                res["roofline"]["traffic_gb_per_step"] = gb
+                res["roofline"]["traffic_source"] = rel + " (tools/train_hbm.py: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the step, separate passes; a committed profile, not this run)"
+                break
+            except (OSError, ValueError, KeyError):
+                continue
     return res
 
 
@@ -226,12 +248,16 @@ def coarse_fine(dev, rays, coarse=64, fine=128, iters=3):
         config.set_precision(keep)
 
 
-def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2, only=None):
-    """BASELINE configs 1, 3, 4 and 5 (both SDF networks) through the model layer on a fixed 200 x 800 x 128 slab: whole
-    forward (every launch of the config's inference path), HIP events on the launch stream, one warm-up + `iters` timed
-    calls per (config, precision).  FLOP/sample = sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same
-    numbers); `frac` is against the dense bf16 MFMA peak for every precision.  "f16x" rows: the one-kernel renderers run f16x, the
-    generic fused MLP launches of a config (D-NeRF: the deformation network unless the opt-in LS kernel is on) stay in bf16x3 -- `kernels` says which."""
+def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None):
+    """BASELINE configs 1, 3, 4 and 5 (both SDF networks) and the reference's two shipped recipes with other colour heads (`make
+    original`: PlainNeRF + Positional, makefile:8-13; `make dnerf`: D-NeRF over PlainNeRF + PosLinearView with --dyn-refl-latent 3,
+    makefile:106-114) through the model layer: whole forward (every launch of the config's inference path), HIP events on the launch
+    stream, one warm-up + `iters` timed calls per (config, precision).  The 1 x MI355X configs (1, 3, 2-pos) are timed on the WHOLE
+    800 x 800 x 128 frame; the 8 x MI355X configs (4, 5) on one GPU's shard of it (a 100-row band = 10.24 M samples).  FLOP/sample =
+    sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same numbers); `frac` is against the dense bf16
+    MFMA peak for every precision.  "f16x" rows: the one-kernel renderers run f16x, the generic fused MLP launches of a config (D-NeRF:
+    the deformation network) stay in bf16x3 -- `kernels` says which.  Rows whose arithmetic is OUTSIDE north_star's 1e-4 on the
+    reference's goldens are returned separately (third value)."""
     import types
     import nerf_atlas_amd.nerf as nerf
     import nerf_atlas_amd.refl as refl
@@ -241,26 +267,38 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2, only=None
     T = STEPS_PER_RAY
     focal = 0.5 * SIZE / math.tan(0.5 * FOV)
     c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]], device=dev)
-    rays = ops.raygen(c2w, focal, SIZE, OTHER_SLAB)
-    n = OTHER_SLAB[2] * OTHER_SLAB[3] * T
     common = dict(steps=T, t_near=NEAR, t_far=FAR, sigmoid_kind="upshifted")
 
     def volsdf(kind):
         r = refl.View(latent_size=64, act="upshifted", out_features=3)
         return nerf.VolSDF(sdf=sdf.SDF(sdf.sdf_kinds[kind](intermediate_size=64), r, isect=None, t_near=0.3, t_far=1.8),
                            steps=T, t_near=0.3, t_far=1.8, sigmoid_kind="upshifted")
+
+    def plain_pos():
+        m = nerf.PlainNeRF(intermediate_size=64, **common)
+        m.set_refl(refl.refl_kinds["pos"](latent_size=64, act="upshifted", out_features=3))
+        return m
+
+    def dnerf_plv():
+        m = nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6, refl_latent=3)
+        m.set_refl(refl.refl_kinds["pos-linear-view"](latent_size=m.intermediate_size, act="upshifted", out_features=3))
+        return m
+    # (name, constructor, FLOP/sample, takes (rays, t), crop, precisions)
     models = [
-        ("1 TinyNeRF", lambda: nerf.TinyNeRF(**common), 793088, False),
-        ("3 PlainNeRF + mip (cylinder IPE)", lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False),
-        ("4 D-NeRF (spline 6) at t = 0.5", lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True),
-        ("5m VolSDF, Fourier-MLP SDF", lambda: volsdf("mlp"), 1814016, False),
-        ("5 VolSDF, SIREN SDF", lambda: volsdf("siren"), 1289728, False),
+        ("1 TinyNeRF", lambda: nerf.TinyNeRF(**common), 793088, False, FULL_FRAME, precisions),
+        ("2-pos PlainNeRF + Positional head (`make original`)", plain_pos, 1410048, False, FULL_FRAME, ("f16x",)),
+        ("3 PlainNeRF + mip (cylinder IPE)", lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False, FULL_FRAME, precisions),
+        ("4 D-NeRF (spline 6) at t = 0.5", lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True, OTHER_SLAB, precisions),
+        ("4-plv D-NeRF (spline 6, refl_latent 3) over PlainNeRF + PosLinearView (`make dnerf`) at t = 0.5", dnerf_plv, 1855232, True, OTHER_SLAB, ("f16x", "bf16x3")),
+        ("5m VolSDF, Fourier-MLP SDF", lambda: volsdf("mlp"), 1814016, False, OTHER_SLAB, precisions),
+        ("5 VolSDF, SIREN SDF", lambda: volsdf("siren"), 1289728, False, OTHER_SLAB, precisions),
     ]
-    rows = []
+    rows, outside = [], []
     keep = config.precision
     t_all = time.perf_counter()
-    for name, cons, flop, dyn in models:
-        if only is not None and name.split()[0] not in only:
+    for name, cons, flop, dyn, crop, precs in models:
+        key = name.split()[0]
+        if only is not None and key not in only:
             continue
         torch.manual_seed(2)
         try:
@@ -268,10 +306,14 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2, only=None
         except Exception as e:  # noqa: BLE001
             rows.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             continue
+        rays = ops.raygen(c2w, focal, SIZE, crop)
+        n = crop[2] * crop[3] * T
+        what = (f"whole {SIZE}x{SIZE} frame x {T} samples/ray ({n} samples)" if crop == FULL_FRAME else
+                f"per-GPU shard of the 8-GPU config: {crop[2]}x{crop[3]} row band x {T} samples/ray ({n} samples)")
         inp = (rays, torch.tensor([0.5], device=dev)) if dyn else rays
-        plist = list(precisions)
-        if name.split()[0] == "4" and "f16x" in plist:
-            plist.insert(plist.index("f16x") + 1, "f16x+ls-deformation")  # the deformation network on the LS engine too (opt-in)
+        plist = list(precs)
+        if key == "4" and "f16x" in plist:
+            plist.append("f16x+ls-deformation")  # the deformation network on the LS engine in f16x too (opt-in; outside 1e-4 on g9)
         for prec in plist:
             lsdef = prec == "f16x+ls-deformation"
             try:
@@ -286,19 +328,20 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=2, only=None
                     e1.record()
                     torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / iters
-                rows.append({"config": name, "workload": f"{OTHER_SLAB[2]}x{OTHER_SLAB[3]} slab x {T} samples/ray ({n} samples)",
-                             "dtype": prec, "kernels": ("canonical model: one kernel, f16x; deformation MLP: ONE launch of the layer-synchronous engine, "
-                                                        "f16x (config.deformation_engine = 'ls', opt-in: its rows carry 3x the error of the split-bf16 "
-                                                        "rows -- reference golden 1.0-1.6e-4 end to end, trained model 2.4e-5)") if lsdef
-                             else KERNELS_F16X.get(name.split()[0], "f16x") if prec == "f16x" else prec,
-                             "Msamples_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 3),
-                             "flop_per_sample": flop, "frac": round(n * flop / (ms * 1e-3) / PEAK_BF16, 4)})
+                row = {"config": name, "workload": what, "launches_timed": iters,
+                       "dtype": prec, "kernels": ("canonical model: one kernel, f16x; deformation MLP: ONE f16x launch of the layer-synchronous engine "
+                                                  "(opt-in: its rows carry 3x the error of the split-bf16 rows -- reference golden 1.0-1.6e-4 end to end, "
+                                                  "trained model 2.4e-5)") if lsdef
+                       else KERNELS_F16X.get(key, "f16x") if prec == "f16x" else prec,
+                       "Msamples_s": round(n / ms / 1e3, 1), "kernel_ms": round(ms, 3),
+                       "flop_per_sample": flop, "frac": round(n * flop / (ms * 1e-3) / PEAK_BF16, 4)}
+                (outside if lsdef else rows).append(row)
             except Exception as e:  # noqa: BLE001
                 rows.append({"config": name, "dtype": prec, "error": f"{type(e).__name__}: {e}"})
         del m
     config.set_precision(keep)
     config.set_deformation_engine("generic")
-    return rows, round(time.perf_counter() - t_all, 2)
+    return rows, round(time.perf_counter() - t_all, 2), outside
 
 
 def self_spawn(n):
@@ -332,44 +375,53 @@ def self_spawn(n):
 
 
 def measure_traffic(prec, engine, kernel_name):
-    """roofline.traffic measured by THIS run (the key used to be a constant from an earlier profile): two child runs
-    of this script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, counters only (no trace domain), as
+    """roofline.traffic and roofline.mfma_busy_frac measured by THIS run: three child runs of this script under `rocprofv3 --pmc`
+    -- FETCH_SIZE, WRITE_SIZE and (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) in SEPARATE passes, counters only (no trace domain), as
     MI355X_MICROARCH.md "HBM" prescribes -- each rendering the same full frame three times in the primary mode; bytes per launch
-    = (2 x FETCH_SIZE + WRITE_SIZE) KiB (the guide's gfx950 correction: FETCH_SIZE counts half of a wide coalesced read).
-    Returns (bytes per launch, source text) or (None, why)."""
+    = (2 x FETCH_SIZE + WRITE_SIZE) KiB (the guide's gfx950 correction: FETCH_SIZE counts half of a wide coalesced read);
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs) (tools/pmc_collect.py's derivation).
+    Returns (bytes per launch or None, source text, mfma_busy_frac or None)."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not on PATH"
+        return None, "not measured: rocprofv3 not on PATH", None
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None, "this run is itself under a profiler"
+        return None, "not measured: this run is itself under a profiler", None
     work = tempfile.mkdtemp(prefix="bench_traffic_")
     cmd = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--precision", prec, "--engine", engine, "--steps", "2", "--warmup", "1"]
-    vals = {}
+    vals, why = {}, None
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, ctr)
+        for tag, ctrs in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("MFMA", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+            out = os.path.join(work, tag)
             try:
-                r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "--"] + cmd, cwd="/tmp",
-                                   env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
+                r = subprocess.run(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", out, "--"] + cmd, cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=60)
             except subprocess.TimeoutExpired:
-                return None, f"rocprofv3 --pmc {ctr}: timed out"
-            total, launches = 0.0, set()
+                why = f"rocprofv3 --pmc {tag}: timed out"
+                break
+            total, launches = {c: 0.0 for c in ctrs}, set()
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if kernel_name in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                        total += float(row["Counter_Value"])
+                    if kernel_name in row.get("Kernel_Name", "") and row.get("Counter_Name") in total:
+                        total[row["Counter_Name"]] += float(row["Counter_Value"])
                         launches.add(row.get("Dispatch_Id"))
             if not launches:
-                return None, f"rocprofv3 --pmc {ctr}: no rows for {kernel_name} (rc={r.returncode})"
-            vals[ctr] = total / len(launches)
+                why = f"rocprofv3 --pmc {tag}: no rows for {kernel_name} (rc={r.returncode})"
+                break
+            for c in ctrs:
+                vals[c] = total[c] / len(launches)
     finally:
         shutil.rmtree(work, ignore_errors=True)
+    busy = None
+    if vals.get("GRBM_GUI_ACTIVE"):
+        busy = round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4), 4)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, f"not measured: {why}", busy
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), \
-        "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of `bench.py --traffic-child` (same frame, same mode), (2 x FETCH + WRITE) KiB per launch"
+        "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of `bench.py --traffic-child` (same frame, same mode), (2 x FETCH + WRITE) KiB per launch", busy
 
 
 def main():
@@ -543,12 +595,12 @@ def main():
         value = samples * args.steps / dt / 1e6
         primary_roofline = roofline(prec, kern_ms)
         if world == 1 and not args.no_traffic:
-            t_live, t_src = measure_traffic(prec, engine, primary_roofline["kernel"])
-            if t_live is not None:
-                primary_roofline["traffic_profiled_earlier"] = primary_roofline["traffic"]
-                primary_roofline["traffic"], primary_roofline["traffic_source"] = t_live, t_src
-            else:  # keep the earlier profile's figure, say why
-                primary_roofline["traffic_source"] = f"{primary_roofline['traffic_source']}; live measurement failed: {t_src}"
+            t_live, t_src, mfma_busy = measure_traffic(prec, engine, primary_roofline["kernel"])
+            # ONE method: the live PMC child passes of this very command, or null with the reason -- an earlier
+            # profile's constant is never substituted for the primary mode
+            primary_roofline["traffic"], primary_roofline["traffic_source"] = t_live, t_src
+            if mfma_busy is not None:
+                primary_roofline["mfma_busy_frac"] = mfma_busy
         res = {
             "metric": "Msamples/sec (rays x samples) at 800^2 x 128", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -591,8 +643,9 @@ def main():
                                        "unit": "Msamples/s", "steps": args.steps, "ms_per_step": round(dt4 / args.steps * 1e3, 3),
                                        "roofline": roofline(fourth, kern4_ms)}
         if world == 1 and not args.no_other_configs:
-            res["other_configs"], res["other_configs_s"] = other_configs(dev)
+            res["other_configs"], res["other_configs_s"], res["outside_tolerance"] = other_configs(dev)
             res["train_step"] = train_step(dev)
+            res["train_step_1m"] = train_step(dev, crop=128, iters=5)
             res["coarse_fine"] = coarse_fine(dev, ops.raygen(c2w, focal, SIZE, (0, 0, SIZE, SIZE)))
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, rays_cpu = cpu_baseline(model)

@@ -114,6 +114,16 @@ int na_view_elaz(const float* dirs, int64_t N, float* out, void* stream);
 /* rows [x, y, z, elev, azim] [N, 5] of the View reflectance's input: pts [N = T x R, 3] with the per-RAY directions dirs [R, 3]
  * broadcast along the samples (n = t R + r) -- src/refl.py:190-207's cat([x, dir_to_elev_azim(view)]) in one launch. */
 int na_view_rows(const float* pts, const float* dirs, int64_t N, int64_t R, float* out, void* stream);
+/* training step, the torch glue around the two networks of PlainNeRF(view) as kernels (round 6):
+ * na_hash_encode_rows   out [N, 32 + 3 (include_input + lead)] = [x (lead = 1) | x (include_input) | features]: with lead = 1 the
+ *                       init rows cat([p, enc(p)]) of a hash-encoded SkipConnMLP (src/neural_blocks.py:139-193, 283-287) written by
+ *                       the encoder itself.
+ * na_plain_head_rows    PlainNeRF.from_pts between its networks (src/nerf.py:338-357, src/refl.py:190-207): first_out [N, 1 + C] ->
+ *                       density [N] = first_out[:, 0] and the View MLP's init rows [N, 5 + C] = [x, y, z, elev, azim | first_out[:, 1:]]
+ *                       (pts [N = T x R, 3], per-RAY directions dirs [R, 3], n = t R + r).                                            */
+int na_hash_encode_rows(const float* x, int64_t N, const float* tables, int include_input, int lead, float* out, void* stream);
+int na_plain_head_rows(const float* first_out, const float* pts, const float* dirs, int64_t N, int64_t R, int C, float* density,
+                       float* rows, void* stream);
 
 /* sigmoid_kinds (src/utils.py:484-518) elementwise, in place allowed.                          */
 int na_sigmoid(const float* x, int64_t N, int kind, float* out, void* stream);
@@ -348,9 +358,11 @@ int na_linear_bwd_fused_ok(int64_t N, int out, int in0);
 int na_linear_wgrad_bf16x3_cols(const float* x, int in, int64_t N, const float* dY, int out, int pre_act, float* dW, int ldw,
                                 float* db, void* stream);
 /* workspace: na_linear_bwd_workspace_bytes(N, in0) bytes of device memory for the partial gradients (16-byte aligned; the caller's
- * allocator -- torch's is stream-ordered and costs microseconds), or NULL: the call then takes them from hipMallocAsync, which
- * costs ~230 us of host time per call on ROCm 7.2. */
+ * allocator -- torch's is stream-ordered and costs microseconds), or NULL: the call then takes them from the library's grow-only
+ * scratch of this (device, stream) -- no driver call once it exists; it grows geometrically and a replaced buffer is freed when
+ * the work queued before its replacement has finished. */
 size_t na_linear_bwd_workspace_bytes(int64_t N, int in0);
+int na_linear_bwd_partial_count(int64_t N, int in0);   /* partial gradients in that workspace (the nwg_i of na_train_reduce_many) */
 /* The pass without its reduction (the whole-network backward of a SkipConnMLP: every Linear's partial gradients stay in a
  * workspace of its own -- na_linear_bwd_workspace_bytes(N, in0) bytes = slices x 67 584 floats -- and ONE na_train_reduce_many
  * sums them all: dW_i[out_i, 0:in_i) at leading dimension ldw_i and db_i (nullable) WRITTEN from nwg_i = slices partials).
@@ -367,6 +379,16 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
                             float* tables_grad, void* stream);
 int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,
                                   int include_input, float* g_x, void* stream);
+/* the same two on a gradient read IN PLACE from wider rows (the gradient of a network's init rows [x | x | features | ...] of pitch
+ * g_ld: no slice copy): _backward_rows takes the 32 feature columns at g_col0; _backward_input_rows takes rows
+ * [x (lead) | x (include_input) | features] and adds the leading copy's gradient.
+ * na_plain_head_rows_backward: g_first_out [N, 1 + C] = [g_density (nullable: 0) | g_rows[:, 5:]], g_pts [N, 3] = g_rows[:, :3] (nullable). */
+int na_hash_encode_backward_rows(const float* x, int64_t N, const float* g_rows, int g_ld, int g_col0, float* tables_grad,
+                                 void* stream);
+int na_hash_encode_backward_input_rows(const float* x, int64_t N, const float* tables, const float* g_rows, int g_ld,
+                                       int include_input, int lead, float* g_x, void* stream);
+int na_plain_head_rows_backward(const float* g_density, const float* g_rows, int64_t N, int C, float* g_first_out, float* g_pts,
+                                void* stream);
 /* Forward-mode derivative of the hash features along a per-point direction e (the deformation network's input
  * Jacobian-vector product that the FFJORD divergence estimate needs: runner.py:697-700, src/utils.py:467-478;
  * src/neural_blocks.py:166-190 is what is differentiated).

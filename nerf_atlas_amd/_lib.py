@@ -43,6 +43,11 @@ SIGNATURES = {
     "na_positional_encode": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_view_elaz": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
     "na_view_rows": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, c_f32p, C.c_void_p]),
+    "na_hash_encode_rows": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "na_plain_head_rows": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_i64, C.c_int, c_f32p, c_f32p, C.c_void_p]),
+    "na_hash_encode_backward_rows": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "na_hash_encode_backward_input_rows": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "na_plain_head_rows_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "na_sigmoid": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_mip_encode": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_float, C.c_int,
                                 C.c_int, c_f32p, C.c_void_p]),
@@ -120,6 +125,7 @@ SIGNATURES = {
     "na_train_packed_row_offset": (C.c_size_t, [C.c_int, C.c_int]),
     "na_linear_wgrad_bf16x3_cols": (C.c_int, [c_f32p, C.c_int, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "na_linear_bwd_workspace_bytes": (C.c_size_t, [c_i64, C.c_int]),
+    "na_linear_bwd_partial_count": (C.c_int, [c_i64, C.c_int]),
     "na_linear_bwd_partials_bf16x3_pk": (C.c_int, [c_f32p, C.c_int, c_i64, C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int,
                                                    C.c_void_p, C.c_void_p]),
     "na_train_reduce_many": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),

@@ -93,6 +93,45 @@ class HashEncodeFn(Function):
         return gx, gt, None
 
 
+class HashInitFn(Function):
+    """The init rows cat([p, enc(p)]) = [x | x | features] of a hash-encoded SkipConnMLP without a latent (src/neural_blocks.py:139-193,
+    283-287) as ONE node and ONE kernel (round 6: hash_encode + cat forward; slice copy + scatter backward before).  The backward reads
+    the rows' gradient in place: tables through the scatter kernel, positions (D-NeRF's warped points) through the input-gradient
+    kernel, which adds both copies of x like autograd's accumulation did."""
+
+    @staticmethod
+    def forward(ctx, x, tables, include_input):
+        ctx.save_for_backward(x, tables)
+        ctx.include_input = include_input
+        return ops.hash_encode_rows(x, tables, include_input, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, tables = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gt = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.hash_encode_backward_input_rows(x, tables, g, ctx.include_input, 1)
+        if ctx.needs_input_grad[1]:
+            gt = ops.hash_encode_backward_rows(x, g, 3 * (1 + int(ctx.include_input)))
+        return gx, gt, None
+
+
+class PlainHeadFn(Function):
+    """PlainNeRF between its two networks in training (src/nerf.py:338-357, src/refl.py:190-207): first_out [N, 1 + C] ->
+    (density [N], the View MLP's init rows [N, 5 + C]) by one kernel; the backward writes [g_density | g_rows[:, 5:]] side by side
+    (and the points' three columns when they carry a gradient: D-NeRF)."""
+
+    @staticmethod
+    def forward(ctx, first_out, pts, dirs):
+        return ops.plain_head_rows(first_out, pts, dirs)
+
+    @staticmethod
+    def backward(ctx, g_density, g_rows):
+        g_first, g_pts = ops.plain_head_rows_backward(g_density, g_rows.contiguous(), ctx.needs_input_grad[1])
+        return g_first, g_pts, None
+
+
 class HashJvpFn(Function):
     """d hash_encode(x)/dx . tangent (rows [tangent | per-level features]: na_hash_encode_jvp) as a graph node: the gradient
     w.r.t. the tables is the adjoint scatter na_hash_encode_jvp_backward (the features are linear in the tables); positions
@@ -232,6 +271,7 @@ class CompositeFn(Function):
         ctx.save_for_backward(density, feat, ts, rays)
         ctx.softplus, ctx.bg, ctx.rand = softplus, bg, rand  # (rand: the per-ray draw of bg "random", a constant)
         ctx.mark_non_differentiable(alpha, weights)
+        ctx.set_materialize_grads(False)  # (no zero-filled [T, R] gradients for the two auxiliary outputs: two fill launches per step)
         return out, alpha, weights
 
     @staticmethod

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
                                                             const float* __restrict__ g_out, int include_input,
                                                             HashRes res, float* __restrict__ tables_grad,
                                                             long long* __restrict__ fix,
-                                                            const float* __restrict__ tangent) {
+                                                            const float* __restrict__ tangent, int g_ld = 0, int g_col0 = -1) {
   // tangent != nullptr: g_out is the gradient of the directional derivative J(x).e of hash_jvp_kernel, whose corner
   // weights are N_l * <grad w_corner, e> instead of w_corner
   __shared__ uint32_t tags[HB_ROWS];
@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
       const float fx = floorf(vx), fy = floorf(vy), fz = floorf(vz);
       lx = (int)fx; ly = (int)fy; lz = (int)fz;
       wx = vx - fx; wy = vy - fy; wz = vz - fz;
-      const float* g = g_out + n * odim + 3 * include_input + lvl * 4;
+      // (g_col0 >= 0: the features' gradient sits in columns g_col0 .. g_col0 + 31 of rows of pitch g_ld -- a slice of a wider
+      // gradient, e.g. of a network's init rows, read in place)
+      const float* g = g_col0 >= 0 ? g_out + n * g_ld + g_col0 + lvl * 4 : g_out + n * odim + 3 * include_input + lvl * 4;
       g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
     }
     const float iwx = 1.f - wx, iwy = 1.f - wy, iwz = 1.f - wz;
@@ -300,10 +302,13 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
 //   g_x[a] = g_in[a] (include_input) + sum_lvl N_lvl * sum_corner dW_corner/dw_a * <emb_corner, g_lvl>.
 // One thread per (sample, level); the 8 levels of a sample sit in 8 adjacent lanes and are summed with DPP-free
 // shuffles before a single store.
+// g_ld > 0: rows of pitch g_ld = [`lead` more copies of x | x (include_input) | features] -- the gradient of a network's init rows
+// read in place; the leading copies' gradient is added last (the order autograd's accumulation of the two slices had)
 __global__ void hash_backward_input_kernel(const float* __restrict__ x, int64_t N, const float* __restrict__ tables,
-                                           const float* __restrict__ g_out, int include_input, HashRes res,
-                                           float* __restrict__ g_x) {
-  const int odim = 32 + 3 * include_input;
+                                           const float* __restrict__ g_out_, int include_input, HashRes res,
+                                           float* __restrict__ g_x, int g_ld = 0, int lead = 0) {
+  const int odim = g_ld > 0 ? g_ld : 32 + 3 * include_input;
+  const float* __restrict__ g_out = g_out_ + 3 * lead;
   const int64_t total = (N * 8 + 63) / 64 * 64;  // whole waves, so the shuffles below are convergent
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int lvl = (int)(i & 7);
@@ -343,6 +348,9 @@ __global__ void hash_backward_input_kernel(const float* __restrict__ x, int64_t 
     if (lvl == 0 && n < N) {
       if (include_input) {
         gx += g_out[n * odim]; gy += g_out[n * odim + 1]; gz += g_out[n * odim + 2];
+      }
+      if (lead) {
+        gx = g_out_[n * odim] + gx; gy = g_out_[n * odim + 1] + gy; gz = g_out_[n * odim + 2] + gz;
       }
       g_x[n * 3] = gx; g_x[n * 3 + 1] = gy; g_x[n * 3 + 2] = gz;
     }
@@ -499,6 +507,22 @@ __global__ void bezier_warp_backward_kernel(const float* __restrict__ est, int e
       c0 = 2 + (3 + n_rl) * n;
     }
     for (int c = c0; c < est_stride; ++c) ge[c] = 0.f;
+  }
+}
+
+// gradient of na_plain_head_rows: g_first_out[n] = [g_density[n] | g_rows[n, 5:]], g_pts[n] = g_rows[n, :3] (nullable)
+template <typename I>
+__global__ void plain_head_rows_backward_kernel(const float* __restrict__ g_density, const float* __restrict__ g_rows, int64_t N, int C,
+                                                float* __restrict__ g_first_out, float* __restrict__ g_pts) {
+  const I W = 1 + C, total = (I)N * W;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I n = i / W;
+    const int c = (int)(i - n * W);
+    g_first_out[i] = c == 0 ? (g_density != nullptr ? g_density[n] : 0.f) : g_rows[n * (5 + C) + 4 + c];
+    if (g_pts != nullptr && i < (I)N * 3) {
+      const I m = i / 3;
+      g_pts[i] = g_rows[m * (5 + C) + (i - m * 3)];
+    }
   }
 }
 
@@ -734,6 +758,48 @@ int na_hash_encode_backward(const float* x, int64_t N, const float* g_out, int i
                      g_out, include_input ? 1 : 0, hash_resolutions(), tables_grad, fix, (const float*)nullptr);
   if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_backward");
   return check_launch("na_hash_encode_backward");
+}
+
+int na_hash_encode_backward_rows(const float* x, int64_t N, const float* g_rows, int g_ld, int g_col0, float* tables_grad,
+                                 void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(x && g_rows && tables_grad, NA_ENULL, "na_hash_encode_backward_rows: null pointer");
+  NA_REQUIRE(N > 0 && g_col0 >= 0 && g_ld >= g_col0 + 32, NA_EINVAL, "na_hash_encode_backward_rows: N %lld g_ld %d g_col0 %d", (long long)N,
+             g_ld, g_col0);
+  int rc;
+  const size_t ntab = (size_t)8 * 65536 * 4;
+  long long* fix = det_begin(ntab, (hipStream_t)stream, "na_hash_encode_backward_rows", &rc);
+  if (rc != NA_OK) return rc;
+  hipLaunchKernelGGL(hash_backward_kernel, dim3(grid_for(N, 256, HB_MAXWG), 8), dim3(256), 0, (hipStream_t)stream, x, N,
+                     g_rows, 0, hash_resolutions(), tables_grad, fix, (const float*)nullptr, g_ld, g_col0);
+  if (fix != nullptr) return det_finish(fix, ntab, tables_grad, (hipStream_t)stream, "na_hash_encode_backward_rows");
+  return check_launch("na_hash_encode_backward_rows");
+}
+
+int na_hash_encode_backward_input_rows(const float* x, int64_t N, const float* tables, const float* g_rows, int g_ld,
+                                       int include_input, int lead, float* g_x, void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(x && tables && g_rows && g_x, NA_ENULL, "na_hash_encode_backward_input_rows: null pointer");
+  NA_REQUIRE(N > 0 && (lead == 0 || lead == 1) && g_ld >= 32 + 3 * ((include_input ? 1 : 0) + lead), NA_EINVAL,
+             "na_hash_encode_backward_input_rows: N %lld g_ld %d lead %d", (long long)N, g_ld, lead);
+  hipLaunchKernelGGL(hash_backward_input_kernel, dim3(grid_for(N * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                     x, N, tables, g_rows, include_input ? 1 : 0, hash_resolutions(), g_x, g_ld, lead);
+  return check_launch("na_hash_encode_backward_input_rows");
+}
+
+int na_plain_head_rows_backward(const float* g_density, const float* g_rows, int64_t N, int C, float* g_first_out, float* g_pts,
+                                void* stream) {
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(N > 0 && C >= 3, NA_EINVAL, "na_plain_head_rows_backward: N %lld C %d", (long long)N, C);
+  NA_REQUIRE(g_rows && g_first_out, NA_ENULL, "na_plain_head_rows_backward: null pointer");
+  const int64_t total = N * (1 + C);
+  if (total < (1ll << 31))
+    hipLaunchKernelGGL(plain_head_rows_backward_kernel<int>, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       g_density, g_rows, N, C, g_first_out, g_pts);
+  else
+    hipLaunchKernelGGL(plain_head_rows_backward_kernel<int64_t>, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       g_density, g_rows, N, C, g_first_out, g_pts);
+  return check_launch("na_plain_head_rows_backward");
 }
 
 int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,

@@ -210,16 +210,18 @@ __device__ __forceinline__ void stream_store1(float* dst, float a) {
   if (NA_STREAM_NT) __builtin_nontemporal_store(a, dst);
   else *dst = a;
 }
+// lead = 1: the row starts with one more copy of x -- [x | x | features], the init row cat([p, enc(p)]) of a hash-encoded
+// SkipConnMLP (src/neural_blocks.py:283-287) written by the encoder itself (training: no cat launch, round 6)
 __global__ void hash_encode_kernel(const float* __restrict__ x, int64_t N, const float4* __restrict__ tables,
                                    HashRes res, int include_input, float* __restrict__ out,
-                                   int64_t* __restrict__ idx_out) {
-  const int odim = 32 + 3 * include_input;
+                                   int64_t* __restrict__ idx_out, int lead = 0) {
+  const int odim = 32 + 3 * include_input + 3 * lead;
   // A wave = 64 CONSECUTIVE SAMPLES at ONE level (8 waves of a 512-thread workgroup = the 8 levels of the same 64 samples):
   // neighbouring samples of a ray share grid cells on the coarse levels, so a gather instruction's lanes fall into few cache
   // lines (with the 8 levels of one sample in adjacent lanes every lane of an instruction hit a different table).
   // The rows of the 64 samples (64 x 35 floats, contiguous in memory) are assembled in LDS and leave as one coalesced sweep:
   // 4-byte pieces 140 bytes apart, straight from the registers, cost as much as the gathers.
-  __shared__ __attribute__((aligned(16))) float rows[64 * 35];
+  __shared__ __attribute__((aligned(16))) float rows[64 * 38];
   const int lvl = (int)(threadIdx.x >> 6);
   const int64_t nblocks = (N + 63) >> 6;
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -248,11 +250,11 @@ __global__ void hash_encode_kernel(const float* __restrict__ x, int64_t N, const
         acc.x = acc.x + e.x * w; acc.y = acc.y + e.y * w; acc.z = acc.z + e.z * w; acc.w = acc.w + e.w * w;
       }
     }
-    float* o = rows + (threadIdx.x & 63) * odim + 3 * include_input + lvl * 4;
+    float* o = rows + (threadIdx.x & 63) * odim + 3 * (include_input + lead) + lvl * 4;
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
-    if (include_input && lvl == 0) {
+    if (lvl == 0) {
       float* r = rows + (threadIdx.x & 63) * odim;
-      r[0] = px; r[1] = py; r[2] = pz;
+      for (int k = 0; k < include_input + lead; ++k) { r[3 * k] = px; r[3 * k + 1] = py; r[3 * k + 2] = pz; }
     }
     __syncthreads();
     const int64_t left = N - blk * 64;
@@ -372,6 +374,44 @@ __global__ void view_rows_kernel(const float* __restrict__ pts, const float* __r
     elev_azim(dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2], e, a);
     float* o = out + i * 5;
     o[0] = pts[i * 3]; o[1] = pts[i * 3 + 1]; o[2] = pts[i * 3 + 2]; o[3] = e; o[4] = a;
+  }
+}
+
+// PlainNeRF's step between its two networks in training (src/nerf.py:338-357, src/refl.py:190-207): density = first_out[..., 0]
+// (contiguous) and the View MLP's init rows [x, y, z, elev, azim | first_out[..., 1:]] by ONE kernel (round 6: slice copy + elaz +
+// expand + two cats + the latent's contiguous copy were seven launches, 85 us per step of 262 144 samples).  A workgroup owns 32
+// consecutive rows: its output tile is one contiguous run of 32 (5 + C) floats, written by consecutive lanes; the row of an
+// element comes from a float reciprocal (exact for the tile's < 2^16 elements), elevation / azimuth of the tile's rays once per
+// row by the first 32 threads (a flat one-element-per-thread form made every wave walk through acosf / atan2f: 83 us).  n = t R + r.
+__global__ __launch_bounds__(256) void plain_head_rows_kernel(const float* __restrict__ first_out, const float* __restrict__ pts,
+                                                              const float* __restrict__ dirs, int64_t N, int64_t R, int C,
+                                                              float* __restrict__ density, float* __restrict__ rows) {
+  __shared__ float ea[32][2];
+  const int W = 5 + C;
+  const float invW = 1.0f / (float)W;
+  const int64_t ntile = (N + 31) >> 5;
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t n0 = tile << 5;
+    const int nrow = (int)(N - n0 < 32 ? N - n0 : 32);
+    if (threadIdx.x < nrow) {
+      const int64_t n = n0 + threadIdx.x;
+      const int64_t r = n % R;
+      float e, a;
+      elev_azim(dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2], e, a);
+      ea[threadIdx.x][0] = e; ea[threadIdx.x][1] = a;
+      density[n] = first_out[n * (1 + C)];
+    }
+    __syncthreads();
+    const int total = nrow * W;
+    float* dst = rows + n0 * W;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      int row = (int)(((float)i + 0.5f) * invW);
+      int c = i - row * W;
+      if (c < 0) { --row; c += W; } else if (c >= W) { ++row; c -= W; }
+      const int64_t n = n0 + row;
+      dst[i] = c < 3 ? pts[n * 3 + c] : c < 5 ? ea[row][c - 3] : first_out[n * (1 + C) + 1 + (c - 5)];
+    }
+    __syncthreads();
   }
 }
 
@@ -780,8 +820,18 @@ int na_hash_encode(const float* x, int64_t N, const float* tables, int include_i
   // 16-byte boundary of `out` exactly when `out` itself is aligned); torch allocations are 256-byte aligned
   NA_REQUIRE(((uintptr_t)out & 15) == 0, NA_EINVAL, "na_hash_encode: out must be 16-byte aligned (got %p)", (void*)out);
   hipLaunchKernelGGL(hash_encode_kernel, dim3(grid_for((N + 63) / 64 * 512, 512, 16384)), dim3(512), 0, (hipStream_t)stream, x, N,
-                     (const float4*)tables, hash_resolutions(), include_input ? 1 : 0, out, idx_out);
+                     (const float4*)tables, hash_resolutions(), include_input ? 1 : 0, out, idx_out, 0);
   return check_launch("na_hash_encode");
+}
+
+int na_hash_encode_rows(const float* x, int64_t N, const float* tables, int include_input, int lead, float* out, void* stream) {
+  NA_REQUIRE(N >= 0 && (lead == 0 || lead == 1), NA_EINVAL, "na_hash_encode_rows: N=%lld lead=%d (0 | 1)", (long long)N, lead);
+  if (N == 0) return NA_OK;  // empty: zero-size tensors carry null pointers
+  NA_REQUIRE(x && tables && out, NA_ENULL, "na_hash_encode_rows: null pointer");
+  NA_REQUIRE(((uintptr_t)out & 15) == 0, NA_EINVAL, "na_hash_encode_rows: out must be 16-byte aligned (got %p)", (void*)out);
+  hipLaunchKernelGGL(hash_encode_kernel, dim3(grid_for((N + 63) / 64 * 512, 512, 16384)), dim3(512), 0, (hipStream_t)stream, x, N,
+                     (const float4*)tables, hash_resolutions(), include_input ? 1 : 0, out, (int64_t*)nullptr, lead);
+  return check_launch("na_hash_encode_rows");
 }
 
 int na_fourier_encode(const float* x, int64_t N, int D, const float* basis, int F, float scale, float* out,
@@ -824,6 +874,17 @@ int na_view_rows(const float* pts, const float* dirs, int64_t N, int64_t R, floa
   if (N == 0) return NA_OK;
   hipLaunchKernelGGL(view_rows_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, (hipStream_t)stream, pts, dirs, N, R, out);
   return check_launch("na_view_rows");
+}
+
+int na_plain_head_rows(const float* first_out, const float* pts, const float* dirs, int64_t N, int64_t R, int C, float* density,
+                       float* rows, void* stream) {
+  NA_REQUIRE(N >= 0 && R >= 1 && C >= 1 && N % R == 0, NA_EINVAL, "na_plain_head_rows: N %lld R %lld C %d", (long long)N, (long long)R, C);
+  if (N == 0) return NA_OK;
+  NA_REQUIRE(first_out && pts && dirs && density && rows, NA_ENULL, "na_plain_head_rows: null pointer");
+  NA_REQUIRE(C <= 1024, NA_EINVAL, "na_plain_head_rows: C %d (<= 1024)", C);
+  hipLaunchKernelGGL(plain_head_rows_kernel, dim3(grid_for((N + 31) / 32 * 256, 256, 16384)), dim3(256), 0, (hipStream_t)stream, first_out,
+                     pts, dirs, N, R, C, density, rows);
+  return check_launch("na_plain_head_rows");
 }
 
 int na_sigmoid(const float* x, int64_t N, int kind, float* out, void* stream) {

@@ -60,7 +60,7 @@ constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"
 constexpr int kPartialFloats = 8;
 
 // ---- NA_PREC_F16X (PlainNeRF schedule only): hidden activations and hidden-layer weights in the f16 + 2 x MX-fp6 format
-// (tools/proto/ls_mlp_f16x.hip is the measured prototype of this data flow).
+// (the measured prototype of this data flow, tools/proto/ls_mlp_f16x.hip, left the tree in round 6: git history up to 5f9153f; its logs are profiles/r03/f16x_proto_*.log).
 //   An fp6 OPERAND is 32 bytes per lane, two lane-linear 16-byte parts (1 KiB each): dwords 0..5 = the 32 fp6 values, dword 6 =
 //   its E8M0 scale (byte 0), dword 7 unused -- two 16-byte loads give the scaled MFMA's 8-dword operand AND its scale register.
 //   LDS, per (block, K64 group Q = the row group that produced those 64 features): 4 f16 fragments (4 KiB) | R = fp6 of the f16
@@ -808,7 +808,7 @@ __device__ __forceinline__ void store_block(char* kq, const f32x16& a0, const f3
     r0[u] = a; r1[u] = b; r0[8 + u] = c; r1[8 + u] = d;
   }
   // v_cvt_scalef32_2xpk16_fp6_f32 divides by the scale's power of two, rounds to nearest even, saturates, and puts a[i] into
-  // slot 2 i, b[i] into slot 2 i + 1 (probed on the hardware: tools/proto/ls_f16x.py calibrate)
+  // slot 2 i, b[i] into slot 2 i + 1 (probed on the hardware by the round-3 prototype: profiles/r03/f16x_proto_v1.log)
   const i32x6 Rr = NA_LSX_CVT_ASM ? cvt_fp6_disjoint(r0, r1, sR) : __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(r0, r1, sR);
   const i32x6 Tt = NA_LSX_CVT_ASM ? cvt_fp6_disjoint(v0, v1, sT) : __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(v0, v1, sT);
   char* p = kq + 4096 + lane * 16;

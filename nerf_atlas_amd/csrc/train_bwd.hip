@@ -447,6 +447,9 @@ size_t na_linear_bwd_workspace_bytes(int64_t N, int in0) {
   return N > 0 ? (size_t)lsbw::slices(N, in0 == 256) * lsbw::PART * sizeof(float) : 0;
 }
 
+// partials in that workspace (= its bytes / the size of one partial): what na_train_reduce_many takes as nwg_i
+int na_linear_bwd_partial_count(int64_t N, int in0) { return N > 0 ? lsbw::slices(N, in0 == 256) : 0; }
+
 int na_linear_bwd_bf16x3_pk(const float* dY, int out, int64_t N, const void* wt_packed, const float* x0, int in0, int pre_act,
                             float* g_x0, float* dW, int ldw, float* db, void* workspace, void* stream) {
   NA_REQUIRE((in0 == 256 || (in0 >= 1 && in0 <= 128)) && out >= 1 && out <= 256 && N >= 0 && ldw >= in0, NA_EINVAL,

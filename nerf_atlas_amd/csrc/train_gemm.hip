@@ -1260,17 +1260,43 @@ static int launch(Args a, hipStream_t st, const char* what) {
 
 void* train_scratch(hipStream_t st, size_t bytes) {
   struct Slot { int dev; hipStream_t st; void* p; size_t n; };
+  struct Retired { int dev; hipEvent_t ev; void* p; };
   static std::mutex mu;
   static std::vector<Slot> slots;
+  static std::vector<Retired> retired;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
+  // buffers replaced earlier are freed once the kernels that were queued before their replacement have finished (an event
+  // recorded on the stream at that moment: ADVICE r05 -- they used to stay alive until process exit)
+  for (size_t i = 0; i < retired.size();) {
+    if (retired[i].dev == dev && hipEventQuery(retired[i].ev) == hipSuccess) {
+      (void)hipEventDestroy(retired[i].ev);
+      (void)hipFree(retired[i].p);
+      retired[i] = retired.back();
+      retired.pop_back();
+    } else {
+      (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+      ++i;
+    }
+  }
   for (Slot& s : slots)
     if (s.dev == dev && s.st == st) {
       if (s.n >= bytes) return s.p;
-      void* p = nullptr;  // grow: the old buffer stays alive (in-flight kernels), this slot moves on
-      if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-      s.p = p; s.n = bytes;
+      // grow GEOMETRICALLY: a run whose batch grows step by step (crop schedules, coarse then fine sizes) replaces the buffer
+      // O(log) times, not once per step
+      size_t want = bytes > 2 * s.n ? bytes : 2 * s.n;
+      void* p = nullptr;
+      if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      }
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, st) == hipSuccess)
+        retired.push_back(Retired{dev, ev, s.p});
+      else (void)hipGetLastError();  // (no event: the old buffer stays alive until process exit, as before)
+      s.p = p; s.n = want;
       return p;
     }
   void* p = nullptr;

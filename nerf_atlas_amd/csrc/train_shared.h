@@ -12,14 +12,28 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+// sin / cos of the split-bf16 training GEMMs (round 6): the hardware v_sin_f32 / v_cos_f32 on a revolution count reduced with a
+// two-constant 1 / (2 pi) -- the reduction of mlp_engine.h's sin_hw2, which the inference kernels have used since round 2 (same
+// end-to-end L-inf as the Cody-Waite polynomial there).  One shared reduction for the pair: where a kernel needs act(x) AND act'(x)
+// of the same element (lsbw: the weight gradient's operand and the input gradient's factor) the compiler keeps one.  ~1e-6
+// absolute, far inside the 2^-16 relative error of the three bf16 products downstream; the polynomial pair cost 48 us per sin
+// layer in lsbw (243 against 195 us for LeakyReLU).  NA_TRAIN_POLY_SIN=1 at build time restores the polynomials for A/B runs.
+#ifndef NA_TRAIN_POLY_SIN
+#define NA_TRAIN_POLY_SIN 0
+#endif
+__device__ __forceinline__ float trev(float x) {
+  const float q = rintf(x * 0.15915493667125702f);
+  float r = fmaf(x, 0.15915493667125702f, -q);
+  return fmaf(x, 6.4206382432985265e-09f, r);
+}
 __device__ __forceinline__ float tact(float v, int act) {
   if (act == NA_ACT_LEAKY_RELU) return __builtin_amdgcn_fmed3f(v, v * 0.01f, 3.0e38f);
-  if (act == NA_ACT_SIN) return sin_cw(v);
+  if (act == NA_ACT_SIN) return NA_TRAIN_POLY_SIN ? sin_cw(v) : __builtin_amdgcn_sinf(trev(v));
   return v;
 }
 __device__ __forceinline__ float tact_grad(float v, int act) {
   if (act == NA_ACT_LEAKY_RELU) return v > 0.f ? 1.f : 0.01f;
-  if (act == NA_ACT_SIN) return cos_cw(v);
+  if (act == NA_ACT_SIN) return NA_TRAIN_POLY_SIN ? cos_cw(v) : __builtin_amdgcn_cosf(trev(v));
   return 1.f;
 }
 

@@ -73,21 +73,34 @@ class BandGather:
         want = os.environ.get("NA_DIST_GATHER", "gather")
         if want not in ("gather", "all_gather"):
             raise ValueError(f"NA_DIST_GATHER={want}: 'gather' or 'all_gather'")
-        ok, why = 1, ""
+        # EVERY rank reaches the all_reduce below whatever its probe did: 1 = gather works, 0 = this backend has no
+        # gather, -1 = a hard error (a communicator error, a timeout, a shape problem), re-raised AFTER the group has agreed -- the
+        # peers then raise too instead of waiting for a collective that never comes.  (What this cannot cover: a probe that blocks
+        # inside dist.gather because a peer died -- that is the process group's timeout, as for any collective.)
+        ok, why, hard = 1, "", None
         if want == "gather":
             try:
                 probe = torch.zeros(1, device=cdev, dtype=dtype)
                 dist.gather(probe, [torch.zeros_like(probe) for _ in range(self.world)] if self.rank == self.dst else None, dst=self.dst)
-            except (RuntimeError, NotImplementedError) as e:
+            except Exception as e:  # noqa: BLE001
                 msg = str(e).lower()
-                if not isinstance(e, NotImplementedError) and not any(k in msg for k in ("not supported", "not implemented", "does not support", "unsupported")):
-                    raise  # a communicator error, a timeout, a shape problem: not "this backend has no gather"
-                ok, why = 0, f"{type(e).__name__}: {e}"
+                why = f"{type(e).__name__}: {e}"
+                if isinstance(e, NotImplementedError) or (isinstance(e, RuntimeError) and any(
+                        k in msg for k in ("not supported", "not implemented", "does not support", "unsupported"))):
+                    ok = 0
+                else:
+                    ok, hard = -1, e
         else:
             ok = 0
         flag = torch.tensor([ok], device=cdev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        agreed = int(flag.item())
+        if hard is not None:
+            raise hard
+        if agreed < 0:
+            raise RuntimeError(f"[nerf_atlas_amd.dist] rank {self.rank}: another rank's dist.gather probe failed with a hard error "
+                               f"(backend {dist.get_backend()}); see that rank's traceback")
+        if agreed == 1:
             return "gather"
         if want == "gather":
             import sys

@@ -7,6 +7,7 @@ Protocol kept for callers (runner.py): forward(rays) / forward((rays, times)), f
 forward, .ts, .alpha, .weights (+ .pts/.dp/.rigidity/.rigid_dp for dynamic models, .scale_post_act for VolSDF).
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -377,6 +378,7 @@ class PlainNeRF(CommonNeRF):
 
     def from_pts(self, pts, ts, r_o, r_d, refl_latent=None, rays=None):
         if rays is None: rays = torch.cat([r_o, r_d], dim=-1).contiguous()
+        self.ts_ray = None  # (explicit positions: shared steps -- a stale per-ray row of an earlier coarse -> fine call must not reach render.depth_map)
         if self._fusable(refl_latent) and not ag.needs_grad(pts):
             # explicit sample positions (D-NeRF: spline-warped canonical points) through the same fused kernel
             out, self.alpha, self.weights = self._render_fused(rays, ts, True, pts=pts.contiguous())
@@ -393,6 +395,18 @@ class PlainNeRF(CommonNeRF):
                                 "+ separate compositing")
         latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
         first_out = self.first(pts, latent)
+        if (ag.needs_grad(first_out) and latent is None and refl_latent is None and type(self.refl) is refl.View and pts.is_cuda
+                and not self.refl.mlp.last_layer_act and self.refl.mlp.latent_size == first_out.shape[-1] - 1
+                and r_d.shape == pts.shape[1:] and os.environ.get("NA_TRAIN_ROWS") != "0"):
+            # training: density | the View MLP's init rows [x, elev, azim | intermediate] by ONE kernel (autograd.PlainHeadFn; slice
+            # copies, elaz, expand and two cats before), the network from its rows (SkipConnMLP.forward_rows)
+            C = first_out.shape[-1]
+            density, rows = ag.PlainHeadFn.apply(first_out.reshape(-1, C), pts.reshape(-1, 3), r_d.reshape(-1, 3).contiguous())
+            density = density.reshape(pts.shape[:-1])
+            if self.training and self.noise_std > 0:
+                density = density + utils.randn(density.shape, density.device) * self.noise_std
+            rgb = self.refl.act(self.refl.mlp.forward_rows(rows).reshape(pts.shape[:-1] + (self.refl.out_features,)))
+            return self._composite(density, rgb, ts, rays)
         if ag.needs_grad(first_out):
             density, intermediate = ag.SplitHeadFn.apply(first_out)  # (the slices' gradients written side by side: autograd.py)
         else:

@@ -305,13 +305,26 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         y = ops.linear_f32(x, self.out.weight.data, self.out.bias.data, pre_act=self.act_name)
         return y.reshape(batches + (out_size,))
 
-    def _forward_train(self, flat, lat):
+    def forward_rows(self, init):
+        """Differentiable forward from ready-made init rows [N, dim_p] = [p | enc(p) | latent] (a caller that assembles them with one
+        kernel: PlainNeRF's training path, autograd.PlainHeadFn): src/neural_blocks.py:288-296 without the cats of :283-287."""
+        assert init.dim() == 2 and init.shape[1] == self.init.in_features and self.enc is None, (init.shape, self.init.in_features)
+        return self._forward_train(None, None, init=init)
+
+    def _forward_train(self, flat, lat, init=None):
         """Differentiable forward (fp32 Linears, HIP forward and backward kernels): src/neural_blocks.py:279-296."""
-        init = flat
-        if self.enc is not None:
-            init = torch.cat([init, self.enc(flat)], dim=-1)
-        if lat is not None:
-            init = torch.cat([init, lat], dim=-1)
+        if init is not None:
+            pass
+        elif (isinstance(self.enc, HashEncoder) and lat is None and flat.is_cuda and flat.shape[1] == 3
+              and os.environ.get("NA_TRAIN_ROWS") != "0"):
+            # [p | p | features] written by the encoder itself, its gradient read in place (autograd.HashInitFn: no cat, no slice copy)
+            init = ag.HashInitFn.apply(flat, torch.stack([e.weight for e in self.enc.embs]), self.enc.include_input)
+        else:
+            init = flat
+            if self.enc is not None:
+                init = torch.cat([init, self.enc(flat)], dim=-1)
+            if lat is not None:
+                init = torch.cat([init, lat], dim=-1)
         init = init.contiguous()
         packs = self._train_packs(init)
         if self._mlp_fn_ok(init, packs):

@@ -119,6 +119,65 @@ def hash_encode(x: torch.Tensor, tables: torch.Tensor, include_input: bool = Tru
     return (out, idx) if want_indices else out
 
 
+def hash_encode_rows(x: torch.Tensor, tables: torch.Tensor, include_input: bool = True, lead: int = 1) -> torch.Tensor:
+    """[N, 32 + 3 (include_input + lead)] rows [x (lead) | x (include_input) | features]: with lead = 1 the init rows cat([p, enc(p)])
+    of a hash-encoded SkipConnMLP, written by the encoder (na_hash_encode_rows)."""
+    lib = _lib.load()
+    x, tables = _f32(x, "x"), _f32(tables, "tables")
+    assert x.dim() == 2 and x.shape[-1] == 3 and tables.shape == (8, 65536, 4), (x.shape, tables.shape)
+    N = x.shape[0]
+    out = torch.empty(N, 32 + 3 * (int(include_input) + lead), device=x.device, dtype=torch.float32)
+    check(lib.na_hash_encode_rows(_ptr(x), N, _ptr(tables), int(include_input), lead, _ptr(out), _stream()))
+    return out
+
+
+def plain_head_rows(first_out: torch.Tensor, pts: torch.Tensor, dirs: torch.Tensor):
+    """first_out [N, 1 + C], pts [N = T x R, 3], dirs [R, 3] -> (density [N], rows [N, 5 + C] = [x | elev, azim | first_out[:, 1:]])."""
+    lib = _lib.load()
+    first_out, pts, dirs = _f32(first_out, "first_out"), _f32(pts, "pts"), _f32(dirs, "dirs")
+    N, C = first_out.shape[0], first_out.shape[1] - 1
+    R = dirs.numel() // 3
+    assert pts.numel() == 3 * N and N % R == 0, (pts.shape, dirs.shape, N)
+    density = torch.empty(N, device=pts.device, dtype=torch.float32)
+    rows = torch.empty(N, 5 + C, device=pts.device, dtype=torch.float32)
+    check(lib.na_plain_head_rows(_ptr(first_out), _ptr(pts), _ptr(dirs), N, R, C, _ptr(density), _ptr(rows), _stream()))
+    return density, rows
+
+
+def plain_head_rows_backward(g_density, g_rows: torch.Tensor, want_pts: bool):
+    lib = _lib.load()
+    g_rows = _f32(g_rows, "g_rows")
+    N, C = g_rows.shape[0], g_rows.shape[1] - 5
+    g_density = None if g_density is None else _f32(g_density, "g_density")
+    g_first = torch.empty(N, 1 + C, device=g_rows.device, dtype=torch.float32)
+    g_pts = torch.empty(N, 3, device=g_rows.device, dtype=torch.float32) if want_pts else None
+    check(lib.na_plain_head_rows_backward(None if g_density is None else _ptr(g_density), _ptr(g_rows), N, C, _ptr(g_first),
+                                          None if g_pts is None else _ptr(g_pts), _stream()))
+    return g_first, g_pts
+
+
+def hash_encode_backward_rows(x: torch.Tensor, g_rows: torch.Tensor, col0: int) -> torch.Tensor:
+    """tables gradient from the 32 feature columns col0.. of wider gradient rows, read in place"""
+    lib = _lib.load()
+    x, g_rows = _f32(x, "x"), _f32(g_rows, "g_rows")
+    N = x.numel() // 3
+    assert g_rows.dim() == 2 and g_rows.shape[0] == N
+    tg = torch.zeros(8, 65536, 4, device=x.device, dtype=torch.float32)
+    check(lib.na_hash_encode_backward_rows(_ptr(x), N, _ptr(g_rows), g_rows.shape[1], col0, _ptr(tg), _stream()))
+    return tg
+
+
+def hash_encode_backward_input_rows(x: torch.Tensor, tables: torch.Tensor, g_rows: torch.Tensor, include_input: bool, lead: int) -> torch.Tensor:
+    lib = _lib.load()
+    x, tables, g_rows = _f32(x, "x"), _f32(tables, "tables"), _f32(g_rows, "g_rows")
+    N = x.numel() // 3
+    assert g_rows.dim() == 2 and g_rows.shape[0] == N
+    gx = torch.empty_like(x)
+    check(lib.na_hash_encode_backward_input_rows(_ptr(x), N, _ptr(tables), _ptr(g_rows), g_rows.shape[1], int(include_input), lead,
+                                                 _ptr(gx), _stream()))
+    return gx
+
+
 def fourier_encode(x: torch.Tensor, basis: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     lib = _lib.load()
     x, basis = _f32(x, "x"), _f32(basis, "basis")
@@ -555,7 +614,7 @@ def linear_bwd_partials(dY: torch.Tensor, x0: torch.Tensor, pre_act: str, packed
         assert add.shape == x0.shape
     check(lib.na_linear_bwd_partials_bf16x3_pk(_ptr(dY), out, N, wp, _ptr(x0), in0, ACT[pre_act], _ptr(g0), _ptr(add), int(want_bias),
                                                _ptr(ws), _stream()))
-    return g0, ws, nbytes // (67584 * 4)
+    return g0, ws, int(lib.na_linear_bwd_partial_count(N, in0))
 
 
 def train_reduce_many(entries):

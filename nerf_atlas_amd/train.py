@@ -120,7 +120,13 @@ def load_optim(args, params):
     """runner.py:448-458."""
     if args.opt_kind != "adam":
         raise NotImplementedError(f"opt kind {args.opt_kind}")
-    return torch.optim.Adam(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay)
+    params = list(params)
+    # torch's default (foreach) Adam like the reference's (runner.py:448-458).  NA_ADAM_FUSED=1 selects torch's fused one-kernel form
+    # (seven launches -> one, ~0.1 ms per step of PlainNeRF's 2.9 M parameters) -- opt-in: its update rounds differently, and the
+    # `--dyn-diverge-decay` recipe, whose end point measures accumulation precision (tests/test_gpu_train.py), leaves the reference's
+    # basin with it (14.3 / 17.6 / 13.9 dB against 17.1 / 22.2 / 17.6; profiles/r06/adam_fused_dnerf_div.log)
+    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get("NA_ADAM_FUSED") == "1"
+    return torch.optim.Adam(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay, **({"fused": True} if fused else {}))
 
 
 def offset_decay_term(model, curr_percent: float):

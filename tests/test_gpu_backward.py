@@ -645,3 +645,77 @@ def test_dyn_diverge_term_and_its_gradients(train_prec):
         assert e <= 2e-3, (k, e)
         checked += 1
     assert checked >= 12, checked  # 7 Linears (weights, some biases) + the 8 hash tables
+
+
+def test_training_rows_kernels_match_the_operator_chains_they_replace(ops):
+    """Round 6: the torch glue of PlainNeRF's training step as kernels -- na_hash_encode_rows (init rows [x | x | features] written by
+    the encoder), the two gradient kernels reading the rows' gradient in place, na_plain_head_rows (+ backward).  Each against the
+    chain of operators it replaces: the values bit for bit, the scatter in deterministic mode bit for bit."""
+    from nerf_atlas_amd import config
+    N, R, C = 4 * 777, 777, 64
+    x = (torch.from_numpy(proc_uniform((N, 3), 91, 3.0))).cuda()
+    tables = torch.from_numpy(proc_uniform((8, 65536, 4), 92, 1.0)).cuda()
+    rows = ops.hash_encode_rows(x, tables, True, 1)
+    assert rows.shape == (N, 38) and torch.equal(rows, torch.cat([x, ops.hash_encode(x, tables, True)], dim=-1))
+    assert torch.equal(ops.hash_encode_rows(x, tables, True, 0), ops.hash_encode(x, tables, True))
+    assert torch.equal(ops.hash_encode_rows(x, tables, False, 1), torch.cat([x, ops.hash_encode(x, tables, False)], dim=-1))
+    g = torch.from_numpy(proc_uniform((N, 38), 93, 1.0)).cuda()
+    gx = ops.hash_encode_backward_input_rows(x, tables, g, True, 1)
+    assert torch.equal(gx, g[:, :3] + ops.hash_encode_backward_input(x, tables, g[:, 3:].contiguous(), True))
+    config.set_deterministic(True)
+    try:
+        a = ops.hash_encode_backward_rows(x, g, 6)
+        b = ops.hash_encode_backward(x, g[:, 3:].contiguous(), True)
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+    finally:
+        config.set_deterministic(False)
+    assert rel(ops.hash_encode_backward_rows(x, g, 6), b.cpu()) <= 1e-5   # (fp32 atomics: another order)
+    # density | View init rows
+    first_out = torch.from_numpy(proc_uniform((N, 1 + C), 94, 2.0)).cuda()
+    dirs = torch.from_numpy(proc_uniform((R, 3), 95, 1.0)).cuda()
+    density, vr = ops.plain_head_rows(first_out, x, dirs)
+    elaz = ops.view_elaz(dirs).unsqueeze(0).expand(N // R, R, 2).reshape(N, 2)
+    assert torch.equal(density, first_out[:, 0]) and torch.equal(vr, torch.cat([x, elaz, first_out[:, 1:]], dim=-1))
+    assert torch.equal(vr[:, :5], ops.view_rows(x.reshape(N // R, R, 3), dirs).reshape(N, 5))
+    gd = torch.from_numpy(proc_uniform((N,), 96, 1.0)).cuda()
+    gr = torch.from_numpy(proc_uniform((N, 5 + C), 97, 1.0)).cuda()
+    gf, gp = ops.plain_head_rows_backward(gd, gr, True)
+    assert torch.equal(gf, torch.cat([gd[:, None], gr[:, 5:]], dim=-1)) and torch.equal(gp, gr[:, :3])
+    gf0, none = ops.plain_head_rows_backward(None, gr, False)
+    assert none is None and torch.equal(gf0[:, 1:], gr[:, 5:]) and float(gf0[:, 0].abs().max()) == 0
+    # empty batches
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    assert ops.hash_encode_rows(z(0, 3), tables).shape == (0, 38)
+    assert ops.plain_head_rows(z(0, 65), z(0, 3), dirs)[1].shape == (0, 69)
+
+
+def test_plain_nerf_training_step_is_the_same_with_and_without_the_rows_kernels(ops, monkeypatch):
+    """PlainNeRF(view) loss and every gradient: the round-6 path (HashInitFn + PlainHeadFn + forward_rows) against the chain of cats and
+    slice copies it replaces (NA_TRAIN_ROWS=0), deterministic accumulation: bit for bit."""
+    import nerf_atlas_amd as na
+    import nerf_atlas_amd.nerf  # noqa: F401
+    from nerf_atlas_amd import config
+    h = load_golden("g11_plain_view_b2")
+    m = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").cuda().eval()
+    sd = m.state_dict()
+    for k, v in golden_params(h).items():
+        sd[k].copy_(v)
+    rays = h["rays"].cuda().repeat(1, 8, 8, 1)   # 2 x 48 x 48 rays x 16 steps = 73 728 samples: the fused training kernels' batch class
+    target = torch.from_numpy(proc_uniform(tuple(rays.shape[:-1]) + (3,), 98, 0.5)).cuda() + 0.5
+    config.set_deterministic(True)
+    prev = config.train_precision
+    config.set_train_precision("bf16x3")
+    try:
+        res = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("NA_TRAIN_ROWS", flag)
+            m.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.mse_loss(m(rays), target)
+            loss.backward()
+            res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+        assert torch.equal(res[0][0], res[1][0]) and res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 30
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
+    finally:
+        config.set_deterministic(False)
+        config.set_train_precision(prev)

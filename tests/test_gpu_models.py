@@ -51,6 +51,9 @@ def maxdiff(a, b):
     return float((a.detach().cpu() - b).abs().max())
 
 
+WEIGHTS_BAR = 2e-4  # VolSDF's compositing weights (tests below print the measured value)
+
+
 @pytest.mark.parametrize("kind", ["view", "pos", "pos-linear-view"])
 @pytest.mark.parametrize("B", [1, 2])
 def test_plain_nerf(na, kind, B):
@@ -191,8 +194,9 @@ def test_volsdf(na, kind):
     load_params(m, golden_params(h))
     out = m(h["rays"].cuda())
     # the Fourier-encoded SDF MLP inherits ~1e-4 feature-level fp32 noise; RGB stays within 1e-4
+    print(f"\n[volsdf-{kind} bf16x3] RGB vs the reference {maxdiff(out, h['out']):.2e}, weights {maxdiff(m.weights, h['weights']):.2e}")
     assert maxdiff(out, h["out"]) <= 1e-4
-    assert maxdiff(m.weights, h["weights"]) <= 2e-4
+    assert maxdiff(m.weights, h["weights"]) <= WEIGHTS_BAR
     assert float(m.scale_post_act) == pytest.approx(0.1)
 
 
@@ -672,7 +676,7 @@ def test_volsdf_mlp_f16x_sdf_network_on_the_ls_engine(na):
         out = m(h["rays"].cuda())
         print(f"\\n[volsdf-mlp f16x] RGB vs the reference {maxdiff(out, h['out']):.2e}, weights {maxdiff(m.weights, h['weights']):.2e}")
         assert maxdiff(out, h["out"]) <= 1e-4
-        assert maxdiff(m.weights, h["weights"]) <= 2e-4
+        assert maxdiff(m.weights, h["weights"]) <= WEIGHTS_BAR
         basis = under.mlp.enc.basis.data
         cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1.0]]]),
                                     focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()

@@ -277,7 +277,7 @@ def test_fused_backward_vs_fp64_and_vs_the_two_launch_path(ops, shape, act):
     assert torch.equal(g0, g0b) and torch.equal(dW[:, :in0], dWb[:, :in0]) and torch.equal(db, dbb)
 
 
-@pytest.mark.parametrize("in1", [0, 38, 69, 259])
+@pytest.mark.parametrize("in1", [0, 38, 69, 134, 200, 259])  # (134, 200: the 129..256-column second source, ADVICE r05 -- weight gradient by columns + packed input gradient with only g_x1 requested)
 def test_linear_fn_backward_through_the_fused_kernel_vs_fp64(ops, in1):
     """autograd.LinearFn with packed operands: a 256 wide first source takes the one-pass backward, its narrow second source
     (a skip layer's [256 | 38], [256 | 69]) the narrow kernels; a second source wider than 256 (the Fourier SDF network's skip)

@@ -17,8 +17,8 @@ def main():
         i = argv.index("--prec"); prec = tuple(argv[i + 1].split(",")); del argv[i:i + 2]
     if "--iters" in argv:
         i = argv.index("--iters"); iters = int(argv[i + 1]); del argv[i:i + 2]
-    rows, secs = bench.other_configs(torch.device("cuda", 0), precisions=prec, iters=iters, only=set(argv) or None)
-    for r in rows:
+    rows, secs, outside = bench.other_configs(torch.device("cuda", 0), precisions=prec, iters=iters, only=set(argv) or None)
+    for r in rows + outside:
         r.pop("kernels", None)
         print(json.dumps(r))
 

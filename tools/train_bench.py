@@ -27,11 +27,13 @@ def main():
     c2w = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]], device=dev)
     m = nerf.PlainNeRF(steps=a.steps, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted").to(dev)
     m.eval()  # deterministic sampling; gradients still flow (training noise terms are plumbing)
-    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    import types
+    from nerf_atlas_amd import train
+    opt = train.load_optim(types.SimpleNamespace(opt_kind="adam", learning_rate=2e-4, decay=0), m.parameters())  # (the product's Adam)
     target = torch.rand(1, a.crop, a.crop, 3, device=dev)
     losses = []
     def step():
-        rays = ops.raygen(c2w, focal, size, (368, 368, a.crop, a.crop))
+        rays = ops.raygen(c2w, focal, size, ((size - a.crop) // 2, (size - a.crop) // 2, a.crop, a.crop))
         opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.mse_loss(m(rays), target)
         loss.backward()
@@ -49,7 +51,7 @@ def main():
     if a.cpu_oracle:
         import oracle as O
         p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
-        rays = O.nerf_camera_rays(O.pixel_grid(size, (368, 368, a.crop, a.crop)), c2w.cpu(), focal, size)
+        rays = O.nerf_camera_rays(O.pixel_grid(size, ((size - a.crop) // 2, (size - a.crop) // 2, a.crop, a.crop)), c2w.cpu(), focal, size)
         tgt = target.cpu()
         t0 = time.perf_counter()
         loss = torch.nn.functional.mse_loss(O.plain_nerf(p, rays, 2.0, 6.0, a.steps, "view", act="upshifted"), tgt)
