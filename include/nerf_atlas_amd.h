@@ -389,6 +389,14 @@ int na_hash_encode_backward_input_rows(const float* x, int64_t N, const float* t
                                        int include_input, int lead, float* g_x, void* stream);
 int na_plain_head_rows_backward(const float* g_density, const float* g_rows, int64_t N, int C, float* g_first_out, float* g_pts,
                                 void* stream);
+/* The optimiser step of runner.py:448-458 (optim.Adam(params, lr, eps = 1e-7); amsgrad / maximize / weight decay off) for n tensors
+ * by ONE launch: per element the operations of torch's foreach Adam in its order and rounding (fma_mask: which of its three
+ * multiply-adds ATen contracts -- bit 0 lerp, bit 1 addcmul, bit 2 addcdiv; nerf_atlas_amd/train.py holds the value pinned against
+ * torch bit for bit).  params / grads / exp_avg / exp_avg_sq: HOST arrays of n device pointers, numel[n]; the scalars as torch's
+ * Python computes them in double: 1 - beta1, beta2, 1 - beta2, sqrt(1 - beta2^t), eps, -lr / (1 - beta1^t). */
+int na_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int64_t* numel, double one_minus_beta1, double beta2, double one_minus_beta2, double bias_correction2_sqrt,
+                 double eps, double neg_step_size, int fma_mask, void* stream);
 /* Forward-mode derivative of the hash features along a per-point direction e (the deformation network's input
  * Jacobian-vector product that the FFJORD divergence estimate needs: runner.py:697-700, src/utils.py:467-478;
  * src/neural_blocks.py:166-190 is what is differentiated).

@@ -48,6 +48,8 @@ SIGNATURES = {
     "na_hash_encode_backward_rows": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "na_hash_encode_backward_input_rows": (C.c_int, [c_f32p, c_i64, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "na_plain_head_rows_backward": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, C.c_void_p]),
+    "na_adam_step": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                               C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "na_sigmoid": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "na_mip_encode": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_float, C.c_int,
                                 C.c_int, c_f32p, C.c_void_p]),

@@ -526,6 +526,61 @@ __global__ void plain_head_rows_backward_kernel(const float* __restrict__ g_dens
   }
 }
 
+// ------------------------------------------------------------------------------------ Adam (round 6)
+// torch.optim.Adam's default (foreach) update -- runner.py:448-458 builds optim.Adam(params, lr, eps = 1e-7, weight_decay) -- is
+// seven multi-tensor launches per step (lerp, mul, addcmul, sqrt, div, add, addcdiv: ~0.13 ms for PlainNeRF's 2.9 M parameters, a
+// read-modify-write of the same 35 MB each).  Here ONE launch over all tensors with the SAME per-element operations in the same
+// order, each rounded like the corresponding ATen kernel rounds it -- which of them contract a multiply-add (the ATen kernels are
+// compiled with contraction on) is the `fma` mask, pinned bit for bit against torch by tests/test_gpu_train.py:
+//   m = m + w (g - m)                  w = 1 - beta1              (bit 0: one fma)
+//   v = v beta2;  v = v + c (g g)      c = 1 - beta2              (bit 1: one fma; g g rounded first -- tools/adam_probe.py)
+//   d = sqrt(v) / sqrt(1 - beta2^t) + eps
+//   p = p + a (m / d)                  a = -lr / (1 - beta1^t)     (bit 2: one fma)
+// The scalars arrive as the doubles torch's Python computes and are rounded to float like ATen's opmath conversion does.
+constexpr int kAdamMany = 48;
+struct AdamMany {
+  float* p[kAdamMany];
+  const float* g[kAdamMany];
+  float* m[kAdamMany];
+  float* v[kAdamMany];
+  int first[kAdamMany + 1];   // first block of tensor e (a block = 1024 elements)
+  int64_t numel[kAdamMany];
+  int n, fma;
+  float w, beta2, c, bc2_sqrt, eps, a;
+};
+__global__ __launch_bounds__(256) void adam_many_kernel(AdamMany t) {
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;   // (<= 48 entries: a scalar walk)
+  const int64_t i0 = ((int64_t)blockIdx.x - t.first[e]) * 1024 + threadIdx.x * 4;
+  const int64_t n = t.numel[e];
+  float* __restrict__ P = t.p[e];
+  const float* __restrict__ G = t.g[e];
+  float* __restrict__ M = t.m[e];
+  float* __restrict__ V = t.v[e];
+  auto one = [&](float& p, float g, float& m, float& v) __attribute__((always_inline)) {
+    const float diff = g - m;
+    m = (t.fma & 1) ? fmaf(t.w, diff, m) : m + t.w * diff;
+    v = v * t.beta2;
+    const float gg = g * g;
+    v = (t.fma & 2) ? fmaf(t.c, gg, v) : v + t.c * gg;
+    const float d = sqrtf(v) / t.bc2_sqrt + t.eps;
+    const float q = m / d;
+    p = (t.fma & 4) ? fmaf(t.a, q, p) : p + t.a * q;
+  };
+  if (i0 + 4 <= n && ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0)) {
+    float4 p = *(const float4*)(P + i0), m = *(const float4*)(M + i0), v = *(const float4*)(V + i0);
+    const float4 g = *(const float4*)(G + i0);
+    one(p.x, g.x, m.x, v.x); one(p.y, g.y, m.y, v.y); one(p.z, g.z, m.z, v.z); one(p.w, g.w, m.w, v.w);
+    *(float4*)(P + i0) = p; *(float4*)(M + i0) = m; *(float4*)(V + i0) = v;
+  } else {
+    for (int64_t i = i0; i < i0 + 4 && i < n; ++i) {
+      float p = P[i], m = M[i], v = V[i];
+      one(p, G[i], m, v);
+      P[i] = p; M[i] = m; V[i] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ compositing backward
 // Forward (src/nerf.py:60-80,96-98): a_t = 1-exp(-sigma_t*dist_t), f_t = (1-a_t)+1e-10, T_t = prod_{s<t} f_s,
 // w_t = a_t*T_t, out_c = sum_t w_t*c_tc + sky.  With G_t = dL/dw_t = sum_c g_c*c_tc (- sum_c g_c for the white sky,
@@ -800,6 +855,37 @@ int na_plain_head_rows_backward(const float* g_density, const float* g_rows, int
     hipLaunchKernelGGL(plain_head_rows_backward_kernel<int64_t>, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
                        g_density, g_rows, N, C, g_first_out, g_pts);
   return check_launch("na_plain_head_rows_backward");
+}
+
+int na_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int64_t* numel, double one_minus_beta1, double beta2, double one_minus_beta2, double bias_correction2_sqrt,
+                 double eps, double neg_step_size, int fma_mask, void* stream) {
+  NA_REQUIRE(n >= 0, NA_EINVAL, "na_adam_step: n %d", n);
+  if (n == 0) return NA_OK;
+  NA_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, NA_ENULL, "na_adam_step: null pointer");
+  for (int base = 0; base < n; base += kAdamMany) {
+    AdamMany t{};
+    t.n = 0;
+    int blocks = 0;
+    for (int i = base; i < n && t.n < kAdamMany; ++i) {
+      NA_REQUIRE(numel[i] >= 0, NA_EINVAL, "na_adam_step: numel[%d] = %lld", i, (long long)numel[i]);
+      if (numel[i] == 0) continue;
+      NA_REQUIRE(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i], NA_ENULL, "na_adam_step: tensor %d has a null pointer", i);
+      const int e = t.n++;
+      t.p[e] = params[i]; t.g[e] = grads[i]; t.m[e] = exp_avg[i]; t.v[e] = exp_avg_sq[i]; t.numel[e] = numel[i];
+      t.first[e] = blocks;
+      const int64_t nb = (numel[i] + 1023) / 1024;
+      NA_REQUIRE(blocks + nb < (1ll << 30), NA_EINVAL, "na_adam_step: too many elements");
+      blocks += (int)nb;
+    }
+    t.first[t.n] = blocks;
+    if (t.n == 0) continue;
+    t.fma = fma_mask;
+    t.w = (float)one_minus_beta1; t.beta2 = (float)beta2; t.c = (float)one_minus_beta2; t.bc2_sqrt = (float)bias_correction2_sqrt;
+    t.eps = (float)eps; t.a = (float)neg_step_size;
+    hipLaunchKernelGGL(adam_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  return check_launch("na_adam_step");
 }
 
 int na_hash_encode_backward_input(const float* x, int64_t N, const float* tables, const float* g_out,

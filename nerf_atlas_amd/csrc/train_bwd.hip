@@ -39,6 +39,9 @@
 #include "train_shared.h"
 
 namespace na {
+#ifndef TBW_EXP
+#define TBW_EXP 0     // experiments: 1 non-temporal stores of g_x, 2 non-temporal row fetches
+#endif
 #ifndef TBW_ABLATE
 #define TBW_ABLATE 0  // timing experiments: 1 no row fetches, 2 no convert / LDS fill, 4 no MFMAs, 8 no g_x stores, 16 no partials
 #endif
@@ -123,13 +126,13 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       // ONE 16-byte load per piece whatever the row length: raw-buffer loads of 16 bytes need only 4-byte alignment and are
       // range-checked per dword (profiles/r03/unaligned_probe.log); a piece that crosses the end of its row (65, 3 columns) brings
       // elements of the NEXT row along, which the conversion zeroes (og[1..3] keep the per-element validity)
-      gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, 0));
+      gs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, og[0], 8 * j * g.out * 4, (TBW_EXP & 2) ? 2 : 0));
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       // (one 16-byte load per piece here too; the elements of the next row a piece of a 38 / 69 wide source brings along are
       // zeroed at conversion.  The STORES of such a source stay dwords: a 16-byte store across the row end would clobber.)
-      xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, oxe[0], 16 * j * g.ldx * 4, 0));
+      xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, oxe[0], 16 * j * g.ldx * 4, (TBW_EXP & 2) ? 2 : 0));
     }
     if constexpr (!FULL) {  // the addend of the stage that is FINISHED in the next step (this fetch is for stage st = step + 2, the
       // next step finishes stage step = st - 2); no pointer: an empty buffer, zeros
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       }
       // (the row step in the VECTOR offset, soffset 0: with an SGPR soffset the compiler inserts no wait between a 16-byte store
       // and a VALU write of its data registers, and gfx950 needs one -- build.check_store_data_overwrite, tools/hw/store_soffset_hazard.hip)
-      if constexpr (XA) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, oxe[0] + (uint32_t)(16 * j * g.ldx * 4), 0, 0);
+      if constexpr (XA) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, oxe[0] + (uint32_t)(16 * j * g.ldx * 4), 0, (TBW_EXP & 1) ? 2 : 0);
       else {
         const u32x4 u = __builtin_bit_cast(u32x4, v);  // (the whole vector: a bit cast of v[e] in an unrolled loop reads element 0 four times)
 #pragma unroll

@@ -26,6 +26,9 @@ namespace na {
 #ifndef TFW_ABLATE
 #define TFW_ABLATE 0  // timing experiments: 1 no row fetches, 2 no convert / LDS fill, 4 no MFMAs, 8 no stores
 #endif
+#ifndef TFW_EXP
+#define TFW_EXP 0     // experiments: 1 non-temporal stores of y, 2 non-temporal row fetches, 4 finish AFTER convert + fetch (MODE 0), 8 unconditional second half
+#endif
 namespace lsfw {
 constexpr int SS = 32;                  // samples per stage
 constexpr int KMAX = 336;               // 256 + 80
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     if constexpr (X0) {
       const __amdgpu_buffer_rsrc_t r0s = stage_rsrc(g.x0, 256, st);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0s, o0, 8 * j * 256 * 4, 0));
+      for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0s, o0, 8 * j * 256 * 4, (TFW_EXP & 2) ? 2 : 0));
     }
     if constexpr (X1) {
       const __amdgpu_buffer_rsrc_t r1s = stage_rsrc(g.x1, g.in1, st);
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += bias4[e];
       // (row step in the vector offset, soffset 0: build.check_store_data_overwrite, tools/hw/store_soffset_hazard.hip)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, o0 + (uint32_t)(8 * j * 256 * 4), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, o0 + (uint32_t)(8 * j * 256 * 4), 0, (TFW_EXP & 1) ? 2 : 0);
     }
   };
 
@@ -220,18 +223,24 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     __syncthreads();
     for (int s = 0; s < nst; s += 2) {
       if (mfirst) { mma(smem, otile); __builtin_amdgcn_sched_barrier(0); }
-      finish(s - 1);
+      if (!(TFW_EXP & 4)) finish(s - 1);
       convert(a1, b1, smem + G::STAGE);
       load(a1, b1, s + 3);
       __builtin_amdgcn_sched_barrier(0);  // (the scheduler sinks the fetches below the MFMAs otherwise)
+      if (TFW_EXP & 4) { finish(s - 1); __builtin_amdgcn_sched_barrier(0); }
       if (!mfirst) mma(smem, otile);
       __syncthreads();
-      if (s + 1 < nst) {
+      // (round 6) the second half is UNCONDITIONAL: a stage past the slice fetches from an empty buffer and its stores are dropped.
+      // Under `if (s + 1 < nst)` the control-flow graph had a path half A -> half A, and the compiler's waitcnt insertion, which
+      // must hold on every path, waited for this half's fetches with vmcnt(7) instead of vmcnt(15): every fetch had to be back
+      // ONE stage after its issue, not two -- fetch time and compute time added up (ablations: 49 + 67 us of 132)
+      if ((TFW_EXP & 8) || s + 1 < nst) {
         if (mfirst) { mma(smem + G::STAGE, otile + OT); __builtin_amdgcn_sched_barrier(0); }
-        finish(s);
+        if (!(TFW_EXP & 4)) finish(s);
         convert(a0, b0, smem);
         load(a0, b0, s + 4);
         __builtin_amdgcn_sched_barrier(0);
+        if (TFW_EXP & 4) { finish(s); __builtin_amdgcn_sched_barrier(0); }
         if (!mfirst) mma(smem + G::STAGE, otile + OT);
         __syncthreads();
       }
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       __builtin_amdgcn_sched_barrier(0);
       if (!mfirst) mma(smem, otile);
       __syncthreads();
-      if (s + 1 < nst) {
+      if ((TFW_EXP & 8) || s + 1 < nst) {
         if (mfirst) { mma(smem + G::STAGE, otile + OT); __builtin_amdgcn_sched_barrier(0); }
         finish(s);
         convert(a0, b0, smem);
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
       }
     }
   }
-  finish(nst - 1);
+  if (!(TFW_EXP & 8) || !(nst & 1)) finish(nst - 1);  // (TFW_EXP & 8, an odd count: the unconditional second half of the last iteration has stored stage nst - 1)
 }
 
 // NA_TRAIN_FUSED_FWD=0: never (the streaming kernel lsnt::kernel<0> for A/B runs).

@@ -632,6 +632,22 @@ def train_reduce_many(entries):
         _stream()))
 
 
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, one_minus_beta1: float, beta2: float, one_minus_beta2: float,
+              bias_correction2_sqrt: float, eps: float, neg_step_size: float, fma_mask: int):
+    """torch's foreach Adam update of every tensor by ONE launch (na_adam_step): lists of contiguous fp32 device tensors."""
+    lib = _lib.load()
+    n = len(params)
+    if n == 0:
+        return
+    for t in (*params, *grads, *exp_avgs, *exp_avg_sqs):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("adam_step: contiguous fp32 device tensors only")
+    vp, ip = C.c_void_p * n, C.c_int64 * n
+    check(lib.na_adam_step(n, vp(*[t.data_ptr() for t in params]), vp(*[t.data_ptr() for t in grads]), vp(*[t.data_ptr() for t in exp_avgs]),
+                           vp(*[t.data_ptr() for t in exp_avg_sqs]), ip(*[t.numel() for t in params]), float(one_minus_beta1), float(beta2),
+                           float(one_minus_beta2), float(bias_correction2_sqrt), float(eps), float(neg_step_size), int(fma_mask), _stream()))
+
+
 def linear_wgrad_cols(x: torch.Tensor, dY: torch.Tensor, pre_act: str, dW: torch.Tensor, col0: int):
     """dW[:, col0:col0 + x.shape[1]] = dY^T . act(x) WRITTEN (na_linear_wgrad_bf16x3_cols): one source of a concatenated input."""
     lib = _lib.load()

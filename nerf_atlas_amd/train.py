@@ -116,17 +116,73 @@ def load_loss_fn(args):
     return lambda x, ref: sum(fn(x, ref) for fn in fns) / len(fns)
 
 
+class NaAdam(torch.optim.Adam):
+    """torch.optim.Adam whose step is ONE kernel (na_adam_step) for the parameter groups it fits: fp32 contiguous device tensors with
+    dense gradients, no amsgrad / maximize / weight decay / capturable / differentiable -- per element exactly the operations of
+    torch's foreach implementation (torch/optim/adam.py::_multi_tensor_adam) in its order, each rounded like the ATen kernel rounds it
+    (FMA_MASK: which multiply-adds ATen contracts).  Same state (`step`, `exp_avg`, `exp_avg_sq`): state_dicts interchange with
+    torch.optim.Adam.  Any other group takes torch's own step."""
+    FMA_MASK = 7
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import ops
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            ok = (not group.get("amsgrad") and not group.get("maximize") and group.get("weight_decay", 0) == 0
+                  and not group.get("capturable") and not group.get("differentiable") and not group.get("fused")
+                  and not isinstance(group["lr"], torch.Tensor)
+                  and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and not p.grad.is_sparse
+                          and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in ps))
+            if not ok or not ps:
+                self._torch_group_step(group)
+                continue
+            beta1, beta2 = group["betas"]
+            exp_avgs, exp_avg_sqs, steps = [], [], []
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:  # (torch.optim.Adam._init_group's state)
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                steps.append(float(st["step"]))
+                exp_avgs.append(st["exp_avg"])
+                exp_avg_sqs.append(st["exp_avg_sq"])
+            # one launch per distinct step count (parameters that joined later): the scalars as torch's Python computes them
+            for t in sorted(set(steps)):
+                idx = [i for i, s in enumerate(steps) if s == t]
+                bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+                ops.adam_step([ps[i] for i in idx], [ps[i].grad for i in idx], [exp_avgs[i] for i in idx], [exp_avg_sqs[i] for i in idx],
+                              1 - beta1, beta2, 1 - beta2, bc2 ** 0.5, group["eps"], (group["lr"] / bc1) * -1, self.FMA_MASK)
+        return loss
+
+    def _torch_group_step(self, group):
+        """torch.optim.Adam.step for ONE group (a group the kernel does not fit)"""
+        keep = self.param_groups
+        try:
+            self.param_groups = [group]
+            torch.optim.Adam.step(self)
+        finally:
+            self.param_groups = keep
+
+
 def load_optim(args, params):
     """runner.py:448-458."""
     if args.opt_kind != "adam":
         raise NotImplementedError(f"opt kind {args.opt_kind}")
     params = list(params)
-    # torch's default (foreach) Adam like the reference's (runner.py:448-458).  NA_ADAM_FUSED=1 selects torch's fused one-kernel form
-    # (seven launches -> one, ~0.1 ms per step of PlainNeRF's 2.9 M parameters) -- opt-in: its update rounds differently, and the
-    # `--dyn-diverge-decay` recipe, whose end point measures accumulation precision (tests/test_gpu_train.py), leaves the reference's
-    # basin with it (14.3 / 17.6 / 13.9 dB against 17.1 / 22.2 / 17.6; profiles/r06/adam_fused_dnerf_div.log)
-    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get("NA_ADAM_FUSED") == "1"
-    return torch.optim.Adam(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay, **({"fused": True} if fused else {}))
+    # torch.optim.Adam's update (runner.py:448-458) as ONE launch where every parameter lives on the GPU (NaAdam below: the foreach
+    # form's operations, order and rounding -- bit for bit the same trajectory, tests/test_gpu_train.py); NA_ADAM=torch keeps
+    # torch's own seven launches.  (torch's `fused=True` is NOT used: its update rounds differently and the `--dyn-diverge-decay`
+    # recipe, whose end point measures accumulation precision, leaves the reference's basin with it --
+    # profiles/r06/adam_fused_dnerf_div.log.)
+    cls = NaAdam if os.environ.get("NA_ADAM") != "torch" else torch.optim.Adam
+    return cls(params, lr=args.learning_rate, eps=1e-7, weight_decay=args.decay)
 
 
 def offset_decay_term(model, curr_percent: float):

@@ -311,3 +311,63 @@ def test_f16x_fourier_sdf_schedule_on_self_trained_weights(tmp_path):
           f"oracle {err:.2e}; test PSNR {np.round(px, 2).tolist()}")
     assert torch.isfinite(frames[0]).all() and err <= 1e-4, err
     assert dpx.max() <= 0.01, (px, res["test_psnr"])
+
+
+def test_one_launch_adam_is_torch_foreach_adam_bit_for_bit():
+    """train.NaAdam (na_adam_step: ONE launch per step) against torch.optim.Adam's default foreach implementation: the same
+    parameters, moments and step counts after every one of 12 steps, bit for bit -- tensors of 1 .. 262 144 elements (ragged
+    tails, a 1-element bias), gradients over eight orders of magnitude, a changing learning rate, a parameter that only gets
+    its gradient from step 4 on (its own step count), state_dict interchange.  Prints which contraction masks reproduce torch."""
+    import nerf_atlas_amd.train as T
+    torch.manual_seed(11)
+    shapes = [(256, 256), (65,), (1,), (8, 65536, 4)[1:], (256, 294), (3, 256), (19,), (1023,), (1025,)]
+
+    def make():
+        torch.manual_seed(12)
+        return [torch.nn.Parameter(torch.randn(*s, device="cuda") * 0.1) for s in shapes]
+
+    def grads(step):
+        g = torch.Generator(device="cuda").manual_seed(100 + step)
+        return [torch.randn(*s, device="cuda", generator=g) * (10.0 ** ((i % 9) - 6)) for i, s in enumerate(shapes)]
+
+    def run(opt_cls, ps, **kw):
+        opt = opt_cls(ps, lr=5e-4, eps=1e-7, **kw)
+        for step in range(12):
+            for i, (p, g) in enumerate(zip(ps, grads(step))):
+                p.grad = None if (i == 1 and step < 4) else g
+            if step == 6:
+                opt.param_groups[0]["lr"] = 2e-4
+            opt.step()
+        return opt
+
+    ref_p = make()
+    ref = run(torch.optim.Adam, ref_p, foreach=True)
+    matching = []
+    for mask in range(8):
+        T.NaAdam.FMA_MASK, keep = mask, T.NaAdam.FMA_MASK
+        try:
+            ps = make()
+            opt = run(T.NaAdam, ps)
+        finally:
+            T.NaAdam.FMA_MASK = keep
+        same = all(torch.equal(a, b) for a, b in zip(ps, ref_p)) and all(
+            torch.equal(opt.state[a][k], ref.state[b][k]) for a, b in zip(ps, ref_p) for k in ("exp_avg", "exp_avg_sq"))
+        if same:
+            matching.append(mask)
+    print(f"\n[adam] contraction masks that reproduce torch's foreach Adam bit for bit: {matching}; pinned: {T.NaAdam.FMA_MASK}")
+    assert T.NaAdam.FMA_MASK in matching, matching
+    ps = make()
+    opt = run(T.NaAdam, ps)
+    assert all(float(opt.state[a]["step"]) == float(ref.state[b]["step"]) for a, b in zip(ps, ref_p))
+    # state_dicts interchange
+    ref2 = torch.optim.Adam(make(), lr=5e-4, eps=1e-7)
+    ref2.load_state_dict(opt.state_dict())
+    opt2 = T.NaAdam(make(), lr=5e-4, eps=1e-7)
+    opt2.load_state_dict(ref.state_dict())
+    # weight decay: torch's own step for that group (same class, same results as torch)
+    pa, pb = make(), make()
+    oa, ob = T.NaAdam(pa, lr=5e-4, eps=1e-7, weight_decay=0.01), torch.optim.Adam(pb, lr=5e-4, eps=1e-7, weight_decay=0.01)
+    for p, q, g in zip(pa, pb, grads(0)):
+        p.grad, q.grad = g, g.clone()
+    oa.step(); ob.step()
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
