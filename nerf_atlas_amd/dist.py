@@ -19,6 +19,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = os.environ.get("NA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            # one rank per GPU: a visibility subset shorter than the job (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set by a driver)
+            # ends THIS rank here, before the rendezvous, with the reason -- the launcher (torchrun, bench.py's own spawner) then
+            # takes the other ranks down instead of leaving them in a rendezvous that can never complete
+            ndev = torch.cuda.device_count()
+            if local >= ndev:
+                vis = {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if k in os.environ}
+                raise SystemExit(f"[nerf_atlas_amd.dist] rank {rank} needs GPU {local} but only {ndev} are visible ({vis or 'no visibility variables set'}): "
+                                 f"one rank per GPU with backend nccl (= RCCL); NA_DIST_BACKEND=gloo shares GPUs between ranks for flow tests")
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

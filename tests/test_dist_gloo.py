@@ -161,3 +161,19 @@ def test_world2_gradient_allreduce_and_batch_shards():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert all(res), res
+
+
+def test_a_visibility_subset_shorter_than_the_job_ends_the_rank_before_the_rendezvous(monkeypatch):
+    """a driver-set HIP_VISIBLE_DEVICES shorter than N must give the "needs GPU k but only n are visible"
+    exit, not a hang at the rendezvous: init_from_env checks before it touches the device or the process group."""
+    import pytest
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    from nerf_atlas_amd import dist as nd
+    for k, v in dict(RANK="3", WORLD_SIZE="4", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1", HIP_VISIBLE_DEVICES="0,1").items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        nd.init_from_env(backend="nccl")
+    assert "rank 3 needs GPU 3 but only 2 are visible" in str(e.value) and "HIP_VISIBLE_DEVICES" in str(e.value)
+    assert not dist.is_initialized()

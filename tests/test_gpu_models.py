@@ -51,7 +51,10 @@ def maxdiff(a, b):
     return float((a.detach().cpu() - b).abs().max())
 
 
-WEIGHTS_BAR = 2e-4  # VolSDF's compositing weights (tests below print the measured value)
+# VolSDF's compositing weights: north_star's 1e-4 like the colour (round 6; was 2e-4).  Measured against the reference's g10:
+# 3.7e-5 (Fourier-MLP SDF) / 5.5e-5 (SIREN) in bf16x3 -- larger than the colour's 1.5e-5 because the density is
+# 1/beta x laplace_cdf(-sdf / beta) with beta = 0.1: an SDF error e becomes a density error of up to e / (2 beta^2) = 50 e.
+WEIGHTS_BAR = 1e-4
 
 
 @pytest.mark.parametrize("kind", ["view", "pos", "pos-linear-view"])
@@ -674,7 +677,7 @@ def test_volsdf_mlp_f16x_sdf_network_on_the_ls_engine(na):
     try:
         assert m._fusable_fourier_sdf()
         out = m(h["rays"].cuda())
-        print(f"\\n[volsdf-mlp f16x] RGB vs the reference {maxdiff(out, h['out']):.2e}, weights {maxdiff(m.weights, h['weights']):.2e}")
+        print(f"\n[volsdf-mlp f16x] RGB vs the reference {maxdiff(out, h['out']):.2e}, weights {maxdiff(m.weights, h['weights']):.2e}")
         assert maxdiff(out, h["out"]) <= 1e-4
         assert maxdiff(m.weights, h["weights"]) <= WEIGHTS_BAR
         basis = under.mlp.enc.basis.data
