@@ -201,6 +201,9 @@ __device__ __forceinline__ float wave_total_lane63(float x) {
 #ifndef HB_MAXWG
 #define HB_MAXWG 512  // workgroups per level (tools/hash_bwd_run.py, N = 262 144: 128 -> 173.9 us, 256 -> 157.0, 512 -> 144.6, 1024 -> 146.6; 64 -> 280)
 #endif
+#ifndef HB_ABLATE
+#define HB_ABLATE 0   // timing experiments: 1 no main loop, 2 no flush of the LDS table, 4 no LDS adds (leader rounds only)
+#endif
 constexpr int HB_ROWS = 1024;
 __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restrict__ x, int64_t N,
                                                             const float* __restrict__ g_out, int include_input,
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
   };
   const int64_t per = ((N + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;  // samples of this workgroup: whole rounds
   const int64_t n_lo = blockIdx.x * per, n_hi = n_lo + per < N ? n_lo + per : N;
-  for (int64_t base = n_lo; base < n_hi; base += 256) {
+  for (int64_t base = n_lo; base < ((HB_ABLATE & 1) ? n_lo : n_hi); base += 256) {
     const int64_t n = base + threadIdx.x;
     const bool live = n < n_hi;
     float wx = 0.f, wy = 0.f, wz = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
@@ -278,14 +281,14 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(const float* __restr
         const bool mine = todo && id == lid;
         const float s0 = wave_total_lane63(mine ? a0 : 0.f), s1 = wave_total_lane63(mine ? a1 : 0.f);
         const float s2 = wave_total_lane63(mine ? a2 : 0.f), s3 = wave_total_lane63(mine ? a3 : 0.f);
-        if ((threadIdx.x & 63) == 63) add_row(lid, s0, s1, s2, s3);
+        if ((threadIdx.x & 63) == 63 && !((HB_ABLATE & 4) && s0 != 1.2345f)) add_row(lid, s0, s1, s2, s3);
         todo = todo && !mine;
       }
       if (todo) add_row(id, a0, a1, a2, a3);
     }
   }
   __syncthreads();
-  for (int row = threadIdx.x; row < HB_ROWS; row += 256) {
+  for (int row = threadIdx.x; row < ((HB_ABLATE & 2) ? 0 : HB_ROWS); row += 256) {
     const uint32_t id = tags[row];
     if (id == 0xffffffffu) continue;
 #pragma unroll

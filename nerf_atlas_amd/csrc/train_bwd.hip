@@ -215,10 +215,15 @@ __global__ __launch_bounds__(512) void kernel(Args g) {
     const int T = 4 * h + wave;  // 32-column tile of W^T's rows (= input columns)
     bf16x8 bh[16], bl[16];
     {
-      const char* base = g.wp + (size_t)(T >> 1) * (2 * 2 * lsnt::SEG) + lane * 16;
+      // (round 6) a narrow source's W^T has ceil(in / 64) row groups in the packed stream: a wave whose 32-column tile lies past
+      // the source (it idles below: nks = 0) must not fetch "its" fragments -- they are past the end of the stream, a plain
+      // global read that faulted once the allocation behind the stream was unmapped (in0 = 64 / 38: waves 2, 3).  Such waves
+      // read the first tile's fragments (valid memory, never used).
+      const int Tl = (FULL || 32 * wave < g.in) ? T : 0;
+      const char* base = g.wp + (size_t)(Tl >> 1) * (2 * 2 * lsnt::SEG) + lane * 16;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const char* f = base + (size_t)(((ks >> 3) * 2 + (T & 1)) * 8 + (ks & 7)) * 2048;
+        const char* f = base + (size_t)(((ks >> 3) * 2 + (Tl & 1)) * 8 + (ks & 7)) * 2048;
         bh[ks] = *(const bf16x8*)f;
         bl[ks] = *(const bf16x8*)(f + 1024);
       }
