@@ -633,22 +633,30 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   };
   // raw rows of a K64 group (the lane's 32 accumulator values) parked in global memory: slot `slot` of block b of this sample group.
   // Written and read by waves of ONE workgroup with a workgroup barrier in between (L2-resident: 32 KiB per workgroup).
-  auto park_ptr = [&](int b, int slot) -> float* {
-    return a.park + ((((int64_t)blockIdx.x * 2 + g) * 2 + b) * kParkSlots + slot) * 2048 + lane * 4;
+  // (round 6: through a buffer resource -- a uniform base, the slot's byte offset in an SGPR, 16 bytes x lane in the vector offset.
+  // As plain global accesses every (block, slot) combination was a per-lane 64-bit pointer that the compiler hoisted out of the
+  // pass loop and spilled: 10 of MODEL 8's reloads per pass)
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)a.park, 0, a.park != nullptr ? (int)kParkBytes : 0, 0x00020000);
+  auto park_soff = [&](int b, int slot) -> uint32_t {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(((((uint32_t)blockIdx.x * 2 + g) * 2 + b) * kParkSlots + slot) * 8192u));
   };
   auto park_store = [&](int b, int slot, const f32x16& v0, const f32x16& v1) {
-    float* p = park_ptr(b, slot);
+    // (the slot offset in the VECTOR offset, soffset 0: a 16-byte store with an SGPR soffset is the store-data hazard of DESIGN 3d)
+    const uint32_t vo = (uint32_t)lane * 16 + park_soff(b, slot);
+    typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *(f32x4*)(p + j * 256) = f32x4{v0[4 * j], v0[4 * j + 1], v0[4 * j + 2], v0[4 * j + 3]};
-      *(f32x4*)(p + (4 + j) * 256) = f32x4{v1[4 * j], v1[4 * j + 1], v1[4 * j + 2], v1[4 * j + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, f32x4{v0[4 * j], v0[4 * j + 1], v0[4 * j + 2], v0[4 * j + 3]}), prs, vo + j * 1024, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, f32x4{v1[4 * j], v1[4 * j + 1], v1[4 * j + 2], v1[4 * j + 3]}), prs, vo + (4 + j) * 1024, 0, 0);
     }
   };
   auto park_load = [&](int b, int slot, f32x16& v0, f32x16& v1) {
-    const float* p = park_ptr(b, slot);
+    const uint32_t vo = (uint32_t)lane * 16 + park_soff(b, slot);
+    typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 u = *(const f32x4*)(p + j * 256), w = *(const f32x4*)(p + (4 + j) * 256);
+      const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo + j * 1024, 0, 0));
+      const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo + (4 + j) * 1024, 0, 0));
       v0[4 * j] = u[0]; v0[4 * j + 1] = u[1]; v0[4 * j + 2] = u[2]; v0[4 * j + 3] = u[3];
       v1[4 * j] = w[0]; v1[4 * j + 1] = w[1]; v1[4 * j + 2] = w[2]; v1[4 * j + 3] = w[3];
     }

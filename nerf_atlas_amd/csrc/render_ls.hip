@@ -260,6 +260,9 @@ static int render_plain_head_ls_impl(const char* what, int model, const float* r
   NA_REQUIRE(rays && ts && hash_tables && hash_tables_refl && packed && out && workspace, NA_ENULL, "%s: null pointer", what);
   NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "%s: precision %d (f16x only)", what, precision);
   NA_REQUIRE(sigmoid_kind >= 0 && sigmoid_kind <= NA_SIG_IDENTITY, NA_EUNSUPPORTED, "%s: sigmoid %d", what, sigmoid_kind);
+  // (MODEL 8 applies the activation to 67 rows per sample inside the kernel: the four sigmoid-shaped kinds only)
+  NA_REQUIRE(model != 8 || sigmoid_kind == NA_SIG_NORMAL || sigmoid_kind == NA_SIG_THIN || sigmoid_kind == NA_SIG_FAT || sigmoid_kind == NA_SIG_UPSHIFTED,
+             NA_EUNSUPPORTED, "%s: sigmoid kind %d (normal | thin | fat | upshifted)", what, sigmoid_kind);
   NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE, NA_EUNSUPPORTED, "%s: bg %d", what, bg_kind);
   NA_REQUIRE(n_rl >= 0 && n_rl <= 3 && (n_rl == 0 || (refl_latent && rl_ld >= n_rl && rl_ld < (1 << 20))), NA_EINVAL,
              "%s: refl_latent n=%d ld=%lld", what, n_rl, (long long)rl_ld);

@@ -255,7 +255,8 @@ class PlainNeRF(CommonNeRF):
         n_rl = 0 if refl_latent is None else refl_latent.shape[-1]
         if type(self.refl) is refl.Positional and n_rl == 0 and self.refl.latent_size == 64:
             return "pos"
-        if type(self.refl) is refl.PosLinearView and n_rl <= 3 and self.refl.latent_size == 64 + n_rl and self.refl.im == 64:
+        if (type(self.refl) is refl.PosLinearView and n_rl <= 3 and self.refl.latent_size == 64 + n_rl and self.refl.im == 64
+                and self.refl.act_kind in ("normal", "thin", "fat", "upshifted")):  # (the kinds MODEL 8 applies to its 67 rows in the kernel)
             return "plv"
         return None
 

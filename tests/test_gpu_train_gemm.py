@@ -481,3 +481,31 @@ def test_one_pass_backward_adds_another_gradient_of_the_same_tensor(ops, shape):
     ops.train_reduce_many([(ws1, n1, out, in0, dW, 0, db)])
     _, dW_ref, db_ref = ops.linear_bwd_fused(gy, x, act, pt)
     assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
+
+
+def test_library_scratch_grows_and_retires_buffers_without_changing_results(ops):
+    """the per-(device, stream) scratch behind workspace = NULL grows geometrically and frees a replaced buffer once the
+    work queued before its replacement has finished (it used to leak every earlier buffer).  A batch that grows call by call, on two
+    streams, with launches still in flight when the buffer is replaced: every result equals the caller-workspace call bit for bit."""
+    from nerf_atlas_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    W = torch.randn(256, 256, device="cuda") / 16
+    (pt,) = ops.train_pack_many([(W, True)])
+    side = torch.cuda.Stream()
+    for rep in range(2):
+        for N in (8192, 40000, 70000, 300000, 20000, 600000):
+            x = torch.randn(N, 256, device="cuda")
+            gy = torch.randn(N, 256, device="cuda")
+            g_ref, dW_ref, db_ref = ops.linear_bwd_fused(gy, x, "leaky_relu", pt)   # (torch's allocator provides the workspace)
+            for stream in (torch.cuda.current_stream(), side):
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    g = torch.empty_like(x)
+                    acc = torch.empty(256 * 256 + 256, device="cuda")
+                    dW, db = acc[:256 * 256].view(256, 256), acc[256 * 256:]
+                    for _ in range(3):   # back to back: the next call may replace the buffer while this one's kernels are queued
+                        _lib.check(lib.na_linear_bwd_bf16x3_pk(gy.data_ptr(), 256, N, pt.data_ptr(), x.data_ptr(), 256, ops.ACT["leaky_relu"],
+                                                               g.data_ptr(), dW.data_ptr(), 256, db.data_ptr(), None, stream.cuda_stream))
+                stream.synchronize()
+                assert torch.equal(g, g_ref) and torch.equal(dW, dW_ref) and torch.equal(db, db_ref), (rep, N)

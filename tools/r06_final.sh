@@ -5,7 +5,7 @@
 O=gpurun_out/r06_final; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs --no-cpu-baseline --no-traffic > $O/bench_profiled.json 2>/dev/null)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $GRAFT_REPO_ROOT/bench.py --no-other-configs --no-cpu-baseline --no-traffic > $GRAFT_REPO_ROOT/$O/bench_profiled.json 2>/dev/null)
 find /tmp/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bench.csv
 for i in 1 2 3; do python tools/train_bench.py --iters 30 2>/dev/null | tail -1; done > $O/train_step.json
 python tools/train_bench.py --crop 128 --iters 10 2>/dev/null | tail -1 >> $O/train_step.json
