@@ -145,6 +145,7 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
 
 KERNELS_F16X = {"3": "ONE f16x launch of the layer-synchronous engine (MODEL 6: IPE groups generated in the kernel for the four Linears that take them)",
                 "2-pos": "ONE f16x launch of the layer-synchronous engine (MODEL 7: both hash grids gathered in the kernel)",
+                "2-plv": "ONE f16x launch of the layer-synchronous engine (MODEL 8)",
                 "4": "deformation MLP bf16x3 + canonical model f16x (one launch)",
                 "4-plv": "deformation MLP bf16x3 + na_bezier_warp_latent + canonical model f16x (MODEL 8, one launch: warped points and the 3 latent columns by pitch)",
                 "5m": "SDF MLP: ONE f16x launch of the layer-synchronous engine (Fourier features generated in the kernel) + View half f16x"}
@@ -252,7 +253,7 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None
     """BASELINE configs 1, 3, 4 and 5 (both SDF networks) and the reference's two shipped recipes with other colour heads (`make
     original`: PlainNeRF + Positional, makefile:8-13; `make dnerf`: D-NeRF over PlainNeRF + PosLinearView with --dyn-refl-latent 3,
     makefile:106-114) through the model layer: whole forward (every launch of the config's inference path), HIP events on the launch
-    stream, one warm-up + `iters` timed calls per (config, precision).  The 1 x MI355X configs (1, 3, 2-pos) are timed on the WHOLE
+    stream, one warm-up + `iters` timed calls per (config, precision).  The 1 x MI355X configs (1, 3, 2-pos, 2-plv) are timed on the WHOLE
     800 x 800 x 128 frame; the 8 x MI355X configs (4, 5) on one GPU's shard of it (a 100-row band = 10.24 M samples).  FLOP/sample =
     sum 2 * in * out over the config's MLPs (tools/kernel_bench.py uses the same numbers); `frac` is against the dense bf16
     MFMA peak for every precision.  "f16x" rows: the one-kernel renderers run f16x, the generic fused MLP launches of a config (D-NeRF:
@@ -279,6 +280,11 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None
         m.set_refl(refl.refl_kinds["pos"](latent_size=64, act="upshifted", out_features=3))
         return m
 
+    def plain_plv():
+        m = nerf.PlainNeRF(intermediate_size=64, **common)
+        m.set_refl(refl.refl_kinds["pos-linear-view"](latent_size=64, act="upshifted", out_features=3))
+        return m
+
     def dnerf_plv():
         m = nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6, refl_latent=3)
         m.set_refl(refl.refl_kinds["pos-linear-view"](latent_size=m.intermediate_size, act="upshifted", out_features=3))
@@ -287,6 +293,7 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None
     models = [
         ("1 TinyNeRF", lambda: nerf.TinyNeRF(**common), 793088, False, FULL_FRAME, precisions),
         ("2-pos PlainNeRF + Positional head (`make original`)", plain_pos, 1410048, False, FULL_FRAME, ("f16x",)),
+        ("2-plv PlainNeRF + PosLinearView head (the canonical model of `make dnerf`, alone)", plain_plv, 1131776, False, FULL_FRAME, ("f16x",)),
         ("3 PlainNeRF + mip (cylinder IPE)", lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False, FULL_FRAME, precisions),
         ("4 D-NeRF (spline 6) at t = 0.5", lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True, OTHER_SLAB, precisions),
         ("4-plv D-NeRF (spline 6, refl_latent 3) over PlainNeRF + PosLinearView (`make dnerf`) at t = 0.5", dnerf_plv, 1855232, True, OTHER_SLAB, ("f16x", "bf16x3")),
