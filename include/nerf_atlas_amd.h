@@ -595,7 +595,9 @@ int na_render_plain_mip_ls(const float* rays, int B, int H, int W, const float* 
  *                            view.init [128,134+n], view.layers.0 [128,262+n], view.layers.1 [128,128], view.out [1,128]}.
  *                            n = n_rl in 0..3: DynamicNeRF's refl_latent columns (src/nerf.py:1245-1248, 1272-1278, 1303:
  *                            `--dyn-refl-latent`), rows refl_latent[T * R, rl_ld] (sample t * R + ray), appended to the latent of
- *                            both MLPs as the reference does (src/nerf.py:352-358).
+ *                            both MLPs as the reference does (src/nerf.py:352-358).  sigmoid_kind: normal | thin | fat | upshifted
+ *                            (the activation covers all 67 rows of `pos` inside the kernel: NA_EUNSUPPORTED for the other kinds,
+ *                            which the host layer renders through the unfused operators).
  * rays / pts / ts / hash_tables (of `first`) / outputs / range guard as na_render_plain_view_ls; hash_tables_refl [8,65536,4] = the
  * head's own encoder.  workspace: na_render_head_ls_workspace_bytes(T, R) bytes (per-ray scratch + an 8-MiB L2-resident park
  * where a workgroup keeps the raw latent rows of its blocks between the Linears that consume them).                            */

@@ -165,3 +165,29 @@ def test_whole_frame_band_equals_slab_rows(na):
         assert torch.isfinite(a).all()
         assert torch.equal(a[:, 7:12], b), kind
         assert torch.equal(m(slab, want_weights=False), a), "not reproducible"
+
+
+@pytest.mark.parametrize("act", ["normal", "thin", "fat", "upshifted", "tanh", "cyclic"])
+def test_pos_linear_view_activation_kinds(na, monkeypatch, act):
+    """MODEL 8 applies the head's activation to 67 rows per sample inside the kernel and takes the four sigmoid-shaped kinds (round 6:
+    the rolled loop that served the others cost every kind 32 spilled registers per pass); any other kind renders through the
+    unfused operators -- same model object, same result class -- and the C ABI refuses it instead of computing something else."""
+    from nerf_atlas_amd import _lib
+    na.config.set_precision("f16x")
+    m = build(na, "pos-linear-view", 16, 2.0, 6.0, act=act)
+    torch.manual_seed(3)
+    rays = torch.cat([torch.tensor([0.0, 0.0, 4.0]).expand(2, 5, 5, 3), torch.randn(2, 5, 5, 3) * 0.05 + torch.tensor([0.0, 0.0, -1.0])], -1).cuda().contiguous()
+    calls = count_calls(monkeypatch, na.ops, "render_plain_plv_ls")
+    with torch.no_grad():
+        out = m(rays)
+        fused = act in ("normal", "thin", "fat", "upshifted")
+        assert (m._fusable_head() == "plv") == fused and len(calls) == (1 if fused else 0)
+        na.config.set_precision("bf16x3")
+        ref = m(rays)   # the unfused chain in the split-bf16 class
+    assert len(calls) == (1 if fused else 0)
+    assert maxdiff(out, ref) <= 1e-4
+    if not fused:
+        with pytest.raises(_lib.NaError):
+            r = m.refl
+            na.ops.render_plain_plv_ls(rays, m.ts if m.ts is not None else na.ops.compute_ts(2.0, 6.0, 16, rays.device)[0], m.first.enc.tables(), r.pos.enc.tables(),
+                                       m.packed_head_ls("plv", "f16x", 0), "f16x", act, "black", False)
