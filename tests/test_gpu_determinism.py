@@ -81,3 +81,19 @@ def test_one_launch_mip_renderer_is_reproducible_on_a_wide_band():
     _keep("mip_band", r)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "25 repeats, 0 mismatching pixels" in r.stdout and ", 0 mismatching weights" in r.stdout, r.stdout[-500:]
+
+
+def test_head_renderers_are_reproducible_also_in_the_timing_stress_build():
+    """MODEL 7 / 8 (round 6): the one-launch PlainNeRF + Positional / PosLinearView renderers on a slab that fills every workgroup, 60
+    repeats per head (plv also in its D-NeRF form: explicit points + three refl_latent columns), shipped library and the lag-3
+    timing-stress build: no run differs from the first, and both builds give the same frame (checksums of colour and weights)."""
+    from nerf_atlas_amd import build as B
+    assert os.path.exists(B.STRESS_LIB)
+    outs = []
+    for tag, env in (("shipped", os.environ), ("lag3", dict(os.environ, NA_LIB_PATH=B.STRESS_LIB))):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "head_repeat.py"), "60"], capture_output=True, text=True, timeout=900, env=env)
+        _keep(f"heads_{tag}", r)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "\n0 irreproducible runs" in r.stdout
+        outs.append([l.split("checksum")[1] for l in r.stdout.splitlines() if "checksum" in l])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
