@@ -296,7 +296,7 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None
         ("2-plv PlainNeRF + PosLinearView head (the canonical model of `make dnerf`, alone)", plain_plv, 1131776, False, FULL_FRAME, ("f16x",)),
         ("3 PlainNeRF + mip (cylinder IPE)", lambda: nerf.PlainNeRF(intermediate_size=64, mip=load_mip(types.SimpleNamespace(mip="cylinder")), **common), 1389568, False, FULL_FRAME, precisions),
         ("4 D-NeRF (spline 6) at t = 0.5", lambda: nerf.DynamicNeRF(canonical=nerf.PlainNeRF(intermediate_size=64, **common), spline=6), 1916416, True, OTHER_SLAB, precisions),
-        ("4-plv D-NeRF (spline 6, refl_latent 3) over PlainNeRF + PosLinearView (`make dnerf`) at t = 0.5", dnerf_plv, 1855232, True, OTHER_SLAB, ("f16x", "bf16x3")),
+        ("4-plv D-NeRF (spline 6, refl_latent 3) over PlainNeRF + PosLinearView (`make dnerf`) at t = 0.5", dnerf_plv, 1855232, True, OTHER_SLAB, ("f16x",)),
         ("5m VolSDF, Fourier-MLP SDF", lambda: volsdf("mlp"), 1814016, False, OTHER_SLAB, precisions),
         ("5 VolSDF, SIREN SDF", lambda: volsdf("siren"), 1289728, False, OTHER_SLAB, precisions),
     ]

@@ -40,6 +40,7 @@ def procedural_init(model):
 @pytest.mark.parametrize("name,train_prec", [("plain", "fp32"), ("plain", "bf16x3"), ("dnerf", "bf16x3"),
                                              ("volsdf", "bf16x3"), ("dnerf", "fp32"), ("volsdf", "fp32"),
                                              ("dnerf_make", "bf16x3"), ("dnerf_make", "fp32"),
+                                             ("dnerf_make_rl3", "bf16x3"), ("dnerf_make_rl3", "fp32"),
                                              ("volsdf_smooth", "bf16x3"), ("volsdf_smooth", "fp32"),
                                              ("dnerf_div", "bf16x3"), ("dnerf_div", "fp32")])
 def test_training_tracks_the_reference(name, train_prec, tmp_path):
@@ -72,6 +73,8 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     # iterations.  With config.set_deterministic the build's own trajectory is bit-reproducible (test below), so the
     # numbers are fixed per build: first-10 deviation 1.9e-4 (bf16x3) / 1.5e-4 (fp32), per-view PSNR 0.38 / 0.41 dB (below).
     assert np.abs(got[:5] - ref[:5]).max() <= 2e-4, (got[:5], ref[:5])
+    # dnerf_make_rl3 = `make dnerf` AS SHIPPED (round 6: + --dyn-refl-latent 3, the deformation network's latent columns through the
+    # spline into the PosLinearView head and back through na_bezier_warp_latent_backward).
     # dnerf_make = `make dnerf`'s regularisers (offset decay 60, the FFJORD estimate whose randn draw advances the RNG
     # stream, opt-step 3, pos-linear-view): not chaotic -- it tracks the reference to 2e-6 in the loss and 0.0007 dB, so it
     # gets the strict bars; only the plain `dnerf` recipe needs the chaotic ones
@@ -86,7 +89,7 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     print(f"[{name}/{train_prec}] smoothed-curve deviation {dev:.4f} of the curve's maximum")
     assert dev <= (0.35 if dyn else 0.1), dev
     # (dnerf_make steps the optimiser every third iteration: 67 updates in the 200 iterations)
-    assert ref[-k:].mean() < (0.7 if name == "dnerf_make" else 0.5) * ref[:k].mean(), "the recipe must actually learn"
+    assert ref[-k:].mean() < (0.7 if name.startswith("dnerf_make") else 0.5) * ref[:k].mean(), "the recipe must actually learn"
     if dyn:
         # Chaotic recipe.  What is NOT chaotic is pinned strictly: the first losses above, and -- for the divergence recipe -- the
         # regulariser's own effect on the trajectory: over the first 10 iterations the reference's `dnerf_div` losses differ from

@@ -45,6 +45,12 @@ RECIPES = {
     "dnerf_make": (True, ["--model", "plain", "--refl-kind", "pos-linear-view", "--data-kind", "dnerf", "--dyn-model",
                           "plain", "--spline", "6", "--higher-end-chance", "1", "--offset-decay", "60",
                           "--ffjord-div-decay", "0.5", "--sigmoid-kind", "upshifted", "--opt-step", "3"]),
+    # `make dnerf` AS SHIPPED (makefile:106-114): the same + `--dyn-refl-latent 3` -- the deformation network's extra columns ride
+    # through the spline into the PosLinearView head (round 6: src/nerf.py:1245-1248, 1272-1278, 1303)
+    "dnerf_make_rl3": (True, ["--model", "plain", "--refl-kind", "pos-linear-view", "--data-kind", "dnerf", "--dyn-model",
+                              "plain", "--spline", "6", "--higher-end-chance", "1", "--offset-decay", "60",
+                              "--ffjord-div-decay", "0.5", "--sigmoid-kind", "upshifted", "--opt-step", "3",
+                              "--dyn-refl-latent", "3"]),
     # the "exact divergence" regulariser of the deformation field (runner.py:694-696): autograd of model.dp w.r.t. model.pts with
     # create_graph -- a double backward through the hash encoder, the deformation MLP and the spline in the reference
     "dnerf_div": (True, ["--model", "plain", "--refl-kind", "view", "--data-kind", "dnerf", "--dyn-model", "plain",
