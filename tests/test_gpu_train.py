@@ -41,6 +41,7 @@ def procedural_init(model):
                                              ("volsdf", "bf16x3"), ("dnerf", "fp32"), ("volsdf", "fp32"),
                                              ("dnerf_make", "bf16x3"), ("dnerf_make", "fp32"),
                                              ("dnerf_make_rl3", "bf16x3"), ("dnerf_make_rl3", "fp32"),
+                                             ("original", "bf16x3"), ("original", "fp32"),
                                              ("volsdf_smooth", "bf16x3"), ("volsdf_smooth", "fp32"),
                                              ("dnerf_div", "bf16x3"), ("dnerf_div", "fp32")])
 def test_training_tracks_the_reference(name, train_prec, tmp_path):
@@ -73,6 +74,7 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     # iterations.  With config.set_deterministic the build's own trajectory is bit-reproducible (test below), so the
     # numbers are fixed per build: first-10 deviation 1.9e-4 (bf16x3) / 1.5e-4 (fp32), per-view PSNR 0.38 / 0.41 dB (below).
     assert np.abs(got[:5] - ref[:5]).max() <= 2e-4, (got[:5], ref[:5])
+    # original = `make original` (makefile:8-13: --refl-kind pos -lr 2e-4 --loss-fns l2; round 6).
     # dnerf_make_rl3 = `make dnerf` AS SHIPPED (round 6: + --dyn-refl-latent 3, the deformation network's latent columns through the
     # spline into the PosLinearView head and back through na_bezier_warp_latent_backward).
     # dnerf_make = `make dnerf`'s regularisers (offset decay 60, the FFJORD estimate whose randn draw advances the RNG

@@ -38,6 +38,8 @@ REF = "/root/reference"
 RECIPES = {
     # name: (dynamic scene?, reference argv after the data flags)
     "plain": (False, ["--model", "plain", "--refl-kind", "view"]),
+    # `make original` (reference makefile:8-13: --model plain --refl-kind pos -lr 2e-4 --loss-fns l2) on the small scene
+    "original": (False, ["--model", "plain", "--refl-kind", "pos", "--loss-fns", "l2", "-lr", "2e-4"]),
     "dnerf": (True, ["--model", "plain", "--refl-kind", "view", "--data-kind", "dnerf", "--dyn-model", "plain",
                      "--spline", "4"]),
     # `make dnerf`'s regularisers (reference makefile:106-114) on the small scene: NR-NeRF offset decay + the FFJORD
