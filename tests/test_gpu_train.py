@@ -160,7 +160,7 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     # the headline parity mode on TRAINED weights (VERDICT r03 "weak" 1: every f16x assertion of the suite used procedural or
     # random-init weights): the fused f16x renderers on the model this run just trained -- every test view within 0.01 dB of the
     # bf16x3 render, and view 0 within 1e-4 L-inf of the CPU oracle evaluated on the trained state_dict
-    if train_prec == "bf16x3" and name in ("plain", "volsdf", "dnerf"):
+    if train_prec == "bf16x3" and name in ("plain", "volsdf", "dnerf", "original", "dnerf_make_rl3"):
         import oracle as O
         model = res["model"]
         cam, labels = _test_set(T, args)
@@ -177,6 +177,11 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
             ref = O.plain_nerf(params, rays, args.near, args.far, args.steps, "view", act=args.sigmoid_kind)
         elif name == "volsdf":
             ref = O.volsdf(params, rays, args.near, args.far, args.steps, sdf_kind="siren", act=args.sigmoid_kind)
+        elif name == "original":   # round 6: PlainNeRF + Positional through the one-launch renderer (MODEL 7)
+            ref = O.plain_nerf(params, rays, args.near, args.far, args.steps, "pos", act=args.sigmoid_kind)
+        elif name == "dnerf_make_rl3":   # D-NeRF with three refl_latent columns over PlainNeRF + PosLinearView (MODEL 8)
+            ref = O.dynamic_nerf_spline(params, rays, labels[-1][0:1], args.near, args.far, args.steps, 6, "pos-linear-view",
+                                        act=args.sigmoid_kind, refl_latent=3)
         else:
             ref = O.dynamic_nerf_spline(params, rays, labels[-1][0:1], args.near, args.far, args.steps, 4, act=args.sigmoid_kind)
         err = float((frames[0].cpu() - ref[0]).abs().max())
