@@ -42,6 +42,7 @@ def procedural_init(model):
                                              ("dnerf_make", "bf16x3"), ("dnerf_make", "fp32"),
                                              ("dnerf_make_rl3", "bf16x3"), ("dnerf_make_rl3", "fp32"),
                                              ("original", "bf16x3"), ("original", "fp32"),
+                                             ("volsdf_mlp", "bf16x3"), ("volsdf_mlp", "fp32"),
                                              ("volsdf_smooth", "bf16x3"), ("volsdf_smooth", "fp32"),
                                              ("dnerf_div", "bf16x3"), ("dnerf_div", "fp32")])
 def test_training_tracks_the_reference(name, train_prec, tmp_path):
@@ -91,7 +92,9 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
     print(f"[{name}/{train_prec}] smoothed-curve deviation {dev:.4f} of the curve's maximum")
     assert dev <= (0.35 if dyn else 0.1), dev
     # (dnerf_make steps the optimiser every third iteration: 67 updates in the 200 iterations)
-    assert ref[-k:].mean() < (0.7 if name.startswith("dnerf_make") else 0.5) * ref[:k].mean(), "the recipe must actually learn"
+    # (volsdf_mlp drops from 0.17 to 0.03 within its first 20 iterations: its start is the first three losses)
+    start = ref[:3].mean() if name == "volsdf_mlp" else ref[:k].mean()
+    assert ref[-k:].mean() < (0.7 if name.startswith("dnerf_make") else 0.5) * start, "the recipe must actually learn"
     if dyn:
         # Chaotic recipe.  What is NOT chaotic is pinned strictly: the first losses above, and -- for the divergence recipe -- the
         # regulariser's own effect on the trajectory: over the first 10 iterations the reference's `dnerf_div` losses differ from

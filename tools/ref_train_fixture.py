@@ -58,6 +58,10 @@ RECIPES = {
     "dnerf_div": (True, ["--model", "plain", "--refl-kind", "view", "--data-kind", "dnerf", "--dyn-model", "plain",
                          "--spline", "4", "--dyn-diverge-decay", "0.05"]),
     "volsdf": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6"]),
+    # BASELINE config 5's other SDF network (`make volsdf`'s --sdf-kind mlp: Fourier-encoded SkipConnMLP, src/sdf.py:250-258) with
+    # the eikonal term of the VolSDF recipes and the upshifted sigmoid (makefile:21-28, 127-133)
+    "volsdf_mlp": (False, ["--model", "volsdf", "--sdf-kind", "mlp", "--refl-kind", "view", "--near", "2", "--far", "6",
+                           "--sdf-eikonal", "1e-5", "--sigmoid-kind", "upshifted", "-lr", "3e-4"]),
     # the SDF regularisers of the reference's VolSDF recipes (makefile:85-95): eikonal + normal smoothing by the unisurf
     # epsilon perturbation with a random radius (one random.random() and two randn draws per iteration in the RNG streams)
     "volsdf_smooth": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6",
