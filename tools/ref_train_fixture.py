@@ -60,6 +60,8 @@ RECIPES = {
     "volsdf": (False, ["--model", "volsdf", "--sdf-kind", "siren", "--refl-kind", "view", "--near", "2", "--far", "6"]),
     # BASELINE config 5's other SDF network (`make volsdf`'s --sdf-kind mlp: Fourier-encoded SkipConnMLP, src/sdf.py:250-258) with
     # the eikonal term of the VolSDF recipes and the upshifted sigmoid (makefile:21-28, 127-133)
+    # (`make dnerf_volsdf`, makefile:127-133 -- D-NeRF over a VolSDF canonical model with --sdf-eikonal -- cannot be recorded: the reference
+    # raises at runner.py:807, `pts + dp` with dp the (dp, enc) tuple of DynamicNeRF.time_estim.)
     "volsdf_mlp": (False, ["--model", "volsdf", "--sdf-kind", "mlp", "--refl-kind", "view", "--near", "2", "--far", "6",
                            "--sdf-eikonal", "1e-5", "--sigmoid-kind", "upshifted", "-lr", "3e-4"]),
     # the SDF regularisers of the reference's VolSDF recipes (makefile:85-95): eikonal + normal smoothing by the unisurf
