@@ -146,8 +146,8 @@ def cpu_baseline(model, sample_hw=100, repeats=3):
 KERNELS_F16X = {"3": "ONE f16x launch of the layer-synchronous engine (MODEL 6: IPE groups generated in the kernel for the four Linears that take them)",
                 "2-pos": "ONE f16x launch of the layer-synchronous engine (MODEL 7: both hash grids gathered in the kernel)",
                 "2-plv": "ONE f16x launch of the layer-synchronous engine (MODEL 8)",
-                "4": "deformation MLP bf16x3 + canonical model f16x (one launch)",
-                "4-plv": "deformation MLP bf16x3 + na_bezier_warp_latent + canonical model f16x (MODEL 8, one launch: warped points and the 3 latent columns by pitch)",
+                "4": "deformation MLP: one bf16x3 launch of the layer-synchronous engine (MODEL 4) + canonical model f16x (one launch)",
+                "4-plv": "deformation MLP: one bf16x3 launch of the layer-synchronous engine (MODEL 4, 38 output rows) + na_bezier_warp_latent + canonical model f16x (MODEL 8, one launch: warped points and the 3 latent columns by pitch)",
                 "5m": "SDF MLP: ONE f16x launch of the layer-synchronous engine (Fourier features generated in the kernel) + View half f16x"}
 FULL_FRAME = (0, 0, SIZE, SIZE)    # BASELINE's 1 x MI355X configs (1, 2, 3): the whole 800 x 800 frame, 81.92 M samples
 OTHER_SLAB = (300, 0, 100, SIZE)   # BASELINE's 8 x MI355X configs (4, 5): ONE GPU's shard of the frame = a 100-row band (rows 300..399), 10.24 M samples
@@ -325,7 +325,7 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None
             lsdef = prec == "f16x+ls-deformation"
             try:
                 config.set_precision("f16x" if lsdef else prec)
-                config.set_deformation_engine("ls" if lsdef else "generic")
+                config.set_deformation_engine("ls" if lsdef else "ls-bf16x3")
                 with torch.no_grad():
                     m(inp)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -347,7 +347,7 @@ def other_configs(dev, precisions=("f16x", "bf16x3", "bf16"), iters=5, only=None
                 rows.append({"config": name, "dtype": prec, "error": f"{type(e).__name__}: {e}"})
         del m
     config.set_precision(keep)
-    config.set_deformation_engine("generic")
+    config.set_deformation_engine("ls-bf16x3")
     return rows, round(time.perf_counter() - t_all, 2), outside
 
 

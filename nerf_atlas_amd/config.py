@@ -109,18 +109,20 @@ def set_engine(e: str):
     engine = e
 
 
-# D-NeRF's deformation network under precision "f16x": "generic" = the register-engine fused MLP in the 3-product split (its rows
-# are 3x closer to fp32 than f16x rows: 1.3e-5 against 3.8e-5 relative on the reference's golden weights, and the canonical
-# model's hash grid amplifies position errors -- on that adversarial fixture the end-to-end RGB is 4.6e-5 with it and
-# 1.0-1.6e-4 with the f16x rows, i.e. over north_star's 1e-4); "ls" = ONE launch of the layer-synchronous engine in f16x
-# (csrc/render_ls.hip MODEL 4: +20 % on the config's sample rate; 2.4e-5 against the CPU oracle on the trained model of
-# tests/test_gpu_train.py).  The parity default is "generic".
-deformation_engine = "generic"
+# D-NeRF's deformation network in inference (precisions "f16x" / "bf16x3"; the fast modes run it in their own arithmetic):
+#   "ls-bf16x3" (default since round 6): ONE launch of the layer-synchronous engine in the three-product bf16 split (csrc/render_ls.hip
+#       MODEL 4, bf16x3) -- the accuracy class of the register engine's rows (1.3e-5 relative on the reference's golden weights), the
+#       weights streamed once per 2 x NBLK blocks instead of per tile; up to 64 output rows (`--dyn-refl-latent`);
+#   "generic": the register-engine fused MLP in the same three-product split (the default of rounds 2-5);
+#   "ls": the layer-synchronous engine in f16x under precision "f16x" (MODEL 4, f16x: the fastest, but its rows carry 3x the error and
+#       the canonical model's hash grid amplifies position errors -- on the reference's adversarial golden g9 the end-to-end RGB is
+#       1.0-1.6e-4 with it, i.e. over north_star's 1e-4; 2.4e-5 on the trained model of tests/test_gpu_train.py).  Opt-in.
+deformation_engine = "ls-bf16x3"
 
 
 def set_deformation_engine(e: str):
     global deformation_engine
-    if e not in ("generic", "ls"):
+    if e not in ("generic", "ls", "ls-bf16x3"):
         raise ValueError(e)
     deformation_engine = e
 

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   constexpr bool HEAD2 = MODEL == 7 || MODEL == 8;  // the reflectance head has a hash encoder of its own (src/refl.py:230-290)
   constexpr bool MIP = MODEL == 6;
   constexpr int PPP = PREC == NA_PREC_F16X ? x::hdr_units(MODEL)
-                      : MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : kPairsPerPass;  // pairs per pass and row group
+                      : MODEL == 1 ? kTinyPairs : MODEL == 2 ? kViewPairs : MODEL == 3 ? kSirenPairs : MODEL == 4 ? kHashMlpPairs : kPairsPerPass;  // pairs per pass and row group
   // rays / elaz are read with scalar (SMEM) loads below; both were written by kernels that ran just before this one, into
   // buffers the allocator recycles from call to call: drop whatever the scalar cache still holds of those addresses
   __builtin_amdgcn_s_dcache_inv();
@@ -27,7 +27,11 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
     const uint32_t* hdr = (const uint32_t*)a.packed;
     if (hdr[0] != kMagic || hdr[1] != (uint32_t)PREC || hdr[2] != (uint32_t)PPP) {
       const float nan = __builtin_nanf("");
-      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.R * 3; i += (int64_t)gridDim.x * blockDim.x) a.out[i] = nan;
+      if constexpr (MODEL == 4 || MODEL == 5) {  // (rows to HBM: there is no colour buffer)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)a.T * a.R * a.y_ld; i += (int64_t)gridDim.x * blockDim.x) a.y[i] = nan;
+      } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.R * 3; i += (int64_t)gridDim.x * blockDim.x) a.out[i] = nan;
+      }
       return;
     }
   }

@@ -172,6 +172,76 @@ __global__ void pack_ls_tiny_kernel(TinyPackArgs w, int planes, int f16, char* _
   }
 }
 
+// Hash-encoded SkipConnMLP stream (MODEL 4 outside f16x, round 6): same element order, phases per hashmlp_phase_pairs; the out phase
+// holds two 32-row tiles chunk-major (fragment f = 2 c + j, the order m_out<.., 2, ..> consumes) and seven zero pairs
+struct HashMlpPackArgs {
+  const float* w[7];  // init, layers.0..4, out   (nn.Linear layout [out,in])
+  const float* b[7];
+  int n_out;
+};
+__global__ void pack_ls_hashmlp_kernel(HashMlpPackArgs w, int planes, int f16, char* __restrict__ dst) {
+  const NaMlpDesc d = {3, NA_ENC_HASH, 35, 0, 5, 256, w.n_out, 3, NA_ACT_LEAKY_RELU, NA_LAYOUT_GENERIC};
+  const int dim_p = d.in_size + d.enc_dims + d.latent_size;  // 38
+  const int frag_bytes = 1024 * planes;
+  const int64_t nfrag_rg = 2 * kHashMlpPairs;
+  const int64_t nelem = 4 * nfrag_rg * 512;
+  const int64_t nbias = 4 * kNPhase * 256;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nelem + nbias; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nelem) {
+      const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+      const int64_t fg = i >> 9;
+      const int rg = (int)(fg / nfrag_rg);
+      int f = (int)(fg % nfrag_rg);
+      int p = 0;
+      while (f >= 2 * hashmlp_phase_pairs(p)) { f -= 2 * hashmlp_phase_pairs(p); ++p; }
+      const int kappa = 8 * (l >> 5) + e;
+      const float* W = w.w[p];  // p: 0 init, 1..5 layers.0..4, 6 out
+      int row = -1, col = -1, in_dim = kHidden, out_dim = kHidden;
+      if (p == 6) {
+        if (f < 32) {  // fragment f = chunk c of tile j
+          const int c = f >> 1, j = f & 1;
+          row = out_row_map(d, 32 * j + (l & 31));
+          col = 16 * c + pi_perm(kappa);
+        }
+        in_dim = kHidden; out_dim = d.out_size;
+      } else {
+        const int q = f >> 1, t = f & 1;
+        row = 32 * (2 * rg + t) + (l & 31);
+        if (p == 0) { col = init_slot_feature(d, q, kappa); in_dim = dim_p; }
+        else if (p == 1 || p == 4) {  // [hidden | init] in the reference's column order, the three init chunks first in the stream
+          if (q < 3) { col = init_slot_feature(d, q, kappa); if (col >= 0) col += kHidden; }
+          else col = 16 * (q - 3) + pi_perm(kappa);
+          in_dim = kHidden + dim_p;
+        } else { col = 16 * q + pi_perm(kappa); in_dim = kHidden; }
+      }
+      float v = 0.f;
+      if (row >= 0 && row < out_dim && col >= 0 && col < in_dim) v = W[(int64_t)row * in_dim + col];
+      char* o = dst + kHeaderBytes + kBiasBytes + ((int64_t)rg * nfrag_rg + (fg % nfrag_rg)) * frag_bytes + l * 16 + e * 2;
+      const __bf16 h = f16 ? to_elem<NA_PREC_F16>(v) : (__bf16)v;
+      *(uint16_t*)o = __builtin_bit_cast(uint16_t, h);
+      if (planes == 2) {
+        const __bf16 lo = (__bf16)(v - (float)h);
+        *(uint16_t*)(o + 1024) = __builtin_bit_cast(uint16_t, lo);
+      }
+    } else {
+      const int64_t q = i - nelem;
+      const int k = (int)(q & 255), p = (int)((q >> 8) % kNPhase), rg = (int)((q >> 8) / kNPhase);
+      const int slot = k >> 5, hi = (k >> 4) & 1, r = k & 15;
+      const int rin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v = 0.f;
+      if (p < kHashMlpPhases && w.b[p] != nullptr) {
+        if (p == 6) {
+          const int row = slot < 2 ? out_row_map(d, 32 * slot + rin) : -1;
+          if (row >= 0 && row < d.out_size) v = w.b[p][row];
+        } else if (slot < 2) {
+          v = w.b[p][32 * (2 * rg + slot) + rin];
+        }
+      }
+      *(float*)(dst + kHeaderBytes + ((int64_t)rg * kNPhase + p) * 1024 + k * 4) = v;
+    }
+  }
+}
+
 // View head stream (MODEL 2): same element order, phases per view_phase_pairs; the last two pairs of the out phase are zero
 struct ViewPackArgs {
   const float* w[6];  // init, layers.0..3, out

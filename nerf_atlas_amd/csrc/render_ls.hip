@@ -64,7 +64,8 @@ int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
 #elif NA_PREC_INST == 1
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16X3, 2>(a, s)
-         : model == 3 ? ls::launch<NA_PREC_BF16X3, 3>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
+         : model == 3 ? ls::launch<NA_PREC_BF16X3, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_BF16X3, 4>(a, s)
+         : ls::launch<NA_PREC_BF16X3>(a, s);
 }
 #elif NA_PREC_INST == 2
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
@@ -470,14 +471,26 @@ extern "C" int na_render_volsdf_siren_ls(const float* rays, const float* pts, in
 // ---- a hash-encoded SkipConnMLP on the layer-synchronous engine, rows to HBM (D-NeRF's deformation network, src/nerf.py:1250-1257,
 // 1267-1270): NA_PREC_F16X only -- the other precisions run it through na_mlp_forward
 extern "C" size_t na_mlp_hash_ls_packed_bytes(int precision) {
+  if (precision == NA_PREC_BF16X3) return ls::packed_bytes(precision, ls::kHashMlpPairs);
   return precision == NA_PREC_F16X ? ls::packed_bytes_x(4) : 0;
 }
 
 extern "C" int na_mlp_hash_ls_pack(int precision, const float* const* w, const float* const* b, int n_out, void* packed, void* stream) {
   NA_REQUIRE(w && b && packed, NA_ENULL, "na_mlp_hash_ls_pack: null pointer");
-  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: precision %d (f16x only)", precision);
-  NA_REQUIRE(n_out >= 1 && n_out <= 32, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: n_out %d (1..32: one output tile)", n_out);
+  NA_REQUIRE(precision == NA_PREC_F16X || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: precision %d (f16x | bf16x3)", precision);
   for (int i = 0; i < 7; ++i) NA_REQUIRE(w[i], NA_ENULL, "na_mlp_hash_ls_pack: weights[%d] is null", i);
+  if (precision == NA_PREC_BF16X3) {  // round 6: the three-product stream (two output tiles: up to 64 rows)
+    NA_REQUIRE(n_out >= 1 && n_out <= 64, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: n_out %d (bf16x3: 1..64, two output tiles)", n_out);
+    ls::HashMlpPackArgs pw;
+    for (int i = 0; i < 7; ++i) { pw.w[i] = w[i]; pw.b[i] = b[i]; }
+    pw.n_out = n_out;
+    hipLaunchKernelGGL(ls::pack_ls_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ls::kMagic, (uint32_t)precision,
+                       (uint32_t*)packed, (uint32_t)ls::kHashMlpPairs);
+    const int64_t total = 4 * 2 * (int64_t)ls::kHashMlpPairs * 512 + 4 * ls::kNPhase * 256;
+    hipLaunchKernelGGL(ls::pack_ls_hashmlp_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, pw, 2, 0, (char*)packed);
+    return check_launch("na_mlp_hash_ls_pack");
+  }
+  NA_REQUIRE(n_out >= 1 && n_out <= 32, NA_EUNSUPPORTED, "na_mlp_hash_ls_pack: n_out %d (f16x: 1..32, one output tile)", n_out);
   return render_lsx_pack_hashmlp(w, b, n_out, (char*)packed, (hipStream_t)stream);
 }
 
@@ -486,19 +499,21 @@ extern "C" int na_mlp_hash_ls(const float* rays, const float* pts, int64_t R, co
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_mlp_hash_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;
   NA_REQUIRE(rays && ts && hash_tables && packed && y, NA_ENULL, "na_mlp_hash_ls: null pointer");
-  NA_REQUIRE(precision == NA_PREC_F16X, NA_EUNSUPPORTED, "na_mlp_hash_ls: precision %d (f16x only)", precision);
-  NA_REQUIRE(n_out >= 1 && n_out <= 32 && y_ld >= n_out && y_ld < (1 << 20), NA_EINVAL, "na_mlp_hash_ls: n_out %d, y_ld %lld", n_out,
-             (long long)y_ld);
+  NA_REQUIRE(precision == NA_PREC_F16X || precision == NA_PREC_BF16X3, NA_EUNSUPPORTED, "na_mlp_hash_ls: precision %d (f16x | bf16x3)", precision);
+  NA_REQUIRE(n_out >= 1 && n_out <= (precision == NA_PREC_BF16X3 ? 64 : 32) && y_ld >= n_out && y_ld < (1 << 20), NA_EINVAL,
+             "na_mlp_hash_ls: n_out %d, y_ld %lld", n_out, (long long)y_ld);
   ls::Args a;
   a.rays = rays; a.ts = ts; a.pts = pts; a.tables = (const float4*)hash_tables;
   a.feat = nullptr; a.beta = nullptr; a.feat_ld = 0;
-  a.packed = (const char*)packed; a.packed_size = (uint32_t)ls::packed_bytes_x(4);
+  a.packed = (const char*)packed;
+  a.packed_size = (uint32_t)(precision == NA_PREC_BF16X3 ? ls::packed_bytes(precision, ls::kHashMlpPairs) : ls::packed_bytes_x(4));
   a.alpha = nullptr; a.weights = nullptr; a.out = nullptr; a.bg_kind = NA_BG_BLACK;
   a.R = R; a.T = T; a.nb = (T + 31) / 32;
   a.elaz = nullptr; a.sigmoid_kind = 0;
   a.res = hash_resolutions();
   a.trace = nullptr;
   a.y = y; a.y_ld = (int)y_ld; a.n_out = n_out;
+  if (precision == NA_PREC_BF16X3) return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 4);
   return render_ls_dispatch_f16x(a, (hipStream_t)stream, 4);
 }
 // ---- a Fourier-encoded SkipConnMLP on the layer-synchronous engine, rows to HBM (VolSDF's MLP SDF network, src/sdf.py:250-258):

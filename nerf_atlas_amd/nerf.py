@@ -613,15 +613,26 @@ class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
         _, ddp, _ = ag.BezierWarpFn.apply(dest.contiguous(), self.pts, self._tt, self.spline_n)
         return ddp.sum(dim=-1, keepdim=True)
 
-    def _fusable_deformation(self):
-        """the deformation network as ONE launch of the layer-synchronous engine in the 1.5-product parity mode (csrc/render_ls.hip,
-        MODEL 4): inference with `config.precision == "f16x"` and `config.deformation_engine == "ls"` (opt-in: config.py says
-        why); every other case runs the generic fused MLP / the training path"""
+    def _deformation_ls_mode(self):
+        """the deformation network as ONE launch of the layer-synchronous engine (csrc/render_ls.hip MODEL 4) in inference: "bf16x3"
+        (the three-product split, the parity default under precisions f16x / bf16x3: config.deformation_engine "ls-bf16x3"), "f16x"
+        (the 1.5-product mode, opt-in: config.py says why) or None (the generic fused MLP / the training path)"""
         wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         d = self.delta_estim
-        return (config.engine == "ls" and config.precision == "f16x" and config.deformation_engine == "ls"
-                and not self.training and not wants_grad and isinstance(d.enc, HashEncoder) and len(d.layers) == 5 and d.init.out_features == 256 and d.skip == 3
-                and d.out.out_features <= 32 and d.latent_size == 0 and d.act_name == "leaky_relu")
+        if not (config.engine == "ls" and config.deformation_engine != "generic" and not self.training and not wants_grad
+                and isinstance(d.enc, HashEncoder) and len(d.layers) == 5 and d.init.out_features == 256 and d.skip == 3
+                and d.latent_size == 0 and d.act_name == "leaky_relu"):
+            return None
+        n_out = d.out.out_features
+        if config.precision == "f16x" and config.deformation_engine == "ls" and n_out <= 32:
+            return "f16x"
+        if config.precision in ("f16x", "bf16x3") and n_out <= 64:
+            return "bf16x3"
+        return None
+
+    def _fusable_deformation(self):
+        """the f16x instance of the above (opt-in)"""
+        return self._deformation_ls_mode() == "f16x"
 
     def packed_deformation_ls(self, precision: str):
         lin = self.delta_estim._linears()
@@ -640,8 +651,9 @@ class DynamicNeRF(utils.PackedCacheMixin, nn.Module):
                                                         perturb=1 if self.training else 0)
         c.ts = self.ts
         tt = self._tt = t[None, :, None, None].expand(*self.pts.shape[:-1]).contiguous()
-        if self._fusable_deformation():
-            est = ops.mlp_hash_ls(rays, self.ts, self.delta_estim.enc.tables(), self.packed_deformation_ls("f16x"), "f16x",
+        mode = self._deformation_ls_mode()
+        if mode is not None:
+            est = ops.mlp_hash_ls(rays, self.ts, self.delta_estim.enc.tables(), self.packed_deformation_ls(mode), mode,
                                   self.delta_estim.out.out_features)
         else:
             est = self.delta_estim(self.pts)

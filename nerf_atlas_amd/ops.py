@@ -1152,8 +1152,8 @@ def render_plain_plv_ls(rays, ts, hash_tables, hash_tables_refl, packed, precisi
 
 
 def mlp_hash_ls_pack(precision: str, weights, biases) -> torch.Tensor:
-    """Pack a hash-encoded SkipConnMLP (in 3, HashEncoder, 5 x 256, skip 3, out <= 32: {init, layers.0..4, out}) into the weight
-    stream of the layer-synchronous engine (f16x only; D-NeRF's deformation network)."""
+    """Pack a hash-encoded SkipConnMLP (in 3, HashEncoder, 5 x 256, skip 3: {init, layers.0..4, out}) into the weight stream of the
+    layer-synchronous engine (D-NeRF's deformation network): "f16x" (out <= 32) or, round 6, "bf16x3" (the three-product split, out <= 64)."""
     lib = _lib.load()
     assert len(weights) == 7 and len(biases) == 7
     ws = [_f32(w.detach(), "weight") for w in weights]
@@ -1164,8 +1164,8 @@ def mlp_hash_ls_pack(precision: str, weights, biases) -> torch.Tensor:
         if tuple(w.shape) != shp:
             raise ValueError(f"LS hash MLP: weight shape {tuple(w.shape)} != {shp}")
     nbytes = int(lib.na_mlp_hash_ls_packed_bytes(PREC[precision]))
-    if nbytes == 0 or not 1 <= n_out <= 32:
-        raise _lib.NaError(f"LS hash MLP: precision {precision} / {n_out} output rows not supported (f16x, <= 32 rows)")
+    if nbytes == 0 or not 1 <= n_out <= (64 if precision == "bf16x3" else 32):
+        raise _lib.NaError(f"LS hash MLP: precision {precision} / {n_out} output rows not supported (f16x: <= 32 rows, bf16x3: <= 64)")
     wp = (C.c_void_p * 7)(*[w.data_ptr() for w in ws])
     bp = (C.c_void_p * 7)(*[0 if b is None else b.data_ptr() for b in bs])
     packed = torch.empty(nbytes, device=ws[0].device, dtype=torch.uint8)

@@ -606,6 +606,66 @@ def test_bg_random(na, prec):
         config.set_precision("bf16x3")
 
 
+@pytest.mark.parametrize("name", ["g9_dnerf_spline6", "g9_dnerf_spline4", "g9_dnerf_spline6_rl3_plv"])
+def test_dynamic_nerf_deformation_rows_on_the_ls_engine_in_the_three_product_split(na, name):
+    """Round 6: D-NeRF's deformation network as ONE bf16x3 launch of the layer-synchronous engine (MODEL 4 outside f16x; the default
+    under precisions f16x / bf16x3, config.deformation_engine "ls-bf16x3"): rows of 19 / 13 / 38 columns (the last: `make dnerf`'s
+    --dyn-refl-latent 3 = two output tiles) against the CPU oracle and against the register engine's rows (the same arithmetic
+    class), on a slab that fills every workgroup with a ragged step count, explicit points == generated points bit for bit, and the
+    reference's golden frame end to end <= 1e-4 in both parity precisions with this engine AND with the generic one."""
+    import math
+    import oracle as O
+    from nerf_atlas_amd import config, ops
+    h = load_golden(name)
+    p = golden_params(h)
+    spline = int(name.split("spline")[1][0])
+    n_rl = int(h["n_rl"]) if "n_rl" in h else 0
+    canon = na.nerf.PlainNeRF(steps=int(h["steps"]), t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    m = na.nerf.DynamicNeRF(canonical=canon, spline=spline, refl_latent=n_rl)
+    if n_rl:
+        m.set_refl(na.refl.refl_kinds[str(h["refl_kind"])](latent_size=m.intermediate_size, act="upshifted", out_features=3))
+    m = m.cuda().eval()
+    load_params(m, p)
+    n_out = m.delta_estim.out.out_features
+    assert n_out == 3 * spline + 1 + (spline * n_rl + 1 if n_rl else 0)
+    try:
+        for prec in ("bf16x3", "f16x"):
+            config.set_precision(prec)
+            frames = {}
+            for eng in ("ls-bf16x3", "generic"):
+                config.set_deformation_engine(eng)
+                assert m._deformation_ls_mode() == ("bf16x3" if eng == "ls-bf16x3" else None)
+                frames[eng] = m((h["rays"].cuda(), h["times"].cuda()))
+                assert maxdiff(frames[eng], h["out"]) <= 1e-4, (prec, eng)
+                assert maxdiff(m.dp, h["dp"]) <= 1e-4 and maxdiff(m.rigidity, h["rigidity"]) <= 1e-4
+            assert maxdiff(frames["ls-bf16x3"], frames["generic"].cpu()) <= 5e-5
+        config.set_precision("bf16x3")
+        config.set_deformation_engine("ls-bf16x3")
+        cam = na.cameras.NeRFCamera(cam_to_world=torch.tensor([[[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]]]),
+                                    focal=0.5 * 800 / math.tan(0.5 * 0.6911)).cuda()
+        for T, size in ((130, 40), (32, 8), (1, 3)):
+            rays = cam.sample_positions((380, 390, size, size), size=800, with_noise=False)
+            ts, _ = ops.compute_ts(2.0, 6.0, T, "cuda")
+            packed = m.packed_deformation_ls("bf16x3")
+            est = ops.mlp_hash_ls(rays, ts, m.delta_estim.enc.tables(), packed, "bf16x3", n_out)
+            assert est.shape == (T,) + tuple(rays.shape[:-1]) + (n_out,) and torch.isfinite(est).all()
+            pts = ops.compute_pts(rays, ts)
+            sel = torch.arange(0, T, max(T // 40, 1))
+            ref = O.skip_mlp(p, "delta_estim.", pts[sel][:, :, ::7, ::5].cpu(), enc=O.nerf_oracle._hash_enc_from(p, "delta_estim.enc."))
+            scale = max(1.0, float(ref.abs().max()))
+            err = maxdiff(est[sel][:, :, ::7, ::5], ref) / scale
+            gen = m.delta_estim(pts)   # the register engine, bf16x3
+            print(f"\n[{name}] T = {T}: LS bf16x3 rows vs the oracle {err:.2e} (relative to {scale:.2f}); vs the register engine's rows {maxdiff(est, gen.cpu()) / scale:.2e}")
+            assert err <= 5e-5
+            assert maxdiff(est, gen.cpu()) <= 5e-5 * scale
+            est2 = ops.mlp_hash_ls(rays, ts, m.delta_estim.enc.tables(), packed, "bf16x3", n_out, pts=pts)
+            assert torch.equal(est, est2)
+            assert torch.equal(ops.mlp_hash_ls(rays, ts, m.delta_estim.enc.tables(), packed, "bf16x3", n_out), est)   # reproducible
+    finally:
+        config.set_precision("bf16x3")
+        config.set_deformation_engine("ls-bf16x3")
+
+
 @pytest.mark.parametrize("spline", [6, 4])
 def test_dynamic_nerf_f16x_deformation_on_the_ls_engine(na, spline):
     """Config 4 in the 1.5-product parity mode end to end: the deformation network runs as ONE launch of
@@ -655,7 +715,7 @@ def test_dynamic_nerf_f16x_deformation_on_the_ls_engine(na, spline):
         assert not m._fusable_deformation()
     finally:
         config.set_precision("bf16x3")
-        config.set_deformation_engine("generic")
+        config.set_deformation_engine("ls-bf16x3")
 
 
 def test_volsdf_mlp_f16x_sdf_network_on_the_ls_engine(na):

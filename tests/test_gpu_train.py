@@ -199,7 +199,7 @@ def test_training_tracks_the_reference(name, train_prec, tmp_path):
                 px2, frames2 = T.test(model, cam, labels, args)
             finally:
                 config.set_precision("bf16x3")
-                config.set_deformation_engine("generic")
+                config.set_deformation_engine("ls-bf16x3")
             err2 = float((frames2[0].cpu() - ref[0]).abs().max())
             print(f"[dnerf] f16x with the LS deformation kernel: view 0 L-inf vs the CPU oracle {err2:.2e}")
             assert err2 <= 1e-4 and np.abs(np.array(px2) - np.array(res["test_psnr"])).max() <= 0.01
