@@ -536,8 +536,10 @@ int na_occlusion_apply(const float* spectrum, const uint8_t* visible, const floa
  * A hash-encoded SkipConnMLP alone on the layer-synchronous engine (round 4): D-NeRF's deformation network
  * (src/nerf.py:1250-1257 delta_estim = SkipConnMLP(in 3, HashEncoder, 5 x 256, skip 3, out 3 n + 1), evaluated at
  * :1267-1270) at the samples of rays x ts (or explicit pts [T,R,3]); rows y[(t * R + ray) * y_ld + 0..n_out).
- * weights / biases: init, layers.0..4, out (nn.Linear layout).  NA_PREC_F16X only (the other precisions use na_mlp_forward);
- * n_out <= 32.  The output turns NaN as a whole if an activation saturates the half range (see na_render_plain_view_ls). */
+ * weights / biases: init, layers.0..4, out (nn.Linear layout).  NA_PREC_F16X (n_out <= 32; the output turns NaN as a whole if an
+ * activation saturates the half range, see na_render_plain_view_ls) or, round 6, NA_PREC_BF16X3 -- the three-product bf16 split, the
+ * accuracy class of na_mlp_forward's rows, n_out <= 64 (with `--dyn-refl-latent`, src/nerf.py:1246-1248: 3 n + 1 + n rl + 1 rows).
+ * The other precisions use na_mlp_forward. */
 size_t na_mlp_hash_ls_packed_bytes(int precision);
 int na_mlp_hash_ls_pack(int precision, const float* const* weights, const float* const* biases, int n_out, void* packed,
                         void* stream);
