@@ -48,6 +48,20 @@ def main():
                     diff += 1
             bad += diff
             print(f"{kind} n_rl={n_rl}: {diff} of {n} runs differ; checksum {float(first.double().sum()):.9f} {float(fw.double().sum()):.6f}", flush=True)
+        # the deformation network as one bf16x3 launch (MODEL 4 outside f16x, round 6): rows [T, R, 38] of `make dnerf`'s network
+        torch.manual_seed(4)
+        dyn = nerf.DynamicNeRF(canonical=nerf.PlainNeRF(steps=T, t_near=2.0, t_far=6.0, intermediate_size=64), spline=6, refl_latent=3).to(dev).eval()
+        with torch.no_grad():
+            for l in dyn.delta_estim._linears():
+                l.weight.mul_(1.0).add_(torch.randn_like(l.weight) * 0.02)   # (the out layer is zero-initialised: give it rows)
+        ts, _ = ops.compute_ts(2.0, 6.0, T, dev)
+        packed = dyn.packed_deformation_ls("bf16x3")
+        fn = lambda: ops.mlp_hash_ls(rays, ts, dyn.delta_estim.enc.tables(), packed, "bf16x3", 38)  # noqa: E731
+        first = fn().clone()
+        assert torch.isfinite(first).all()
+        diff = sum(0 if torch.equal(fn(), first) else 1 for _ in range(n))
+        bad += diff
+        print(f"deformation rows bf16x3: {diff} of {n} runs differ; checksum {float(first.double().sum()):.9f} {float(first.double().abs().sum()):.6f}", flush=True)
     print(f"\n{bad} irreproducible runs")
     return 1 if bad else 0
 
