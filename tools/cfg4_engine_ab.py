@@ -1,5 +1,11 @@
-import sys, json, torch
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Same-call A/B of config 4's deformation engines (round 6): bench.other_configs rows `4` and `4-plv` with
+config.deformation_engine = "ls-bf16x3" (one bf16x3 launch of the layer-synchronous engine, the default) against "generic" (the
+register engine), twice.      python tools/cfg4_engine_ab.py        (GPU box)"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from nerf_atlas_amd import config
 dev = torch.device("cuda", 0)
