@@ -55,12 +55,13 @@ __host__ __device__ constexpr int siren_phase_pairs(int p) {
 }
 constexpr int kSirenPairs = 176;
 // A hash-encoded SkipConnMLP alone, rows to HBM (MODEL 4: D-NeRF's deformation network) in the bf16 / bf16x3 / f16 formats (round 6;
-// the f16x stream is ls_xsched.h's): init (3 chunks [hash | x]), L0 (3 skip + 16), L1, L2, L3 (3 + 16), L4, out (TWO 32-row tiles,
-// block per wave: up to 64 output rows -- 3 n + 1 + (n refl_latent + 1) = 38 for `make dnerf`) + 7 zero pairs that keep a pass a
-// multiple of the ring depth and its count distinct from the other schedules'
+// the f16x stream is ls_xsched.h's): init (3 chunks [hash | x]), L0 (3 skip + 16), L1, L2, L3 (3 + 16), L4, out (ONE 32-row tile per
+// wave: row groups 0, 1 hold rows 0..31 for their block; row groups 2, 3 -- which own no block in the two-plane formats and would
+// only shadow their partner -- rows 32..63 for block rg - 2: up to 64 output rows, 3 n + 1 + (n refl_latent + 1) = 38 for
+// `make dnerf`) + 3 zero pairs that keep a pass a multiple of the ring depth
 constexpr int kHashMlpPhases = 7;
-__host__ __device__ constexpr int hashmlp_phase_pairs(int p) { return p == 0 ? 3 : (p == 1 || p == 4) ? 19 : p == 6 ? 16 + 7 : 16; }
-constexpr int kHashMlpPairs = 112;
+__host__ __device__ constexpr int hashmlp_phase_pairs(int p) { return p == 0 ? 3 : (p == 1 || p == 4) ? 19 : p == 6 ? 8 + 3 : 16; }
+constexpr int kHashMlpPairs = 100;
 constexpr int kHeaderBytes = 1024;
 constexpr int kBiasBytes = 4 * kNPhase * 1024;  // [row group][phase] 1-KiB blocks: floats [slot][hi(2)][16]
 constexpr uint32_t kMagic = 0x4C533032u;        // "LS02"

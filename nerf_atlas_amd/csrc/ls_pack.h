@@ -173,7 +173,7 @@ __global__ void pack_ls_tiny_kernel(TinyPackArgs w, int planes, int f16, char* _
 }
 
 // Hash-encoded SkipConnMLP stream (MODEL 4 outside f16x, round 6): same element order, phases per hashmlp_phase_pairs; the out phase
-// holds two 32-row tiles chunk-major (fragment f = 2 c + j, the order m_out<.., 2, ..> consumes) and seven zero pairs
+// of row group rg holds ONE 32-row tile (rows 32 (rg >> 1) ..: fragment f = chunk c) and three zero pairs
 struct HashMlpPackArgs {
   const float* w[7];  // init, layers.0..4, out   (nn.Linear layout [out,in])
   const float* b[7];
@@ -198,10 +198,9 @@ __global__ void pack_ls_hashmlp_kernel(HashMlpPackArgs w, int planes, int f16, c
       const float* W = w.w[p];  // p: 0 init, 1..5 layers.0..4, 6 out
       int row = -1, col = -1, in_dim = kHidden, out_dim = kHidden;
       if (p == 6) {
-        if (f < 32) {  // fragment f = chunk c of tile j
-          const int c = f >> 1, j = f & 1;
-          row = out_row_map(d, 32 * j + (l & 31));
-          col = 16 * c + pi_perm(kappa);
+        if (f < 16) {  // fragment f = chunk c of this row group's tile
+          row = out_row_map(d, 32 * (rg >> 1) + (l & 31));
+          col = 16 * f + pi_perm(kappa);
         }
         in_dim = kHidden; out_dim = d.out_size;
       } else {
@@ -231,7 +230,7 @@ __global__ void pack_ls_hashmlp_kernel(HashMlpPackArgs w, int planes, int f16, c
       float v = 0.f;
       if (p < kHashMlpPhases && w.b[p] != nullptr) {
         if (p == 6) {
-          const int row = slot < 2 ? out_row_map(d, 32 * slot + rin) : -1;
+          const int row = slot < 1 ? out_row_map(d, 32 * (rg >> 1) + rin) : -1;   // (slot 0 = this row group's tile)
           if (row >= 0 && row < d.out_size) v = w.b[p][row];
         } else if (slot < 2) {
           v = w.b[p][32 * (2 * rg + slot) + rin];
