@@ -70,7 +70,7 @@ def test_timing_stress_build_is_reproducible():
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.split()[0] in ("bf16x3", "f16x", "bf16")])
-    assert len(outs[0]) == 4 and outs[0] == outs[1], outs   # (three heads + the bf16x3 deformation rows of MODEL 4)
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
 
 
 def test_one_launch_mip_renderer_is_reproducible_on_a_wide_band():
