@@ -153,14 +153,15 @@ FULL_FRAME = (0, 0, SIZE, SIZE)    # BASELINE's 1 x MI355X configs (1, 2, 3): th
 OTHER_SLAB = (300, 0, 100, SIZE)   # BASELINE's 8 x MI355X configs (4, 5): ONE GPU's shard of the frame = a 100-row band (rows 300..399), 10.24 M samples
 
 
-def train_algorithmic_bytes_per_sample():
-    """HBM bytes per sample a LAYER-BY-LAYER training step of PlainNeRF(view) has to move: every Linear's forward reads its
-    input row(s) once and writes its output row once (4 (in + out) B), its backward reads dY and the forward input once and writes the
-    input gradient once (4 (out + 2 in) B); fp32 rows; the two networks' Linears (src/nerf.py:320-324, src/refl.py:201-204).  Encoder,
-    compositing and weight traffic are < 2 % and not counted."""
+def train_algorithmic_bytes_per_sample(forward="ls"):
+    """HBM bytes per sample a training step of PlainNeRF(view) has to move: every Linear's backward reads dY and the forward
+    input once and writes the input gradient once (4 (out + 2 in) B); its forward writes its output row once (4 out B) and -- in the
+    LAYER-BY-LAYER forward ("layers": csrc/train_fwd.hip) -- reads its input row(s) once (4 in B); the one-launch forward ("ls",
+    round 6: csrc/ls_kernel.h MODEL 9) keeps the rows in LDS from layer to layer and reads none back.  fp32 rows; the two networks'
+    Linears (src/nerf.py:320-324, src/refl.py:201-204).  Encoder, compositing and weight traffic are < 2 % and not counted."""
     first = [(38, 256), (256 + 38, 256), (256, 256), (256, 256), (256, 256), (256, 65)]
     view = [(69, 256), (256 + 69, 256), (256, 256), (256, 256), (256, 256), (256, 3)]
-    return sum(4 * (i + o) + 4 * (o + 2 * i) for i, o in first + view)
+    return sum(4 * o + (4 * i if forward == "layers" else 0) + 4 * (o + 2 * i) for i, o in first + view)
 
 
 def train_step(dev, crop=64, steps_per_ray=64, iters=10):
@@ -198,12 +199,17 @@ def train_step(dev, crop=64, steps_per_ray=64, iters=10):
     res = {"workload": f"PlainNeRF(view) training step, {crop} x {crop} rays x {steps_per_ray} samples, fwd + bwd + Adam",
            "dtype": "bf16x3", "samples_per_step": n, "ms_per_step": round(dt * 1e3, 2), "Msamples_s": round(n / dt / 1e6, 2),
            "iters": iters, "seconds": round(time.perf_counter() - t_all, 2)}
-    # HBM-bound path.  `achieved` / `frac` = ALGORITHMIC bytes of the layer-by-layer design (train_algorithmic_bytes_per_sample) over
+    # HBM-bound path.  `achieved` / `frac` = ALGORITHMIC bytes of the design that ran (train_algorithmic_bytes_per_sample) over
     # this run's step time; `traffic_gb_per_step` = the PMC counters of the committed profile of the 262 144-sample workload (NOT
     # measured by this run; keyed to that size only)
-    alg = train_algorithmic_bytes_per_sample() * n / 1e9
+    from nerf_atlas_amd import config
+    fwd = config.train_forward if 8192 <= n <= ops.TRAIN_LS_MAX_ROWS else "layers"
+    res["forward"] = {"ls": "one launch of the layer-synchronous engine, every Linear's output rows written once (MODEL 9)",
+                      "layers": "one training Linear per layer"}[fwd]
+    alg = train_algorithmic_bytes_per_sample(fwd) * n / 1e9
     res["roofline"] = {"bound": "hbm", "algorithmic_gb": round(alg, 2), "achieved": round(alg / dt / 1e3, 2), "peak": 8.0, "unit": "TB/s",
-                       "frac": round(alg / dt / 1e3 / 8.0, 3)}
+                       "frac": round(alg / dt / 1e3 / 8.0, 3),
+                       "algorithmic_gb_layer_by_layer": round(train_algorithmic_bytes_per_sample("layers") * n / 1e9, 2)}
     if n == 262144:
         for rel in ("profiles/r06/train_hbm.json", "profiles/r05/train_hbm.json"):
             try:

@@ -569,6 +569,20 @@ int na_render_plain_view_ls_rayts(const float* rays, int64_t R, const float* ts_
                                   const void* packed, int precision, int sigmoid_kind, int bg_kind, float* alpha,
                                   float* weights, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The training iteration's FORWARD of PlainNeRF(view) as ONE launch (round 6; runner.py:647-825 drives src/nerf.py:326-361, whose two
+ * SkipConnMLPs are src/neural_blocks.py:279-296): na_render_plain_view_ls's kernel in NA_PREC_BF16X3 -- the three-product bf16 split
+ * of the training GEMMs -- with explicit sample positions pts [T,R,3], which also leaves in HBM what the backward pass reads: the output
+ * rows (bias added, BEFORE the next layer's activation: what na_linear_bwd_partials takes as the next Linear's forward input) of the ten
+ * 256-wide Linears, planes[(p * T * R + t * R + ray) * 256 + c], p = 0..4 `first`.init, layers.0..3; 5..9 the View MLP's;
+ * first_out [T*R, 65] (density | intermediate, the reference's column order) and rgb_pre [T*R, 3] (before the sigmoid).  The layer-by-
+ * layer forward (na_linear_f32 with split_bf16) writes every one of those rows AND reads it back as the next layer's input; here the
+ * activations stay in LDS.  packed: na_render_ls_pack(NA_PREC_BF16X3) of the CURRENT weights; out [R,3] receives the kernel's own
+ * composited colour (black background; callers that composite with noise or a random background ignore it); workspace:
+ * na_render_ls_workspace_bytes.  T * R < 4 194 304 (32-bit row offsets). */
+int na_train_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                           const void* packed, int sigmoid_kind, float* planes, float* first_out, float* rgb_pre, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* PlainNeRF(view) with mip's integrated positional encoding (config 3: src/nerf.py:256-261 hook, :326-361 forward,
  * src/utils.py:23-27, 60-140 cylinder / conic Gaussians) as ONE launch of the layer-synchronous engine, NA_PREC_F16X only.
  * rays [B,H,W,6] of whole crops (pixel radii difference neighbouring rows: H >= 2); ts [T]; weights of `first`

@@ -323,10 +323,18 @@ class MlpTrainFn(Function):
         L = len(Ws)
         acts = ["none"] + [act] * (L - 1)
         x1s = [None] + [init if s else None for s in skips] + [None]
-        xs, x = [], init
-        for li in range(L):
-            xs.append(x)
-            x = ops.linear_f32(x, Ws[li], bs[li], pre_act=acts[li], x1=x1s[li], split_bf16=True, packed=packs[li][0])
+        pre = spec.get("pre")
+        if pre is not None:
+            # round 6: the forward has run already -- both networks of PlainNeRF in ONE launch of the layer-synchronous engine
+            # (ops.train_plain_view_ls), which left every Linear's output rows in HBM: pre = ([L - 1 row tensors], the network's output)
+            rows, x = pre
+            assert len(rows) == L - 1 and all(r.shape == (init.shape[0], W.shape[0]) for r, W in zip(rows, Ws)), (L, [r.shape for r in rows])
+            xs = [init] + list(rows)
+        else:
+            xs, x = [], init
+            for li in range(L):
+                xs.append(x)
+                x = ops.linear_f32(x, Ws[li], bs[li], pre_act=acts[li], x1=x1s[li], split_bf16=True, packed=packs[li][0])
         ctx.save_for_backward(*xs, *Ws)
         ctx.L, ctx.acts, ctx.has_x1 = L, acts, [t is not None for t in x1s]
         ctx.has_b = [b is not None for b in bs]

@@ -97,6 +97,21 @@ class train_precision_as:
         set_train_precision(self.prev)
 
 
+# Forward of a PlainNeRF(view) training step (round 6): "ls" = both networks in ONE launch of the layer-synchronous engine in the
+# three-product split, every Linear's output rows written once for the backward pass (csrc/ls_kernel.h MODEL 9;
+# PlainNeRF._train_forward_ls); "layers" = one training Linear per layer (csrc/train_fwd.hip).  Same arithmetic class, another
+# summation order.  NA_TRAIN_LS=0 in the environment selects "layers" at import.
+import os as _os
+train_forward = "layers" if _os.environ.get("NA_TRAIN_LS") == "0" else "ls"
+
+
+def set_train_forward(kind: str):
+    global train_forward
+    if kind not in ("ls", "layers"):
+        raise ValueError(kind)
+    train_forward = kind
+
+
 # Fused PlainNeRF(view) renderer: "ls" = layer-synchronous engine (csrc/render_ls.hip: activations in LDS, weights
 # streamed into registers, two sample groups in antiphase), "reg" = register-resident engine (csrc/render_fused.hip).
 engine = "ls"

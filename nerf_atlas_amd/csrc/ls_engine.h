@@ -182,6 +182,10 @@ struct Args {
   float* park = nullptr;            // per-workgroup scratch: [workgroup][group][block] x 8 KiB of raw latent rows
   const float* rl = nullptr;        // MODEL 8: refl_latent rows [T * R, rl_ld] (--dyn-refl-latent), nullable
   int rl_ld = 0, n_rl = 0;
+  // MODEL 9 (the training forward, round 6) takes its three output buffers through fields the PlainNeRF schedule does not use -- y
+  // (planes [10][N, 256], N = T * R, dense), park ([N, 65] first.out, the reference's column order), feat ([N, 3] view.out) -- so that
+  // the argument block keeps its size: the implicit kernel arguments behind it, and with them three instructions of the pinned
+  // headline kernel (csrc/ls_headline_isa.sha256), do not move
 };
 constexpr int kParkSlots = 1;       // raw K64 groups a block parks in global memory: the latent rows (8 KiB)
 constexpr size_t kParkBytes = (size_t)256 * 2 * 2 * kParkSlots * 8192;  // 256 workgroups x 2 groups x 2 blocks
@@ -293,6 +297,10 @@ __device__ __forceinline__ void mma_c(f32x16& acc, const f32x16& cin, const Frag
 __device__ __forceinline__ f32x16 bias_tile(__amdgpu_buffer_rsrc_t rs, int bias_soff, int slot, int lane) {
   const int voff = (lane >> 5) * 64;
   f32x16 a;
+#if defined(NA_LS_TRAIN_EXP) && (NA_LS_TRAIN_EXP & 16)  // timing experiment (wrong values): no bias loads at all
+  for (int q = 0; q < 16; ++q) a[q] = 0.f;
+  return a;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, bias_soff + slot * 128 + q * 16, 0));

@@ -5,6 +5,14 @@
 #pragma once
 #include "ls_engine.h"
 
+#ifndef NA_LS_TRAIN_EXP
+#define NA_LS_TRAIN_EXP 0  // timing experiments on MODEL 9 (tools/ls_variant.py): 1 no plane stores, 16 no bias loads (wrong values)
+#endif
+#ifndef NA_LS_TRAIN_AUX
+// cache policy of MODEL 9's row stores: 2 = nt (non-temporal).  The 2.7 GB a step writes otherwise pass through the L2 that holds the
+// weight stream and the hash tables: measured (one box, 262 144 / 1 048 576 samples) 0: 1.27 / 4.93 ms, 2: 1.12 / 4.00, 17 (sc0 sc1): 1.23 / 4.62
+#define NA_LS_TRAIN_AUX 2
+#endif
 namespace na {
 namespace ls {
 
@@ -13,7 +21,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<PREC>;
   constexpr int NB = C::NBLK, FR = C::FRAG;
-  constexpr bool M0 = MODEL == 0 || MODEL == 6 || MODEL == 7 || MODEL == 8;  // the PlainNeRF schedules (0: View head, 6: + mip, 7: Positional, 8: PosLinearView)
+  constexpr bool M0 = MODEL == 0 || MODEL == 6 || MODEL == 7 || MODEL == 8 || MODEL == 9;  // the PlainNeRF schedules (0: View head, 6: + mip, 7: Positional, 8: PosLinearView, 9: 0 as the training forward)
+  constexpr bool TRAIN = MODEL == 9;  // MODEL 0 that also leaves every Linear's output rows in HBM for the backward pass (train_store below)
   constexpr bool HEAD2 = MODEL == 7 || MODEL == 8;  // the reflectance head has a hash encoder of its own (src/refl.py:230-290)
   constexpr bool MIP = MODEL == 6;
   constexpr int PPP = PREC == NA_PREC_F16X ? x::hdr_units(MODEL)
@@ -663,6 +672,92 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo + (4 + j) * 1024, 0, 0));
       v0[4 * j] = u[0]; v0[4 * j + 1] = u[1]; v0[4 * j + 2] = u[2]; v0[4 * j + 3] = u[3];
       v1[4 * j] = w[0]; v1[4 * j + 1] = w[1]; v1[4 * j + 2] = w[2]; v1[4 * j + 3] = w[3];
+    }
+  };
+  // ---- MODEL 9 (round 6): the training step's forward of PlainNeRF(view) as ONE launch (src/neural_blocks.py:279-296 twice, between
+  // them src/nerf.py:338-357).  The layer-by-layer training forward (csrc/train_fwd.hip) writes every Linear's output rows [N, 256]
+  // and READS them back as the next Linear's input; here the rows stay in LDS from layer to layer as in inference, and the fp32
+  // accumulators -- exactly what the backward kernel of the NEXT Linear wants as its input (it applies act and act' itself:
+  // csrc/train_bwd.hip) -- are written once on the way: plane p of Args::y = output rows of Linear p (0..4 first.init, L0..L3;
+  // 5..9 view.init, L0..L3), sample row t * R + ray like every [T, R, .] tensor of the path; first.out's 65 rows in the reference's
+  // column order (density first) and view.out's 3 rows go to their own buffers.  A lane holds rows 8 j + 4 hi .. + 3 of a tile for
+  // its sample in registers 4 j .. 4 j + 3: one 16-byte store per (tile, block, j), 128 contiguous bytes per sample and tile.
+  // (buffer stores, the row offset in the VECTOR offset and soffset 0: DESIGN 3d's store-data hazard)
+  auto train_row = [&](int pl, int b, bool& ok) -> uint32_t {
+    const Loc L = locate(pl, b);
+    const int t = L.tb * 32 + ln;
+    ok = L.ok && t < a.T;
+    return (uint32_t)((int64_t)t * a.R + L.ray);
+  };
+  auto train_store = [&](const f32x16 (&av)[2][NB], int pl, int plane) {
+    if constexpr (TRAIN) {
+      static_assert(!TRAIN || FR == 2048, "MODEL 9: the two-plane formats (a tile's two output fragments = 4 KiB of LDS)");
+      const int64_t N = (int64_t)a.T * a.R;  // (< 2^22: checked by the host)
+      const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (int64_t)plane * N * 256), 0, (int)(N * 1024), 0x00020000);
+      typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+      // Straight from the accumulators a store instruction would write 32-byte pieces of 32 different rows (measured: the write path
+      // then takes 4 cycles per piece and CU -- 0.63 ms per 262 144 samples on top of 0.86); every tile goes through LDS instead and
+      // leaves as WHOLE 128-byte lines, 8 lanes per row.  The staging area is the 4 KiB this wave is about to overwrite with the
+      // tile's two activation fragments anyway (dead since the barrier that closed the MFMA phase; nobody else writes it): sample-major
+      // [32][128 B], 16-byte piece q of sample s at slot q ^ (s & 7) -- conflict-free for the 8-lane groups of ds_write_b128 and the
+      // 16-lane groups of ds_read_b128 (MI355X_MICROARCH "LDS").  LDS operations of one wave execute in order: no wait in between.
+      const int s0 = lane >> 3, pc = lane & 7;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const Loc L = locate(pl, b);
+        if (!L.ok || (NA_LS_TRAIN_EXP & 1)) continue;
+        const int t0 = L.tb * 32 + s0;
+        const uint32_t vo = (uint32_t)((int64_t)t0 * a.R + L.ray) * 1024u + (uint32_t)(rg * 256 + pc * 16);
+        const uint32_t step = (uint32_t)a.R * 8192u;  // 8 samples on
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          char* stg = hb + (b * 16 + 4 * rg + 2 * t) * FR;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *(f32x4*)(stg + ln * 128 + (((2 * j + hi) ^ (ln & 7)) * 16)) = f32x4{av[t][b][4 * j], av[t][b][4 * j + 1], av[t][b][4 * j + 2], av[t][b][4 * j + 3]};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const f32x4 v = *(const f32x4*)(stg + (8 * k + s0) * 128 + ((pc ^ (s0 & 7)) * 16));
+            if (t0 + 8 * k < a.T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), trs, vo + k * step + t * 128, 0, NA_LS_TRAIN_AUX);
+          }
+        }
+      }
+    }
+  };
+  // first.out: row group rg < 2 holds the intermediate rows 32 rg .. + 31 (reference columns 1 + ...), row group 2 the density
+  // (register 0 of the hi = 0 lanes: reference column 0) of the NB blocks -> Args::park as [N, 65]
+  auto train_store_first = [&](const f32x16 (&oq)[NB], int pl) {
+    if constexpr (TRAIN) {
+      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)a.park, 0, (int)((int64_t)a.T * a.R * 260), 0x00020000);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        bool ok;
+        const uint32_t row = train_row(pl, b, ok);
+        if (ok && rg < 2) {
+          const uint32_t vo = row * 260u + (uint32_t)(4 * (1 + 32 * rg + 4 * hi));
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float v = oq[b][i];  // (__builtin_bit_cast of a vector ELEMENT expression reads element 0: through a scalar)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), frs, vo + 4 * (8 * (i >> 2) + (i & 3)), 0, 0);
+          }
+        } else if (ok && rg == 2 && hi == 0) {
+          const float v = oq[b][0];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), frs, row * 260u, 0, 0);
+        }
+      }
+    }
+  };
+  // view.out: rows 0..2 (registers 0..2 of the hi = 0 lanes) of the owner's block -> Args::feat as [N, 3] (before the sigmoid)
+  auto train_store_rgb = [&](const f32x16& o, int pl) {
+    if constexpr (TRAIN) {
+      if (owner && hi == 0) {
+        bool ok;
+        const uint32_t row = train_row(pl, blk, ok);
+        if (ok) {
+          float* dst = const_cast<float*>(a.feat) + (int64_t)row * 3;
+          dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        }
+      }
     }
   };
   if constexpr (M0 || MODEL == 4) {

@@ -65,7 +65,7 @@ int render_ls_dispatch_bf16(ls::Args& a, hipStream_t s, int model) {
 int render_ls_dispatch_bf16x3(ls::Args& a, hipStream_t s, int model) {
   return model == 1 ? ls::launch<NA_PREC_BF16X3, 1>(a, s) : model == 2 ? ls::launch<NA_PREC_BF16X3, 2>(a, s)
          : model == 3 ? ls::launch<NA_PREC_BF16X3, 3>(a, s) : model == 4 ? ls::launch<NA_PREC_BF16X3, 4>(a, s)
-         : ls::launch<NA_PREC_BF16X3>(a, s);
+         : model == 9 ? ls::launch<NA_PREC_BF16X3, 9>(a, s) : ls::launch<NA_PREC_BF16X3>(a, s);
 }
 #elif NA_PREC_INST == 2
 int render_ls_dispatch_f16(ls::Args& a, hipStream_t s, int model) {
@@ -125,10 +125,11 @@ extern "C" size_t na_render_ls_workspace_bytes(int T, int64_t R) {
   return (size_t)R * 2 * sizeof(float) + 256 + (NA_LS_TRACE ? 4096 + 256 : 0);
 }
 
+struct LsTrainOut { float* planes; float* first_out; float* rgb; };
 static int render_plain_view_ls_impl(const float* rays, const float* pts, int64_t R, const float* ts, int64_t ts_stride, int T,
                                      const float* hash_tables, const void* packed, int precision, int sigmoid_kind,
                                      int bg_kind, float* alpha, float* weights, float* out, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     size_t workspace_bytes, void* stream, const LsTrainOut* tr = nullptr) {
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_render_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;  // empty batch: a no-op before any pointer check (zero-size tensors carry null pointers)
   NA_REQUIRE(rays && ts && hash_tables && packed && out && workspace, NA_ENULL, "na_render_plain_view_ls: null pointer");
@@ -152,10 +153,32 @@ static int render_plain_view_ls_impl(const float* rays, const float* pts, int64_
   a.sigmoid_kind = sigmoid_kind;
   a.res = hash_resolutions();
   a.trace = NA_LS_TRACE ? (unsigned long long*)(((uintptr_t)(elaz + R * 2) + 255) & ~(uintptr_t)255) : nullptr;
+  if (tr != nullptr) {  // MODEL 9: the training forward (bf16x3 only)
+    const int64_t N = (int64_t)T * R;
+    (void)N;
+    a.y = tr->planes; a.park = tr->first_out; a.feat = tr->rgb;  // (ls_engine.h Args: MODEL 9's outputs ride in fields MODEL 0 leaves alone)
+    return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 9);
+  }
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 0);
   if (precision == NA_PREC_F16) return render_ls_dispatch_f16(a, (hipStream_t)stream, 0);
   if (precision == NA_PREC_F16X) return render_ls_dispatch_f16x(a, (hipStream_t)stream, 0);
   return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 0);
+}
+
+// The training step's forward of PlainNeRF(view) as ONE launch (MODEL 9 = MODEL 0 in bf16x3 that also writes every Linear's output rows
+// for the backward pass: ls_kernel.h train_store; what csrc/train_fwd.hip does layer by layer).  Replaces the twelve forward Linears of
+// src/neural_blocks.py:279-296 (x 2) in a training iteration (runner.py:647-825).
+extern "C" int na_train_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
+                                      const void* packed, int sigmoid_kind, float* planes, float* first_out,
+                                      float* rgb_pre, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_train_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
+  if (R == 0) return NA_OK;
+  NA_REQUIRE(pts && planes && first_out && rgb_pre, NA_ENULL, "na_train_plain_view_ls: null pointer");
+  const int64_t N = (int64_t)T * R;
+  NA_REQUIRE(N * 1024 < (1ll << 32), NA_EINVAL, "na_train_plain_view_ls: %lld samples (the row offsets are 32-bit: < 4 194 304)", (long long)N);
+  const LsTrainOut tr = {planes, first_out, rgb_pre};
+  return render_plain_view_ls_impl(rays, pts, R, ts, 0, T, hash_tables, packed, NA_PREC_BF16X3, sigmoid_kind, NA_BG_BLACK, nullptr, nullptr,
+                                   out, workspace, workspace_bytes, stream, &tr);
 }
 
 extern "C" int na_render_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T,

@@ -330,6 +330,28 @@ class PlainNeRF(CommonNeRF):
         return ops.render_plain_view(rays, ts, self.first.enc.tables(), pf, pv, prec, self.sigmoid_kind, self._kernel_bg(),
                                      want_weights, pts=pts)
 
+    def _train_forward_ls(self, rays, ts, pts, r_d):
+        """Training (round 6): both networks' forwards as ONE launch of the layer-synchronous engine in the three-product bf16 split
+        (csrc/ls_kernel.h MODEL 9) instead of twelve training Linears -- every Linear's output rows are written once for the backward
+        pass and never read back by the forward.  Returns (planes [10, N, 256], first_out [N, 65], rgb_pre [N, 3]) or None when the
+        step does not have the shape the kernel serves (then the layer-by-layer forward runs: the same three-product arithmetic with
+        another summation order).  `config.set_train_forward("layers")` / NA_TRAIN_LS=0 switch it off."""
+        N = pts.numel() // 3
+        if (config.train_forward != "ls" or config.train_precision != "bf16x3" or not torch.is_grad_enabled() or not pts.is_cuda
+                or type(self.refl) is not refl.View or self.mip is not None or self.intermediate_size != 64 or self.refl.out_features != 3
+                or self.refl.mlp.last_layer_act or self.first.last_layer_act or self.refl.mlp.latent_size != 64
+                or r_d.shape != pts.shape[1:] or ts.dim() != 1 or ts.shape[0] != pts.shape[0]
+                or not (8192 <= N <= ops.TRAIN_LS_MAX_ROWS) or os.environ.get("NA_TRAIN_ROWS") == "0"
+                or os.environ.get("NA_TRAIN_MLP_FN") == "0" or os.environ.get("NA_TRAIN_FUSED_BWD") == "0"
+                or not all(p.requires_grad for p in self.first.parameters()) or not all(p.requires_grad for p in self.refl.mlp.parameters())):
+            return None
+        enc = self.first.enc
+        tables = torch.stack([e.weight for e in enc.embs])  # (differentiable: the encoder's node of this step takes the same tensor)
+        with torch.no_grad():
+            planes, first_out, rgb_pre, _ = ops.train_plain_view_ls(rays.reshape(-1, 6), ts, pts.detach(), tables.detach(),
+                                                                    self.packed_ls("bf16x3"), self.sigmoid_kind)
+        return planes, first_out, rgb_pre, tables
+
     @_f16x_policy
     def forward(self, rays, want_weights: bool = True):
         self.ts_ray = None  # (only forward_coarse_fine integrates over per-ray steps)
@@ -395,7 +417,8 @@ class PlainNeRF(CommonNeRF):
                                 "fused renderer's schedules (View head, intermediate 64, 3 channels): inference runs the generic MLP kernels "
                                 "+ separate compositing")
         latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
-        first_out = self.first(pts, latent)
+        pre = self._train_forward_ls(rays, ts, pts, r_d) if latent is None and refl_latent is None else None
+        first_out = self.first(pts, latent, pre=None if pre is None else (list(pre[0][:5]), pre[1], pre[3]))
         if (ag.needs_grad(first_out) and latent is None and refl_latent is None and type(self.refl) is refl.View and pts.is_cuda
                 and not self.refl.mlp.last_layer_act and self.refl.mlp.latent_size == first_out.shape[-1] - 1
                 and r_d.shape == pts.shape[1:] and os.environ.get("NA_TRAIN_ROWS") != "0"):
@@ -406,7 +429,8 @@ class PlainNeRF(CommonNeRF):
             density = density.reshape(pts.shape[:-1])
             if self.training and self.noise_std > 0:
                 density = density + utils.randn(density.shape, density.device) * self.noise_std
-            rgb = self.refl.act(self.refl.mlp.forward_rows(rows).reshape(pts.shape[:-1] + (self.refl.out_features,)))
+            rgb = self.refl.act(self.refl.mlp.forward_rows(rows, pre=None if pre is None else (list(pre[0][5:]), pre[2]))
+                                .reshape(pts.shape[:-1] + (self.refl.out_features,)))
             return self._composite(density, rgb, ts, rays)
         if ag.needs_grad(first_out):
             density, intermediate = ag.SplitHeadFn.apply(first_out)  # (the slices' gradients written side by side: autograd.py)

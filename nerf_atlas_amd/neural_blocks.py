@@ -248,7 +248,9 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
             return b if self.enc.extra_scale == 1 else (b * self.enc.extra_scale)
         return None
 
-    def forward(self, p, latent: Optional[torch.Tensor] = None):
+    def forward(self, p, latent: Optional[torch.Tensor] = None, pre=None):
+        """pre (training only): (output rows of init and of every hidden layer but the last Linear, the network's output) of a forward that
+        has already run (PlainNeRF's one-launch training forward); the node then only records what its backward needs."""
         batches = p.shape[:-1]
         mip = None
         if isinstance(latent, utils.MipLatent):
@@ -283,7 +285,7 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         flat = p.reshape(-1, p.shape[-1]).contiguous()
         lat = None if latent is None else latent.reshape(-1, self.latent_size).contiguous()
         if ag.needs_grad(flat, lat, *self.parameters()):
-            return self._forward_train(flat, lat).reshape(batches + (out_size,))
+            return self._forward_train(flat, lat, pre=pre).reshape(batches + (out_size,))
         # any-shape path: exact-fp32 Linears (src/neural_blocks.py:288-296)
         if not self.last_layer_act and flat.is_cuda:
             utils.note_fallback(f"mlp-fp32-{self.in_size}-{self.init.out_features}-{len(self.layers)}-{self.out.out_features}",
@@ -305,20 +307,22 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         y = ops.linear_f32(x, self.out.weight.data, self.out.bias.data, pre_act=self.act_name)
         return y.reshape(batches + (out_size,))
 
-    def forward_rows(self, init):
+    def forward_rows(self, init, pre=None):
         """Differentiable forward from ready-made init rows [N, dim_p] = [p | enc(p) | latent] (a caller that assembles them with one
         kernel: PlainNeRF's training path, autograd.PlainHeadFn): src/neural_blocks.py:288-296 without the cats of :283-287."""
         assert init.dim() == 2 and init.shape[1] == self.init.in_features and self.enc is None, (init.shape, self.init.in_features)
-        return self._forward_train(None, None, init=init)
+        return self._forward_train(None, None, init=init, pre=pre)
 
-    def _forward_train(self, flat, lat, init=None):
+    def _forward_train(self, flat, lat, init=None, pre=None):
         """Differentiable forward (fp32 Linears, HIP forward and backward kernels): src/neural_blocks.py:279-296."""
         if init is not None:
             pass
         elif (isinstance(self.enc, HashEncoder) and lat is None and flat.is_cuda and flat.shape[1] == 3
               and os.environ.get("NA_TRAIN_ROWS") != "0"):
             # [p | p | features] written by the encoder itself, its gradient read in place (autograd.HashInitFn: no cat, no slice copy)
-            init = ag.HashInitFn.apply(flat, torch.stack([e.weight for e in self.enc.embs]), self.enc.include_input)
+            # (pre[2]: the stacked tables of this step, when the caller has built them already)
+            tables = pre[2] if pre is not None and len(pre) > 2 else torch.stack([e.weight for e in self.enc.embs])
+            init = ag.HashInitFn.apply(flat, tables, self.enc.include_input)
         else:
             init = flat
             if self.enc is not None:
@@ -330,7 +334,7 @@ class SkipConnMLP(utils.PackedCacheMixin, nn.Module):
         if self._mlp_fn_ok(init, packs):
             # every Linear takes the fused training kernels: the network is ONE autograd node (autograd.MlpTrainFn)
             n = len(self.layers)
-            spec = {"act": self.act_name, "skips": [i != n - 1 and (i % self.skip) == 0 for i in range(n)], "packs": packs}
+            spec = {"act": self.act_name, "skips": [i != n - 1 and (i % self.skip) == 0 for i in range(n)], "packs": packs, "pre": None if pre is None else pre[:2]}
             params = []
             for lin in self._linears():
                 params += [lin.weight, lin.bias]

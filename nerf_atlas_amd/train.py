@@ -159,6 +159,10 @@ class NaAdam(torch.optim.Adam):
                 bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
                 ops.adam_step([ps[i] for i in idx], [ps[i].grad for i in idx], [exp_avgs[i] for i in idx], [exp_avg_sqs[i] for i in idx],
                               1 - beta1, beta2, 1 - beta2, bc2 ** 0.5, group["eps"], (group["lr"] / bc1) * -1, self.FMA_MASK)
+            # the kernel wrote the parameters through raw pointers: tell torch (an in-place update, like torch.optim.Adam's own) -- the
+            # packed weight streams of the fused renderers are keyed on the version counters (utils.pack_stamp) and a validation render
+            # between two training steps would otherwise keep the weights of its first call
+            torch.autograd.graph.increment_version(ps)
         return loss
 
     def _torch_group_step(self, group):
