@@ -705,6 +705,7 @@ def test_plain_nerf_training_step_is_the_same_with_and_without_the_rows_kernels(
     config.set_deterministic(True)
     prev = config.train_precision
     config.set_train_precision("bf16x3")
+    config.set_train_forward("layers")  # (the one-launch forward sums in another order and needs the rows kernels: tests/test_gpu_train_ls.py)
     try:
         res = []
         for flag in ("1", "0"):
@@ -719,3 +720,4 @@ def test_plain_nerf_training_step_is_the_same_with_and_without_the_rows_kernels(
     finally:
         config.set_deterministic(False)
         config.set_train_precision(prev)
+        config.set_train_forward("ls")
