@@ -214,7 +214,10 @@ def train_step(dev, crop=64, steps_per_ray=64, iters=10):
         for rel in ("profiles/r06/train_hbm.json", "profiles/r05/train_hbm.json"):
             try:
                 with open(os.path.join(REPO, rel)) as f:
-                    gb = float(json.load(f)["GB_per_step"])
+                    prof = json.load(f)
+                if prof.get("train_forward", "layers") != fwd:
+                    continue  # (a profile of the other forward: not this step's traffic)
+                gb = float(prof["GB_per_step"])
                 res["roofline"]["traffic_gb_per_step"] = gb
                 res["roofline"]["traffic_source"] = rel + " (tools/train_hbm.py: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the step, separate passes; a committed profile, not this run)"
                 break

@@ -3,7 +3,7 @@
 passes, no trace domains -- MI355X_MICROARCH.md "HBM"), summed per kernel name and divided by the steps of the run.
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (the guide's gfx950 correction: FETCH_SIZE reports half of a wide coalesced read).
     python tools/train_hbm.py --out gpurun_out/train_hbm.json [--iters 10]"""
-import argparse, csv, glob, json, os, shutil, subprocess, sys, tempfile
+import argparse, os, csv, glob, json, os, shutil, subprocess, sys, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -44,7 +44,9 @@ def main():
         rows.append({"kernel": k, "launches_per_step": round(calls.get(k, 0) / steps, 2), "MB_per_step": round(b / 1e6, 1)})
     total = sum(r["MB_per_step"] for r in rows)
     res = {"what": "HBM bytes per PlainNeRF(view) training step of 262 144 samples (tools/train_bench.py), (2 x FETCH_SIZE + WRITE_SIZE) KiB",
-           "steps_profiled": steps, "GB_per_step": round(total / 1e3, 2), "kernels": rows}
+           "steps_profiled": steps, "GB_per_step": round(total / 1e3, 2),
+           # which forward the profiled step ran (bench.py quotes this file only for the same one)
+           "train_forward": "layers" if os.environ.get("NA_TRAIN_LS") == "0" else "ls", "kernels": rows}
     os.makedirs(os.path.dirname(os.path.abspath(a.out)) or ".", exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
     print(json.dumps({"GB_per_step": res["GB_per_step"], "top": rows[:8]}, indent=1))
