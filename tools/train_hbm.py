@@ -3,7 +3,7 @@
 passes, no trace domains -- MI355X_MICROARCH.md "HBM"), summed per kernel name and divided by the steps of the run.
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (the guide's gfx950 correction: FETCH_SIZE reports half of a wide coalesced read).
     python tools/train_hbm.py --out gpurun_out/train_hbm.json [--iters 10]"""
-import argparse, os, csv, glob, json, os, shutil, subprocess, sys, tempfile
+import argparse, csv, glob, json, os, shutil, subprocess, sys, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
