@@ -6,7 +6,9 @@
 #include "ls_engine.h"
 
 #ifndef NA_LS_TRAIN_EXP
-#define NA_LS_TRAIN_EXP 0  // timing experiments on MODEL 9 (tools/ls_variant.py): 1 no plane stores, 16 no bias loads (wrong values)
+#define NA_LS_TRAIN_EXP 0  // timing experiments on MODEL 9 (tools/ls_variant.py; wrong or missing rows): 1 no plane stores, 2 the LDS staging
+                           // alone, 4 the store instructions into a 64-KiB window (no HBM stream), 16 no bias loads.  1 048 576 samples, one
+                           // box: 1: 3.20 ms, 2: 3.28, 4: 3.42, shipped 4.08 -- the staging costs 2.5 %, the instructions 4 %, the stream the rest
 #endif
 #ifndef NA_LS_TRAIN_AUX
 // cache policy of MODEL 9's row stores: 2 = nt (non-temporal).  The 2.7 GB a step writes otherwise pass through the L2 that holds the
@@ -718,7 +720,13 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const f32x4 v = *(const f32x4*)(stg + (8 * k + s0) * 128 + ((pc ^ (s0 & 7)) * 16));
+#if NA_LS_TRAIN_EXP & 2   // (timing: the LDS staging alone -- the values are consumed, nothing is stored)
+            asm volatile("" :: "v"(v));
+#elif NA_LS_TRAIN_EXP & 4  // (timing: the same store instructions into a 64-KiB window per plane: no HBM stream behind them)
+            if (t0 + 8 * k < a.T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), trs, (vo + k * step + t * 128) & 0xFFFFu, 0, NA_LS_TRAIN_AUX);
+#else
             if (t0 + 8 * k < a.T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), trs, vo + k * step + t * 128, 0, NA_LS_TRAIN_AUX);
+#endif
           }
         }
       }
