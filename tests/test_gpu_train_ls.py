@@ -137,3 +137,35 @@ def test_one_launch_adam_invalidates_the_packed_streams():
         fresh = m(rays).clone()
     assert torch.equal(after, fresh)
     assert float((after - before).abs().max()) > 1e-3
+
+
+def test_dnerf_step_through_the_one_launch_forward():
+    """D-NeRF (src/nerf.py:1250-1303): the canonical PlainNeRF's points are the spline-warped ones and carry a gradient back into the
+    deformation network -- the one-launch forward takes them as explicit positions, the backward nodes (hash input gradient, PlainHeadFn's
+    point columns) are the layer path's: loss equal, every gradient incl. the deformation network's within 2e-3 of its maximum."""
+    import nerf_atlas_amd.nerf as nerf
+    m0, rays = _model_and_rays(16, 64, batch=2)
+    torch.manual_seed(5)
+    m = nerf.DynamicNeRF(canonical=m0, spline=4).to(rays.device).eval()
+    with torch.no_grad():
+        m.delta_estim.out.weight.normal_(0, 0.02)  # (the reference's zero initialisation would leave the warp at the identity)
+    times = torch.tensor([0.3, 0.8], device=rays.device)
+    target = torch.rand(rays.shape[:-1] + (3,), device=rays.device)
+    res = {}
+    from nerf_atlas_amd import config
+    for kind in ("layers", "ls"):
+        config.set_train_forward(kind)
+        try:
+            m.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.mse_loss(m((rays, times)), target)
+            loss.backward()
+            res[kind] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            config.set_train_forward("ls")
+    (l0, g0), (l1, g1) = res["layers"], res["ls"]
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys() and any(n.startswith("delta_estim.") for n in g0)
+    for n in g0:
+        err = float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-30))
+        assert err <= 2e-3, (n, err)
+    assert float(g1["delta_estim.init.weight"].abs().max()) > 0
