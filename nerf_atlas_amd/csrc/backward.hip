@@ -3,6 +3,8 @@
 // alpha compositing.  fp32 throughout; matrix work on the exact f32 MFMA.  Gradients are pinned against
 // torch.autograd of the CPU oracle (tests/test_gpu_backward.py).
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace na {
 
@@ -670,6 +672,114 @@ __global__ void composite_backward_kernel(const float* __restrict__ density, con
   }
 }
 
+// The same gradients with the T steps of a ray split into segments of CB_SEG (round 6): one thread per (ray, segment), a workgroup =
+// 64 consecutive rays x all S segments (wave s = segment s: every load and store stays coalesced along the rays).  The chain of a
+// thread is CB_SEG steps instead of T and there are S times as many waves (4 096 rays x 64 steps: 256 instead of 64; the one-thread-
+// per-ray kernel takes 63 us whether the batch has 4 096 or 16 384 rays -- it is bound by its dependent exp / log chain per step).
+// Segment-local prefix products / suffix sums meet in LDS: T_t = (prod of the earlier segments' products) * (local prefix), the suffix
+// sum likewise -- the same terms in another association, so the last bits differ from the sequential kernel (tests: both against the
+// oracle's autograd).
+constexpr int CB_SEG = 16;
+template <int C>
+__global__ __launch_bounds__(512) void composite_backward_seg_kernel(const float* __restrict__ density, const float* __restrict__ feat,
+                                              const float* __restrict__ ts, const float* __restrict__ rays, int T,
+                                              int64_t R, int density_kind, int bg_kind, const float* __restrict__ g_out,
+                                              float* __restrict__ g_density, float* __restrict__ g_feat,
+                                              const float* __restrict__ sky_rand) {
+  extern __shared__ float cb_lds[];  // [2][S][64]
+  const int tx = threadIdx.x, seg = threadIdx.y, S = blockDim.y;
+  const int64_t r = (int64_t)blockIdx.x * 64 + tx;
+  const bool live = r < R;
+  const int64_t rc = live ? r : R - 1;
+  const int t_lo = seg * CB_SEG;
+  const float* ry = rays + rc * 6 + 3;
+  const float nrm = sqrtf((ry[0] * ry[0] + ry[1] * ry[1]) + ry[2] * ry[2]);
+  float g[C];
+  float gsum = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { g[c] = g_out[rc * C + c]; gsum += g[c]; }
+  const float gsky = bg_kind == NA_BG_WHITE ? gsum : bg_kind == NA_BG_RANDOM ? gsum * sky_rand[rc] : 0.f;
+  float dv[CB_SEG], cv[CB_SEG][C];
+#pragma unroll
+  for (int u = 0; u < CB_SEG; ++u) {
+    const int t = t_lo + u < T ? t_lo + u : T - 1;
+    dv[u] = density[(int64_t)t * R + rc];
+    const float* ct = feat + ((int64_t)t * R + rc) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) cv[u][c] = ct[c];
+  }
+  float ev[CB_SEG], fv[CB_SEG], lp[CB_SEG], dist[CB_SEG];
+  float run = 1.0f;
+#pragma unroll
+  for (int u = 0; u < CB_SEG; ++u) {
+    const int t = t_lo + u;
+    const float d = dv[u];
+    const float sigma = density_kind == NA_DENSITY_SOFTPLUS_M1 ? softplusf_(d - 1.0f) : fmaxf(d, 0.f);
+    float di = t < T - 1 ? fmaxf(ts[t + 1] - ts[t < T ? t : T - 1], 1e-5f) : 1e10f;
+    di *= nrm;
+    dist[u] = di;
+    const float e = expf(-sigma * di);
+    ev[u] = e;
+    const float a = 1.0f - e;
+    fv[u] = (1.0f - a) + 1e-10f;
+    lp[u] = run;
+    if (t < T) run = run * fv[u];
+  }
+  float* P = cb_lds;
+  float* Q = cb_lds + S * 64;
+  P[seg * 64 + tx] = run;
+  __syncthreads();
+  float t_start = 1.0f;
+  for (int s2 = 0; s2 < seg; ++s2) t_start = t_start * P[s2 * 64 + tx];
+  float Gv[CB_SEG], Tv[CB_SEG], sl[CB_SEG];
+  float run2 = 0.f;
+#pragma unroll
+  for (int u = CB_SEG - 1; u >= 0; --u) {
+    const int t = t_lo + u;
+    const float Tt = t_start * lp[u];
+    const float w = (1.0f - ev[u]) * Tt;
+    float G = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      G += g[c] * cv[u][c];
+      if (live && t < T) g_feat[((int64_t)t * R + r) * C + c] = w * g[c];
+    }
+    if (t < T - 1) G -= gsky;
+    Gv[u] = G; Tv[u] = Tt; sl[u] = run2;
+    if (t < T) run2 += G * w;
+  }
+  Q[seg * 64 + tx] = run2;
+  __syncthreads();
+  float suffix0 = 0.f;
+  for (int s2 = S - 1; s2 > seg; --s2) suffix0 += Q[s2 * 64 + tx];
+#pragma unroll
+  for (int u = 0; u < CB_SEG; ++u) {
+    const int t = t_lo + u;
+    if (live && t < T) {
+      const float d = dv[u];
+      const float dLda = Gv[u] * Tv[u] - (suffix0 + sl[u]) / fv[u];
+      const float dsig = density_kind == NA_DENSITY_SOFTPLUS_M1 ? sigmoidf_(d - 1.0f) : (d > 0.f ? 1.f : 0.f);
+      g_density[(int64_t)t * R + r] = dLda * dist[u] * ev[u] * dsig;
+    }
+  }
+}
+
+template <int C>
+static void launch_composite_backward(const float* density, const float* feat, const float* ts, const float* rays, int T, int64_t R,
+                                      int density_kind, int bg_kind, const float* g_out, float* g_density, float* g_feat,
+                                      const float* sky_rand, hipStream_t stream) {
+  static const bool seq = [] { const char* e = getenv("NA_COMPOSITE_BWD"); return e != nullptr && strcmp(e, "seq") == 0; }();
+  const int S = (T + CB_SEG - 1) / CB_SEG;
+  if (S >= 2 && S <= 8 && !seq) {  // (T <= 128: 512 threads, the register budget of a segment held in registers)
+    hipLaunchKernelGGL(composite_backward_seg_kernel<C>, dim3((unsigned)((R + 63) / 64)), dim3(64, S), 2 * S * 64 * sizeof(float), stream,
+                       density, feat, ts, rays, T, R, density_kind, bg_kind, g_out, g_density, g_feat, sky_rand);
+  } else {
+    dim3 g(grid_for(R, 64, 1 << 16)), b(64);  // (one wave per workgroup: 4 096 rays reach 64 CUs instead of 32)
+    hipLaunchKernelGGL(composite_backward_kernel<C>, g, b, 0, stream, density, feat, ts, rays, T, R, density_kind, bg_kind, g_out,
+                       g_density, g_feat, sky_rand);
+  }
+}
+
 // out = (sigmoid(lin)/2 + 0.5) * pos[:, :C]  (src/refl.py:288-290): one thread per row.
 //   g_lin[n]    = sum_c g[n,c] * pos[n,c] * s (1 - s) / 2
 //   g_pos[n, c] = g[n,c] * (s/2 + 0.5) for c < C, 0 for the remaining (pass-through) columns
@@ -985,13 +1095,8 @@ int na_composite_backward(const float* density, const float* feat, const float* 
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_composite_backward: bad shape");
   NA_REQUIRE(C == 3 || C == 1, NA_EUNSUPPORTED, "na_composite_backward: C=%d (1 or 3)", C);
   if (R == 0) return NA_OK;
-  dim3 g(grid_for(R, 64, 1 << 16)), b(64);  // (one wave per workgroup: 4 096 rays reach 64 CUs instead of 32)
-  if (C == 3)
-    hipLaunchKernelGGL(composite_backward_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
-                       density_kind, bg_kind, g_out, g_density, g_feat);
-  else
-    hipLaunchKernelGGL(composite_backward_kernel<1>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
-                       density_kind, bg_kind, g_out, g_density, g_feat);
+  if (C == 3) launch_composite_backward<3>(density, feat, ts, rays, T, R, density_kind, bg_kind, g_out, g_density, g_feat, nullptr, (hipStream_t)stream);
+  else launch_composite_backward<1>(density, feat, ts, rays, T, R, density_kind, bg_kind, g_out, g_density, g_feat, nullptr, (hipStream_t)stream);
   return check_launch("na_composite_backward");
 }
 
@@ -1003,13 +1108,8 @@ int na_composite_random_bg_backward(const float* density, const float* feat, con
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_composite_random_bg_backward: bad shape");
   NA_REQUIRE(C == 3 || C == 1, NA_EUNSUPPORTED, "na_composite_random_bg_backward: C=%d (1 or 3)", C);
   if (R == 0) return NA_OK;
-  dim3 g(grid_for(R, 64, 1 << 16)), b(64);  // (one wave per workgroup: 4 096 rays reach 64 CUs instead of 32)
-  if (C == 3)
-    hipLaunchKernelGGL(composite_backward_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
-                       density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand);
-  else
-    hipLaunchKernelGGL(composite_backward_kernel<1>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R,
-                       density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand);
+  if (C == 3) launch_composite_backward<3>(density, feat, ts, rays, T, R, density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand, (hipStream_t)stream);
+  else launch_composite_backward<1>(density, feat, ts, rays, T, R, density_kind, (int)NA_BG_RANDOM, g_out, g_density, g_feat, rand, (hipStream_t)stream);
   return check_launch("na_composite_random_bg_backward");
 }
 

@@ -84,6 +84,36 @@ def test_composite_backward(ops):
             assert rel(gd, d.grad) <= 2e-4, (sp, bg)
 
 
+@pytest.mark.parametrize("T,R", [(17, 70), (48, 129), (64, 64), (100, 200), (128, 65), (129, 40)])
+def test_composite_backward_segmented_kernel(ops, T, R):
+    """Round 6: above 16 steps the compositing backward runs one thread per (ray, 16-step segment) with the segments' prefix products /
+    suffix sums combined in LDS (csrc/backward.hip composite_backward_seg_kernel; T > 128: the sequential kernel): ragged T and ray counts,
+    both density kinds, black / white / random backgrounds, 3 and 1 channels, against the oracle's autograd in fp64."""
+    ts = torch.linspace(2.0, 6.0, T)
+    r_d = torch.from_numpy(proc_uniform((1, 1, R, 3), 21, 1.0))   # (the oracle's compositing takes [T, B, H, W] batches)
+    rays = torch.cat([torch.zeros_like(r_d), r_d], -1)
+    for C in (3, 1):
+        dens = torch.from_numpy(proc_uniform((T, 1, 1, R), 22 + C, 3.0))
+        rgb = torch.from_numpy(proc_uniform((T, 1, 1, R, C), 23 + C, 0.5)) + 0.5
+        go = torch.from_numpy(proc_uniform((1, 1, R, C), 24 + C, 1.0))
+        rand = torch.from_numpy(proc_uniform((1, 1, R, 1), 25, 0.5)) + 0.5
+        for sp in (True, False):
+            for bg in ("black", "white", "random"):
+                d = dens.double().requires_grad_()
+                c = rgb.double().requires_grad_()
+                a, w = O.alpha_from_density(d, ts.double(), r_d.double(), softplus=sp)
+                out = O.volumetric_integrate(w, c)
+                if bg == "white":
+                    out = out + O.sky_white(w)
+                elif bg == "random":
+                    out = out + O.sky_random(w, rand.double())
+                (out * go.double()).sum().backward()
+                gd, gf = ops.composite_backward(dens.cuda(), rgb.cuda(), ts.cuda(), rays.cuda(), go.cuda(), sp, bg,
+                                                rand=rand.reshape(1, 1, R).cuda() if bg == "random" else None)
+                assert rel(gf.double(), c.grad) <= 1e-5, (C, sp, bg)
+                assert rel(gd.double(), d.grad) <= 5e-5, (C, sp, bg)
+
+
 @pytest.mark.parametrize("act", ["none", "leaky_relu", "sin"])
 def test_linear_backward(ops, act, train_prec):
     from nerf_atlas_amd.autograd import LinearFn
