@@ -574,14 +574,16 @@ int na_render_plain_view_ls_rayts(const float* rays, int64_t R, const float* ts_
  * of the training GEMMs -- with explicit sample positions pts [T,R,3], which also leaves in HBM what the backward pass reads: the output
  * rows (bias added, BEFORE the next layer's activation: what na_linear_bwd_partials takes as the next Linear's forward input) of the ten
  * 256-wide Linears, planes[(p * T * R + t * R + ray) * 256 + c], p = 0..4 `first`.init, layers.0..3; 5..9 the View MLP's;
- * first_out [T*R, 65] (density | intermediate, the reference's column order) and rgb_pre [T*R, 3] (before the sigmoid).  The layer-by-
+ * view_rows [T*R, 69] = the View MLP's init rows [x, y, z, elev, azim | intermediate] (src/nerf.py:338-357, src/refl.py:190-207: what
+ * na_plain_head_rows builds from `first`'s output, which is not materialised), density [T*R] (first.out's column 0) and rgb_pre [T*R, 3]
+ * (before the sigmoid).  The layer-by-
  * layer forward (na_linear_f32 with split_bf16) writes every one of those rows AND reads it back as the next layer's input; here the
  * activations stay in LDS.  packed: na_render_ls_pack(NA_PREC_BF16X3) of the CURRENT weights; out [R,3] receives the kernel's own
  * composited colour (black background; callers that composite with noise or a random background ignore it); workspace:
  * na_render_ls_workspace_bytes.  T * R < 4 194 304 (32-bit row offsets). */
 int na_train_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
-                           const void* packed, int sigmoid_kind, float* planes, float* first_out, float* rgb_pre, float* out,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           const void* packed, int sigmoid_kind, float* planes, float* view_rows, float* density, float* rgb_pre,
+                           float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* PlainNeRF(view) with mip's integrated positional encoding (config 3: src/nerf.py:256-261 hook, :326-361 forward,
  * src/utils.py:23-27, 60-140 cylinder / conic Gaussians) as ONE launch of the layer-synchronous engine, NA_PREC_F16X only.

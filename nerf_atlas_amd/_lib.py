@@ -161,7 +161,7 @@ SIGNATURES = {
     "na_render_plain_view_ls_rayts": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                 c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "na_train_plain_view_ls": (C.c_int, [c_f32p, c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_int, c_f32p, c_f32p,
-                                         c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                         c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "na_render_plain_mip_ls_packed_bytes": (C.c_size_t, [C.c_int]),
     "na_render_plain_mip_ls_pack": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),

@@ -123,13 +123,16 @@ class PlainHeadFn(Function):
     (and the points' three columns when they carry a gradient: D-NeRF)."""
 
     @staticmethod
-    def forward(ctx, first_out, pts, dirs):
+    def forward(ctx, first_out, pts, dirs, pre=None):
+        if pre is not None:
+            # (round 6: the one-launch training forward wrote density and rows itself; `first_out` is a placeholder nobody reads)
+            return pre
         return ops.plain_head_rows(first_out, pts, dirs)
 
     @staticmethod
     def backward(ctx, g_density, g_rows):
         g_first, g_pts = ops.plain_head_rows_backward(g_density, g_rows.contiguous(), ctx.needs_input_grad[1])
-        return g_first, g_pts, None
+        return g_first, g_pts, None, None
 
 
 class HashJvpFn(Function):
@@ -330,6 +333,10 @@ class MlpTrainFn(Function):
             rows, x = pre
             assert len(rows) == L - 1 and all(r.shape == (init.shape[0], W.shape[0]) for r, W in zip(rows, Ws)), (L, [r.shape for r in rows])
             xs = [init] + list(rows)
+            if x is None:
+                # the network's output went straight into its consumer's format (PlainNeRF's `first`: density + the View MLP's init
+                # rows, PlainHeadFn with `pre`): a placeholder of the right shape keeps the graph's edges, its values are never read
+                x = torch.empty((init.shape[0], Ws[-1].shape[0]), device=init.device, dtype=torch.float32)
         else:
             xs, x = [], init
             for li in range(L):

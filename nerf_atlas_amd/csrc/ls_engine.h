@@ -182,8 +182,8 @@ struct Args {
   float* park = nullptr;            // per-workgroup scratch: [workgroup][group][block] x 8 KiB of raw latent rows
   const float* rl = nullptr;        // MODEL 8: refl_latent rows [T * R, rl_ld] (--dyn-refl-latent), nullable
   int rl_ld = 0, n_rl = 0;
-  // MODEL 9 (the training forward, round 6) takes its three output buffers through fields the PlainNeRF schedule does not use -- y
-  // (planes [10][N, 256], N = T * R, dense), park ([N, 65] first.out, the reference's column order), feat ([N, 3] view.out) -- so that
+  // MODEL 9 (the training forward, round 6) takes its four output buffers through fields the PlainNeRF schedule does not use -- y
+  // (planes [10][N, 256], N = T * R, dense), park ([N, 69] the View MLP's init rows), rl ([N] density), feat ([N, 3] view.out) -- so that
   // the argument block keeps its size: the implicit kernel arguments behind it, and with them three instructions of the pinned
   // headline kernel (csrc/ls_headline_isa.sha256), do not move
 };

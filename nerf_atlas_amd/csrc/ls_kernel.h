@@ -681,8 +681,8 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
   // and READS them back as the next Linear's input; here the rows stay in LDS from layer to layer as in inference, and the fp32
   // accumulators -- exactly what the backward kernel of the NEXT Linear wants as its input (it applies act and act' itself:
   // csrc/train_bwd.hip) -- are written once on the way: plane p of Args::y = output rows of Linear p (0..4 first.init, L0..L3;
-  // 5..9 view.init, L0..L3), sample row t * R + ray like every [T, R, .] tensor of the path; first.out's 65 rows in the reference's
-  // column order (density first) and view.out's 3 rows go to their own buffers.  A lane holds rows 8 j + 4 hi .. + 3 of a tile for
+  // 5..9 view.init, L0..L3), sample row t * R + ray like every [T, R, .] tensor of the path; first.out's 65 rows (train_store_first) and
+  // view.out's 3 rows go to their own buffers.  A lane holds rows 8 j + 4 hi .. + 3 of a tile for
   // its sample in registers 4 j .. 4 j + 3: one 16-byte store per (tile, block, j), 128 contiguous bytes per sample and tile.
   // (buffer stores, the row offset in the VECTOR offset and soffset 0: DESIGN 3d's store-data hazard)
   auto train_row = [&](int pl, int b, bool& ok) -> uint32_t {
@@ -732,25 +732,34 @@ __global__ __launch_bounds__(512) void render_ls_kernel(Args a) {
       }
     }
   };
-  // first.out: row group rg < 2 holds the intermediate rows 32 rg .. + 31 (reference columns 1 + ...), row group 2 the density
-  // (register 0 of the hi = 0 lanes: reference column 0) of the NB blocks -> Args::park as [N, 65]
+  // first.out: row group rg < 2 holds the intermediate rows 32 rg .. + 31, row group 2 the density (register 0 of the hi = 0 lanes) of
+  // the NB blocks.  They leave as what the step's NEXT consumers read (src/nerf.py:338-357, src/refl.py:190-207): the View MLP's init
+  // rows [x, y, z, elev, azim | intermediate] -> Args::park as [N, 69] (the geometry columns by the density lanes: the explicit
+  // position of the sample and the ray's angles from the pre-kernel, geo_setup(pl) has run) and the density -> Args::rl as [N];
+  // first_out [N, 65] itself is never materialised (na_plain_head_rows built the same rows from it: one more pass over 68 MB)
   auto train_store_first = [&](const f32x16 (&oq)[NB], int pl) {
     if constexpr (TRAIN) {
-      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)a.park, 0, (int)((int64_t)a.T * a.R * 260), 0x00020000);
+      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)a.park, 0, (int)((int64_t)a.T * a.R * 276), 0x00020000);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         bool ok;
         const uint32_t row = train_row(pl, b, ok);
         if (ok && rg < 2) {
-          const uint32_t vo = row * 260u + (uint32_t)(4 * (1 + 32 * rg + 4 * hi));
+          const uint32_t vo = row * 276u + (uint32_t)(4 * (5 + 32 * rg + 4 * hi));
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float v = oq[b][i];  // (__builtin_bit_cast of a vector ELEMENT expression reads element 0: through a scalar)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), frs, vo + 4 * (8 * (i >> 2) + (i & 3)), 0, 0);
           }
         } else if (ok && rg == 2 && hi == 0) {
-          const float v = oq[b][0];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), frs, row * 260u, 0, 0);
+          const_cast<float*>(a.rl)[row] = oq[b][0];
+          const float* p = a.pts + (int64_t)row * 3;
+          const float gx = p[0], gy = p[1], gz = p[2], el = geo_u[b][6], az = geo_u[b][7];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gx), frs, row * 276u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gy), frs, row * 276u + 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gz), frs, row * 276u + 8, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, el), frs, row * 276u + 12, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, az), frs, row * 276u + 16, 0, 0);
         }
       }
     }

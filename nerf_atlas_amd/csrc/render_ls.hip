@@ -125,7 +125,7 @@ extern "C" size_t na_render_ls_workspace_bytes(int T, int64_t R) {
   return (size_t)R * 2 * sizeof(float) + 256 + (NA_LS_TRACE ? 4096 + 256 : 0);
 }
 
-struct LsTrainOut { float* planes; float* first_out; float* rgb; };
+struct LsTrainOut { float* planes; float* view_rows; float* density; float* rgb; };
 static int render_plain_view_ls_impl(const float* rays, const float* pts, int64_t R, const float* ts, int64_t ts_stride, int T,
                                      const float* hash_tables, const void* packed, int precision, int sigmoid_kind,
                                      int bg_kind, float* alpha, float* weights, float* out, void* workspace,
@@ -156,7 +156,7 @@ static int render_plain_view_ls_impl(const float* rays, const float* pts, int64_
   if (tr != nullptr) {  // MODEL 9: the training forward (bf16x3 only)
     const int64_t N = (int64_t)T * R;
     (void)N;
-    a.y = tr->planes; a.park = tr->first_out; a.feat = tr->rgb;  // (ls_engine.h Args: MODEL 9's outputs ride in fields MODEL 0 leaves alone)
+    a.y = tr->planes; a.park = tr->view_rows; a.rl = tr->density; a.feat = tr->rgb;  // (ls_engine.h Args: MODEL 9's outputs ride in fields MODEL 0 leaves alone)
     return render_ls_dispatch_bf16x3(a, (hipStream_t)stream, 9);
   }
   if (precision == NA_PREC_BF16) return render_ls_dispatch_bf16(a, (hipStream_t)stream, 0);
@@ -169,14 +169,14 @@ static int render_plain_view_ls_impl(const float* rays, const float* pts, int64_
 // for the backward pass: ls_kernel.h train_store; what csrc/train_fwd.hip does layer by layer).  Replaces the twelve forward Linears of
 // src/neural_blocks.py:279-296 (x 2) in a training iteration (runner.py:647-825).
 extern "C" int na_train_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
-                                      const void* packed, int sigmoid_kind, float* planes, float* first_out,
+                                      const void* packed, int sigmoid_kind, float* planes, float* view_rows, float* density,
                                       float* rgb_pre, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   NA_REQUIRE(T >= 1 && R >= 0, NA_EINVAL, "na_train_plain_view_ls: bad shape T=%d R=%lld", T, (long long)R);
   if (R == 0) return NA_OK;
-  NA_REQUIRE(pts && planes && first_out && rgb_pre, NA_ENULL, "na_train_plain_view_ls: null pointer");
+  NA_REQUIRE(pts && planes && view_rows && density && rgb_pre, NA_ENULL, "na_train_plain_view_ls: null pointer");
   const int64_t N = (int64_t)T * R;
   NA_REQUIRE(N * 1024 < (1ll << 32), NA_EINVAL, "na_train_plain_view_ls: %lld samples (the row offsets are 32-bit: < 4 194 304)", (long long)N);
-  const LsTrainOut tr = {planes, first_out, rgb_pre};
+  const LsTrainOut tr = {planes, view_rows, density, rgb_pre};
   return render_plain_view_ls_impl(rays, pts, R, ts, 0, T, hash_tables, packed, NA_PREC_BF16X3, sigmoid_kind, NA_BG_BLACK, nullptr, nullptr,
                                    out, workspace, workspace_bytes, stream, &tr);
 }

@@ -333,7 +333,8 @@ class PlainNeRF(CommonNeRF):
     def _train_forward_ls(self, rays, ts, pts, r_d):
         """Training (round 6): both networks' forwards as ONE launch of the layer-synchronous engine in the three-product bf16 split
         (csrc/ls_kernel.h MODEL 9) instead of twelve training Linears -- every Linear's output rows are written once for the backward
-        pass and never read back by the forward.  Returns (planes [10, N, 256], first_out [N, 65], rgb_pre [N, 3]) or None when the
+        pass and never read back by the forward.  Returns (planes [10, N, 256], (density [N], the View MLP's init rows [N, 69]), rgb_pre [N, 3],
+        the stacked hash tables) or None when the
         step does not have the shape the kernel serves (then the layer-by-layer forward runs: the same three-product arithmetic with
         another summation order).  `config.set_train_forward("layers")` / NA_TRAIN_LS=0 switch it off."""
         N = pts.numel() // 3
@@ -348,9 +349,9 @@ class PlainNeRF(CommonNeRF):
         enc = self.first.enc
         tables = torch.stack([e.weight for e in enc.embs])  # (differentiable: the encoder's node of this step takes the same tensor)
         with torch.no_grad():
-            planes, first_out, rgb_pre, _ = ops.train_plain_view_ls(rays.reshape(-1, 6), ts, pts.detach(), tables.detach(),
-                                                                    self.packed_ls("bf16x3"), self.sigmoid_kind)
-        return planes, first_out, rgb_pre, tables
+            planes, rows, density, rgb_pre, _ = ops.train_plain_view_ls(rays.reshape(-1, 6), ts, pts.detach(), tables.detach(),
+                                                                        self.packed_ls("bf16x3"), self.sigmoid_kind)
+        return planes, (density, rows), rgb_pre, tables
 
     @_f16x_policy
     def forward(self, rays, want_weights: bool = True):
@@ -418,20 +419,22 @@ class PlainNeRF(CommonNeRF):
                                 "+ separate compositing")
         latent = self.mip_latent(rays, ts)  # lazy: generated in the prologues of `first` and of the View MLP
         pre = self._train_forward_ls(rays, ts, pts, r_d) if latent is None and refl_latent is None else None
-        first_out = self.first(pts, latent, pre=None if pre is None else (list(pre[0][:5]), pre[1], pre[3]))
+        first_out = self.first(pts, latent, pre=None if pre is None else (list(pre[0][:5]), None, pre[3]))
         if (ag.needs_grad(first_out) and latent is None and refl_latent is None and type(self.refl) is refl.View and pts.is_cuda
                 and not self.refl.mlp.last_layer_act and self.refl.mlp.latent_size == first_out.shape[-1] - 1
                 and r_d.shape == pts.shape[1:] and os.environ.get("NA_TRAIN_ROWS") != "0"):
             # training: density | the View MLP's init rows [x, elev, azim | intermediate] by ONE kernel (autograd.PlainHeadFn; slice
             # copies, elaz, expand and two cats before), the network from its rows (SkipConnMLP.forward_rows)
             C = first_out.shape[-1]
-            density, rows = ag.PlainHeadFn.apply(first_out.reshape(-1, C), pts.reshape(-1, 3), r_d.reshape(-1, 3).contiguous())
+            density, rows = ag.PlainHeadFn.apply(first_out.reshape(-1, C), pts.reshape(-1, 3), r_d.reshape(-1, 3).contiguous(),
+                                                 None if pre is None else pre[1])
             density = density.reshape(pts.shape[:-1])
             if self.training and self.noise_std > 0:
                 density = density + utils.randn(density.shape, density.device) * self.noise_std
             rgb = self.refl.act(self.refl.mlp.forward_rows(rows, pre=None if pre is None else (list(pre[0][5:]), pre[2]))
                                 .reshape(pts.shape[:-1] + (self.refl.out_features,)))
             return self._composite(density, rgb, ts, rays)
+        assert pre is None, "the one-launch training forward implies the rows path above (its `first_out` is a placeholder)"
         if ag.needs_grad(first_out):
             density, intermediate = ag.SplitHeadFn.apply(first_out)  # (the slices' gradients written side by side: autograd.py)
         else:

@@ -966,8 +966,9 @@ TRAIN_LS_MAX_ROWS = (1 << 22) - 1  # na_train_plain_view_ls: 32-bit byte offsets
 
 def train_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, pts: torch.Tensor, hash_tables: torch.Tensor, packed: torch.Tensor,
                         sigmoid_kind: str = "thin"):
-    """The training forward of PlainNeRF(view) as one launch (na_train_plain_view_ls): returns (planes [10, N, 256], first_out [N, 65],
-    rgb_pre [N, 3], out [*batch, 3]) with N = T * R, rows t * R + ray.  `packed`: render_ls_pack("bf16x3", ...) of the current weights."""
+    """The training forward of PlainNeRF(view) as one launch (na_train_plain_view_ls): returns (planes [10, N, 256], view_rows [N, 69],
+    density [N], rgb_pre [N, 3], out [*batch, 3]) with N = T * R, rows t * R + ray.  `packed`: render_ls_pack("bf16x3", ...) of the
+    current weights."""
     lib = _lib.load()
     rays, ts, pts, hash_tables = _f32(rays, "rays"), _f32(ts, "ts"), _f32(pts, "pts"), _f32(hash_tables, "hash_tables")
     R, T = rays.numel() // 6, ts.numel()
@@ -975,14 +976,15 @@ def train_plain_view_ls(rays: torch.Tensor, ts: torch.Tensor, pts: torch.Tensor,
     assert pts.numel() == N * 3, (pts.shape, T, R)
     dev = rays.device
     planes = torch.empty((10, N, 256), device=dev, dtype=torch.float32)
-    first_out = torch.empty((N, 65), device=dev, dtype=torch.float32)
+    view_rows = torch.empty((N, 69), device=dev, dtype=torch.float32)
+    density = torch.empty((N,), device=dev, dtype=torch.float32)
     rgb_pre = torch.empty((N, 3), device=dev, dtype=torch.float32)
     out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=dev, dtype=torch.float32)
     workspace = torch.empty(int(lib.na_render_ls_workspace_bytes(T, R)), device=dev, dtype=torch.uint8)
     check(lib.na_train_plain_view_ls(_ptr(rays), _ptr(pts), R, _ptr(ts), T, _ptr(hash_tables), _ptr(packed), SIGMOID[sigmoid_kind],
-                                     _ptr(planes), _ptr(first_out), _ptr(rgb_pre), _ptr(out), _ptr(workspace), workspace.numel(),
-                                     _stream()))
-    return planes, first_out, rgb_pre, out
+                                     _ptr(planes), _ptr(view_rows), _ptr(density), _ptr(rgb_pre), _ptr(out), _ptr(workspace),
+                                     workspace.numel(), _stream()))
+    return planes, view_rows, density, rgb_pre, out
 
 
 def resample_ts(ts: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Optional[torch.Tensor] = None, want_fine: bool = False):

@@ -50,18 +50,21 @@ def test_rows_of_the_one_launch_forward_vs_fp64(crop, steps):
     m, rays = _model_and_rays(crop, steps)
     pts, ts, r_o, r_d, _ = compute_pts_ts(rays, 2.0, 6.0, steps, perturb=0)
     with torch.no_grad():
-        planes, first_out, rgb_pre, out = ops.train_plain_view_ls(rays.reshape(-1, 6), ts, pts, m.first.enc.tables(), m.packed_ls("bf16x3"), "upshifted")
+        planes, vrows_ls, dens_ls, rgb_pre, out = ops.train_plain_view_ls(rays.reshape(-1, 6), ts, pts, m.first.enc.tables(), m.packed_ls("bf16x3"), "upshifted")
         N = pts.numel() // 3
         init = ops.hash_encode_rows(pts.reshape(-1, 3), m.first.enc.tables(), True, 1)
         rows1, fo = _mlp_fp64(m.first, init, torch.nn.functional.leaky_relu)
-        _, vrows = ops.plain_head_rows(fo.float().contiguous(), pts.reshape(-1, 3), r_d.reshape(-1, 3).contiguous())
+        dens, vrows = ops.plain_head_rows(fo.float().contiguous(), pts.reshape(-1, 3), r_d.reshape(-1, 3).contiguous())
         rows2, rgb = _mlp_fp64(m.refl.mlp, vrows, torch.sin)
         worst = 0.0
         for p, want in enumerate(rows1 + rows2):
             err = float((planes[p].double() - want).abs().max() / want.abs().max())
             worst = max(worst, err)
             assert err <= 3e-5, (p, err)
-        assert float((first_out.double() - fo).abs().max() / fo.abs().max()) <= 3e-5
+        # first.out leaves the kernel as its consumers' inputs: density [N] and the View MLP's init rows [x, y, z, elev, azim | intermediate]
+        assert torch.equal(vrows_ls[:, :5], vrows[:, :5])  # (the sample's position and the ray's angles: copies)
+        assert float((vrows_ls[:, 5:].double() - fo[:, 1:]).abs().max() / fo.abs().max()) <= 3e-5
+        assert float((dens_ls.double() - fo[:, 0]).abs().max() / fo.abs().max()) <= 3e-5
         assert float((rgb_pre.double() - rgb).abs().max() / rgb.abs().max().clamp_min(1.0)) <= 3e-5
         # the kernel's own composited colour = the inference renderer's (same schedule, same stream)
         ref, _, _ = ops.render_plain_view_ls(rays, ts, m.first.enc.tables(), m.packed_ls("bf16x3"), "bf16x3", "upshifted", "black", False, pts=pts)
