@@ -426,8 +426,9 @@ class PlainNeRF(CommonNeRF):
             # training: density | the View MLP's init rows [x, elev, azim | intermediate] by ONE kernel (autograd.PlainHeadFn; slice
             # copies, elaz, expand and two cats before), the network from its rows (SkipConnMLP.forward_rows)
             C = first_out.shape[-1]
-            density, rows = ag.PlainHeadFn.apply(first_out.reshape(-1, C), pts.reshape(-1, 3), r_d.reshape(-1, 3).contiguous(),
-                                                 None if pre is None else pre[1])
+            # (with precomputed values the node reads neither positions nor directions: no copy of the direction slice)
+            density, rows = ag.PlainHeadFn.apply(first_out.reshape(-1, C), pts.reshape(-1, 3),
+                                                 r_d.reshape(-1, 3).contiguous() if pre is None else None, None if pre is None else pre[1])
             density = density.reshape(pts.shape[:-1])
             if self.training and self.noise_std > 0:
                 density = density + utils.randn(density.shape, density.device) * self.noise_std
