@@ -576,9 +576,8 @@ int na_render_plain_view_ls_rayts(const float* rays, int64_t R, const float* ts_
  * 256-wide Linears, planes[(p * T * R + t * R + ray) * 256 + c], p = 0..4 `first`.init, layers.0..3; 5..9 the View MLP's;
  * view_rows [T*R, 69] = the View MLP's init rows [x, y, z, elev, azim | intermediate] (src/nerf.py:338-357, src/refl.py:190-207: what
  * na_plain_head_rows builds from `first`'s output, which is not materialised), density [T*R] (first.out's column 0) and rgb_pre [T*R, 3]
- * (before the sigmoid).  The layer-by-
- * layer forward (na_linear_f32 with split_bf16) writes every one of those rows AND reads it back as the next layer's input; here the
- * activations stay in LDS.  packed: na_render_ls_pack(NA_PREC_BF16X3) of the CURRENT weights; out [R,3] receives the kernel's own
+ * (before the sigmoid).  The layer-by-layer forward (na_linear_bf16x3_pk per Linear) writes every one of those rows AND reads it back as
+ * the next layer's input; here the activations stay in LDS and the rows leave as whole 128-byte lines, non-temporal.  packed: na_render_ls_pack(NA_PREC_BF16X3) of the CURRENT weights; out [R,3] receives the kernel's own
  * composited colour (black background; callers that composite with noise or a random background ignore it); workspace:
  * na_render_ls_workspace_bytes.  T * R < 4 194 304 (32-bit row offsets). */
 int na_train_plain_view_ls(const float* rays, const float* pts, int64_t R, const float* ts, int T, const float* hash_tables,
