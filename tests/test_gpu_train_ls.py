@@ -43,7 +43,7 @@ def _mlp_fp64(m, init, act):
     return rows, x
 
 
-@pytest.mark.parametrize("crop,steps", [(16, 64), (24, 48), (13, 80)])
+@pytest.mark.parametrize("crop,steps", [(16, 64), (24, 48), (13, 80), (24, 16), (15, 40)])
 def test_rows_of_the_one_launch_forward_vs_fp64(crop, steps):
     from nerf_atlas_amd import ops
     from nerf_atlas_amd.nerf import compute_pts_ts
