@@ -1,6 +1,7 @@
-"""timing of ops.train_plain_view_ls alone (NA_LIB_PATH picks a variant library)"""
+"""Timing of the one-launch training forward alone (ops.train_plain_view_ls, 262 144 and 1 048 576 samples); NA_LIB_PATH picks a variant
+library built by tools/ls_variant.py (e.g. `build tr_nostore --prec bf16x3 -DNA_LS_TRAIN_EXP=1`): the ablation table of DESIGN 3d."""
 import math, os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nerf_atlas_amd.nerf as nerf
 from nerf_atlas_amd import ops
 from nerf_atlas_amd.nerf import compute_pts_ts
