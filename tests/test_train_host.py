@@ -101,3 +101,35 @@ def test_packed_caches_drop_on_load_state_dict_and_apply():
         assert utils.pack_stamp(lin) is None
     finally:
         config.set_repack_always(False)
+
+
+def test_train_forward_switch_and_the_step_byte_model():
+    """config.train_forward ("ls" = the one-launch training forward, "layers" = one Linear per launch) and bench.py's model of the bytes a
+    training step has to move with either: the one-launch forward saves exactly the forward's input reads, 4 B per input column."""
+    import importlib
+    import os
+    import sys
+    from nerf_atlas_amd import config
+    assert config.train_forward in ("ls", "layers")
+    prev = config.train_forward
+    try:
+        config.set_train_forward("layers")
+        assert config.train_forward == "layers"
+        with pytest.raises(ValueError):
+            config.set_train_forward("fused")
+    finally:
+        config.set_train_forward(prev)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    ls, layers = bench.train_algorithmic_bytes_per_sample("ls"), bench.train_algorithmic_bytes_per_sample("layers")
+    cols_in = (38 + 294 + 256 * 4) + (69 + 325 + 256 * 4)
+    assert layers - ls == 4 * cols_in and layers == 54312
+
+
+def test_plain_nerf_on_the_cpu_never_takes_the_one_launch_forward():
+    """PlainNeRF._train_forward_ls serves CUDA batches of 8 192 .. 2^22 - 1 samples only; anything else returns None (the layer path)."""
+    import torch
+    import nerf_atlas_amd.nerf as nerf
+    m = nerf.PlainNeRF(steps=16, t_near=2.0, t_far=6.0, intermediate_size=64)
+    pts = torch.zeros(16, 1, 4, 4, 3)
+    assert m._train_forward_ls(torch.zeros(1, 4, 4, 6), torch.linspace(2, 6, 16), pts, torch.zeros(1, 4, 4, 3)) is None
