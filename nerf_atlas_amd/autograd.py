@@ -10,6 +10,16 @@ from torch.autograd import Function
 from . import config, ops
 
 
+_NAN = {}
+
+
+def _nan_scalar(device):
+    t = _NAN.get(device)
+    if t is None:
+        t = _NAN[device] = torch.full((1, 1), float("nan"), device=device, dtype=torch.float32)
+    return t
+
+
 def needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -336,7 +346,8 @@ class MlpTrainFn(Function):
             if x is None:
                 # the network's output went straight into its consumer's format (PlainNeRF's `first`: density + the View MLP's init
                 # rows, PlainHeadFn with `pre`): a placeholder of the right shape keeps the graph's edges, its values are never read
-                x = torch.empty((init.shape[0], Ws[-1].shape[0]), device=init.device, dtype=torch.float32)
+                # -- and if a future caller does read them it gets NaN, not stale memory (one cached scalar per device, broadcast: no launch)
+                x = _nan_scalar(init.device).expand(init.shape[0], Ws[-1].shape[0])
         else:
             xs, x = [], init
             for li in range(L):
