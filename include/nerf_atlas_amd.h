@@ -423,20 +423,6 @@ int na_bezier_warp_latent_backward(const float* est, int est_stride, const float
 int na_composite_backward(const float* density, const float* feat, const float* ts, const float* rays,
                           int T, int64_t R, int C, int density_kind, int bg_kind, const float* g_out,
                           float* g_density, float* g_feat, void* stream);
-
-/* The colour head of a training step in one launch each way (round 6): act(feat_pre) -- the reflectance activation of src/refl.py:207
- * on the network's output rows, act_kind one of NA_SIG_NORMAL / THIN / FAT / UPSHIFTED, or -1 for rows that are colours already --
- * applied on load inside na_composite's kernel (src/nerf.py:60-80, 96-103): bit for bit the outputs of na_sigmoid + na_composite, and the
- * backward bit for bit those of na_composite_backward + na_sigmoid_backward (its kernel: one thread per (ray, 16-step segment), hence
- * 16 < T <= 128, C = 3: na_composite_act_ok); bg NA_BG_RANDOM takes the per-ray draw `rand` [R].  The backward returns the gradient
- * w.r.t. feat_pre (times act') and the density. */
-int na_composite_act_ok(int T, int C, int act_kind);
-int na_composite_act(const float* density, const float* feat_pre, const float* ts, const float* rays, int T, int64_t R, int C,
-                     int density_kind, int bg_kind, int act_kind, const float* rand, float* alpha, float* weights, float* out,
-                     void* stream);
-int na_composite_act_backward(const float* density, const float* feat_pre, const float* ts, const float* rays, int T, int64_t R, int C,
-                              int density_kind, int bg_kind, int act_kind, const float* rand, const float* g_out, float* g_density,
-                              float* g_feat_pre, void* stream);
 /* the same for na_composite_random_bg (src/nerf.py:99-103): d sky / d w_t = -rand[r] for t < T-1; rand carries no gradient */
 int na_composite_random_bg_backward(const float* density, const float* feat, const float* ts, const float* rays,
                                     int T, int64_t R, int C, int density_kind, const float* rand, const float* g_out,

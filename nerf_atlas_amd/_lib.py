@@ -146,11 +146,6 @@ SIGNATURES = {
                                                  c_f32p, c_f32p, C.c_void_p]),
     "na_composite_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,
                                         c_f32p, c_f32p, c_f32p, C.c_void_p]),
-    "na_composite_act_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "na_composite_act": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
-                                   c_f32p, c_f32p, c_f32p, C.c_void_p]),
-    "na_composite_act_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
-                                            c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "na_render_workspace_bytes": (C.c_size_t, [C.c_int, c_i64]),
     "na_render_plain_view": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,

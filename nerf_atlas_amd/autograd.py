@@ -294,27 +294,6 @@ class CompositeFn(Function):
         return gd, gf, None, None, None, None, None
 
 
-class CompositeActFn(Function):
-    """CompositeFn with the reflectance activation folded in (round 6: ops.composite_act): `feat_pre` are the reflectance network's rows
-    BEFORE `self.act` (src/refl.py:207), applied on load inside the compositing kernels: the sigmoid's own forward and backward launches
-    are gone, the values and gradients are bit for bit those of SigmoidFn + CompositeFn."""
-
-    @staticmethod
-    def forward(ctx, density, feat_pre, ts, rays, softplus, bg, rand, act_kind):
-        out, alpha, weights = ops.composite_act(density, feat_pre, ts, rays, act_kind, softplus=softplus, bg=bg, rand=rand)
-        ctx.save_for_backward(density, feat_pre, ts, rays)
-        ctx.softplus, ctx.bg, ctx.rand, ctx.act_kind = softplus, bg, rand, act_kind
-        ctx.mark_non_differentiable(alpha, weights)
-        ctx.set_materialize_grads(False)
-        return out, alpha, weights
-
-    @staticmethod
-    def backward(ctx, g_out, _ga, _gw):
-        density, feat_pre, ts, rays = ctx.saved_tensors
-        gd, gf = ops.composite_act_backward(density, feat_pre, ts, rays, g_out.contiguous(), ctx.act_kind, ctx.softplus, ctx.bg, rand=ctx.rand)
-        return gd, gf, None, None, None, None, None, None
-
-
 class SplitHeadFn(Function):
     """(y[..., 0] contiguous, y[..., 1:] as a view) of a network output [.., 1 + C] -- PlainNeRF's density | intermediate
     (src/nerf.py:338-342).  The same values as the two slices; the point is the BACKWARD: autograd's own slice gradients are a

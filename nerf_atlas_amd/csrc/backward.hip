@@ -685,9 +685,7 @@ __global__ __launch_bounds__(512) void composite_backward_seg_kernel(const float
                                               const float* __restrict__ ts, const float* __restrict__ rays, int T,
                                               int64_t R, int density_kind, int bg_kind, const float* __restrict__ g_out,
                                               float* __restrict__ g_density, float* __restrict__ g_feat,
-                                              const float* __restrict__ sky_rand, int act_kind = -1) {
-  // act_kind >= 0 (na_composite_act_backward): `feat` holds the rows BEFORE the reflectance activation -- the colour is act(feat) and
-  // g_feat the gradient w.r.t. those rows (times act'): the sigmoid's own forward and backward launches are gone
+                                              const float* __restrict__ sky_rand) {
   extern __shared__ float cb_lds[];  // [2][S][64]
   const int tx = threadIdx.x, seg = threadIdx.y, S = blockDim.y;
   const int64_t r = (int64_t)blockIdx.x * 64 + tx;
@@ -743,11 +741,8 @@ __global__ __launch_bounds__(512) void composite_backward_seg_kernel(const float
     float G = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      // (act_kind < 0: colour = feat, factor 1 -- the product with 1.0f is exact: the bits of the kernel without this path)
-      const float col = act_kind >= 0 ? apply_sigmoid_kind(cv[u][c], act_kind) : cv[u][c];
-      const float dcol = act_kind >= 0 ? sigmoid_kind_grad(cv[u][c], act_kind) : 1.0f;
-      G += g[c] * col;
-      if (live && t < T) g_feat[((int64_t)t * R + r) * C + c] = (w * g[c]) * dcol;
+      G += g[c] * cv[u][c];
+      if (live && t < T) g_feat[((int64_t)t * R + r) * C + c] = w * g[c];
     }
     if (t < T - 1) G -= gsky;
     Gv[u] = G; Tv[u] = Tt; sl[u] = run2;
@@ -1103,24 +1098,6 @@ int na_composite_backward(const float* density, const float* feat, const float* 
   if (C == 3) launch_composite_backward<3>(density, feat, ts, rays, T, R, density_kind, bg_kind, g_out, g_density, g_feat, nullptr, (hipStream_t)stream);
   else launch_composite_backward<1>(density, feat, ts, rays, T, R, density_kind, bg_kind, g_out, g_density, g_feat, nullptr, (hipStream_t)stream);
   return check_launch("na_composite_backward");
-}
-
-// backward of na_composite_act: feat_pre = the rows before the activation, g_feat_pre their gradient (same shape restrictions)
-int na_composite_act_backward(const float* density, const float* feat_pre, const float* ts, const float* rays, int T, int64_t R, int C,
-                              int density_kind, int bg_kind, int act_kind, const float* rand, const float* g_out, float* g_density,
-                              float* g_feat_pre, void* stream) {
-  NA_REQUIRE(density && feat_pre && ts && rays && g_out && g_density && g_feat_pre, NA_ENULL, "na_composite_act_backward: null pointer");
-  NA_REQUIRE(R >= 0, NA_EINVAL, "na_composite_act_backward: bad shape");
-  const int S = (T + CB_SEG - 1) / CB_SEG;
-  NA_REQUIRE(S >= 2 && S <= 8 && C == 3 && act_kind >= -1 && act_kind <= NA_SIG_UPSHIFTED && act_kind != NA_SIG_TANH, NA_EUNSUPPORTED,
-             "na_composite_act_backward: T=%d C=%d act %d (16 < T <= 128, C = 3, a sigmoid-shaped kind)", T, C, act_kind);
-  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE || (bg_kind == NA_BG_RANDOM && rand != nullptr), NA_EUNSUPPORTED,
-             "na_composite_act_backward: bg kind %d", bg_kind);
-  if (R == 0) return NA_OK;
-  hipLaunchKernelGGL(composite_backward_seg_kernel<3>, dim3((unsigned)((R + 63) / 64)), dim3(64, S), 2 * S * 64 * sizeof(float),
-                     (hipStream_t)stream, density, feat_pre, ts, rays, T, R, density_kind, bg_kind, g_out, g_density, g_feat_pre, rand,
-                     act_kind);
-  return check_launch("na_composite_act_backward");
 }
 
 int na_composite_random_bg_backward(const float* density, const float* feat, const float* ts, const float* rays, int T,

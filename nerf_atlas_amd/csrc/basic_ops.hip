@@ -462,9 +462,7 @@ __global__ void composite_kernel(const float* __restrict__ density, const float*
                                  const float* __restrict__ ts, const float* __restrict__ rays, int T, int64_t R,
                                  int density_kind, int bg_kind, float* __restrict__ alpha_out,
                                  float* __restrict__ weights_out, float* __restrict__ out, int Crt,
-                                 const float* __restrict__ sky_rand = nullptr, int act_kind = -1) {
-  // act_kind >= 0 (na_composite_act, round 6): `feat` holds the reflectance network's rows BEFORE its activation (src/refl.py:207), applied
-  // here on load -- the values na_sigmoid would have written, the same walk: bit-identical to the two launches
+                                 const float* __restrict__ sky_rand = nullptr) {
   const int CC = C > 0 ? C : Crt;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
     const float* ry = rays + r * 6 + 3;
@@ -484,7 +482,7 @@ __global__ void composite_kernel(const float* __restrict__ density, const float*
         const int t = t0 + u < T ? t0 + u : T - 1;  // (clamped: the tail re-reads the last row and ignores it)
         dv[u] = density[(int64_t)t * R + r];
         const float* f = feat + ((int64_t)t * R + r) * CC;
-        for (int c = 0; c < CC; ++c) fv[u][c] = act_kind >= 0 ? apply_sigmoid_kind(f[c], act_kind) : f[c];
+        for (int c = 0; c < CC; ++c) fv[u][c] = f[c];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -969,28 +967,6 @@ int na_composite_random_bg(const float* density, const float* feat, const float*
     hipLaunchKernelGGL(composite_kernel<0>, g, b, 0, (hipStream_t)stream, density, feat, ts, rays, T, R, density_kind,
                        (int)NA_BG_RANDOM, alpha, weights, out, C, rand);
   return check_launch("na_composite_random_bg");
-}
-
-int na_composite_act_ok(int T, int C, int act_kind) {
-  // (the backward's shape: one thread per (ray, 16-step segment), csrc/backward.hip)
-  return T > 16 && T <= 128 && C == 3 && (act_kind == -1 || act_kind == NA_SIG_NORMAL || act_kind == NA_SIG_THIN ||
-                                          act_kind == NA_SIG_FAT || act_kind == NA_SIG_UPSHIFTED);
-}
-
-int na_composite_act(const float* density, const float* feat_pre, const float* ts, const float* rays, int T, int64_t R, int C,
-                     int density_kind, int bg_kind, int act_kind, const float* rand, float* alpha, float* weights, float* out,
-                     void* stream) {
-  NA_REQUIRE(density && feat_pre && ts && rays && out, NA_ENULL, "na_composite_act: null pointer");
-  NA_REQUIRE(R >= 0, NA_EINVAL, "na_composite_act: bad shape");
-  NA_REQUIRE(na_composite_act_ok(T, C, act_kind), NA_EUNSUPPORTED, "na_composite_act: T=%d C=%d act %d (16 < T <= 128, C = 3, a sigmoid-shaped kind)", T, C, act_kind);
-  NA_REQUIRE(density_kind == 0 || density_kind == 1, NA_EUNSUPPORTED, "na_composite_act: density kind %d", density_kind);
-  NA_REQUIRE(bg_kind == NA_BG_BLACK || bg_kind == NA_BG_WHITE || (bg_kind == NA_BG_RANDOM && rand != nullptr), NA_EUNSUPPORTED,
-             "na_composite_act: bg kind %d", bg_kind);
-  if (R == 0) return NA_OK;
-  dim3 g(grid_for(R, 128, 1 << 16)), b(128);
-  hipLaunchKernelGGL(composite_kernel<3>, g, b, 0, (hipStream_t)stream, density, feat_pre, ts, rays, T, R, density_kind, bg_kind, alpha,
-                     weights, out, C, rand, act_kind);
-  return check_launch("na_composite_act");
 }
 
 int na_sky_random(const float* weights, const float* rand, int T, int64_t R, int C, float* out, void* stream) {

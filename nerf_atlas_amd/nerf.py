@@ -131,9 +131,7 @@ class CommonNeRF(utils.PackedCacheMixin, nn.Module):
         act = load_sigmoid(kind)
         self.sigmoid_kind = kind
         self.feat_act = act
-        if hasattr(self, "refl") and self.refl is not None:
-            self.refl.act = act
-            self.refl.act_kind = kind  # (the name the fused paths go by: it used to keep the constructor's default here)
+        if hasattr(self, "refl") and self.refl is not None: self.refl.act = act
 
     def total_latent_size(self) -> int: return self.mip_size()
 
@@ -166,17 +164,11 @@ class CommonNeRF(utils.PackedCacheMixin, nn.Module):
             ops.sky_random(self.weights, self.bg_rand, out)
         return out
 
-    def _composite(self, density, feat, ts, rays, softplus=True, with_sky=True, feat_act=None):
-        """feat_act (training, round 6): `feat` are the reflectance network's rows BEFORE its activation of that kind -- the activation
-        runs inside the compositing kernels (autograd.CompositeActFn; the caller has checked ops.composite_act_ok)."""
+    def _composite(self, density, feat, ts, rays, softplus=True, with_sky=True):
         bg = self.bg if with_sky else "black"
         rand = None
         if bg == "random":
             rand = self.bg_rand = utils.rand(tuple(rays.shape[:-1]) + (1,), rays.device)
-        if feat_act is not None:
-            from .autograd import CompositeActFn
-            out, self.alpha, self.weights = CompositeActFn.apply(density.contiguous(), feat.contiguous(), ts, rays, softplus, bg, rand, feat_act)
-            return out
         if torch.is_grad_enabled() and (density.requires_grad or feat.requires_grad):
             from .autograd import CompositeFn
             out, self.alpha, self.weights = CompositeFn.apply(density.contiguous(), feat.contiguous(), ts, rays, softplus, bg, rand)
@@ -440,14 +432,9 @@ class PlainNeRF(CommonNeRF):
             density = density.reshape(pts.shape[:-1])
             if self.training and self.noise_std > 0:
                 density = density + utils.randn(density.shape, density.device) * self.noise_std
-            rgb_pre = (self.refl.mlp.forward_rows(rows, pre=None if pre is None else (list(pre[0][5:]), pre[2]))
-                       .reshape(pts.shape[:-1] + (self.refl.out_features,)))
-            kind = getattr(self.refl.act, "kind", None)  # (the activation actually applied: utils._Sigmoid carries its name)
-            if (kind is not None and os.environ.get("NA_COMPOSITE_ACT") != "0" and rgb_pre.requires_grad
-                    and ops.composite_act_ok(ts.shape[0], self.refl.out_features, kind)):
-                # the activation inside the compositing kernels, both directions (no sigmoid launches)
-                return self._composite(density, rgb_pre, ts, rays, feat_act=kind)
-            return self._composite(density, self.refl.act(rgb_pre), ts, rays)
+            rgb = self.refl.act(self.refl.mlp.forward_rows(rows, pre=None if pre is None else (list(pre[0][5:]), pre[2]))
+                                .reshape(pts.shape[:-1] + (self.refl.out_features,)))
+            return self._composite(density, rgb, ts, rays)
         assert pre is None, "the one-launch training forward implies the rows path above (its `first_out` is a placeholder)"
         if ag.needs_grad(first_out):
             density, intermediate = ag.SplitHeadFn.apply(first_out)  # (the slices' gradients written side by side: autograd.py)

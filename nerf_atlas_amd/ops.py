@@ -271,48 +271,6 @@ def composite(density: torch.Tensor, feat: torch.Tensor, ts: torch.Tensor, rays:
     return out, alpha, weights
 
 
-BG_ALL = dict(BG, random=2)
-
-
-def composite_act_ok(T: int, C: int, act_kind) -> bool:
-    """does na_composite_act serve this shape (16 < T <= 128, three channels, a sigmoid-shaped activation or None)?"""
-    k = -1 if act_kind is None else SIGMOID.get(act_kind, 99)
-    return bool(_lib.load().na_composite_act_ok(int(T), int(C), k))
-
-
-def composite_act(density: torch.Tensor, feat_pre: torch.Tensor, ts: torch.Tensor, rays: torch.Tensor, act_kind, softplus: bool = True,
-                  bg: str = "black", rand: Optional[torch.Tensor] = None):
-    """act(feat_pre) + compositing in one launch (na_composite_act): density [T,...], feat_pre [T,...,3] = the reflectance network's
-    rows before its activation `act_kind` (a sigmoid_kinds key or None) -> (out [...,3], alpha [T,...], weights [T,...])."""
-    lib = _lib.load()
-    density, feat_pre, ts, rays = _f32(density, "density"), _f32(feat_pre, "feat_pre"), _f32(ts, "ts"), _f32(rays, "rays")
-    T, R = ts.shape[0], rays.numel() // 6
-    assert density.numel() == T * R and feat_pre.numel() == T * R * 3, (density.shape, feat_pre.shape, rays.shape)
-    if bg == "random":
-        rand = _f32(rand, "rand")
-        assert rand.numel() == R, (rand.shape, rays.shape)
-    out = torch.empty(tuple(rays.shape[:-1]) + (3,), device=rays.device, dtype=torch.float32)
-    alpha, weights = torch.empty_like(density), torch.empty_like(density)
-    check(lib.na_composite_act(_ptr(density), _ptr(feat_pre), _ptr(ts), _ptr(rays), T, R, 3, 0 if softplus else 1, BG_ALL[bg],
-                               -1 if act_kind is None else SIGMOID[act_kind], _ptr(rand) if bg == "random" else None, _ptr(alpha),
-                               _ptr(weights), _ptr(out), _stream()))
-    return out, alpha, weights
-
-
-def composite_act_backward(density, feat_pre, ts, rays, g_out, act_kind, softplus: bool = True, bg: str = "black", rand=None):
-    lib = _lib.load()
-    density, feat_pre, ts, rays, g_out = (_f32(density, "density"), _f32(feat_pre, "feat_pre"), _f32(ts, "ts"), _f32(rays, "rays"),
-                                          _f32(g_out, "g_out"))
-    T, R = ts.shape[0], rays.numel() // 6
-    gd, gf = torch.empty_like(density), torch.empty_like(feat_pre)
-    if bg == "random":
-        rand = _f32(rand, "rand")
-    check(lib.na_composite_act_backward(_ptr(density), _ptr(feat_pre), _ptr(ts), _ptr(rays), T, R, 3, 0 if softplus else 1, BG_ALL[bg],
-                                        -1 if act_kind is None else SIGMOID[act_kind], _ptr(rand) if bg == "random" else None,
-                                        _ptr(g_out), _ptr(gd), _ptr(gf), _stream()))
-    return gd, gf
-
-
 def sky_random(weights: torch.Tensor, rand: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out[..., :] += rand[..., 0] * (1 - sum(weights[:-1])) in place (src/nerf.py:101-103); weights [T,...], rand [...,1]."""
     lib = _lib.load()

@@ -114,50 +114,6 @@ def test_composite_backward_segmented_kernel(ops, T, R):
                 assert rel(gd.double(), d.grad) <= 5e-5, (C, sp, bg)
 
 
-@pytest.mark.parametrize("T,R", [(17, 70), (48, 129), (64, 4096), (128, 65)])
-def test_composite_with_the_activation_folded_in(ops, T, R):
-    """Round 6: the training step's colour head as one launch each way (na_composite_act / _backward: the reflectance activation inside
-    the compositing kernels).  Forward and backward bit for bit the unfused chain (na_sigmoid + na_composite, na_composite_backward +
-    na_sigmoid_backward), the backward also against the oracle's autograd in fp64 through sigmoid + compositing; four sigmoid-shaped
-    kinds and None, three backgrounds."""
-    from nerf_atlas_amd import utils as U
-    ts = torch.linspace(2.0, 6.0, T)
-    r_d = torch.from_numpy(proc_uniform((1, 1, R, 3), 31, 1.0))
-    rays = torch.cat([torch.zeros_like(r_d), r_d], -1)
-    dens = torch.from_numpy(proc_uniform((T, 1, 1, R), 32, 3.0))
-    pre = torch.from_numpy(proc_uniform((T, 1, 1, R, 3), 33, 3.0))
-    go = torch.from_numpy(proc_uniform((1, 1, R, 3), 34, 1.0))
-    rand = torch.from_numpy(proc_uniform((1, 1, R, 1), 35, 0.5)) + 0.5
-    for kind in ("normal", "thin", "fat", "upshifted", None):
-        assert ops.composite_act_ok(T, 3, kind)
-        for bg in ("black", "white", "random"):
-            rr = rand.cuda() if bg == "random" else None
-            out, al, w = ops.composite_act(dens.cuda(), pre.cuda(), ts.cuda(), rays.cuda(), kind, True, bg, rand=rr)
-            feat = pre.cuda() if kind is None else U.sigmoid_kinds[kind](pre.cuda())
-            out0, al0, w0 = ops.composite(dens.cuda(), feat, ts.cuda(), rays.cuda(), softplus=True, bg=bg, rand=rr)
-            assert torch.equal(out, out0) and torch.equal(al, al0) and torch.equal(w, w0), (kind, bg)  # (the activation on load: the same walk)
-            d = dens.double().requires_grad_()
-            p = pre.double().requires_grad_()
-            c = p if kind is None else O.sigmoid(kind)(p)
-            a, wr = O.alpha_from_density(d, ts.double(), r_d.double(), softplus=True)
-            ref = O.volumetric_integrate(wr, c)
-            if bg == "white":
-                ref = ref + O.sky_white(wr)
-            elif bg == "random":
-                ref = ref + O.sky_random(wr, rand.double())
-            (ref * go.double()).sum().backward()
-            gd, gf = ops.composite_act_backward(dens.cuda(), pre.cuda(), ts.cuda(), rays.cuda(), go.cuda(), kind, True, bg, rand=rr)
-            assert rel(gf.double(), p.grad) <= 2e-5, (kind, bg)
-            assert rel(gd.double(), d.grad) <= 5e-5, (kind, bg)
-            # ... and bit for bit the unfused chain's gradients (na_composite_backward + na_sigmoid_backward)
-            gd0, gf0 = ops.composite_backward(dens.cuda(), feat, ts.cuda(), rays.cuda(), go.cuda(), True, bg, rand=rr)
-            if kind is not None:
-                gf0 = ops.sigmoid_backward(pre.cuda(), gf0, kind)
-            assert torch.equal(gd, gd0) and torch.equal(gf, gf0), (kind, bg)
-    assert not ops.composite_act_ok(16, 3, "thin") and not ops.composite_act_ok(129, 3, "thin") and not ops.composite_act_ok(64, 1, "thin")
-    assert not ops.composite_act_ok(64, 3, "tanh")
-
-
 @pytest.mark.parametrize("act", ["none", "leaky_relu", "sin"])
 def test_linear_backward(ops, act, train_prec):
     from nerf_atlas_amd.autograd import LinearFn

@@ -172,28 +172,3 @@ def test_dnerf_step_through_the_one_launch_forward():
         err = float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-30))
         assert err <= 2e-3, (n, err)
     assert float(g1["delta_estim.init.weight"].abs().max()) > 0
-
-
-@pytest.mark.parametrize("kind", ["upshifted", "thin"])
-def test_step_with_the_activation_inside_the_compositing_kernels(kind, monkeypatch):
-    """autograd.CompositeActFn (the reflectance activation inside na_composite_act / _backward) against SigmoidFn + CompositeFn
-    (NA_COMPOSITE_ACT=0) on a whole training step in deterministic mode: the same loss and the same gradients, bit for bit (the activation
-    is applied on load inside the same kernels' walks).  `kind` set through set_sigmoid: the name the kernels get is the activation
-    actually applied."""
-    m, rays = _model_and_rays(32, 64)
-    m.set_sigmoid(kind)
-    assert m.refl.act.kind == kind and m.refl.act_kind == kind
-    target = torch.rand(rays.shape[:-1] + (3,), device=rays.device)
-    from nerf_atlas_amd import config
-    config.set_deterministic(True)  # (fixed-point cross-workgroup sums: two runs of ONE path are bit-identical, so two paths can be compared)
-    try:
-        res = []
-        for flag in ("0", "1"):
-            monkeypatch.setenv("NA_COMPOSITE_ACT", flag)
-            res.append(_step(m, rays, target, "ls"))
-    finally:
-        config.set_deterministic(False)
-    (l0, g0), (l1, g1) = res
-    assert l0 == l1, (l0, l1)
-    for n in g0:
-        assert torch.equal(g0[n], g1[n]), n
