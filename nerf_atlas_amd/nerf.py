@@ -131,7 +131,9 @@ class CommonNeRF(utils.PackedCacheMixin, nn.Module):
         act = load_sigmoid(kind)
         self.sigmoid_kind = kind
         self.feat_act = act
-        if hasattr(self, "refl") and self.refl is not None: self.refl.act = act
+        if hasattr(self, "refl") and self.refl is not None:
+            self.refl.act = act
+            self.refl.act_kind = kind  # (the name the fused paths go by: it used to keep the constructor's default here)
 
     def total_latent_size(self) -> int: return self.mip_size()
 

@@ -133,3 +133,12 @@ def test_plain_nerf_on_the_cpu_never_takes_the_one_launch_forward():
     m = nerf.PlainNeRF(steps=16, t_near=2.0, t_far=6.0, intermediate_size=64)
     pts = torch.zeros(16, 1, 4, 4, 3)
     assert m._train_forward_ls(torch.zeros(1, 4, 4, 6), torch.linspace(2, 6, 16), pts, torch.zeros(1, 4, 4, 3)) is None
+
+
+def test_set_sigmoid_renames_the_reflectance_activation():
+    """CommonNeRF.set_sigmoid (src/nerf.py:147-151) replaces refl.act; the name the fused renderers gate on (refl.act_kind) follows it."""
+    import nerf_atlas_amd.nerf as nerf
+    m = nerf.PlainNeRF(steps=16, t_near=2.0, t_far=6.0, intermediate_size=64, sigmoid_kind="upshifted")
+    assert m.sigmoid_kind == "upshifted" and m.refl.act.kind == "upshifted" and m.refl.act_kind == "upshifted"
+    m.set_sigmoid("fat")
+    assert m.refl.act.kind == "fat" and m.refl.act_kind == "fat"
