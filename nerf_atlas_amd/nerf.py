@@ -335,10 +335,10 @@ class PlainNeRF(CommonNeRF):
     def _train_forward_ls(self, rays, ts, pts, r_d):
         """Training (round 6): both networks' forwards as ONE launch of the layer-synchronous engine in the three-product bf16 split
         (csrc/ls_kernel.h MODEL 9) instead of twelve training Linears -- every Linear's output rows are written once for the backward
-        pass and never read back by the forward.  Returns (planes [10, N, 256], (density [N], the View MLP's init rows [N, 69]), rgb_pre [N, 3],
-        the stacked hash tables) or None when the
-        step does not have the shape the kernel serves (then the layer-by-layer forward runs: the same three-product arithmetic with
-        another summation order).  `config.set_train_forward("layers")` / NA_TRAIN_LS=0 switch it off."""
+        pass and never read back by the forward.  Returns (planes [10, N, 256], (density [N], the View MLP's init rows [N, 69]),
+        rgb_pre [N, 3], the stacked hash tables), or None when the step does not have the shape the kernel serves (then the
+        layer-by-layer forward runs: the same three-product arithmetic with another summation order).
+        `config.set_train_forward("layers")` / NA_TRAIN_LS=0 switch it off."""
         N = pts.numel() // 3
         if (config.train_forward != "ls" or config.train_precision != "bf16x3" or not torch.is_grad_enabled() or not pts.is_cuda
                 or type(self.refl) is not refl.View or self.mip is not None or self.intermediate_size != 64 or self.refl.out_features != 3
